@@ -1,0 +1,257 @@
+/*
+ * jxl_hip.h -- C ABI of the MI355X (gfx950) VarDCT decode back-end.
+ *
+ * This is the drop-in boundary for ONE hot path of libjxl: everything between
+ * "quantized AC coefficients + per-block side info are in memory" and "float
+ * pixels are in the output buffer":
+ *
+ *   dequant + chroma-from-luma + LLF-from-DC + variable-size inverse transform
+ *   -> [Gaborish] -> [EPF0] [EPF1] [EPF2] -> XYB -> linear RGB
+ *
+ * Each entry point cites the reference interface (path relative to the libjxl
+ * tree) that it replaces.  Plain C: pointers + sizes only, no C++/torch types.
+ * All functions return JXLHIP_OK (0) or a negative jxlhip_status; nothing
+ * throws; there is NO CPU fallback (a missing device is an error).
+ *
+ * Coordinate / layout conventions are the reference's own:
+ *   - block  = 8x8 px; group = 256x256 px = 32x32 blocks; colour tile = 64x64 px
+ *     (lib/jxl/frame_dimensions.h:21-27, lib/jxl/chroma_from_luma.h:28-32)
+ *   - channel order c = 0:X 1:Y 2:B
+ *   - AC coefficient stream per group and channel: varblocks in raster visit
+ *     order of their top-left block, 64*covered_blocks coefficients each, in the
+ *     layout of the dequant matrix (rows = short side, lib/jxl/dec_group.cc:221,
+ *     334-359; lib/jxl/coeff_order_fwd.h:27-43); group g starts at element
+ *     g*65536 (lib/jxl/dec_frame.cc:423, lib/jxl/dct_util.h:23-96)
+ */
+#ifndef JXL_HIP_H_
+#define JXL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define JXLHIP_EXPORT __attribute__((visibility("default")))
+#else
+#define JXLHIP_EXPORT
+#endif
+
+#define JXLHIP_BLOCK_DIM 8
+#define JXLHIP_GROUP_DIM 256
+#define JXLHIP_GROUP_DIM_IN_BLOCKS 32
+#define JXLHIP_GROUP_COEFFS 65536 /* per channel */
+#define JXLHIP_COLOR_TILE_DIM_IN_BLOCKS 8
+#define JXLHIP_NUM_STRATEGIES 27
+#define JXLHIP_NUM_QUANT_TABLES 17
+/* lib/jxl/quant_weights.h:412-417: sum(required_size_x*required_size_y)=2056 */
+#define JXLHIP_DEQUANT_TABLE_FLOATS (2056 * 64 * 3)
+
+typedef enum {
+  JXLHIP_OK = 0,
+  JXLHIP_ERR_INVALID_ARGUMENT = -1,
+  JXLHIP_ERR_NO_DEVICE = -2,
+  JXLHIP_ERR_OUT_OF_MEMORY = -3,
+  JXLHIP_ERR_HIP = -4,         /* a HIP runtime call failed; see last_error */
+  JXLHIP_ERR_BAD_STREAM = -5,  /* side info violates a format constraint */
+  JXLHIP_ERR_STATE = -6        /* call sequence error */
+} jxlhip_status;
+
+/* ACType, lib/jxl/dct_util.h:23; chosen per frame at lib/jxl/dec_frame.cc:421-431 */
+typedef enum { JXLHIP_COEFF_I16 = 0, JXLHIP_COEFF_I32 = 1 } jxlhip_coeff_type;
+
+typedef enum {
+  /* 3 planes of xsize*ysize floats (plane stride = out_plane_stride floats):
+     the frame after the loop filters, still in XYB (ColorSpace::kXYB output) */
+  JXLHIP_OUT_XYB_PLANAR = 0,
+  /* interleaved linear RGB float, 3 floats per pixel, row stride in bytes
+     given at decode time: what XYBStage + WriteToOutputStage(float) produce
+     (lib/jxl/render_pipeline/stage_xyb.cc:42-98, stage_write.cc:334-368) */
+  JXLHIP_OUT_LINEAR_RGB_F32 = 1
+} jxlhip_output_kind;
+
+/* Mirrors jxl::LoopFilter (lib/jxl/loop_filter.h:20-70); values as decoded. */
+typedef struct jxlhip_loop_filter {
+  uint32_t gab;          /* LoopFilter::gab */
+  float gab_weights[6];  /* gab_{x,y,b}_weight{1,2}: x1,x2,y1,y2,b1,b2 */
+  uint32_t epf_iters;    /* 0..3 */
+  float epf_sharp_lut[8];
+  float epf_channel_scale[3];
+  float epf_quant_mul;
+  float epf_pass0_sigma_scale;
+  float epf_pass2_sigma_scale;
+  float epf_border_sad_mul;
+} jxlhip_loop_filter;
+
+/* The scalar members of PassesSharedState / PassesDecoderState the hot path
+ * reads (lib/jxl/passes_state.h:48-95, lib/jxl/dec_cache.h:86-229). */
+typedef struct jxlhip_frame_params {
+  uint32_t xsize, ysize;       /* FrameDimensions::xsize/ysize (true size) */
+  uint32_t coeff_type;         /* jxlhip_coeff_type */
+  uint32_t output_kind;        /* jxlhip_output_kind */
+  int32_t global_scale;        /* Quantizer::global_scale_ (quantizer.h:82-85) */
+  int32_t quant_dc;            /* Quantizer::quant_dc_ */
+  float x_dm_multiplier;       /* 0.8^(x_qm_scale-2), dec_cache.h:161 */
+  float b_dm_multiplier;       /* 0.8^(b_qm_scale-2), dec_cache.h:162 */
+  float quant_biases[4];       /* OpsinParams::quant_biases (dec_xyb.h:27-33) */
+  float cfl_base_x;            /* ColorCorrelation::base_correlation_x_ */
+  float cfl_base_b;            /* ColorCorrelation::base_correlation_b_ */
+  uint32_t cfl_color_factor;   /* ColorCorrelation::color_factor_ (default 84) */
+  jxlhip_loop_filter lf;
+  float opsin_biases[3];       /* OpsinParams::opsin_biases (negated biases) */
+  /* row-major inverse opsin absorbance matrix ALREADY multiplied by
+     255/intensity_target (InitSIMDInverseMatrix, opsin_params.cc:35-45) */
+  float inverse_opsin_matrix[9];
+  /* Multi-GPU: this context decodes AC-group rows [stripe_group_y0,
+     stripe_group_y0+stripe_group_rows) of the frame.  0,0 = whole frame. */
+  uint32_t stripe_group_y0;
+  uint32_t stripe_group_rows;
+} jxlhip_frame_params;
+
+/* Device pointers of one frame's inputs.  Same content the reference keeps in
+ * PassesSharedState (ac_strategy, raw_quant_field, epf_sharpness, cmap, dc) and
+ * in PassesDecoderState::coefficients (ACImage).  All frame-sized planes are
+ * dense row-major with row stride xsize_blocks (resp. xsize_tiles) elements
+ * and cover the WHOLE frame, also when the context only decodes a stripe;
+ * coeffs[c] likewise holds all groups (only the stripe's groups are read). */
+typedef struct jxlhip_frame_inputs {
+  const void* coeffs[3];        /* int16_t or int32_t [num_groups*65536] */
+  const uint8_t* ac_strategy;   /* (raw_strategy<<1)|is_first, ac_strategy.h:187-198 */
+  const int32_t* raw_quant;     /* 1..256, valid at first blocks (dec_modular.cc:552) */
+  const uint8_t* epf_sharpness; /* 0..7 per block */
+  const int8_t* ytox_map;       /* per 64x64 tile */
+  const int8_t* ytob_map;
+  const float* dc[3];           /* dequantized (+smoothed) DC, per block */
+  const float* dequant_table;   /* DequantMatrices::table_ layout, see
+                                   jxlhip_dequant_table_offset() */
+} jxlhip_frame_inputs;
+
+typedef struct jxlhip_ctx jxlhip_ctx;
+
+/* ---- static geometry helpers (host, no device needed) ------------------- */
+/* AcStrategy::covered_blocks_x/y, log2_covered_blocks (ac_strategy.h:148-173) */
+JXLHIP_EXPORT int jxlhip_covered_blocks_x(int raw_strategy);
+JXLHIP_EXPORT int jxlhip_covered_blocks_y(int raw_strategy);
+JXLHIP_EXPORT int jxlhip_log2_covered_blocks(int raw_strategy);
+/* kAcStrategyToQuantTableMap (quant_weights.h:337-348) */
+JXLHIP_EXPORT int jxlhip_quant_table_of_strategy(int raw_strategy);
+/* DequantMatrices::Matrix(kind,c) - table_ (quant_weights.h:364-367); floats */
+JXLHIP_EXPORT size_t jxlhip_dequant_table_offset(int raw_strategy, int c);
+JXLHIP_EXPORT const char* jxlhip_status_string(int status);
+
+/* ---- context ------------------------------------------------------------ */
+/* Replaces the per-decoder state setup of PassesDecoderState::Init
+ * (dec_cache.h:153-229).  device = HIP device ordinal. */
+JXLHIP_EXPORT int jxlhip_create(int device, jxlhip_ctx** out);
+JXLHIP_EXPORT void jxlhip_destroy(jxlhip_ctx* ctx);
+JXLHIP_EXPORT const char* jxlhip_last_error(const jxlhip_ctx* ctx);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) for all
+ * launches; NULL restores the context's own stream. */
+JXLHIP_EXPORT int jxlhip_set_stream(jxlhip_ctx* ctx, void* hip_stream);
+
+/* Replaces PassesDecoderState::InitForAC + PreparePipeline
+ * (dec_cache.cc:78-96,117-371): fixes the frame geometry and the stage list
+ * and (re)allocates the device intermediates (XYB planes, sigma image, block
+ * offset table). */
+JXLHIP_EXPORT int jxlhip_frame_begin(jxlhip_ctx* ctx,
+                                     const jxlhip_frame_params* params);
+
+/* Zero-copy path: the caller already has the inputs in device memory. */
+JXLHIP_EXPORT int jxlhip_frame_set_inputs(jxlhip_ctx* ctx,
+                                          const jxlhip_frame_inputs* dev);
+
+/* Host-upload path (what a libjxl FrameDecoder would call).
+ * Replaces the reads of shared->ac_strategy/raw_quant_field/epf_sharpness/
+ * cmap/dc in DecodeGroupImpl (dec_group.cc:275-316).  Host pointers, dense
+ * frame-sized planes; copied asynchronously into context-owned HBM. */
+JXLHIP_EXPORT int jxlhip_upload_side_info(
+    jxlhip_ctx* ctx, const uint8_t* ac_strategy, const int32_t* raw_quant,
+    const uint8_t* epf_sharpness, const int8_t* ytox_map,
+    const int8_t* ytob_map, const float* const dc[3],
+    const float* dequant_table);
+/* Replaces GetBlockFromEncoder/GetBlockFromBitstream -> DequantBlock hand-off
+ * (dec_group.cc:334-359,662-706): the group's quantized coefficient stream, as
+ * produced by DecodeACVarBlock, ncoeffs <= 65536 elements per channel.
+ * Thread-safe w.r.t. other groups; copies on a pooled stream. */
+JXLHIP_EXPORT int jxlhip_submit_group(jxlhip_ctx* ctx, uint32_t group_idx,
+                                      const void* const coeffs[3],
+                                      size_t ncoeffs);
+
+/* Phase 1, replaces DecodeGroupImpl's DequantBlock + TransformToPixels for
+ * every group of the stripe (dec_group.cc:431-450) and ComputeSigma
+ * (epf.cc:39-133).  Result: XYB planes in context memory. */
+JXLHIP_EXPORT int jxlhip_decode_blocks(jxlhip_ctx* ctx);
+
+/* Multi-GPU halo hand-off between phase 1 and 2.  Number of rows a stripe
+ * needs from each neighbour = LoopFilter::Padding() (loop_filter.h:26-29). */
+JXLHIP_EXPORT int jxlhip_halo_rows(const jxlhip_ctx* ctx);
+/* Device pointers to this stripe's rows to SEND (top/bottom `halo` rows of the
+ * stripe's own XYB planes) and to the slots to RECEIVE the neighbours' rows
+ * into; each region is 3 planes x halo rows, plane c at +c*plane_stride,
+ * row stride *row_stride floats.  which: 0 send-up 1 send-down 2 recv-from-up
+ * 3 recv-from-down. */
+JXLHIP_EXPORT int jxlhip_halo_region(jxlhip_ctx* ctx, int which, float** base,
+                                     size_t* row_stride, size_t* plane_stride);
+
+/* Phase 2, replaces the render pipeline stages Gaborish/EPF0/EPF1/EPF2/XYB
+ * (+ float WriteToOutput) run by RenderPipeline::InputReady ->
+ * ProcessBuffers (low_memory_render_pipeline.cc:832-934) with the
+ * SimpleRenderPipeline border semantics (simple_render_pipeline.cc:129-164).
+ * out: device pointer; for LINEAR_RGB_F32 out_stride = bytes per row
+ * (>= xsize*12), for XYB_PLANAR out_stride = floats per row and the 3 planes
+ * are out_plane_stride floats apart.  Rows written: the stripe's rows only
+ * (row 0 of `out` = first row of the stripe). */
+JXLHIP_EXPORT int jxlhip_decode_filters(jxlhip_ctx* ctx, void* out,
+                                        size_t out_stride,
+                                        size_t out_plane_stride);
+
+/* Both phases (single GPU). */
+JXLHIP_EXPORT int jxlhip_decode_frame(jxlhip_ctx* ctx, void* out,
+                                      size_t out_stride,
+                                      size_t out_plane_stride);
+
+JXLHIP_EXPORT int jxlhip_sync(jxlhip_ctx* ctx);
+
+/* Debug/test taps on context-owned intermediates (device pointers). */
+JXLHIP_EXPORT int jxlhip_get_xyb_planes(jxlhip_ctx* ctx, float* planes[3],
+                                        size_t* row_stride, size_t* rows);
+JXLHIP_EXPORT int jxlhip_get_sigma(jxlhip_ctx* ctx, float** inv_sigma,
+                                   size_t* row_stride);
+
+/* Per-kernel timing with HIP events on the launch stream.  enable!=0 starts
+ * recording around every launch of subsequent decode calls;
+ * jxlhip_profile_read syncs and returns accumulated milliseconds and launch
+ * counts per kernel slot (see JXLHIP_KERNEL_*), then resets. */
+enum {
+  JXLHIP_KERNEL_OFFSETS = 0,  /* block-offset scan */
+  JXLHIP_KERNEL_BLOCKS = 1,   /* dequant+CfL+LLF+inverse transforms */
+  JXLHIP_KERNEL_SIGMA = 2,
+  JXLHIP_KERNEL_FILTERS = 3,  /* fused Gaborish/EPF/XYB->RGB */
+  JXLHIP_KERNEL_COUNT = 8
+};
+JXLHIP_EXPORT int jxlhip_profile_enable(jxlhip_ctx* ctx, int enable);
+JXLHIP_EXPORT int jxlhip_profile_read(jxlhip_ctx* ctx,
+                                      float ms[JXLHIP_KERNEL_COUNT],
+                                      uint32_t launches[JXLHIP_KERNEL_COUNT]);
+
+/* ---- device-side helpers for rows of SURVEY 8(a) outside the two phases -- */
+/* a5: DequantMatrices::EnsureComputed for the default library
+ * (quant_weights.cc:163-358,1211-1271): fills a JXLHIP_DEQUANT_TABLE_FLOATS
+ * device buffer with the default dequant tables. */
+JXLHIP_EXPORT int jxlhip_default_dequant_tables(jxlhip_ctx* ctx,
+                                                float* table_dev);
+/* a8: DequantDC + AdaptiveDCSmoothing (compressed_dc.cc:128-250).
+ * quant_dc[c]: int32 planes from the modular DC decode (device), dc_out[c]:
+ * float planes (device), both xsize_blocks*ysize_blocks dense.
+ * dc_factors = cfl factors at DC {ytox_dc ratio, ytob_dc ratio}. */
+JXLHIP_EXPORT int jxlhip_dequant_dc(jxlhip_ctx* ctx,
+                                    const int32_t* const quant_dc[3],
+                                    float* const dc_out[3], float cfl_x_dc,
+                                    float cfl_b_dc, int smooth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_HIP_H_ */

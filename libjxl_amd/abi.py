@@ -1,0 +1,136 @@
+"""ctypes binding of the C ABI in include/jxl_hip.h (libjxl_hip.so)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "csrc", "libjxl_hip.so")
+_RUNNER_SO = os.path.join(_HERE, "csrc", "libjxl_threads_hip.so")
+
+KERNEL_COUNT = 8
+KERNEL_NAMES = ["offsets", "blocks", "sigma", "filters", "blocks_large", "k5", "k6", "k7"]
+
+
+class JxlHipError(RuntimeError):
+    pass
+
+
+class LoopFilter(C.Structure):
+    _fields_ = [("gab", C.c_uint32), ("gab_weights", C.c_float * 6),
+                ("epf_iters", C.c_uint32), ("epf_sharp_lut", C.c_float * 8),
+                ("epf_channel_scale", C.c_float * 3),
+                ("epf_quant_mul", C.c_float),
+                ("epf_pass0_sigma_scale", C.c_float),
+                ("epf_pass2_sigma_scale", C.c_float),
+                ("epf_border_sad_mul", C.c_float)]
+
+
+class FrameParams(C.Structure):
+    _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32),
+                ("coeff_type", C.c_uint32), ("output_kind", C.c_uint32),
+                ("global_scale", C.c_int32), ("quant_dc", C.c_int32),
+                ("x_dm_multiplier", C.c_float), ("b_dm_multiplier", C.c_float),
+                ("quant_biases", C.c_float * 4),
+                ("cfl_base_x", C.c_float), ("cfl_base_b", C.c_float),
+                ("cfl_color_factor", C.c_uint32),
+                ("lf", LoopFilter),
+                ("opsin_biases", C.c_float * 3),
+                ("inverse_opsin_matrix", C.c_float * 9),
+                ("stripe_group_y0", C.c_uint32),
+                ("stripe_group_rows", C.c_uint32)]
+
+
+class FrameInputs(C.Structure):
+    _fields_ = [("coeffs", C.c_void_p * 3),
+                ("ac_strategy", C.c_void_p), ("raw_quant", C.c_void_p),
+                ("epf_sharpness", C.c_void_p),
+                ("ytox_map", C.c_void_p), ("ytob_map", C.c_void_p),
+                ("dc", C.c_void_p * 3),
+                ("dequant_table", C.c_void_p)]
+
+
+def make_params(d):
+    """dict (libjxl_amd.synth.synth_frame) -> FrameParams."""
+    p = FrameParams()
+    for k in ("xsize", "ysize", "coeff_type", "output_kind", "global_scale",
+              "quant_dc", "x_dm_multiplier", "b_dm_multiplier", "cfl_base_x",
+              "cfl_base_b", "cfl_color_factor", "stripe_group_y0",
+              "stripe_group_rows"):
+        setattr(p, k, d[k])
+    p.quant_biases[:] = d["quant_biases"]
+    p.opsin_biases[:] = d["opsin_biases"]
+    p.inverse_opsin_matrix[:] = d["inverse_opsin_matrix"]
+    p.lf.gab = d["gab"]
+    p.lf.gab_weights[:] = d["gab_weights"]
+    p.lf.epf_iters = d["epf_iters"]
+    p.lf.epf_sharp_lut[:] = d["epf_sharp_lut"]
+    p.lf.epf_channel_scale[:] = d["epf_channel_scale"]
+    p.lf.epf_quant_mul = d["epf_quant_mul"]
+    p.lf.epf_pass0_sigma_scale = d["epf_pass0_sigma_scale"]
+    p.lf.epf_pass2_sigma_scale = d["epf_pass2_sigma_scale"]
+    p.lf.epf_border_sad_mul = d["epf_border_sad_mul"]
+    return p
+
+
+def library_path():
+    return _SO
+
+
+def runner_library_path():
+    return _RUNNER_SO
+
+
+_lib = None
+
+# every symbol include/jxl_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "jxlhip_covered_blocks_x", "jxlhip_covered_blocks_y",
+    "jxlhip_log2_covered_blocks", "jxlhip_quant_table_of_strategy",
+    "jxlhip_dequant_table_offset", "jxlhip_status_string", "jxlhip_create",
+    "jxlhip_destroy", "jxlhip_last_error", "jxlhip_set_stream",
+    "jxlhip_frame_begin", "jxlhip_frame_set_inputs", "jxlhip_upload_side_info",
+    "jxlhip_submit_group", "jxlhip_decode_blocks", "jxlhip_halo_rows",
+    "jxlhip_halo_region", "jxlhip_decode_filters", "jxlhip_decode_frame",
+    "jxlhip_sync", "jxlhip_get_xyb_planes", "jxlhip_get_sigma",
+    "jxlhip_profile_enable", "jxlhip_profile_read",
+    "jxlhip_default_dequant_tables", "jxlhip_dequant_dc",
+]
+
+
+def load_library():
+    """Loads libjxl_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise JxlHipError(
+            f"{_SO} not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(_SO)
+    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+    L.jxlhip_dequant_table_offset.restype = sz
+    L.jxlhip_dequant_table_offset.argtypes = [i32, i32]
+    L.jxlhip_status_string.restype = C.c_char_p
+    L.jxlhip_last_error.restype = C.c_char_p
+    L.jxlhip_last_error.argtypes = [vp]
+    L.jxlhip_create.argtypes = [i32, C.POINTER(vp)]
+    L.jxlhip_destroy.argtypes = [vp]
+    L.jxlhip_destroy.restype = None
+    L.jxlhip_set_stream.argtypes = [vp, vp]
+    L.jxlhip_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
+    L.jxlhip_frame_set_inputs.argtypes = [vp, C.POINTER(FrameInputs)]
+    L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]
+    L.jxlhip_submit_group.argtypes = [vp, u32, vp * 3, sz]
+    L.jxlhip_decode_blocks.argtypes = [vp]
+    L.jxlhip_halo_rows.argtypes = [vp]
+    L.jxlhip_halo_region.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.jxlhip_decode_filters.argtypes = [vp, vp, sz, sz]
+    L.jxlhip_decode_frame.argtypes = [vp, vp, sz, sz]
+    L.jxlhip_sync.argtypes = [vp]
+    L.jxlhip_get_xyb_planes.argtypes = [vp, vp * 3, C.POINTER(sz), C.POINTER(sz)]
+    L.jxlhip_get_sigma.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.jxlhip_profile_enable.argtypes = [vp, i32]
+    L.jxlhip_profile_read.argtypes = [vp, C.c_float * KERNEL_COUNT, u32 * KERNEL_COUNT]
+    L.jxlhip_default_dequant_tables.argtypes = [vp, vp]
+    L.jxlhip_dequant_dc.argtypes = [vp, vp * 3, vp * 3, C.c_float * 3, C.c_float, C.c_float, i32]
+    _lib = L
+    return L

@@ -1,0 +1,174 @@
+"""Host-side mirror of the reference's per-frame decode state for the VarDCT
+back-end (PassesDecoderState + RenderPipeline, lib/jxl/dec_cache.h:86-229,
+lib/jxl/render_pipeline/render_pipeline.h:139-152) on top of the C ABI.
+
+PyTorch is plumbing only: it owns the HBM tensors and the stream; every
+computation happens in libjxl_hip.so's HIP kernels.
+"""
+import ctypes as C
+
+import torch
+
+from . import abi
+
+
+def _check(L, ctx, rc, what):
+    if rc != 0:
+        msg = L.jxlhip_last_error(ctx) if ctx else b""
+        raise abi.JxlHipError(
+            f"{what}: {L.jxlhip_status_string(rc).decode()} ({rc}) {msg.decode() if msg else ''}")
+
+
+class VarDctDecoder:
+    """One decoder context bound to one GPU (one per process / rank)."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        self.L = abi.load_library()
+        self.device = int(device)
+        if not torch.cuda.is_available():
+            raise abi.JxlHipError("no HIP device visible: the VarDCT back-end has no CPU path")
+        self.ctx = C.c_void_p()
+        _check(self.L, None, self.L.jxlhip_create(self.device, C.byref(self.ctx)), "jxlhip_create")
+        if use_torch_stream:
+            s = torch.cuda.current_stream(self.device).cuda_stream
+            _check(self.L, self.ctx, self.L.jxlhip_set_stream(self.ctx, C.c_void_p(s)), "set_stream")
+        self.params = None
+        self._keep = None
+        self.out = None
+
+    def close(self):
+        if self.ctx:
+            self.L.jxlhip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- frame set-up ------------------------------------------------------
+    def begin_frame(self, params):
+        """params: abi.FrameParams (or dict from synth.synth_frame)."""
+        if isinstance(params, dict):
+            params = abi.make_params(params)
+        self.params = params
+        _check(self.L, self.ctx, self.L.jxlhip_frame_begin(self.ctx, C.byref(params)), "frame_begin")
+
+    def default_dequant_tables(self):
+        t = torch.empty(2056 * 64 * 3, dtype=torch.float32, device=f"cuda:{self.device}")
+        _check(self.L, self.ctx, self.L.jxlhip_default_dequant_tables(self.ctx, C.c_void_p(t.data_ptr())), "default_dequant_tables")
+        return t
+
+    def set_inputs(self, tensors, dequant_table):
+        """tensors: dict of CUDA tensors laid out as jxlhip_frame_inputs."""
+        dev = f"cuda:{self.device}"
+        for k, v in tensors.items():
+            for t in (v if isinstance(v, (list, tuple)) else [v]):
+                assert t.is_cuda and t.is_contiguous(), k
+        fi = abi.FrameInputs()
+        for c in range(3):
+            fi.coeffs[c] = tensors["coeffs"][c].data_ptr()
+            fi.dc[c] = tensors["dc"][c].data_ptr()
+        fi.ac_strategy = tensors["ac_strategy"].data_ptr()
+        fi.raw_quant = tensors["raw_quant"].data_ptr()
+        fi.epf_sharpness = tensors["epf_sharpness"].data_ptr()
+        fi.ytox_map = tensors["ytox_map"].data_ptr()
+        fi.ytob_map = tensors["ytob_map"].data_ptr()
+        fi.dequant_table = dequant_table.data_ptr()
+        self._keep = (tensors, dequant_table, dev)
+        _check(self.L, self.ctx, self.L.jxlhip_frame_set_inputs(self.ctx, C.byref(fi)), "frame_set_inputs")
+
+    # -- geometry ------------------------------------------------------------
+    def stripe_rows(self):
+        p = self.params
+        ysg = (p.ysize + 255) // 256
+        g0 = p.stripe_group_y0
+        gr = p.stripe_group_rows if p.stripe_group_rows else ysg - g0
+        y0 = g0 * 256
+        y1 = min(p.ysize, (g0 + gr) * 256)
+        return y0, y1
+
+    def alloc_output(self):
+        p = self.params
+        y0, y1 = self.stripe_rows()
+        dev = f"cuda:{self.device}"
+        if p.output_kind == 1:
+            return torch.empty((y1 - y0, p.xsize, 3), dtype=torch.float32, device=dev)
+        return torch.empty((3, y1 - y0, p.xsize), dtype=torch.float32, device=dev)
+
+    def _out_args(self, out):
+        p = self.params
+        if p.output_kind == 1:
+            return C.c_void_p(out.data_ptr()), out.stride(0) * 4, 0
+        return C.c_void_p(out.data_ptr()), out.stride(1), out.stride(0)
+
+    # -- decode ----------------------------------------------------------------
+    def decode_blocks(self):
+        _check(self.L, self.ctx, self.L.jxlhip_decode_blocks(self.ctx), "decode_blocks")
+
+    def decode_filters(self, out):
+        a = self._out_args(out)
+        _check(self.L, self.ctx, self.L.jxlhip_decode_filters(self.ctx, *a), "decode_filters")
+
+    def decode_frame(self, out=None):
+        if out is None:
+            out = self.alloc_output()
+        a = self._out_args(out)
+        _check(self.L, self.ctx, self.L.jxlhip_decode_frame(self.ctx, *a), "decode_frame")
+        return out
+
+    def sync(self):
+        _check(self.L, self.ctx, self.L.jxlhip_sync(self.ctx), "sync")
+
+    # -- taps / profiling --------------------------------------------------------
+    def xyb_planes(self):
+        """Copies of the phase-1 XYB planes (rows of the stripe incl. halo)."""
+        ptrs = (C.c_void_p * 3)()
+        stride, rows = C.c_size_t(), C.c_size_t()
+        _check(self.L, self.ctx, self.L.jxlhip_get_xyb_planes(self.ctx, ptrs, C.byref(stride), C.byref(rows)), "get_xyb_planes")
+        return [_as_tensor(ptrs[c], rows.value * stride.value, torch.float32, self.device).reshape(rows.value, stride.value).clone()
+                for c in range(3)]
+
+    def sigma(self):
+        ptr, stride = C.c_void_p(), C.c_size_t()
+        _check(self.L, self.ctx, self.L.jxlhip_get_sigma(self.ctx, C.byref(ptr), C.byref(stride)), "get_sigma")
+        p = self.params
+        ysb = (p.ysize + 7) // 8
+        return _as_tensor(ptr.value, ysb * stride.value, torch.float32, self.device).reshape(ysb, stride.value).clone()
+
+    def halo_rows(self):
+        return self.L.jxlhip_halo_rows(self.ctx)
+
+    def halo_region(self, which):
+        """Zero-copy torch view [3, halo, xsize_padded] of a halo region."""
+        base, rs, ps = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _check(self.L, self.ctx, self.L.jxlhip_halo_region(self.ctx, which, C.byref(base), C.byref(rs), C.byref(ps)), "halo_region")
+        h = self.halo_rows()
+        n = 2 * ps.value + h * rs.value
+        flat = _as_tensor(base.value, n, torch.float32, self.device)
+        return torch.as_strided(flat, (3, h, rs.value), (ps.value, rs.value, 1))
+
+    def profile(self, enable=True):
+        _check(self.L, self.ctx, self.L.jxlhip_profile_enable(self.ctx, int(enable)), "profile_enable")
+
+    def profile_read(self):
+        ms = (C.c_float * abi.KERNEL_COUNT)()
+        n = (C.c_uint32 * abi.KERNEL_COUNT)()
+        _check(self.L, self.ctx, self.L.jxlhip_profile_read(self.ctx, ms, n), "profile_read")
+        return {abi.KERNEL_NAMES[i]: (ms[i], n[i]) for i in range(abi.KERNEL_COUNT) if n[i]}
+
+
+class _CudaArray:
+    """Minimal __cuda_array_interface__ holder for zero-copy torch views of
+    context-owned HBM."""
+
+    def __init__(self, ptr, nelem, typestr):
+        self.__cuda_array_interface__ = {
+            "shape": (nelem,), "typestr": typestr, "data": (int(ptr), False),
+            "version": 2, "strides": None}
+
+
+def _as_tensor(ptr, nelem, dtype, device):
+    assert dtype == torch.float32
+    return torch.as_tensor(_CudaArray(ptr, nelem, "<f4"), device=f"cuda:{device}")

@@ -1,0 +1,228 @@
+"""ctypes binding of the CPU oracle (oracle/*.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from libjxl_amd/ (the product).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libjxl_oracle.so")
+
+NUM_STRATEGIES = 27
+DEQUANT_TABLE_FLOATS = 2056 * 64 * 3
+
+
+def build(force=False):
+    """Compile the oracle with gcc (make); a no-op when up to date."""
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
+            for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+class LoopFilter(C.Structure):
+    _fields_ = [("gab", C.c_uint32), ("gab_weights", C.c_float * 6),
+                ("epf_iters", C.c_uint32), ("epf_sharp_lut", C.c_float * 8),
+                ("epf_channel_scale", C.c_float * 3),
+                ("epf_quant_mul", C.c_float),
+                ("epf_pass0_sigma_scale", C.c_float),
+                ("epf_pass2_sigma_scale", C.c_float),
+                ("epf_border_sad_mul", C.c_float)]
+
+
+class FrameParams(C.Structure):
+    """Mirror of jxlhip_frame_params (include/jxl_hip.h)."""
+    _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32),
+                ("coeff_type", C.c_uint32), ("output_kind", C.c_uint32),
+                ("global_scale", C.c_int32), ("quant_dc", C.c_int32),
+                ("x_dm_multiplier", C.c_float), ("b_dm_multiplier", C.c_float),
+                ("quant_biases", C.c_float * 4),
+                ("cfl_base_x", C.c_float), ("cfl_base_b", C.c_float),
+                ("cfl_color_factor", C.c_uint32),
+                ("lf", LoopFilter),
+                ("opsin_biases", C.c_float * 3),
+                ("inverse_opsin_matrix", C.c_float * 9),
+                ("stripe_group_y0", C.c_uint32),
+                ("stripe_group_rows", C.c_uint32)]
+
+
+class OracleFrame(C.Structure):
+    _fields_ = [("p", FrameParams),
+                ("coeffs", C.c_void_p * 3),
+                ("ac_strategy", C.c_void_p), ("raw_quant", C.c_void_p),
+                ("epf_sharpness", C.c_void_p),
+                ("ytox_map", C.c_void_p), ("ytob_map", C.c_void_p),
+                ("dc", C.c_void_p * 3),
+                ("dequant_table", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        f32p = C.POINTER(C.c_float)
+        L.jxo_dequant_table_offset.restype = C.c_size_t
+        L.jxo_afv_basis.restype = f32p
+        L.jxo_fast_powf.restype = C.c_float
+        L.jxo_fast_powf.argtypes = [C.c_float, C.c_float]
+        L.jxo_adjust_quant_bias.restype = C.c_float
+        L.jxo_adjust_quant_bias.argtypes = [C.c_int, C.c_int32, f32p]
+        L.jxo_idct1d.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.jxo_dct1d.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        L.jxo_scaled_idct.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.jxo_scaled_dct.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.jxo_idct1d_slow.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.jxo_dct1d_slow.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.jxo_transform_to_pixels.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.jxo_transform_from_pixels.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.jxo_llf_from_dc.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.jxo_dc_from_llf.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.jxo_default_dequant_tables.argtypes = [C.c_void_p, C.c_void_p]
+        L.jxo_decode_groups.argtypes = [C.POINTER(OracleFrame), C.c_void_p * 3, C.c_size_t, C.c_uint32, C.c_uint32]
+        L.jxo_compute_sigma.argtypes = [C.POINTER(OracleFrame), C.c_void_p]
+        L.jxo_gaborish.argtypes = [C.POINTER(OracleFrame), C.c_void_p * 3, C.c_void_p * 3, C.c_size_t, C.c_uint32, C.c_uint32]
+        L.jxo_epf.argtypes = [C.POINTER(OracleFrame), C.c_int, C.c_void_p, C.c_void_p * 3, C.c_void_p * 3, C.c_size_t, C.c_uint32, C.c_uint32]
+        L.jxo_xyb_to_linear_rgb.argtypes = [C.POINTER(OracleFrame), C.c_void_p * 3, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]
+        L.jxo_decode_frame.argtypes = [C.POINTER(OracleFrame), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.jxo_dequant_dc.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p * 3, C.c_void_p * 3, C.c_void_p, C.c_float, C.c_float]
+        L.jxo_adaptive_dc_smoothing.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p * 3]
+        L.jxo_linear_rgb_to_xyb.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _p3(arrs):
+    return (C.c_void_p * 3)(*[a.ctypes.data for a in arrs])
+
+
+# ---- small numpy conveniences used by the tests ---------------------------
+def covered_blocks(s):
+    L = lib()
+    return L.jxo_covered_blocks_x(s), L.jxo_covered_blocks_y(s)
+
+
+def default_dequant_tables():
+    t = np.zeros(DEQUANT_TABLE_FLOATS, np.float32)
+    rc = lib().jxo_default_dequant_tables(_p(t), None)
+    assert rc == 0
+    return t
+
+
+def transform_to_pixels(strategy, coeffs):
+    cx, cy = covered_blocks(strategy)
+    co = np.ascontiguousarray(coeffs, np.float32).copy()
+    px = np.zeros((8 * cy, 8 * cx), np.float32)
+    lib().jxo_transform_to_pixels(strategy, _p(co), _p(px), 8 * cx)
+    return px
+
+
+def transform_from_pixels(strategy, pixels):
+    cx, cy = covered_blocks(strategy)
+    px = np.ascontiguousarray(pixels, np.float32)
+    co = np.zeros(64 * cx * cy, np.float32)
+    lib().jxo_transform_from_pixels(strategy, _p(px), 8 * cx, _p(co))
+    return co
+
+
+def llf_from_dc(strategy, dc):
+    cx, cy = covered_blocks(strategy)
+    d = np.ascontiguousarray(dc, np.float32)
+    llf = np.zeros(64 * cx * cy, np.float32)
+    lib().jxo_llf_from_dc(strategy, _p(d), cx, _p(llf))
+    return llf
+
+
+def dc_from_llf(strategy, block):
+    cx, cy = covered_blocks(strategy)
+    b = np.ascontiguousarray(block, np.float32)
+    dc = np.zeros((cy, cx), np.float32)
+    lib().jxo_dc_from_llf(strategy, _p(b), _p(dc), cx)
+    return dc
+
+
+class Frame:
+    """Holds numpy inputs alive and exposes the jxo_frame struct."""
+
+    def __init__(self, params, coeffs, ac_strategy, raw_quant, epf_sharpness,
+                 ytox_map, ytob_map, dc, dequant_table):
+        self.keep = (coeffs, ac_strategy, raw_quant, epf_sharpness, ytox_map,
+                     ytob_map, dc, dequant_table)
+        f = OracleFrame()
+        f.p = params
+        for c in range(3):
+            f.coeffs[c] = coeffs[c].ctypes.data
+            f.dc[c] = dc[c].ctypes.data
+        f.ac_strategy = ac_strategy.ctypes.data
+        f.raw_quant = raw_quant.ctypes.data
+        f.epf_sharpness = epf_sharpness.ctypes.data
+        f.ytox_map = ytox_map.ctypes.data
+        f.ytob_map = ytob_map.ctypes.data
+        f.dequant_table = dequant_table.ctypes.data
+        self.c = f
+        self.params = params
+
+    @property
+    def dims(self):
+        p = self.params
+        return (p.xsize + 7) // 8, (p.ysize + 7) // 8
+
+    def decode_groups(self):
+        xsb, ysb = self.dims
+        planes = [np.zeros((ysb * 8, xsb * 8), np.float32) for _ in range(3)]
+        ng = ((self.params.xsize + 255) // 256) * ((self.params.ysize + 255) // 256)
+        rc = lib().jxo_decode_groups(C.byref(self.c), _p3(planes), xsb * 8, 0, ng)
+        if rc != 0:
+            raise ValueError("malformed strategy map")
+        return planes
+
+    def compute_sigma(self):
+        xsb, ysb = self.dims
+        s = np.zeros((ysb, xsb), np.float32)
+        lib().jxo_compute_sigma(C.byref(self.c), _p(s))
+        return s
+
+    def gaborish(self, planes):
+        out = [np.zeros_like(p) for p in planes]
+        lib().jxo_gaborish(C.byref(self.c), _p3(planes), _p3(out),
+                           planes[0].shape[1], 0, self.params.ysize)
+        return out
+
+    def epf(self, which, sigma, planes):
+        out = [np.zeros_like(p) for p in planes]
+        lib().jxo_epf(C.byref(self.c), which, _p(sigma), _p3(planes), _p3(out),
+                      planes[0].shape[1], 0, self.params.ysize)
+        return out
+
+    def xyb_to_rgb(self, planes):
+        p = self.params
+        rgb = np.zeros((p.ysize, p.xsize, 3), np.float32)
+        lib().jxo_xyb_to_linear_rgb(C.byref(self.c), _p3(planes),
+                                    planes[0].shape[1], _p(rgb), p.xsize * 3,
+                                    0, p.ysize)
+        return rgb
+
+    def decode(self, threads=1):
+        p = self.params
+        if p.output_kind == 1:
+            out = np.zeros((p.ysize, p.xsize, 3), np.float32)
+            rc = lib().jxo_decode_frame(C.byref(self.c), _p(out), p.xsize * 3, 0, threads)
+        else:
+            out = np.zeros((3, p.ysize, p.xsize), np.float32)
+            rc = lib().jxo_decode_frame(C.byref(self.c), _p(out), p.xsize,
+                                        p.xsize * p.ysize, threads)
+        if rc != 0:
+            raise ValueError("oracle decode failed")
+        return out
