@@ -225,10 +225,11 @@ JXLHIP_EXPORT int jxlhip_get_sigma(jxlhip_ctx* ctx, float** inv_sigma,
  * jxlhip_profile_read syncs and returns accumulated milliseconds and launch
  * counts per kernel slot (see JXLHIP_KERNEL_*), then resets. */
 enum {
-  JXLHIP_KERNEL_OFFSETS = 0,  /* block-offset scan */
-  JXLHIP_KERNEL_BLOCKS = 1,   /* dequant+CfL+LLF+inverse transforms */
-  JXLHIP_KERNEL_SIGMA = 2,
-  JXLHIP_KERNEL_FILTERS = 3,  /* fused Gaborish/EPF/XYB->RGB */
+  JXLHIP_KERNEL_PREPARE = 0,  /* block-offset scan, work lists, sigma */
+  JXLHIP_KERNEL_BLOCKS_SMALL = 1,  /* dequant+CfL+inverse transform, 8x8 kinds */
+  JXLHIP_KERNEL_BLOCKS_MEDIUM = 2, /* 16x8 .. 32x32 */
+  JXLHIP_KERNEL_BLOCKS_LARGE = 3,  /* 64x32 .. 256x256 */
+  JXLHIP_KERNEL_FILTERS = 4,  /* fused Gaborish/EPF/XYB->RGB */
   JXLHIP_KERNEL_COUNT = 8
 };
 JXLHIP_EXPORT int jxlhip_profile_enable(jxlhip_ctx* ctx, int enable);
@@ -242,13 +243,18 @@ JXLHIP_EXPORT int jxlhip_profile_read(jxlhip_ctx* ctx,
  * device buffer with the default dequant tables. */
 JXLHIP_EXPORT int jxlhip_default_dequant_tables(jxlhip_ctx* ctx,
                                                 float* table_dev);
-/* a8: DequantDC + AdaptiveDCSmoothing (compressed_dc.cc:128-250).
+/* a8: DequantDC + AdaptiveDCSmoothing (compressed_dc.cc:128-250), 4:4:4.
  * quant_dc[c]: int32 planes from the modular DC decode (device), dc_out[c]:
  * float planes (device), both xsize_blocks*ysize_blocks dense.
- * dc_factors = cfl factors at DC {ytox_dc ratio, ytob_dc ratio}. */
+ * dc_quant = DequantMatrices::DCQuant(c) (quant_weights.h:289-299; NULL = the
+ * defaults 1/4096, 1/512, 1/256); the step is inv_global_scale / quant_dc *
+ * dc_quant[c] (quantizer.h:133-139) with the current frame's global_scale and
+ * quant_dc.  cfl_*_dc = ColorCorrelation::YtoXRatio(ytox_dc) / YtoBRatio.
+ * smooth != 0 runs AdaptiveDCSmoothing afterwards. */
 JXLHIP_EXPORT int jxlhip_dequant_dc(jxlhip_ctx* ctx,
                                     const int32_t* const quant_dc[3],
-                                    float* const dc_out[3], float cfl_x_dc,
+                                    float* const dc_out[3],
+                                    const float dc_quant[3], float cfl_x_dc,
                                     float cfl_b_dc, int smooth);
 
 #ifdef __cplusplus

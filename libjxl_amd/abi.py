@@ -7,7 +7,7 @@ _SO = os.path.join(_HERE, "csrc", "libjxl_hip.so")
 _RUNNER_SO = os.path.join(_HERE, "csrc", "libjxl_threads_hip.so")
 
 KERNEL_COUNT = 8
-KERNEL_NAMES = ["offsets", "blocks", "sigma", "filters", "blocks_large", "k5", "k6", "k7"]
+KERNEL_NAMES = ["prepare", "blocks_small", "blocks_medium", "blocks_large", "filters", "k5", "k6", "k7"]
 
 
 class JxlHipError(RuntimeError):
@@ -131,6 +131,6 @@ def load_library():
     L.jxlhip_profile_enable.argtypes = [vp, i32]
     L.jxlhip_profile_read.argtypes = [vp, C.c_float * KERNEL_COUNT, u32 * KERNEL_COUNT]
     L.jxlhip_default_dequant_tables.argtypes = [vp, vp]
-    L.jxlhip_dequant_dc.argtypes = [vp, vp * 3, vp * 3, C.c_float * 3, C.c_float, C.c_float, i32]
+    L.jxlhip_dequant_dc.argtypes = [vp, vp * 3, vp * 3, vp, C.c_float, C.c_float, i32]
     _lib = L
     return L

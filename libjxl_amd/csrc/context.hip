@@ -1,0 +1,670 @@
+// context.hip -- the C ABI of include/jxl_hip.h: context, frame set-up, input
+// hand-off, the two decode phases, halo regions, profiling.  Host code only;
+// kernels live in kernels_*.hip.  No CPU fallback: every entry point that needs
+// a device fails with JXLHIP_ERR_NO_DEVICE / JXLHIP_ERR_HIP when there is none.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace jxlhip;
+
+namespace {
+
+constexpr int kPoolStreams = 4;
+
+struct ProfSpan {
+  hipEvent_t a, b;
+  int slot;
+};
+
+}  // namespace
+
+struct jxlhip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;  // the one launches go to
+  char err[512] = {0};
+  bool have_frame = false;
+  bool have_inputs = false;
+  bool blocks_done = false;
+  jxlhip_frame_params p{};
+  DevFrame f{};
+  FilterParams fp{};
+  SharpLut lut{};
+  // context-owned device memory
+  float* planes = nullptr;  // 3 planes
+  size_t planes_floats = 0;
+  float* inv_sigma = nullptr;
+  size_t sigma_floats = 0;
+  WorkItem* lists = nullptr;
+  size_t lists_items = 0;
+  uint32_t* counts = nullptr;    // kNumClasses
+  int32_t* error_flag = nullptr; // [0] stream error, [1] table status
+  float* tables = nullptr;       // wc[512] + resample[64]
+  WorkLists wl{};
+  uint32_t max_items[kNumClasses] = {0};
+  // upload path
+  void* up_coeffs[3] = {nullptr, nullptr, nullptr};
+  size_t up_coeff_bytes = 0;
+  uint8_t* up_side = nullptr;  // one slab: acs, quant, sharp, ytox, ytob, dc*3, dequant
+  size_t up_side_bytes = 0;
+  jxlhip_frame_inputs up_inputs{};
+  hipStream_t pool[kPoolStreams] = {nullptr};
+  hipEvent_t pool_ev[kPoolStreams] = {nullptr};
+  bool pool_dirty[kPoolStreams] = {false};
+  std::mutex pool_mu;
+  uint32_t pool_next = 0;
+  // dc scratch
+  float* dc_tmp = nullptr;
+  size_t dc_tmp_floats = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<ProfSpan> spans;
+  hipEvent_t prof_prev = nullptr;
+};
+
+namespace {
+
+int Fail(jxlhip_ctx* c, int code, const char* fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIPCHK(c, call)                                                              \
+  do {                                                                               \
+    hipError_t e_ = (call);                                                          \
+    if (e_ != hipSuccess)                                                            \
+      return Fail(c, e_ == hipErrorOutOfMemory ? JXLHIP_ERR_OUT_OF_MEMORY           \
+                                               : JXLHIP_ERR_HIP,                     \
+                  "%s: %s", #call, hipGetErrorString(e_));                           \
+  } while (0)
+
+template <typename T>
+int Grow(jxlhip_ctx* c, T** ptr, size_t* have, size_t need) {
+  if (need <= *have && *ptr) return JXLHIP_OK;
+  if (*ptr) HIPCHK(c, hipFree(*ptr));
+  *ptr = nullptr;
+  *have = 0;
+  HIPCHK(c, hipMalloc((void**)ptr, need * sizeof(T)));
+  *have = need;
+  return JXLHIP_OK;
+}
+
+void ProfBegin(jxlhip_ctx* c) {
+  if (!c->profiling) return;
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  (void)hipEventRecord(e, c->stream);
+  c->prof_prev = e;
+}
+// closes the span [prev, now) for `slot` and opens the next one
+void ProfMark(jxlhip_ctx* c, int slot) {
+  if (!c->profiling) return;
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  (void)hipEventRecord(e, c->stream);
+  c->spans.push_back({c->prof_prev, e, slot});
+  hipEvent_t n;
+  (void)hipEventCreate(&n);
+  (void)hipEventRecord(n, c->stream);
+  c->prof_prev = n;
+}
+void ProfEnd(jxlhip_ctx* c) {
+  if (!c->profiling || !c->prof_prev) return;
+  // prof_prev of the last span is unused as a start; keep it alive in a
+  // zero-length span so it is destroyed with the others
+  c->spans.push_back({c->prof_prev, c->prof_prev, -1});
+  c->prof_prev = nullptr;
+}
+
+void BlocksMark(void* arg, int sub) {
+  jxlhip_ctx* c = (jxlhip_ctx*)arg;
+  ProfMark(c, JXLHIP_KERNEL_BLOCKS_SMALL + sub);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- static helpers -------------------------------------------------------
+int jxlhip_covered_blocks_x(int s) {
+  return (s >= 0 && s < JXLHIP_NUM_STRATEGIES) ? kCoveredX[s] : 0;
+}
+int jxlhip_covered_blocks_y(int s) {
+  return (s >= 0 && s < JXLHIP_NUM_STRATEGIES) ? kCoveredY[s] : 0;
+}
+int jxlhip_log2_covered_blocks(int s) {
+  if (s < 0 || s >= JXLHIP_NUM_STRATEGIES) return -1;
+  int n = kCoveredX[s] * kCoveredY[s], l = 0;
+  while ((1 << l) < n) l++;
+  return l;
+}
+int jxlhip_quant_table_of_strategy(int s) {
+  return (s >= 0 && s < JXLHIP_NUM_STRATEGIES) ? kQuantKind[s] : -1;
+}
+size_t jxlhip_dequant_table_offset(int s, int c) {
+  if (s < 0 || s >= JXLHIP_NUM_STRATEGIES || c < 0 || c > 2) return (size_t)-1;
+  const int kind = kQuantKind[s];
+  return DequantOffset(s) + (size_t)c * 64u * kKindShort[kind] * kKindLong[kind];
+}
+const char* jxlhip_status_string(int status) {
+  switch (status) {
+    case JXLHIP_OK: return "ok";
+    case JXLHIP_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case JXLHIP_ERR_NO_DEVICE: return "no HIP device";
+    case JXLHIP_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case JXLHIP_ERR_HIP: return "HIP runtime error";
+    case JXLHIP_ERR_BAD_STREAM: return "side info violates a format constraint";
+    case JXLHIP_ERR_STATE: return "call sequence error";
+    default: return "unknown status";
+  }
+}
+
+// ---- context ----------------------------------------------------------------
+int jxlhip_create(int device, jxlhip_ctx** out) {
+  if (!out) return JXLHIP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return JXLHIP_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev) return JXLHIP_ERR_INVALID_ARGUMENT;
+  jxlhip_ctx* c = new (std::nothrow) jxlhip_ctx();
+  if (!c) return JXLHIP_ERR_OUT_OF_MEMORY;
+  c->device = device;
+  auto fail = [&](int code) {
+    jxlhip_destroy(c);
+    return code;
+  };
+  if (hipSetDevice(device) != hipSuccess) return fail(JXLHIP_ERR_HIP);
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return fail(JXLHIP_ERR_HIP);
+  c->stream = c->own_stream;
+  for (int i = 0; i < kPoolStreams; i++) {
+    if (hipStreamCreateWithFlags(&c->pool[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->pool_ev[i], hipEventDisableTiming) != hipSuccess)
+      return fail(JXLHIP_ERR_HIP);
+  }
+  if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kNumClasses) != hipSuccess ||
+      hipMalloc((void**)&c->error_flag, sizeof(int32_t) * 2) != hipSuccess ||
+      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64)) != hipSuccess)
+    return fail(JXLHIP_ERR_OUT_OF_MEMORY);
+  if (hipMemset(c->error_flag, 0, sizeof(int32_t) * 2) != hipSuccess ||
+      hipMemcpy(c->tables, kWcHost, sizeof(float) * 512, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->tables + 512, kResampleUpHost, sizeof(float) * 64, hipMemcpyHostToDevice) !=
+          hipSuccess)
+    return fail(JXLHIP_ERR_HIP);
+  *out = c;
+  return JXLHIP_OK;
+}
+
+void jxlhip_destroy(jxlhip_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (auto& s : c->spans) {
+    if (s.a) (void)hipEventDestroy(s.a);
+    if (s.b && s.b != s.a) (void)hipEventDestroy(s.b);
+  }
+  if (c->prof_prev) (void)hipEventDestroy(c->prof_prev);
+  for (int i = 0; i < kPoolStreams; i++) {
+    if (c->pool[i]) {
+      (void)hipStreamSynchronize(c->pool[i]);
+      (void)hipStreamDestroy(c->pool[i]);
+    }
+    if (c->pool_ev[i]) (void)hipEventDestroy(c->pool_ev[i]);
+  }
+  void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
+                  c->error_flag, c->tables, c->up_coeffs[0], c->up_coeffs[1],
+                  c->up_coeffs[2], c->up_side, c->dc_tmp};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* jxlhip_last_error(const jxlhip_ctx* c) { return c ? c->err : ""; }
+
+int jxlhip_set_stream(jxlhip_ctx* c, void* hip_stream) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return JXLHIP_OK;
+}
+
+// ---- frame set-up -------------------------------------------------------------
+int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
+  if (!c || !p) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (p->xsize == 0 || p->ysize == 0 || p->xsize > (1u << 19) || p->ysize > (1u << 19))
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "frame size %ux%u out of range", p->xsize,
+                p->ysize);
+  if (p->coeff_type > JXLHIP_COEFF_I32 || p->output_kind > JXLHIP_OUT_LINEAR_RGB_F32)
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad coeff_type/output_kind");
+  if (p->global_scale <= 0 || p->quant_dc <= 0 || p->cfl_color_factor == 0)
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad quantizer parameters");
+  if (p->lf.gab > 1 || p->lf.epf_iters > 3)
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad loop filter parameters");
+  HIPCHK(c, hipSetDevice(c->device));
+  DevFrame f{};
+  f.xsize = p->xsize;
+  f.ysize = p->ysize;
+  f.xsb = (p->xsize + 7) / 8;
+  f.ysb = (p->ysize + 7) / 8;
+  f.xsg = (p->xsize + 255) / 256;
+  f.ysg = (p->ysize + 255) / 256;
+  f.xtiles = (f.xsb + 7) / 8;
+  f.group_y0 = p->stripe_group_y0;
+  f.group_rows = p->stripe_group_rows ? p->stripe_group_rows : f.ysg - f.group_y0;
+  if (f.group_y0 >= f.ysg || f.group_y0 + f.group_rows > f.ysg)
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "stripe [%u,+%u) outside %u group rows",
+                f.group_y0, f.group_rows, f.ysg);
+  f.y0 = f.group_y0 * 256;
+  f.y1 = (f.group_y0 + f.group_rows) * 256;
+  if (f.y1 > f.ysize) f.y1 = f.ysize;
+  static const uint32_t kEpfPad[4] = {0, 2, 3, 6};  // loop_filter.h:26-29
+  f.halo = kEpfPad[p->lf.epf_iters] + p->lf.gab;
+  f.coeff_type = p->coeff_type;
+  f.inv_global_scale = (float)(1.0 * 65536 / p->global_scale);   // quantizer.h:82-85
+  f.quant_scale = (float)(p->global_scale * (1.0 / 65536));
+  f.x_dm = p->x_dm_multiplier;
+  f.b_dm = p->b_dm_multiplier;
+  memcpy(f.biases, p->quant_biases, sizeof(f.biases));
+  f.cfl_base_x = p->cfl_base_x;
+  f.cfl_base_b = p->cfl_base_b;
+  f.color_scale = 1.0f / (float)p->cfl_color_factor;
+  // XYB planes: stripe rows padded to whole blocks + halo rows on both sides
+  const uint32_t rows_blocks = (f.group_y0 + f.group_rows) * 32 > f.ysb
+                                   ? f.ysb * 8 - f.y0
+                                   : f.group_rows * 256;
+  f.plane_stride = (f.xsb * 8 + 63) & ~63u;
+  f.plane_y0 = (int32_t)f.y0 - (int32_t)f.halo;
+  f.plane_rows = rows_blocks + 2 * f.halo;
+  const size_t plane_floats = (size_t)f.plane_rows * f.plane_stride;
+  int rc;
+  if ((rc = Grow(c, &c->planes, &c->planes_floats, 3 * plane_floats))) return rc;
+  for (int ch = 0; ch < 3; ch++) f.xyb[ch] = c->planes + ch * plane_floats;
+  if ((rc = Grow(c, &c->inv_sigma, &c->sigma_floats, (size_t)f.xsb * f.ysb))) return rc;
+  f.inv_sigma = c->inv_sigma;
+  f.error_flag = c->error_flag;
+  // work lists, worst case per class
+  const size_t cells = (size_t)f.xsg * f.group_rows * 1024;
+  size_t total = 0;
+  size_t offs[kNumClasses];
+  for (int k = 0; k < kNumClasses; k++) {
+    offs[k] = total;
+    const size_t m = cells / kClassMinCovered[k];
+    c->max_items[k] = (uint32_t)m;
+    total += m;
+  }
+  if ((rc = Grow(c, &c->lists, &c->lists_items, total))) return rc;
+  for (int k = 0; k < kNumClasses; k++) c->wl.list[k] = c->lists + offs[k];
+  c->wl.count = c->counts;
+  // stage parameters, computed as the reference stages do
+  FilterParams fp{};
+  for (int ch = 0; ch < 3; ch++) {
+    float w0 = 1.0f, w1 = p->lf.gab_weights[2 * ch], w2 = p->lf.gab_weights[2 * ch + 1];
+    const float div = w0 + 4 * (w1 + w2);  // stage_gaborish.cc:36-53
+    const float mul = 1.0f / div;
+    fp.gab_w[ch][0] = w0 * mul;
+    fp.gab_w[ch][1] = w1 * mul;
+    fp.gab_w[ch][2] = w2 * mul;
+    fp.ch_scale[ch] = p->lf.epf_channel_scale[ch];
+    fp.opsin_bias[ch] = p->opsin_biases[ch];
+    fp.cbrt_bias[ch] = cbrtf(p->opsin_biases[ch]);  // dec_xyb.cc:158-161
+  }
+  // stage_epf.cc:98-115,237-255,428-446
+  fp.sm[0] = (float)(p->lf.epf_pass0_sigma_scale * 1.65);
+  fp.sm[1] = 1.65f;
+  fp.sm[2] = (float)(p->lf.epf_pass2_sigma_scale * 1.65);
+  for (int i = 0; i < 3; i++) fp.bsm[i] = fp.sm[i] * p->lf.epf_border_sad_mul;
+  memcpy(fp.minv, p->inverse_opsin_matrix, sizeof(fp.minv));
+  memcpy(c->lut.v, p->lf.epf_sharp_lut, sizeof(c->lut.v));
+  c->fp = fp;
+  c->f = f;
+  c->p = *p;
+  c->have_frame = true;
+  c->have_inputs = false;
+  c->blocks_done = false;
+  return JXLHIP_OK;
+}
+
+static void ApplyInputs(jxlhip_ctx* c, const jxlhip_frame_inputs* in) {
+  for (int ch = 0; ch < 3; ch++) {
+    c->f.coeffs[ch] = in->coeffs[ch];
+    c->f.dc[ch] = in->dc[ch];
+  }
+  c->f.acs = in->ac_strategy;
+  c->f.raw_quant = in->raw_quant;
+  c->f.sharp = in->epf_sharpness;
+  c->f.ytox = in->ytox_map;
+  c->f.ytob = in->ytob_map;
+  c->f.dequant = in->dequant_table;
+}
+
+int jxlhip_frame_set_inputs(jxlhip_ctx* c, const jxlhip_frame_inputs* in) {
+  if (!c || !in) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "frame_set_inputs before frame_begin");
+  for (int ch = 0; ch < 3; ch++)
+    if (!in->coeffs[ch] || !in->dc[ch])
+      return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "null coeffs/dc pointer");
+  if (!in->ac_strategy || !in->raw_quant || !in->ytox_map || !in->ytob_map ||
+      !in->dequant_table || (c->p.lf.epf_iters > 0 && !in->epf_sharpness))
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "null side-info pointer");
+  if (((uintptr_t)in->dequant_table & 15) || ((uintptr_t)in->coeffs[0] & 15) ||
+      ((uintptr_t)in->coeffs[1] & 15) || ((uintptr_t)in->coeffs[2] & 15))
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "coeffs/dequant_table must be 16-byte aligned");
+  ApplyInputs(c, in);
+  c->have_inputs = true;
+  c->blocks_done = false;
+  return JXLHIP_OK;
+}
+
+// lays the side-info slab out; returns total bytes
+static size_t SideLayout(const DevFrame& f, size_t off[9]) {
+  const size_t nb = (size_t)f.xsb * f.ysb;
+  const size_t nt = (size_t)f.xtiles * ((f.ysb + 7) / 8);
+  size_t pos = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = pos;
+    pos += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  off[0] = take(nb);                   // acs
+  off[1] = take(nb * 4);               // raw_quant
+  off[2] = take(nb);                   // sharpness
+  off[3] = take(nt);                   // ytox
+  off[4] = take(nt);                   // ytob
+  off[5] = take(nb * 4);               // dc x
+  off[6] = take(nb * 4);               // dc y
+  off[7] = take(nb * 4);               // dc b
+  off[8] = take(sizeof(float) * JXLHIP_DEQUANT_TABLE_FLOATS);
+  return pos;
+}
+
+static int EnsureUploadBuffers(jxlhip_ctx* c) {
+  const DevFrame& f = c->f;
+  const size_t esz = f.coeff_type == JXLHIP_COEFF_I16 ? 2 : 4;
+  const size_t cbytes = (size_t)f.xsg * f.ysg * JXLHIP_GROUP_COEFFS * esz;
+  if (cbytes > c->up_coeff_bytes || !c->up_coeffs[0]) {
+    for (int ch = 0; ch < 3; ch++) {
+      if (c->up_coeffs[ch]) HIPCHK(c, hipFree(c->up_coeffs[ch]));
+      c->up_coeffs[ch] = nullptr;
+    }
+    c->up_coeff_bytes = 0;
+    for (int ch = 0; ch < 3; ch++) HIPCHK(c, hipMalloc(&c->up_coeffs[ch], cbytes));
+    c->up_coeff_bytes = cbytes;
+  }
+  size_t off[9];
+  const size_t sbytes = SideLayout(f, off);
+  int rc;
+  if ((rc = Grow(c, &c->up_side, &c->up_side_bytes, sbytes))) return rc;
+  jxlhip_frame_inputs in{};
+  for (int ch = 0; ch < 3; ch++) {
+    in.coeffs[ch] = c->up_coeffs[ch];
+    in.dc[ch] = (const float*)(c->up_side + off[5 + ch]);
+  }
+  in.ac_strategy = c->up_side + off[0];
+  in.raw_quant = (const int32_t*)(c->up_side + off[1]);
+  in.epf_sharpness = c->up_side + off[2];
+  in.ytox_map = (const int8_t*)(c->up_side + off[3]);
+  in.ytob_map = (const int8_t*)(c->up_side + off[4]);
+  in.dequant_table = (const float*)(c->up_side + off[8]);
+  c->up_inputs = in;
+  return JXLHIP_OK;
+}
+
+int jxlhip_upload_side_info(jxlhip_ctx* c, const uint8_t* ac_strategy, const int32_t* raw_quant,
+                            const uint8_t* epf_sharpness, const int8_t* ytox_map,
+                            const int8_t* ytob_map, const float* const dc[3],
+                            const float* dequant_table) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "upload_side_info before frame_begin");
+  if (!ac_strategy || !raw_quant || !ytox_map || !ytob_map || !dc || !dc[0] || !dc[1] ||
+      !dc[2] || !dequant_table || (c->p.lf.epf_iters > 0 && !epf_sharpness))
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "null side-info pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = EnsureUploadBuffers(c))) return rc;
+  const DevFrame& f = c->f;
+  const size_t nb = (size_t)f.xsb * f.ysb;
+  const size_t nt = (size_t)f.xtiles * ((f.ysb + 7) / 8);
+  const jxlhip_frame_inputs& in = c->up_inputs;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemcpyAsync((void*)in.ac_strategy, ac_strategy, nb, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync((void*)in.raw_quant, raw_quant, nb * 4, hipMemcpyHostToDevice, st));
+  if (epf_sharpness)
+    HIPCHK(c, hipMemcpyAsync((void*)in.epf_sharpness, epf_sharpness, nb, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync((void*)in.ytox_map, ytox_map, nt, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync((void*)in.ytob_map, ytob_map, nt, hipMemcpyHostToDevice, st));
+  for (int ch = 0; ch < 3; ch++)
+    HIPCHK(c, hipMemcpyAsync((void*)in.dc[ch], dc[ch], nb * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync((void*)in.dequant_table, dequant_table,
+                           sizeof(float) * JXLHIP_DEQUANT_TABLE_FLOATS, hipMemcpyHostToDevice, st));
+  ApplyInputs(c, &in);
+  c->have_inputs = true;
+  c->blocks_done = false;
+  return JXLHIP_OK;
+}
+
+int jxlhip_submit_group(jxlhip_ctx* c, uint32_t group_idx, const void* const coeffs[3],
+                        size_t ncoeffs) {
+  if (!c || !coeffs) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "submit_group before frame_begin");
+  const DevFrame& f = c->f;
+  if (group_idx >= f.xsg * f.ysg || ncoeffs > JXLHIP_GROUP_COEFFS || !coeffs[0] || !coeffs[1] ||
+      !coeffs[2])
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad group %u / ncoeffs %zu", group_idx, ncoeffs);
+  const size_t esz = f.coeff_type == JXLHIP_COEFF_I16 ? 2 : 4;
+  int slot;
+  {
+    std::lock_guard<std::mutex> lock(c->pool_mu);
+    if (hipSetDevice(c->device) != hipSuccess) return JXLHIP_ERR_HIP;
+    if (!c->up_coeffs[0]) {
+      int rc = EnsureUploadBuffers(c);
+      if (rc) return rc;
+    }
+    slot = (int)(c->pool_next++ % kPoolStreams);
+    c->pool_dirty[slot] = true;
+    // copies of one slot are issued under the lock so the stream sees them in order
+    for (int ch = 0; ch < 3; ch++) {
+      char* dst = (char*)c->up_coeffs[ch] + (size_t)group_idx * JXLHIP_GROUP_COEFFS * esz;
+      hipError_t e = hipMemcpyAsync(dst, coeffs[ch], ncoeffs * esz, hipMemcpyHostToDevice,
+                                    c->pool[slot]);
+      if (e != hipSuccess) return Fail(c, JXLHIP_ERR_HIP, "submit_group: %s", hipGetErrorString(e));
+    }
+  }
+  return JXLHIP_OK;
+}
+
+// ---- decode -------------------------------------------------------------------
+int jxlhip_decode_blocks(jxlhip_ctx* c) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame || !c->have_inputs)
+    return Fail(c, JXLHIP_ERR_STATE, "decode_blocks needs frame_begin + inputs");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  {
+    std::lock_guard<std::mutex> lock(c->pool_mu);
+    for (int i = 0; i < kPoolStreams; i++) {
+      if (!c->pool_dirty[i]) continue;
+      HIPCHK(c, hipEventRecord(c->pool_ev[i], c->pool[i]));
+      HIPCHK(c, hipStreamWaitEvent(st, c->pool_ev[i], 0));
+      c->pool_dirty[i] = false;
+    }
+  }
+  HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kNumClasses, st));
+  ProfBegin(c);
+  LaunchPrepare(c->f, c->wl, c->p.lf.epf_iters > 0, c->p.lf.epf_quant_mul, c->lut, st);
+  ProfMark(c, JXLHIP_KERNEL_PREPARE);
+  LaunchBlocks(c->f, c->wl, c->max_items, c->tables, c->tables + 512, st, BlocksMark, c);
+  ProfEnd(c);
+  HIPCHK(c, hipGetLastError());
+  c->blocks_done = true;
+  return JXLHIP_OK;
+}
+
+int jxlhip_halo_rows(const jxlhip_ctx* c) {
+  if (!c || !c->have_frame) return JXLHIP_ERR_STATE;
+  return (int)c->f.halo;
+}
+
+int jxlhip_halo_region(jxlhip_ctx* c, int which, float** base, size_t* row_stride,
+                       size_t* plane_stride) {
+  if (!c || !base || !row_stride || !plane_stride || which < 0 || which > 3)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "halo_region before frame_begin");
+  const DevFrame& f = c->f;
+  const uint32_t stripe_rows = f.y1 - f.y0;
+  if (f.halo > stripe_rows)
+    return Fail(c, JXLHIP_ERR_STATE, "stripe of %u rows is shorter than the %u-row halo",
+                stripe_rows, f.halo);
+  uint32_t row;  // plane row index
+  switch (which) {
+    case 0: row = f.halo; break;                          // send up: first rows of the stripe
+    case 1: row = f.halo + stripe_rows - f.halo; break;   // send down: last rows
+    case 2: row = 0; break;                               // recv from above
+    default: row = f.halo + stripe_rows; break;           // recv from below
+  }
+  *base = f.xyb[0] + (size_t)row * f.plane_stride;
+  *row_stride = f.plane_stride;
+  *plane_stride = (size_t)f.plane_rows * f.plane_stride;
+  return JXLHIP_OK;
+}
+
+int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
+  if (!c || !out) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->blocks_done) return Fail(c, JXLHIP_ERR_STATE, "decode_filters before decode_blocks");
+  const DevFrame& f = c->f;
+  if (c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32) {
+    if (out_stride < (size_t)f.xsize * 12 || (out_stride & 3))
+      return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "RGB row stride %zu too small", out_stride);
+  } else if (out_stride < f.xsize || out_plane_stride < out_stride * (size_t)(f.y1 - f.y0 - 1) + f.xsize) {
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "XYB strides too small");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  FilterParams fp = c->fp;
+  fp.out = out;
+  fp.out_stride = out_stride;
+  fp.out_plane_stride = out_plane_stride;
+  ProfBegin(c);
+  if (LaunchFilters(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind,
+                    c->stream) != 0)
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "unsupported filter configuration");
+  ProfMark(c, JXLHIP_KERNEL_FILTERS);
+  ProfEnd(c);
+  HIPCHK(c, hipGetLastError());
+  return JXLHIP_OK;
+}
+
+int jxlhip_decode_frame(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
+  int rc = jxlhip_decode_blocks(c);
+  if (rc) return rc;
+  return jxlhip_decode_filters(c, out, out_stride, out_plane_stride);
+}
+
+int jxlhip_sync(jxlhip_ctx* c) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(c, hipSetDevice(c->device));
+  int32_t flag[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(flag, c->error_flag, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (flag[0] || flag[1]) {
+    HIPCHK(c, hipMemsetAsync(c->error_flag, 0, sizeof(flag), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return Fail(c, JXLHIP_ERR_BAD_STREAM,
+                flag[0] ? "AC strategy map violates the group/stream constraints "
+                          "(dec_modular.cc:539-549, dec_group.cc:359)"
+                        : "dequant table weight out of range (quant_weights.cc:329-339)");
+  }
+  return JXLHIP_OK;
+}
+
+// ---- taps ------------------------------------------------------------------------
+int jxlhip_get_xyb_planes(jxlhip_ctx* c, float* planes[3], size_t* row_stride, size_t* rows) {
+  if (!c || !planes || !row_stride || !rows) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "no frame");
+  for (int ch = 0; ch < 3; ch++) planes[ch] = c->f.xyb[ch];
+  *row_stride = c->f.plane_stride;
+  *rows = c->f.plane_rows;
+  return JXLHIP_OK;
+}
+
+int jxlhip_get_sigma(jxlhip_ctx* c, float** inv_sigma, size_t* row_stride) {
+  if (!c || !inv_sigma || !row_stride) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "no frame");
+  *inv_sigma = c->f.inv_sigma;
+  *row_stride = c->f.xsb;
+  return JXLHIP_OK;
+}
+
+int jxlhip_profile_enable(jxlhip_ctx* c, int enable) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  c->profiling = enable != 0;
+  return JXLHIP_OK;
+}
+
+int jxlhip_profile_read(jxlhip_ctx* c, float ms[JXLHIP_KERNEL_COUNT],
+                        uint32_t launches[JXLHIP_KERNEL_COUNT]) {
+  if (!c || !ms || !launches) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < JXLHIP_KERNEL_COUNT; i++) {
+    ms[i] = 0;
+    launches[i] = 0;
+  }
+  for (auto& s : c->spans) {
+    if (s.slot >= 0 && s.slot < JXLHIP_KERNEL_COUNT) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {
+        ms[s.slot] += t;
+        launches[s.slot]++;
+      }
+    }
+    (void)hipEventDestroy(s.a);
+    if (s.b != s.a) (void)hipEventDestroy(s.b);
+  }
+  c->spans.clear();
+  return JXLHIP_OK;
+}
+
+// ---- a5 / a8 ------------------------------------------------------------------------
+int jxlhip_default_dequant_tables(jxlhip_ctx* c, float* table_dev) {
+  if (!c || !table_dev) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIPCHK(c, hipSetDevice(c->device));
+  LaunchDefaultDequant(table_dev, c->error_flag + 1, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return JXLHIP_OK;
+}
+
+int jxlhip_dequant_dc(jxlhip_ctx* c, const int32_t* const quant_dc[3], float* const dc_out[3],
+                      const float dc_quant[3], float cfl_x_dc, float cfl_b_dc, int smooth) {
+  if (!c || !quant_dc || !dc_out) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "dequant_dc before frame_begin");
+  for (int ch = 0; ch < 3; ch++)
+    if (!quant_dc[ch] || !dc_out[ch]) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "null plane");
+  HIPCHK(c, hipSetDevice(c->device));
+  const DevFrame& f = c->f;
+  static const float kDefaultDcQuant[3] = {1.0f / 4096.0f, 1.0f / 512.0f, 1.0f / 256.0f};
+  const float* dq = dc_quant ? dc_quant : kDefaultDcQuant;
+  float mul_dc[3];
+  for (int ch = 0; ch < 3; ch++)
+    mul_dc[ch] = (f.inv_global_scale / (float)c->p.quant_dc) * dq[ch];  // quantizer.h:133-139
+  const size_t n = (size_t)f.xsb * f.ysb;
+  int rc;
+  if ((rc = Grow(c, &c->dc_tmp, &c->dc_tmp_floats, 3 * n))) return rc;
+  float* tmp[3] = {c->dc_tmp, c->dc_tmp + n, c->dc_tmp + 2 * n};
+  LaunchDequantDC(f.xsb, f.ysb, quant_dc, dc_out, tmp, mul_dc, cfl_x_dc, cfl_b_dc, smooth,
+                  c->stream);
+  HIPCHK(c, hipGetLastError());
+  return JXLHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// dev_common.h -- shared between the HIP translation units of libjxl_hip.so.
+// Geometry LUTs, the per-frame kernel argument block and the in-register
+// 1-D transforms.  gfx950 only (wave = 64).
+#ifndef JXLHIP_DEV_COMMON_H_
+#define JXLHIP_DEV_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/jxl_hip.h"
+
+#define JXL_FMT_CONST static constexpr
+#include "dct_constants.inc"
+#include "format_constants.inc"
+
+namespace jxlhip {
+
+// ---- strategy geometry (lib/jxl/ac_strategy.h:148-173,
+// lib/jxl/quant_weights.h:337-348,401-417) --------------------------------
+static constexpr uint8_t kCoveredX[27] = {1, 1, 1, 1, 2, 4, 1, 2, 1, 4, 2, 4, 1, 1,
+                                          1, 1, 1, 1, 8, 4, 8, 16, 8, 16, 32, 16, 32};
+static constexpr uint8_t kCoveredY[27] = {1, 1, 1, 1, 2, 4, 2, 1, 4, 1, 4, 2, 1, 1,
+                                          1, 1, 1, 1, 8, 8, 4, 16, 16, 8, 32, 32, 16};
+static constexpr uint8_t kQuantKind[27] = {0,  1,  2,  3,  4,  5,  6,  6,  7,
+                                           7,  8,  8,  9,  9,  10, 10, 10, 10,
+                                           11, 12, 12, 13, 14, 14, 15, 16, 16};
+static constexpr uint8_t kKindShort[17] = {1, 1, 1, 1, 2, 4, 1, 1, 2,
+                                           1, 1, 8, 4, 16, 8, 32, 16};
+static constexpr uint8_t kKindLong[17] = {1, 1, 1, 1, 2, 4, 2, 4, 4,
+                                          1, 1, 8, 8, 16, 16, 32, 32};
+
+__host__ __device__ constexpr uint32_t DequantOffset(int strategy) {
+  uint32_t pos = 0;
+  for (int k = 0; k < kQuantKind[strategy]; k++)
+    pos += 3u * 64u * kKindShort[k] * kKindLong[k];
+  return pos;
+}
+
+// Work classes: one compacted varblock list per class, built by k_prepare.
+enum WorkClass : int {
+  kClsDct8 = 0,     // strategy 0
+  kClsSpecial = 1,  // 1,2,3,12..17 (single 8x8 block, non-DCT8)
+  kClsMedium0 = 2,  // 8 medium kinds follow, see kMediumStrategy
+  kClsLarge = 10,   // 18..26 (any side >= 64)
+  kNumClasses = 11
+};
+// medium class index -> strategy
+static constexpr uint8_t kMediumStrategy[8] = {6, 7, 4, 8, 9, 10, 11, 5};
+__host__ __device__ constexpr int ClassOfStrategy(int s) {
+  if (s == 0) return kClsDct8;
+  if (s <= 3 || (s >= 12 && s <= 17)) return kClsSpecial;
+  if (s >= 18) return kClsLarge;
+  for (int i = 0; i < 8; i++)
+    if (kMediumStrategy[i] == s) return kClsMedium0 + i;
+  return -1;
+}
+// worst-case entries per block cell of each class = 1/covered_blocks
+static constexpr uint16_t kClassMinCovered[kNumClasses] = {1, 1, 2, 2,  4, 4,
+                                                           4, 8, 8, 16, 32};
+
+struct WorkItem {
+  uint32_t pos;  // (aby << 16) | abx : absolute block coordinates
+  uint32_t off;  // group*1024 + offset/64 into the coefficient stream
+};
+
+// Per-frame kernel arguments (by value).
+struct DevFrame {
+  uint32_t xsize, ysize;      // true size
+  uint32_t xsb, ysb;          // size in blocks
+  uint32_t xsg, ysg;          // size in groups
+  uint32_t xtiles;            // colour tiles per row
+  uint32_t group_y0, group_rows;  // stripe (in groups)
+  uint32_t y0, y1;            // stripe rows [y0, y1) in pixels (y1 clipped to ysize)
+  uint32_t halo;              // LoopFilter::Padding()
+  uint32_t coeff_type;
+  float inv_global_scale, quant_scale;
+  float x_dm, b_dm;
+  float biases[4];
+  float cfl_base_x, cfl_base_b, color_scale;
+  // inputs
+  const void* coeffs[3];
+  const uint8_t* acs;
+  const int32_t* raw_quant;
+  const uint8_t* sharp;
+  const int8_t* ytox;
+  const int8_t* ytob;
+  const float* dc[3];
+  const float* dequant;
+  // intermediates: XYB planes hold rows [plane_y0, plane_y0 + plane_rows)
+  float* xyb[3];
+  uint32_t plane_stride;  // floats per row (>= xsb*8)
+  int32_t plane_y0;       // pixel row of plane row 0 (= y0 - halo, may be < 0)
+  uint32_t plane_rows;
+  float* inv_sigma;       // xsb*ysb, whole frame indexing
+  int32_t* error_flag;
+};
+
+__device__ __forceinline__ float* PlanePtr(const DevFrame& f, int c, uint32_t y,
+                                           uint32_t x) {
+  return f.xyb[c] + (size_t)((int32_t)y - f.plane_y0) * f.plane_stride + x;
+}
+
+// ---- in-register 1-D transforms (lib/jxl/dct-inl.h:158-232) --------------
+static constexpr float kSqrt2 = 1.41421356237f;  // lib/jxl/dct_scales.h:15
+
+// IDCT1DImpl<N>: even/odd split, recurse, B-transpose, butterfly with
+// W_N[i] = 1/(2cos((i+1/2)pi/N)).  v is a fully-unrolled private array.
+template <int N>
+__device__ __forceinline__ void IdctReg(float* __restrict__ v) {
+  if constexpr (N == 1) {
+    return;
+  } else if constexpr (N == 2) {
+    const float a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  } else {
+    constexpr int H = N / 2;
+    float e[H], o[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      e[i] = v[2 * i];
+      o[i] = v[2 * i + 1];
+    }
+    IdctReg<H>(e);
+#pragma unroll
+    for (int i = H - 1; i > 0; i--) o[i] = o[i] + o[i - 1];
+    o[0] = o[0] * kSqrt2;
+    IdctReg<H>(o);
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      const float mul = kWcHost[N + i];
+      v[i] = __builtin_fmaf(mul, o[i], e[i]);
+      v[N - 1 - i] = __builtin_fmaf(-mul, o[i], e[i]);
+    }
+  }
+}
+
+// DCT1DImpl<N> (unscaled), used for LLF-from-DC.
+template <int N>
+__device__ __forceinline__ void DctReg(float* __restrict__ v) {
+  if constexpr (N == 1) {
+    return;
+  } else if constexpr (N == 2) {
+    const float a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  } else {
+    constexpr int H = N / 2;
+    float s[H], d[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) s[i] = v[i] + v[N - 1 - i];
+    DctReg<H>(s);
+#pragma unroll
+    for (int i = 0; i < H; i++) d[i] = v[i] - v[N - 1 - i];
+#pragma unroll
+    for (int i = 0; i < H; i++) d[i] = d[i] * kWcHost[N + i];
+    DctReg<H>(d);
+    d[0] = __builtin_fmaf(d[0], kSqrt2, d[1]);
+#pragma unroll
+    for (int i = 1; i + 1 < H; i++) d[i] = d[i] + d[i + 1];
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      v[2 * i] = s[i];
+      v[2 * i + 1] = d[i];
+    }
+  }
+}
+
+// ComputeScaledIDCT<R,C> (dct-inl.h:376-397) entirely in registers.
+// m: coefficient matrix min(R,C) x max(R,C) (transposed storage when R >= C);
+// out: R x C pixels, row-major.
+template <int R, int C>
+__device__ __forceinline__ void Idct2dReg(const float* __restrict__ m,
+                                          float* __restrict__ out) {
+  float t[R * C];  // t[u][x]
+#pragma unroll
+  for (int u = 0; u < R; u++) {
+    float v[C];
+#pragma unroll
+    for (int j = 0; j < C; j++) v[j] = (R < C) ? m[u * C + j] : m[j * R + u];
+    IdctReg<C>(v);
+#pragma unroll
+    for (int j = 0; j < C; j++) t[u * C + j] = v[j];
+  }
+#pragma unroll
+  for (int x = 0; x < C; x++) {
+    float v[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) v[j] = t[j * C + x];
+    IdctReg<R>(v);
+#pragma unroll
+    for (int j = 0; j < R; j++) out[j * C + x] = v[j];
+  }
+}
+
+// AdjustQuantBias (lib/jxl/quantizer-inl.h:34-67).  The reciprocal is the
+// hardware v_rcp_f32 (1 ulp), like the reference's ApproximateReciprocal on
+// SIMD targets.
+__device__ __forceinline__ float AdjustQuantBias(int32_t q, float bias_c,
+                                                 float bias3) {
+  const float quant = (float)q;
+  const float aq = __builtin_fabsf(quant);
+  const float small = aq > 0.0f ? __builtin_copysignf(bias_c, quant) : 0.0f;
+  const float big = __builtin_fmaf(-bias3, __builtin_amdgcn_rcpf(quant), quant);
+  return aq < 1.125f ? small : big;
+}
+
+template <typename CT>
+__device__ __forceinline__ int32_t LoadCoeff(const void* base, size_t i) {
+  return (int32_t)((const CT*)base)[i];
+}
+
+}  // namespace jxlhip
+#endif

@@ -1,0 +1,50 @@
+// kernels.h -- host-callable launchers of the HIP kernels (internal).
+#ifndef JXLHIP_KERNELS_H_
+#define JXLHIP_KERNELS_H_
+
+#include "dev_common.h"
+
+namespace jxlhip {
+
+struct WorkLists {
+  WorkItem* list[kNumClasses];
+  uint32_t* count;  // kNumClasses counters, zeroed before k_prepare
+};
+
+struct SharpLut {
+  float v[8];
+};
+
+// Stage parameters of phase 2, precomputed on the host exactly as the
+// reference stages do in their constructors / per-row prologues.
+struct FilterParams {
+  float gab_w[3][3];     // per channel: normalised w0, w1, w2 (stage_gaborish.cc:36-53)
+  float ch_scale[3];     // epf_channel_scale
+  float sm[3], bsm[3];   // per EPF stage: sigma multiplier inside / on 8x8 borders
+  float opsin_bias[3];   // OpsinParams::opsin_biases
+  float cbrt_bias[3];    // cbrt(opsin_biases)
+  float minv[9];         // inverse opsin matrix * 255/intensity_target
+  void* out;
+  size_t out_stride;        // RGB: bytes per row; XYB: floats per row
+  size_t out_plane_stride;  // XYB only
+};
+
+void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
+                   const SharpLut& lut, hipStream_t st);
+// mark(arg, i) is called after the launches of sub-phase i (0 small, 1 medium,
+// 2 large) so the caller can record profiling events.
+void LaunchBlocks(const DevFrame& f, const WorkLists& wl, const uint32_t* max_items,
+                  const float* wc, const float* resample, hipStream_t st,
+                  void (*mark)(void*, int), void* mark_arg);
+// Returns 0, or -1 when the (gab, epf_iters, output_kind) combination is invalid.
+int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
+                  int output_kind, hipStream_t st);
+
+// a5 / a8 helpers
+void LaunchDefaultDequant(float* table, int32_t* status, hipStream_t st);
+void LaunchDequantDC(uint32_t xsb, uint32_t ysb, const int32_t* const q[3], float* const dc[3],
+                     float* const tmp[3], const float mul_dc[3], float cfl_x, float cfl_b,
+                     int smooth, hipStream_t st);
+
+}  // namespace jxlhip
+#endif

@@ -1,0 +1,797 @@
+// kernels_blocks.hip -- phase 1 of the VarDCT back-end on gfx950:
+//   k_prepare   : per-group coefficient-offset scan + per-class work lists
+//                 (the block walk of DecodeGroupImpl, lib/jxl/dec_group.cc:275-359,
+//                 turned into a data-parallel scan) and ComputeSigma
+//                 (lib/jxl/epf.cc:39-133)
+//   k_dct8      : dequant + CfL + 8x8 IDCT, one thread per block, in registers
+//   k_special   : IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4 / AFV0-3
+//   k_medium    : 16x8 .. 32x32, LDS-staged, one lane per 1-D transform
+//   k_large     : 64x32 .. 256x256, output plane used as scratch
+// replacing DequantBlock + LowestFrequenciesFromDC + TransformToPixels
+// (lib/jxl/dec_group.cc:115-181,431-450, lib/jxl/dec_transforms-inl.h:456-818).
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace jxlhip {
+
+// ---------------------------------------------------------------- k_prepare
+// One workgroup (1024 threads) per AC group of the stripe; thread i owns cell
+// (i / gw, i % gw) of the group's clipped block rectangle (BlockGroupRect,
+// lib/jxl/frame_dimensions.h:70-77) in the raster order DecodeGroupImpl visits.
+__global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl,
+                                                  int with_sigma, float epf_quant_mul,
+                                                  SharpLut lut) {
+  __shared__ uint32_t wave_tot[16];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+  const uint32_t gx = blockIdx.x % f.xsg;
+  const uint32_t gy = f.group_y0 + blockIdx.x / f.xsg;
+  const uint32_t g = gy * f.xsg + gx;
+  const uint32_t bx0 = gx * 32, by0 = gy * 32;
+  const uint32_t gw = min(32u, f.xsb - bx0), gh = min(32u, f.ysb - by0);
+  const bool valid = tid < gw * gh;
+  const uint32_t by = valid ? tid / gw : 0, bx = valid ? tid % gw : 0;
+  const uint32_t aby = by0 + by, abx = bx0 + bx;
+  const uint32_t raw = valid ? f.acs[(size_t)aby * f.xsb + abx] : 0;
+  bool first = raw & 1;
+  uint32_t s = raw >> 1;
+  bool bad = false;
+  if (s >= JXLHIP_NUM_STRATEGIES) {
+    bad = valid;
+    s = 0;
+    first = false;
+  }
+  const uint32_t cx = kCoveredX[s], cy = kCoveredY[s];
+  if (first && (bx + cx > gw || by + cy > gh)) {
+    bad = true;
+    first = false;
+  }
+  const uint32_t n64 = first ? cx * cy : 0;
+  // exclusive scan of n64 over the 1024 threads
+  uint32_t incl = n64;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d, 64);
+    if ((int)lane >= d) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    const uint32_t t = wave_tot[w];
+    if (w < (int)wave) base += t;
+    total += t;
+  }
+  const uint32_t off64 = base + incl - n64;
+  if (total > 1024) bad = true;  // would overflow the group's 65536-coefficient stream
+  if (__any(bad)) {
+    if (bad) atomicOr(f.error_flag, 1);
+  }
+  if (total > 1024) return;
+  // class lists: wave-level compaction, one atomic per wave and class
+  const int cls = first ? ClassOfStrategy((int)s) : -1;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll 1
+  for (int c = 0; c < kNumClasses; c++) {
+    const unsigned long long m = __ballot(cls == c);
+    if (m == 0) continue;
+    uint32_t wbase = 0;
+    if (lane == (uint32_t)__builtin_ctzll(m))
+      wbase = atomicAdd(&wl.count[c], (uint32_t)__builtin_popcountll(m));
+    wbase = __shfl(wbase, __builtin_ctzll(m), 64);
+    if (cls == c) {
+      WorkItem it;
+      it.pos = (aby << 16) | abx;
+      it.off = g * 1024u + off64;
+      wl.list[c][wbase + __builtin_popcountll(m & lt)] = it;
+    }
+  }
+  // ComputeSigma (epf.cc:69-79) for every cell the varblock covers
+  if (with_sigma && first) {
+    const float kInvSigmaNum = -1.1715728752538099024f;
+    const int q = f.raw_quant[(size_t)aby * f.xsb + abx];
+    const float sigma_quant = epf_quant_mul / (f.quant_scale * (float)q * kInvSigmaNum);
+    for (uint32_t iy = 0; iy < cy; iy++)
+      for (uint32_t ix = 0; ix < cx; ix++) {
+        const size_t i = (size_t)(aby + iy) * f.xsb + abx + ix;
+        float sigma = sigma_quant * lut.v[f.sharp[i] & 7];
+        sigma = sigma < -1e-4f ? sigma : -1e-4f;
+        f.inv_sigma[i] = 1.0f / sigma;
+      }
+  }
+}
+
+// ------------------------------------------------------------ block header
+struct BlockHdr {
+  uint32_t abx, aby;
+  size_t coef;  // element offset into coeffs[c]
+  float sx, sy, sb, x_cc, b_cc;
+};
+
+__device__ __forceinline__ BlockHdr MakeHdr(const DevFrame& f, const WorkItem it) {
+  BlockHdr h;
+  h.abx = it.pos & 0xffffu;
+  h.aby = it.pos >> 16;
+  h.coef = (size_t)it.off * 64u;
+  const int quant = f.raw_quant[(size_t)h.aby * f.xsb + h.abx];
+  const float s = f.inv_global_scale / (float)quant;  // dec_group.cc:164
+  h.sx = s * f.x_dm;
+  h.sy = s;
+  h.sb = s * f.b_dm;
+  const size_t tile = (size_t)(h.aby >> 3) * f.xtiles + (h.abx >> 3);
+  h.x_cc = f.cfl_base_x + (float)f.ytox[tile] * f.color_scale;
+  h.b_cc = f.cfl_base_b + (float)f.ytob[tile] * f.color_scale;
+  return h;
+}
+
+// 64 consecutive coefficients of one channel -> registers
+template <typename CT>
+__device__ __forceinline__ void Load64(const void* base, size_t off, int32_t* q) {
+  if constexpr (sizeof(CT) == 2) {
+    const uint4* p = (const uint4*)((const int16_t*)base + off);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint4 v = p[i];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        q[i * 8 + 2 * j] = (int32_t)(int16_t)(w[j] & 0xffffu);
+        q[i * 8 + 2 * j + 1] = (int32_t)w[j] >> 16;
+      }
+    }
+  } else {
+    const int4* p = (const int4*)((const int32_t*)base + off);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int4 v = p[i];
+      q[i * 4] = v.x;
+      q[i * 4 + 1] = v.y;
+      q[i * 4 + 2] = v.z;
+      q[i * 4 + 3] = v.w;
+    }
+  }
+}
+
+__device__ __forceinline__ void StoreBlock8x8(const DevFrame& f, int c,
+                                              const BlockHdr& h, const float* px) {
+  float* dst = PlanePtr(f, c, h.aby * 8, h.abx * 8);
+#pragma unroll
+  for (int y = 0; y < 8; y++) {
+    float4* d = (float4*)(dst + (size_t)y * f.plane_stride);
+    d[0] = make_float4(px[y * 8], px[y * 8 + 1], px[y * 8 + 2], px[y * 8 + 3]);
+    d[1] = make_float4(px[y * 8 + 4], px[y * 8 + 5], px[y * 8 + 6], px[y * 8 + 7]);
+  }
+}
+
+// ------------------------------------------------- single-block transforms
+// TransformToPixels for the one-block strategies, all in registers
+// (dec_transforms-inl.h:463-581, 399-454).  co: 64 coefficients (co[0] = DC
+// already inserted), px: 8x8 pixels row-major.
+template <int S>
+__device__ __forceinline__ void Idct2TopT(float* b) {
+  constexpr int H = S / 2;
+  float t[S * S];
+#pragma unroll
+  for (int y = 0; y < H; y++)
+#pragma unroll
+    for (int x = 0; x < H; x++) {
+      const float c00 = b[y * 8 + x], c01 = b[y * 8 + H + x];
+      const float c10 = b[(y + H) * 8 + x], c11 = b[(y + H) * 8 + H + x];
+      t[(y * 2) * S + x * 2] = c00 + c01 + c10 + c11;
+      t[(y * 2) * S + x * 2 + 1] = c00 + c01 - c10 - c11;
+      t[(y * 2 + 1) * S + x * 2] = c00 - c01 + c10 - c11;
+      t[(y * 2 + 1) * S + x * 2 + 1] = c00 - c01 - c10 + c11;
+    }
+#pragma unroll
+  for (int y = 0; y < S; y++)
+#pragma unroll
+    for (int x = 0; x < S; x++) b[y * 8 + x] = t[y * S + x];
+}
+
+template <int KIND>
+__device__ __forceinline__ void AfvToPixels(const float* co, float* px) {
+  constexpr int afv_x = KIND & 1, afv_y = KIND / 2;
+  const float b00 = co[0], b01 = co[1], b10 = co[8];
+  const float dc0 = (b00 + b10 + b01) * 4.0f;
+  const float dc1 = (b00 + b10 - b01);
+  const float dc2 = b00 - b10;
+  float coeff[16], block[32], out[32];
+  coeff[0] = dc0;
+#pragma unroll
+  for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+    for (int ix = 0; ix < 4; ix++)
+      if (ix | iy) coeff[iy * 4 + ix] = co[iy * 2 * 8 + ix * 2];
+  // AFVIDCT4x4: pixel[i] = sum_j coeff[j] * basis[j][i]
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    float p = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) p = __builtin_fmaf(coeff[j], kAfvBasis[j * 16 + i], p);
+    block[i] = p;
+  }
+#pragma unroll
+  for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+    for (int ix = 0; ix < 4; ix++)
+      px[(iy + afv_y * 4) * 8 + afv_x * 4 + ix] =
+          block[(afv_y == 1 ? 3 - iy : iy) * 4 + (afv_x == 1 ? 3 - ix : ix)];
+  block[0] = dc1;
+#pragma unroll
+  for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+    for (int ix = 0; ix < 4; ix++)
+      if (ix | iy) block[iy * 4 + ix] = co[iy * 2 * 8 + ix * 2 + 1];
+  Idct2dReg<4, 4>(block, out);
+#pragma unroll
+  for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+    for (int ix = 0; ix < 4; ix++)
+      px[(afv_y * 4 + iy) * 8 + (afv_x == 1 ? 0 : 4) + ix] = out[iy * 4 + ix];
+  block[0] = dc2;
+#pragma unroll
+  for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+    for (int ix = 0; ix < 8; ix++)
+      if (ix | iy) block[iy * 8 + ix] = co[(1 + iy * 2) * 8 + ix];
+  Idct2dReg<4, 8>(block, out);
+#pragma unroll
+  for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+    for (int ix = 0; ix < 8; ix++)
+      px[((afv_y == 1 ? 0 : 4) + iy) * 8 + ix] = out[iy * 8 + ix];
+}
+
+template <int STRATEGY>
+__device__ __forceinline__ void Transform64(const float* co, float* px) {
+  if constexpr (STRATEGY == 0) {
+    Idct2dReg<8, 8>(co, px);
+  } else if constexpr (STRATEGY == 1) {  // IDENTITY
+    const float b00 = co[0], b01 = co[1], b10 = co[8], b11 = co[9];
+    const float dcs[4] = {b00 + b01 + b10 + b11, b00 + b01 - b10 - b11,
+                          b00 - b01 + b10 - b11, b00 - b01 - b10 + b11};
+#pragma unroll
+    for (int y = 0; y < 2; y++)
+#pragma unroll
+      for (int x = 0; x < 2; x++) {
+        float residual_sum = 0;
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+          for (int ix = 0; ix < 4; ix++)
+            if (ix | iy) residual_sum += co[(y + iy * 2) * 8 + x + ix * 2];
+        const float base = dcs[y * 2 + x] - residual_sum * (1.0f / 16);
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+          for (int ix = 0; ix < 4; ix++) {
+            if (ix == 1 && iy == 1) continue;
+            px[(y * 4 + iy) * 8 + x * 4 + ix] = co[(y + iy * 2) * 8 + x + ix * 2] + base;
+          }
+        px[(4 * y + 1) * 8 + 4 * x + 1] = base;
+        px[(y * 4) * 8 + x * 4] = co[(y + 2) * 8 + x + 2] + base;
+      }
+  } else if constexpr (STRATEGY == 2) {  // DCT2X2
+    float c[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) c[i] = co[i];
+    Idct2TopT<2>(c);
+    Idct2TopT<4>(c);
+    Idct2TopT<8>(c);
+#pragma unroll
+    for (int i = 0; i < 64; i++) px[i] = c[i];
+  } else if constexpr (STRATEGY == 3) {  // DCT4X4
+    const float b00 = co[0], b01 = co[1], b10 = co[8], b11 = co[9];
+    const float dcs[4] = {b00 + b01 + b10 + b11, b00 + b01 - b10 - b11,
+                          b00 - b01 + b10 - b11, b00 - b01 - b10 + b11};
+#pragma unroll
+    for (int y = 0; y < 2; y++)
+#pragma unroll
+      for (int x = 0; x < 2; x++) {
+        float block[16], out[16];
+        block[0] = dcs[y * 2 + x];
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+          for (int ix = 0; ix < 4; ix++)
+            if (ix | iy) block[iy * 4 + ix] = co[(y + iy * 2) * 8 + x + ix * 2];
+        Idct2dReg<4, 4>(block, out);
+#pragma unroll
+        for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+          for (int ix = 0; ix < 4; ix++) px[(y * 4 + iy) * 8 + x * 4 + ix] = out[iy * 4 + ix];
+      }
+  } else if constexpr (STRATEGY == 12) {  // DCT4X8: two 4-row halves
+    const float b0 = co[0], b1 = co[8];
+    const float dcs[2] = {b0 + b1, b0 - b1};
+#pragma unroll
+    for (int y = 0; y < 2; y++) {
+      float block[32], out[32];
+      block[0] = dcs[y];
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 8; ix++)
+          if (ix | iy) block[iy * 8 + ix] = co[(y + iy * 2) * 8 + ix];
+      Idct2dReg<4, 8>(block, out);
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 8; ix++) px[(y * 4 + iy) * 8 + ix] = out[iy * 8 + ix];
+    }
+  } else if constexpr (STRATEGY == 13) {  // DCT8X4: two 4-column halves
+    const float b0 = co[0], b1 = co[8];
+    const float dcs[2] = {b0 + b1, b0 - b1};
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+      float block[32], out[32];
+      block[0] = dcs[x];
+#pragma unroll
+      for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 8; ix++)
+          if (ix | iy) block[iy * 8 + ix] = co[(x + iy * 2) * 8 + ix];
+      Idct2dReg<8, 4>(block, out);
+#pragma unroll
+      for (int iy = 0; iy < 8; iy++)
+#pragma unroll
+        for (int ix = 0; ix < 4; ix++) px[iy * 8 + x * 4 + ix] = out[iy * 4 + ix];
+    }
+  } else {
+    AfvToPixels<STRATEGY - 14>(co, px);
+  }
+}
+
+// Dequantises the 64 coefficients of one single-block varblock and runs its
+// transform for the three channels (DequantLane, dec_group.cc:115-153).
+template <int STRATEGY, typename CT>
+__device__ __forceinline__ void DecodeBlock64(const DevFrame& f, const BlockHdr& h) {
+  constexpr uint32_t kTab = DequantOffset(STRATEGY);
+  const float* __restrict__ tab = f.dequant + kTab;
+  const size_t dci = (size_t)h.aby * f.xsb + h.abx;
+  float dy[64], v[64], px[64];
+  {
+    int32_t q[64];
+    Load64<CT>(f.coeffs[1], h.coef, q);
+#pragma unroll
+    for (int k = 0; k < 64; k++)
+      dy[k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tab[64 + k] * h.sy);
+  }
+  {
+    int32_t q[64];
+    Load64<CT>(f.coeffs[0], h.coef, q);
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+      const float dx = AdjustQuantBias(q[k], f.biases[0], f.biases[3]) * (tab[k] * h.sx);
+      v[k] = __builtin_fmaf(h.x_cc, dy[k], dx);
+    }
+    v[0] = f.dc[0][dci];
+    Transform64<STRATEGY>(v, px);
+    StoreBlock8x8(f, 0, h, px);
+  }
+  {
+    int32_t q[64];
+    Load64<CT>(f.coeffs[2], h.coef, q);
+#pragma unroll
+    for (int k = 0; k < 64; k++) {
+      const float db = AdjustQuantBias(q[k], f.biases[2], f.biases[3]) * (tab[128 + k] * h.sb);
+      v[k] = __builtin_fmaf(h.b_cc, dy[k], db);
+    }
+    v[0] = f.dc[2][dci];
+    Transform64<STRATEGY>(v, px);
+    StoreBlock8x8(f, 2, h, px);
+  }
+  dy[0] = f.dc[1][dci];
+  Transform64<STRATEGY>(dy, px);
+  StoreBlock8x8(f, 1, h, px);
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void k_dct8(DevFrame f, const WorkItem* __restrict__ list,
+                                              const uint32_t* __restrict__ count) {
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= *count) return;
+  const BlockHdr h = MakeHdr(f, list[idx]);
+  DecodeBlock64<0, CT>(f, h);
+}
+
+template <typename CT>
+__global__ __launch_bounds__(64) void k_special(DevFrame f, const WorkItem* __restrict__ list,
+                                                const uint32_t* __restrict__ count) {
+  const uint32_t idx = blockIdx.x * 64u + threadIdx.x;
+  if (idx >= *count) return;
+  const BlockHdr h = MakeHdr(f, list[idx]);
+  const int s = f.acs[(size_t)h.aby * f.xsb + h.abx] >> 1;
+  switch (s) {
+    case 1: DecodeBlock64<1, CT>(f, h); break;
+    case 2: DecodeBlock64<2, CT>(f, h); break;
+    case 3: DecodeBlock64<3, CT>(f, h); break;
+    case 12: DecodeBlock64<12, CT>(f, h); break;
+    case 13: DecodeBlock64<13, CT>(f, h); break;
+    case 14: DecodeBlock64<14, CT>(f, h); break;
+    case 15: DecodeBlock64<15, CT>(f, h); break;
+    case 16: DecodeBlock64<16, CT>(f, h); break;
+    case 17: DecodeBlock64<17, CT>(f, h); break;
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------ k_medium
+// LowestFrequenciesFromDC via ReinterpretingDCT (dec_transforms-inl.h:35-64,
+// 691-818) for a CY x CX patch of DC values, in registers; result written
+// into the coefficient matrix m (row stride lp) at its top-left corner.
+template <int CY, int CX>
+__device__ __forceinline__ void LlfFromDcReg(const float* __restrict__ dc, size_t dc_stride,
+                                             float* __restrict__ m, int lp) {
+  float a[CY * CX];  // a[y][x]
+#pragma unroll
+  for (int y = 0; y < CY; y++)
+#pragma unroll
+    for (int x = 0; x < CX; x++) a[y * CX + x] = dc[(size_t)y * dc_stride + x];
+  // vertical CY-point DCT (scaled 1/CY), then horizontal CX-point (1/CX)
+#pragma unroll
+  for (int x = 0; x < CX; x++) {
+    float v[CY];
+#pragma unroll
+    for (int y = 0; y < CY; y++) v[y] = a[y * CX + x];
+    DctReg<CY>(v);
+#pragma unroll
+    for (int y = 0; y < CY; y++) a[y * CX + x] = (1.0f / CY) * v[y];
+  }
+#pragma unroll
+  for (int y = 0; y < CY; y++) {
+    float v[CX];
+#pragma unroll
+    for (int x = 0; x < CX; x++) v[x] = a[y * CX + x];
+    DctReg<CX>(v);
+#pragma unroll
+    for (int x = 0; x < CX; x++) a[y * CX + x] = (1.0f / CX) * v[x];
+  }
+  // a[u][v]; stored transposed when CY >= CX
+#pragma unroll
+  for (int y = 0; y < CY; y++)
+#pragma unroll
+    for (int x = 0; x < CX; x++) {
+      const float val = a[y * CX + x];
+      if constexpr (CY < CX) {
+        m[y * lp + x] = val * kResampleUpHost[CY + y] * kResampleUpHost[CX + x];
+      } else {
+        m[x * lp + y] = val * kResampleUpHost[CX + x] * kResampleUpHost[CY + y];
+      }
+    }
+}
+
+// R x C pixel varblocks (R rows tall, C cols wide), 16x8 .. 32x32.
+// Workgroup = 3 waves, wave w handles channel w in the transform passes; each
+// 1-D transform lives in one lane's registers; LDS holds the coefficient
+// matrix (padded rows) between the passes.
+template <int R, int C, int STRATEGY, typename CT>
+__global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __restrict__ list,
+                                                const uint32_t* __restrict__ count) {
+  constexpr int S = R < C ? R : C, L = R < C ? C : R;
+  constexpr int ML = L;            // lanes per varblock and channel
+  constexpr int NB = 64 / ML;      // varblocks per workgroup
+  constexpr int LP = L + 1;        // coefficient matrix row stride
+  constexpr int TP = C + 1;        // intermediate T[u][x] row stride
+  constexpr int BUF = (S * LP > R * TP ? S * LP : R * TP);
+  constexpr int CY = R / 8, CX = C / 8;
+  constexpr int SIZE = R * C;
+  constexpr uint32_t kTab = DequantOffset(STRATEGY);
+  __shared__ float buf[3][NB][BUF];
+  __shared__ BlockHdr hdr[NB];
+
+  const uint32_t n = *count;
+  const uint32_t first = blockIdx.x * NB;
+  if (first >= n) return;
+  const int nb = (int)min((uint32_t)NB, n - first);
+  const int tid = threadIdx.x;
+  if (tid < nb) hdr[tid] = MakeHdr(f, list[first + tid]);
+  __syncthreads();
+
+  // dequant + CfL, 4 coefficients per thread and step
+  const float* __restrict__ tab = f.dequant + kTab;
+  for (int i = tid * 4; i < nb * SIZE; i += 192 * 4) {
+    const int b = i / SIZE, k = i % SIZE;
+    const BlockHdr& h = hdr[b];
+    int32_t qx[4], qy[4], qb[4];
+    if constexpr (sizeof(CT) == 2) {
+      const uint2 vx = *(const uint2*)((const int16_t*)f.coeffs[0] + h.coef + k);
+      const uint2 vy = *(const uint2*)((const int16_t*)f.coeffs[1] + h.coef + k);
+      const uint2 vb = *(const uint2*)((const int16_t*)f.coeffs[2] + h.coef + k);
+      qx[0] = (int16_t)(vx.x & 0xffff); qx[1] = (int32_t)vx.x >> 16;
+      qx[2] = (int16_t)(vx.y & 0xffff); qx[3] = (int32_t)vx.y >> 16;
+      qy[0] = (int16_t)(vy.x & 0xffff); qy[1] = (int32_t)vy.x >> 16;
+      qy[2] = (int16_t)(vy.y & 0xffff); qy[3] = (int32_t)vy.y >> 16;
+      qb[0] = (int16_t)(vb.x & 0xffff); qb[1] = (int32_t)vb.x >> 16;
+      qb[2] = (int16_t)(vb.y & 0xffff); qb[3] = (int32_t)vb.y >> 16;
+    } else {
+      const int4 vx = *(const int4*)((const int32_t*)f.coeffs[0] + h.coef + k);
+      const int4 vy = *(const int4*)((const int32_t*)f.coeffs[1] + h.coef + k);
+      const int4 vb = *(const int4*)((const int32_t*)f.coeffs[2] + h.coef + k);
+      qx[0] = vx.x; qx[1] = vx.y; qx[2] = vx.z; qx[3] = vx.w;
+      qy[0] = vy.x; qy[1] = vy.y; qy[2] = vy.z; qy[3] = vy.w;
+      qb[0] = vb.x; qb[1] = vb.y; qb[2] = vb.z; qb[3] = vb.w;
+    }
+    const float4 tx = *(const float4*)(tab + k);
+    const float4 ty = *(const float4*)(tab + SIZE + k);
+    const float4 tb = *(const float4*)(tab + 2 * SIZE + k);
+    const float mx[4] = {tx.x, tx.y, tx.z, tx.w};
+    const float my[4] = {ty.x, ty.y, ty.z, ty.w};
+    const float mb[4] = {tb.x, tb.y, tb.z, tb.w};
+    const int row = k / L, col = k % L;
+    float* ox = &buf[0][b][row * LP + col];
+    float* oy = &buf[1][b][row * LP + col];
+    float* ob = &buf[2][b][row * LP + col];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float dy = AdjustQuantBias(qy[j], f.biases[1], f.biases[3]) * (my[j] * h.sy);
+      const float dx = AdjustQuantBias(qx[j], f.biases[0], f.biases[3]) * (mx[j] * h.sx);
+      const float db = AdjustQuantBias(qb[j], f.biases[2], f.biases[3]) * (mb[j] * h.sb);
+      ox[j] = __builtin_fmaf(h.x_cc, dy, dx);
+      oy[j] = dy;
+      ob[j] = __builtin_fmaf(h.b_cc, dy, db);
+    }
+  }
+  __syncthreads();
+  // LLF <- DC
+  if (tid < nb * 3) {
+    const int b = tid / 3, c = tid % 3;
+    const BlockHdr& h = hdr[b];
+    LlfFromDcReg<CY, CX>(f.dc[c] + (size_t)h.aby * f.xsb + h.abx, f.xsb, &buf[c][b][0], LP);
+  }
+  __syncthreads();
+  // pass 1: for each vertical frequency u, C-point IDCT along v -> T[u][x]
+  const int c = tid >> 6, lane = tid & 63;
+  const int b = lane / ML, i = lane % ML;
+  const bool active = b < nb;
+  float* m = &buf[c][active ? b : 0][0];
+  {
+    float v[C];
+    if (active && i < R) {
+#pragma unroll
+      for (int j = 0; j < C; j++) v[j] = (R < C) ? m[i * LP + j] : m[j * LP + i];
+      IdctReg<C>(v);
+    }
+    __syncthreads();
+    if (active && i < R) {
+#pragma unroll
+      for (int j = 0; j < C; j++) m[i * TP + j] = v[j];
+    }
+  }
+  __syncthreads();
+  // pass 2: for each pixel column x, R-point IDCT along u -> pixels
+  if (active && i < C) {
+    float v[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) v[j] = m[j * TP + i];
+    IdctReg<R>(v);
+    const BlockHdr& h = hdr[b];
+    float* dst = PlanePtr(f, c, h.aby * 8, h.abx * 8 + i);
+#pragma unroll
+    for (int j = 0; j < R; j++) dst[(size_t)j * f.plane_stride] = v[j];
+  }
+}
+
+// ------------------------------------------------------------------- k_large
+// Strategies 18..26 (64x64 .. 256x256).  One workgroup per varblock; 1-D
+// transforms of up to 256 points run on per-thread scratch arrays; the
+// intermediate T[u][x] is written into the varblock's own output rectangle.
+template <int N>
+__device__ __noinline__ void IdctMemT(float* v, float* tmp, const float* __restrict__ wc) {
+  if constexpr (N == 1) {
+    return;
+  } else if constexpr (N == 2) {
+    const float a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  } else {
+    constexpr int h = N / 2;
+#pragma unroll 1
+    for (int i = 0; i < h; i++) tmp[i] = v[2 * i];
+#pragma unroll 1
+    for (int i = 0; i < h; i++) tmp[h + i] = v[2 * i + 1];
+    IdctMemT<h>(tmp, tmp + N, wc);
+#pragma unroll 1
+    for (int i = h - 1; i > 0; i--) tmp[h + i] = tmp[h + i] + tmp[h + i - 1];
+    tmp[h] = tmp[h] * kSqrt2;
+    IdctMemT<h>(tmp + h, tmp + N, wc);
+#pragma unroll 1
+    for (int i = 0; i < h; i++) {
+      const float mul = wc[N + i];
+      const float e = tmp[i], o = tmp[h + i];
+      v[i] = __builtin_fmaf(mul, o, e);
+      v[N - 1 - i] = __builtin_fmaf(-mul, o, e);
+    }
+  }
+}
+
+template <int N>
+__device__ __noinline__ void DctMemT(float* v, float* tmp, const float* __restrict__ wc) {
+  if constexpr (N == 1) {
+    return;
+  } else if constexpr (N == 2) {
+    const float a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  } else {
+    constexpr int h = N / 2;
+#pragma unroll 1
+    for (int i = 0; i < h; i++) tmp[i] = v[i] + v[N - 1 - i];
+    DctMemT<h>(tmp, tmp + N, wc);
+#pragma unroll 1
+    for (int i = 0; i < h; i++) tmp[h + i] = v[i] - v[N - 1 - i];
+#pragma unroll 1
+    for (int i = 0; i < h; i++) tmp[h + i] = tmp[h + i] * wc[N + i];
+    DctMemT<h>(tmp + h, tmp + N, wc);
+    tmp[h] = __builtin_fmaf(tmp[h], kSqrt2, tmp[h + 1]);
+#pragma unroll 1
+    for (int i = 1; i + 1 < h; i++) tmp[h + i] = tmp[h + i] + tmp[h + i + 1];
+#pragma unroll 1
+    for (int i = 0; i < h; i++) {
+      v[2 * i] = tmp[i];
+      v[2 * i + 1] = tmp[h + i];
+    }
+  }
+}
+
+__device__ __forceinline__ void IdctMem(int n, float* v, float* tmp, const float* wc) {
+  switch (n) {
+    case 32: IdctMemT<32>(v, tmp, wc); break;
+    case 64: IdctMemT<64>(v, tmp, wc); break;
+    case 128: IdctMemT<128>(v, tmp, wc); break;
+    case 256: IdctMemT<256>(v, tmp, wc); break;
+    default: break;
+  }
+}
+__device__ __forceinline__ void DctMem(int n, float* v, float* tmp, const float* wc) {
+  switch (n) {
+    case 2: DctMemT<2>(v, tmp, wc); break;
+    case 4: DctMemT<4>(v, tmp, wc); break;
+    case 8: DctMemT<8>(v, tmp, wc); break;
+    case 16: DctMemT<16>(v, tmp, wc); break;
+    case 32: DctMemT<32>(v, tmp, wc); break;
+    default: break;
+  }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void k_large(DevFrame f, const WorkItem* __restrict__ list,
+                                               const uint32_t* __restrict__ count,
+                                               const float* __restrict__ wc,
+                                               const float* __restrict__ resample) {
+  __shared__ float llf[32 * 33];  // LLF corner of the current channel
+  __shared__ float dcs[32 * 33];
+  if (blockIdx.x >= *count) return;
+  const BlockHdr h = MakeHdr(f, list[blockIdx.x]);
+  const int strategy = f.acs[(size_t)h.aby * f.xsb + h.abx] >> 1;
+  const int cx = kCoveredX[strategy], cy = kCoveredY[strategy];
+  const int R = cy * 8, C = cx * 8;
+  const int L = R < C ? C : R;
+  const size_t size = (size_t)R * C;
+  const float* __restrict__ tab = f.dequant + DequantOffset(strategy);
+  const int tid = threadIdx.x;
+  float v[256], tmp[512];
+  for (int c = 0; c < 3; c++) {
+    // ---- LLF <- DC (cy x cx patch), jxo_llf_from_dc order: vertical then
+    // horizontal forward DCT, each scaled by 1/N
+    for (int i = tid; i < cy * cx; i += 256) {
+      const int y = i / cx, x = i % cx;
+      dcs[y * 33 + x] = f.dc[c][(size_t)(h.aby + y) * f.xsb + h.abx + x];
+    }
+    __syncthreads();
+    if (tid < cx) {
+      for (int y = 0; y < cy; y++) v[y] = dcs[y * 33 + tid];
+      DctMem(cy, v, tmp, wc);
+      const float sc = 1.0f / cy;
+      for (int y = 0; y < cy; y++) dcs[y * 33 + tid] = sc * v[y];
+    }
+    __syncthreads();
+    if (tid < cy) {
+      for (int x = 0; x < cx; x++) v[x] = dcs[tid * 33 + x];
+      DctMem(cx, v, tmp, wc);
+      const float sc = 1.0f / cx;
+      for (int x = 0; x < cx; x++) {
+        const float val = sc * v[x];
+        // coefficient-matrix position of (u = tid, v = x)
+        if (cy < cx) llf[tid * 33 + x] = val * resample[cy + tid] * resample[cx + x];
+        else llf[x * 33 + tid] = val * resample[cx + x] * resample[cy + tid];
+      }
+    }
+    __syncthreads();
+    // ---- pass 1: thread u, C-point IDCT along v, dequant on the fly
+    const float bias_c = f.biases[c], bias3 = f.biases[3];
+    const float sc = c == 0 ? h.sx : (c == 1 ? h.sy : h.sb);
+    const float cc = c == 0 ? h.x_cc : (c == 2 ? h.b_cc : 0.0f);
+    const int srows = R < C ? R : C;  // LLF corner: srows/8 x L/8
+    const int llf_r = srows / 8, llf_c = L / 8;
+    for (int u = tid; u < R; u += 256) {
+      for (int j = 0; j < C; j++) {
+        // matrix element (row, col) holding F[u][v=j]
+        const int row = R < C ? u : j, col = R < C ? j : u;
+        float val;
+        if (row < llf_r && col < llf_c) {
+          val = llf[row * 33 + col];
+        } else {
+          const size_t k = (size_t)row * L + col;
+          const int32_t q = LoadCoeff<CT>(f.coeffs[c], h.coef + k);
+          val = AdjustQuantBias(q, bias_c, bias3) * (tab[c * size + k] * sc);
+          if (c != 1) {
+            const int32_t qy = LoadCoeff<CT>(f.coeffs[1], h.coef + k);
+            const float dy = AdjustQuantBias(qy, f.biases[1], bias3) * (tab[size + k] * h.sy);
+            val = __builtin_fmaf(cc, dy, val);
+          }
+        }
+        v[j] = val;
+      }
+      IdctMem(C, v, tmp, wc);
+      float* dst = PlanePtr(f, c, h.aby * 8 + u, h.abx * 8);
+      for (int j = 0; j < C; j++) dst[j] = v[j];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- pass 2: thread x, R-point IDCT along u, in place in the plane
+    for (int x = tid; x < C; x += 256) {
+      float* col = PlanePtr(f, c, h.aby * 8, h.abx * 8 + x);
+      for (int j = 0; j < R; j++) v[j] = col[(size_t)j * f.plane_stride];
+      IdctMem(R, v, tmp, wc);
+      for (int j = 0; j < R; j++) col[(size_t)j * f.plane_stride] = v[j];
+    }
+    __syncthreads();
+  }
+}
+
+// --------------------------------------------------------------- launchers
+template <typename CT>
+static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, const uint32_t* max_items,
+                          const float* wc, const float* resample, hipStream_t st,
+                          void (*mark)(void*, int), void* mark_arg) {
+  if (max_items[kClsDct8]) {
+    hipLaunchKernelGGL(k_dct8<CT>, dim3((max_items[kClsDct8] + 255) / 256), dim3(256), 0, st, f,
+                       wl.list[kClsDct8], wl.count + kClsDct8);
+  }
+  if (max_items[kClsSpecial]) {
+    hipLaunchKernelGGL(k_special<CT>, dim3((max_items[kClsSpecial] + 63) / 64), dim3(64), 0, st,
+                       f, wl.list[kClsSpecial], wl.count + kClsSpecial);
+  }
+  mark(mark_arg, 0);
+#define JXLHIP_MEDIUM(IDX, RR, CC, STRAT)                                                   \
+  if (max_items[kClsMedium0 + IDX]) {                                                       \
+    constexpr int NB = 64 / ((RR) > (CC) ? (RR) : (CC));                                    \
+    hipLaunchKernelGGL((k_medium<RR, CC, STRAT, CT>),                                       \
+                       dim3((max_items[kClsMedium0 + IDX] + NB - 1) / NB), dim3(192), 0,    \
+                       st, f, wl.list[kClsMedium0 + IDX], wl.count + kClsMedium0 + IDX);    \
+  }
+  JXLHIP_MEDIUM(0, 16, 8, 6)
+  JXLHIP_MEDIUM(1, 8, 16, 7)
+  JXLHIP_MEDIUM(2, 16, 16, 4)
+  JXLHIP_MEDIUM(3, 32, 8, 8)
+  JXLHIP_MEDIUM(4, 8, 32, 9)
+  JXLHIP_MEDIUM(5, 32, 16, 10)
+  JXLHIP_MEDIUM(6, 16, 32, 11)
+  JXLHIP_MEDIUM(7, 32, 32, 5)
+#undef JXLHIP_MEDIUM
+  mark(mark_arg, 1);
+  if (max_items[kClsLarge]) {
+    hipLaunchKernelGGL(k_large<CT>, dim3(max_items[kClsLarge]), dim3(256), 0, st, f,
+                       wl.list[kClsLarge], wl.count + kClsLarge, wc, resample);
+  }
+  mark(mark_arg, 2);
+}
+
+void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
+                   const SharpLut& lut, hipStream_t st) {
+  hipLaunchKernelGGL(k_prepare, dim3(f.xsg * f.group_rows), dim3(1024), 0, st, f, wl,
+                     with_sigma, epf_quant_mul, lut);
+}
+
+void LaunchBlocks(const DevFrame& f, const WorkLists& wl, const uint32_t* max_items,
+                  const float* wc, const float* resample, hipStream_t st,
+                  void (*mark)(void*, int), void* mark_arg) {
+  if (f.coeff_type == JXLHIP_COEFF_I16)
+    LaunchBlocksT<int16_t>(f, wl, max_items, wc, resample, st, mark, mark_arg);
+  else
+    LaunchBlocksT<int32_t>(f, wl, max_items, wc, resample, st, mark, mark_arg);
+}
+
+}  // namespace jxlhip

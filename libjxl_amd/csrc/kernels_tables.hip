@@ -1,0 +1,251 @@
+// kernels_tables.hip -- SURVEY 8(a) rows a5 and a8 on the device:
+//   k_default_dequant : DequantMatrices::EnsureComputed for the default library
+//                       (lib/jxl/quant_weights.cc:48-160,163-358,1190-1271; FastPowf
+//                       lib/jxl/base/fast_math-inl.h:46-92), one thread per table entry
+//   k_dequant_dc      : DequantDC, 4:4:4 (lib/jxl/compressed_dc.cc:201-232)
+//   k_smooth_dc       : AdaptiveDCSmoothing (lib/jxl/compressed_dc.cc:63-197)
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace jxlhip {
+namespace devlib {
+#undef JXL_FMT_CONST
+#define JXL_FMT_CONST __device__ const
+#include "format_constants.inc"
+}  // namespace devlib
+
+__device__ const uint8_t dKindShort[17] = {1, 1, 1, 1, 2, 4, 1, 1, 2, 1, 1, 8, 4, 16, 8, 32, 16};
+__device__ const uint8_t dKindLong[17] = {1, 1, 1, 1, 2, 4, 2, 4, 4, 1, 1, 8, 8, 16, 16, 32, 32};
+
+__device__ float FastLog2f(float x) {
+  const float p0 = -1.8503833400518310E-06f, p1 = 1.4287160470083755E+00f,
+              p2 = 7.4245873327820566E-01f;
+  const float q0 = 9.9032814277590719E-01f, q1 = 1.0096718572241148E+00f,
+              q2 = 1.7409343003366853E-01f;
+  const int32_t x_bits = __float_as_int(x);
+  const int32_t exp_bits = x_bits - 0x3f2aaaab;
+  const int32_t exp_shifted = exp_bits >> 23;
+  const float mantissa = __int_as_float(x_bits - (int32_t)((uint32_t)exp_shifted << 23));
+  const float exp_val = (float)exp_shifted;
+  const float m = mantissa - 1.0f;
+  const float yp = __builtin_fmaf(__builtin_fmaf(p2, m, p1), m, p0);
+  const float yq = __builtin_fmaf(__builtin_fmaf(q2, m, q1), m, q0);
+  return yp / yq + exp_val;
+}
+
+__device__ float FastPow2f(float x) {
+  const float floorx = __builtin_floorf(x);
+  const float expf_ = __int_as_float(((int32_t)floorx + 127) << 23);
+  const float frac = x - floorx;
+  float num = frac + 1.01749063e+01f;
+  num = __builtin_fmaf(num, frac, 4.88687798e+01f);
+  num = __builtin_fmaf(num, frac, 9.85506591e+01f);
+  num = num * expf_;
+  float den = __builtin_fmaf(frac, 2.10242958e-01f, -2.22328856e-02f);
+  den = __builtin_fmaf(den, frac, -1.94414990e+01f);
+  den = __builtin_fmaf(den, frac, 9.85506633e+01f);
+  return num / den;
+}
+
+__device__ float FastPowf(float base, float exponent) {
+  return FastPow2f(FastLog2f(base) * exponent);
+}
+
+__device__ float Mult(float v) { return v > 0.0f ? 1.0f + v : 1.0f / (1.0f - v); }
+
+// distance-band weight of coefficient (y, x) of a rows x cols table
+__device__ float DctWeight(int rows, int cols, const float* bands_in, int nb, int y, int x,
+                           bool* ok) {
+  float bands[8];
+  bands[0] = bands_in[0];
+  if (bands[0] < 1e-8f) *ok = false;
+  for (int i = 1; i < nb; i++) {
+    bands[i] = bands[i - 1] * Mult(bands_in[i]);
+    if (bands[i] < 1e-8f) *ok = false;
+  }
+  if (nb == 1) return bands[0];
+  const float scale = (nb - 1) / (kSqrt2 + 1e-6f);
+  const float rcpcol = scale / (cols - 1);
+  const float rcprow = scale / (rows - 1);
+  const float dy = y * rcprow;
+  const float dy2 = dy * dy;
+  const float dx = (float)x * rcpcol;
+  const float dist = __builtin_sqrtf(__builtin_fmaf(dx, dx, dy2));
+  const int32_t idx = (int32_t)dist;
+  const float frac = dist - (float)idx;
+  const float a = bands[idx], b = bands[idx + 1];
+  return a * FastPowf(b / a, frac);
+}
+
+__device__ float Interpolate(float pos, float max, const float* array, int len) {
+  const float scaled_pos = pos * (len - 1) / max;
+  const int idx = (int)scaled_pos;
+  const float a = array[idx], b = array[idx + 1];
+  return a * FastPowf(b / a, scaled_pos - idx);
+}
+
+__global__ __launch_bounds__(256) void k_default_dequant(float* __restrict__ table,
+                                                         int32_t* __restrict__ status) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= JXLHIP_DEQUANT_TABLE_FLOATS) return;
+  // locate (kind, c, y, x)
+  uint32_t pos = 0;
+  int kind = 0;
+  for (; kind < 17; kind++) {
+    const uint32_t n = 3u * 64u * dKindShort[kind] * dKindLong[kind];
+    if (i < pos + n) break;
+    pos += n;
+  }
+  const int wrows = 8 * dKindShort[kind], wcols = 8 * dKindLong[kind];
+  const int num = wrows * wcols;
+  const int c = (int)(i - pos) / num;
+  const int k = (int)(i - pos) % num;
+  const int y = k / wcols, x = k % wcols;
+  const devlib::QuantLibEntry& e = devlib::kQuantLib[kind];
+  bool ok = true;
+  float w;
+  switch (e.mode) {
+    case 1:  // ID
+      w = (k == 1 || k == 8) ? e.w[c][1] : (k == 9 ? e.w[c][2] : e.w[c][0]);
+      break;
+    case 2:  // DCT2
+      if (y < 2 && x < 2) {
+        w = k == 0 ? (float)0xBAD : (k == 9 ? e.w[c][1] : e.w[c][0]);
+      } else if (y < 4 && x < 4) {
+        w = (y >= 2 && x >= 2) ? e.w[c][3] : e.w[c][2];
+      } else {
+        w = (y >= 4 && x >= 4) ? e.w[c][5] : e.w[c][4];
+      }
+      break;
+    case 3:  // DCT4
+      w = DctWeight(4, 4, e.bands[c], e.nb, y / 2, x / 2, &ok);
+      if (k == 1 || k == 8) w /= e.w[c][0];
+      if (k == 9) w /= e.w[c][1];
+      break;
+    case 4:  // DCT4X8
+      w = DctWeight(4, 8, e.bands[c], e.nb, y / 2, x, &ok);
+      if (k == 8) w /= e.w[c][0];
+      break;
+    case 0:
+      w = DctWeight(wrows, wcols, e.bands[c], e.nb, y, x, &ok);
+      break;
+    default: {  // AFV
+      const float kFreqs[16] = {0xBAD, 0xBAD, 0.8517778890324296f, 5.37778436506804f,
+                                0xBAD, 0xBAD, 4.734747904497923f, 5.449245381693219f,
+                                1.6598270267479331f, 4.0f, 7.275749096817861f,
+                                10.423227632456525f, 2.662932286148962f, 7.630657783650829f,
+                                8.962388608184032f, 12.97166202570235f};
+      const devlib::QuantLibEntry& e48 = devlib::kQuantLib[9];
+      const devlib::QuantLibEntry& e44 = devlib::kQuantLib[3];
+      const float lo = 0.8517778890324296f;
+      const float hi = 12.97166202570235f - lo + 1e-6f;
+      float bands[4];
+      bands[0] = e.w[c][5];
+      if (bands[0] < 1e-8f) ok = false;
+      for (int j = 1; j < 4; j++) {
+        bands[j] = bands[j - 1] * Mult(e.w[c][j + 5]);
+        if (bands[j] < 1e-8f) ok = false;
+      }
+      if (y & 1) {  // odd rows: the 4x8 DCT part
+        w = DctWeight(4, 8, e48.bands[c], e48.nb, y / 2, x, &ok);
+      } else if (x & 1) {  // even rows, odd columns: the 4x4 DCT part
+        w = DctWeight(4, 4, e44.bands[c], e44.nb, y / 2, x / 2, &ok);
+      } else {  // even rows, even columns: the AFV part
+        const int ay = y / 2, ax = x / 2;
+        if (ay < 2 && ax < 2) w = 0;  // placeholders, fixed up below
+        else w = Interpolate(kFreqs[ay * 4 + ax] - lo, hi, bands, 4);
+      }
+      if (k == 0) w = 1;
+      if (k == 1 * 8 + 0) w = e.w[c][0];
+      if (k == 0 * 8 + 1) w = e.w[c][1];
+      if (k == 2 * 8 + 0) w = e.w[c][2];
+      if (k == 0 * 8 + 2) w = e.w[c][3];
+      if (k == 2 * 8 + 2) w = e.w[c][4];
+      break;
+    }
+  }
+  if (!ok || w >= 1.0f / 1e-8f || w < 1e-8f) {
+    atomicOr(status, 1);
+    w = 1.0f;
+  }
+  table[i] = 1.0f / w;
+}
+
+__global__ __launch_bounds__(256) void k_dequant_dc(size_t n, const int32_t* __restrict__ qx,
+                                                    const int32_t* __restrict__ qy,
+                                                    const int32_t* __restrict__ qb,
+                                                    float* __restrict__ ox, float* __restrict__ oy,
+                                                    float* __restrict__ ob, float mx, float my,
+                                                    float mb, float cfl_x, float cfl_b) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float in_x = (float)qx[i] * mx;
+  const float in_y = (float)qy[i] * my;
+  const float in_b = (float)qb[i] * mb;
+  oy[i] = in_y;
+  ox[i] = __builtin_fmaf(in_y, cfl_x, in_x);
+  ob[i] = __builtin_fmaf(in_y, cfl_b, in_b);
+}
+
+struct DcPlanes {
+  const float* in[3];
+  float* out[3];
+  float mul[3];
+};
+
+__global__ __launch_bounds__(256) void k_smooth_dc(uint32_t xs, uint32_t ys, DcPlanes p) {
+  const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= xs || y >= ys) return;
+  const size_t o = (size_t)y * xs + x;
+  if (x == 0 || y == 0 || x + 1 == xs || y + 1 == ys) {
+    for (int c = 0; c < 3; c++) p.out[c][o] = p.in[c][o];
+    return;
+  }
+  const float w1 = 0.20345139757231578f, w2 = 0.0334829185968739f;
+  const float w0 = 1.0f - 4.0f * (w1 + w2);
+  float gap = 0.5f, mcv[3], smv[3];
+  for (int c = 0; c < 3; c++) {
+    const float* r0 = p.in[c] + o - xs;
+    const float* r1 = p.in[c] + o;
+    const float* r2 = p.in[c] + o + xs;
+    const float corner = (r0[-1] + r0[1]) + (r2[-1] + r2[1]);
+    const float side = (r1[-1] + r1[1]) + (r0[0] + r2[0]);
+    mcv[c] = r1[0];
+    smv[c] = __builtin_fmaf(corner, w2, __builtin_fmaf(side, w1, mcv[c] * w0));
+    const float g = __builtin_fabsf((mcv[c] - smv[c]) / p.mul[c]);
+    gap = g > gap ? g : gap;
+  }
+  float factor = __builtin_fmaf(-4.0f, gap, 3.0f);
+  factor = factor < 0.0f ? 0.0f : factor;
+  for (int c = 0; c < 3; c++)
+    p.out[c][o] = __builtin_fmaf(smv[c] - mcv[c], factor, mcv[c]);
+}
+
+void LaunchDefaultDequant(float* table, int32_t* status, hipStream_t st) {
+  hipLaunchKernelGGL(k_default_dequant, dim3((JXLHIP_DEQUANT_TABLE_FLOATS + 255) / 256), dim3(256),
+                     0, st, table, status);
+}
+
+void LaunchDequantDC(uint32_t xsb, uint32_t ysb, const int32_t* const q[3], float* const dc[3],
+                     float* const tmp[3], const float mul_dc[3], float cfl_x, float cfl_b,
+                     int smooth, hipStream_t st) {
+  const size_t n = (size_t)xsb * ysb;
+  const bool do_smooth = smooth && xsb > 2 && ysb > 2;
+  float* const* first = do_smooth ? tmp : dc;
+  hipLaunchKernelGGL(k_dequant_dc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, q[0],
+                     q[1], q[2], first[0], first[1], first[2], mul_dc[0], mul_dc[1], mul_dc[2],
+                     cfl_x, cfl_b);
+  if (do_smooth) {
+    DcPlanes p;
+    for (int c = 0; c < 3; c++) {
+      p.in[c] = tmp[c];
+      p.out[c] = dc[c];
+      p.mul[c] = mul_dc[c];
+    }
+    hipLaunchKernelGGL(k_smooth_dc, dim3((xsb + 63) / 64, (ysb + 3) / 4), dim3(256), 0, st, xsb,
+                       ysb, p);
+  }
+}
+
+}  // namespace jxlhip

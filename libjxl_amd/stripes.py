@@ -1,0 +1,101 @@
+"""Group-row stripe decomposition of a VarDCT frame across ranks (one process
+per GPU) and the halo hand-off between the two decode phases.
+
+AC groups are independent through the inverse transforms; the loop filters
+couple neighbouring stripes through LoopFilter::Padding() rows
+(lib/jxl/loop_filter.h:26-29).  The exchange is point-to-point with the two
+neighbours only (xGMI is point-to-point: no ring, no all-reduce); tensors may be
+CUDA (backend nccl = RCCL) or CPU (backend gloo, used by the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def stripe_partition(ysize, world):
+    """Contiguous group-row stripes: returns [(group_y0, group_rows)] * world.
+    Every rank gets floor or ceil of ysg/world rows (the first `rem` get one
+    more); requires ysg >= world."""
+    ysg = (ysize + 255) // 256
+    if ysg < world:
+        raise ValueError(f"{ysg} group rows cannot be split over {world} ranks")
+    base, rem = divmod(ysg, world)
+    out, g0 = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((g0, n))
+        g0 += n
+    return out
+
+
+def stripe_pixel_rows(ysize, g0, gr):
+    return g0 * 256, min(ysize, (g0 + gr) * 256)
+
+
+def exchange_halos(send_up, send_down, recv_up, recv_down, rank, world, group=None):
+    """send_* / recv_*: tensors [3, halo, width] (any strides).  Rank r sends its
+    first rows to r-1 and its last rows to r+1 and receives theirs.  Edge ranks
+    skip the missing neighbour.  Returns after the received rows are in place."""
+    if world == 1 or send_up.shape[1] == 0:
+        return
+    ops, unpack = [], []
+    if rank > 0:
+        s = send_up.contiguous()
+        r = torch.empty_like(s)
+        ops += [dist.P2POp(dist.isend, s, rank - 1, group), dist.P2POp(dist.irecv, r, rank - 1, group)]
+        unpack.append((recv_up, r))
+    if rank + 1 < world:
+        s = send_down.contiguous()
+        r = torch.empty_like(s)
+        ops += [dist.P2POp(dist.isend, s, rank + 1, group), dist.P2POp(dist.irecv, r, rank + 1, group)]
+        unpack.append((recv_down, r))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    for dst, src in unpack:
+        dst.copy_(src)
+
+
+def gather_stripes(stripe, rows_per_rank, rank, world, dst=0, group=None):
+    """Collects the output stripes ([rows, width, 3] float) on `dst` with
+    point-to-point receives (each stripe travels over its own xGMI link).
+    Returns the full frame on dst, None elsewhere."""
+    if world == 1:
+        return stripe
+    if rank == dst:
+        parts = [None] * world
+        parts[dst] = stripe
+        ops = []
+        for r in range(world):
+            if r == dst:
+                continue
+            parts[r] = torch.empty((rows_per_rank[r],) + tuple(stripe.shape[1:]),
+                                   dtype=stripe.dtype, device=stripe.device)
+            ops.append(dist.P2POp(dist.irecv, parts[r], r, group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return torch.cat(parts, dim=0)
+    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, stripe.contiguous(), dst, group)]):
+        req.wait()
+    return None
+
+
+class StripeDecoder:
+    """VarDctDecoder for this rank's stripe + the halo exchange."""
+
+    def __init__(self, decoder, params, rank, world, group=None):
+        self.dec, self.rank, self.world, self.group = decoder, rank, world, group
+        self.parts = stripe_partition(params["ysize"], world)
+        g0, gr = self.parts[rank]
+        self.params = dict(params, stripe_group_y0=g0, stripe_group_rows=gr)
+        self.rows = [stripe_pixel_rows(params["ysize"], a, b) for a, b in self.parts]
+        decoder.begin_frame(self.params)
+
+    def decode(self, out):
+        d = self.dec
+        d.decode_blocks()
+        if self.world > 1 and d.halo_rows() > 0:
+            w = self.params["xsize"]
+            exchange_halos(d.halo_region(0)[:, :, :w], d.halo_region(1)[:, :, :w],
+                           d.halo_region(2)[:, :, :w], d.halo_region(3)[:, :, :w],
+                           self.rank, self.world, self.group)
+        d.decode_filters(out)
+        return out

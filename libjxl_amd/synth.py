@@ -140,7 +140,8 @@ def synth_frame(xsize, ysize, *, mix=None, gab=True, epf_iters=1, seed=0x4A584C,
         # Laplace(0, b): -b*sign(u)*ln(1-2|u|); chroma channels are sparser
         b = scale * (1.0 if c == 1 else 0.45)
         lap = -b * torch.sign(u) * torch.log1p(-2.0 * u.abs().clamp(max=0.4999999))
-        q = torch.round(lap).clamp(-30000, 30000)
+        lim = 30000 if coeff_type == 0 else (1 << 20)
+        q = torch.round(lap).clamp(-lim, lim)
         coeffs.append(q.to(dtype).reshape(-1).contiguous())
         del u, lap, q
 
