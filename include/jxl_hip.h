@@ -147,9 +147,11 @@ JXLHIP_EXPORT const char* jxlhip_status_string(int status);
 JXLHIP_EXPORT int jxlhip_create(int device, jxlhip_ctx** out);
 JXLHIP_EXPORT void jxlhip_destroy(jxlhip_ctx* ctx);
 JXLHIP_EXPORT const char* jxlhip_last_error(const jxlhip_ctx* ctx);
-/* Use an externally owned hipStream_t (e.g. torch's current stream) for all
- * launches; NULL restores the context's own stream. */
-JXLHIP_EXPORT int jxlhip_set_stream(jxlhip_ctx* ctx, void* hip_stream);
+/* external != 0: all launches go to the caller's hipStream_t `hip_stream`
+ * (NULL = the device's default stream, which is what torch's default stream
+ * is); external == 0: back to the context's own non-blocking stream. */
+JXLHIP_EXPORT int jxlhip_set_stream(jxlhip_ctx* ctx, void* hip_stream,
+                                    int external);
 
 /* Replaces PassesDecoderState::InitForAC + PreparePipeline
  * (dec_cache.cc:78-96,117-371): fixes the frame geometry and the stage list

@@ -115,7 +115,7 @@ def load_library():
     L.jxlhip_create.argtypes = [i32, C.POINTER(vp)]
     L.jxlhip_destroy.argtypes = [vp]
     L.jxlhip_destroy.restype = None
-    L.jxlhip_set_stream.argtypes = [vp, vp]
+    L.jxlhip_set_stream.argtypes = [vp, vp, i32]
     L.jxlhip_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlhip_frame_set_inputs.argtypes = [vp, C.POINTER(FrameInputs)]
     L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]

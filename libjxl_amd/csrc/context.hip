@@ -234,9 +234,9 @@ void jxlhip_destroy(jxlhip_ctx* c) {
 
 const char* jxlhip_last_error(const jxlhip_ctx* c) { return c ? c->err : ""; }
 
-int jxlhip_set_stream(jxlhip_ctx* c, void* hip_stream) {
+int jxlhip_set_stream(jxlhip_ctx* c, void* hip_stream, int external) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
-  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  c->stream = external ? (hipStream_t)hip_stream : c->own_stream;
   return JXLHIP_OK;
 }
 

@@ -38,26 +38,27 @@ __host__ __device__ constexpr uint32_t DequantOffset(int strategy) {
 }
 
 // Work classes: one compacted varblock list per class, built by k_prepare.
+static constexpr int kNumMedium = 11;
 enum WorkClass : int {
   kClsDct8 = 0,     // strategy 0
   kClsSpecial = 1,  // 1,2,3,12..17 (single 8x8 block, non-DCT8)
-  kClsMedium0 = 2,  // 8 medium kinds follow, see kMediumStrategy
-  kClsLarge = 10,   // 18..26 (any side >= 64)
-  kNumClasses = 11
+  kClsMedium0 = 2,  // kNumMedium medium kinds follow, see kMediumStrategy
+  kClsLarge = kClsMedium0 + kNumMedium,  // 21..26 (any side >= 128)
+  kNumClasses = kClsLarge + 1
 };
-// medium class index -> strategy
-static constexpr uint8_t kMediumStrategy[8] = {6, 7, 4, 8, 9, 10, 11, 5};
+// medium class index -> strategy (16x8 .. 64x64)
+static constexpr uint8_t kMediumStrategy[kNumMedium] = {6, 7, 4, 8, 9, 10, 11, 5, 18, 19, 20};
 __host__ __device__ constexpr int ClassOfStrategy(int s) {
   if (s == 0) return kClsDct8;
   if (s <= 3 || (s >= 12 && s <= 17)) return kClsSpecial;
-  if (s >= 18) return kClsLarge;
-  for (int i = 0; i < 8; i++)
+  if (s >= 21) return kClsLarge;
+  for (int i = 0; i < kNumMedium; i++)
     if (kMediumStrategy[i] == s) return kClsMedium0 + i;
   return -1;
 }
 // worst-case entries per block cell of each class = 1/covered_blocks
-static constexpr uint16_t kClassMinCovered[kNumClasses] = {1, 1, 2, 2,  4, 4,
-                                                           4, 8, 8, 16, 32};
+static constexpr uint16_t kClassMinCovered[kNumClasses] = {1, 1, 2, 2,  4,  4,  4,
+                                                           8, 8, 16, 64, 32, 32, 128};
 
 struct WorkItem {
   uint32_t pos;  // (aby << 16) | abx : absolute block coordinates

@@ -5,8 +5,8 @@
 //                 (lib/jxl/epf.cc:39-133)
 //   k_dct8      : dequant + CfL + 8x8 IDCT, one thread per block, in registers
 //   k_special   : IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4 / AFV0-3
-//   k_medium    : 16x8 .. 32x32, LDS-staged, one lane per 1-D transform
-//   k_large     : 64x32 .. 256x256, output plane used as scratch
+//   k_medium    : 16x8 .. 64x64, LDS-staged, one lane per 1-D transform
+//   k_large     : 128x64 .. 256x256, output plane used as scratch
 // replacing DequantBlock + LowestFrequenciesFromDC + TransformToPixels
 // (lib/jxl/dec_group.cc:115-181,431-450, lib/jxl/dec_transforms-inl.h:456-818).
 #include "dev_common.h"
@@ -18,14 +18,20 @@ namespace jxlhip {
 // One workgroup (1024 threads) per AC group of the stripe; thread i owns cell
 // (i / gw, i % gw) of the group's clipped block rectangle (BlockGroupRect,
 // lib/jxl/frame_dimensions.h:70-77) in the raster order DecodeGroupImpl visits.
-__global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl,
+__global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint32_t gy_lo,
                                                   int with_sigma, float epf_quant_mul,
                                                   SharpLut lut) {
   __shared__ uint32_t wave_tot[16];
+  __shared__ uint16_t wave_cls[16][kNumClasses];  // per-wave class counts -> bases
+  __shared__ uint32_t wg_base[kNumClasses];
+  __shared__ float cell_sq[1024];                 // sigma_quant of the covering varblock
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t gx = blockIdx.x % f.xsg;
-  const uint32_t gy = f.group_y0 + blockIdx.x / f.xsg;
+  const uint32_t gy = gy_lo + blockIdx.x / f.xsg;
+  // groups just outside the stripe only contribute their sigma cells (the EPF
+  // stages evaluate halo rows of the neighbouring stripes)
+  const bool in_stripe = gy >= f.group_y0 && gy < f.group_y0 + f.group_rows;
   const uint32_t g = gy * f.xsg + gx;
   const uint32_t bx0 = gx * 32, by0 = gy * 32;
   const uint32_t gw = min(32u, f.xsb - bx0), gh = min(32u, f.ysb - by0);
@@ -55,6 +61,16 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl,
     if ((int)lane >= d) incl += t;
   }
   if (lane == 63) wave_tot[wave] = incl;
+  // per-wave class histogram
+  const int cls = first ? ClassOfStrategy((int)s) : -1;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t rank_in_wave = 0;
+#pragma unroll
+  for (int c = 0; c < kNumClasses; c++) {
+    const unsigned long long m = __ballot(cls == c);
+    if (cls == c) rank_in_wave = (uint32_t)__builtin_popcountll(m & lt);
+    if (lane == 0) wave_cls[wave][c] = (uint16_t)__builtin_popcountll(m);
+  }
   __syncthreads();
   uint32_t base = 0, total = 0;
 #pragma unroll
@@ -65,40 +81,40 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl,
   }
   const uint32_t off64 = base + incl - n64;
   if (total > 1024) bad = true;  // would overflow the group's 65536-coefficient stream
-  if (__any(bad)) {
+  if (in_stripe && __any(bad)) {
     if (bad) atomicOr(f.error_flag, 1);
   }
-  if (total > 1024) return;
-  // class lists: wave-level compaction, one atomic per wave and class
-  const int cls = first ? ClassOfStrategy((int)s) : -1;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll 1
-  for (int c = 0; c < kNumClasses; c++) {
-    const unsigned long long m = __ballot(cls == c);
-    if (m == 0) continue;
-    uint32_t wbase = 0;
-    if (lane == (uint32_t)__builtin_ctzll(m))
-      wbase = atomicAdd(&wl.count[c], (uint32_t)__builtin_popcountll(m));
-    wbase = __shfl(wbase, __builtin_ctzll(m), 64);
-    if (cls == c) {
-      WorkItem it;
-      it.pos = (aby << 16) | abx;
-      it.off = g * 1024u + off64;
-      wl.list[c][wbase + __builtin_popcountll(m & lt)] = it;
-    }
+  const bool group_ok = total <= 1024;
+  // reserve list ranges: one global atomic per class and workgroup
+  if (tid < kNumClasses) {
+    uint32_t n = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) n += wave_cls[w][tid];
+    wg_base[tid] = (n && in_stripe && group_ok) ? atomicAdd(&wl.count[tid], n) : 0;
   }
-  // ComputeSigma (epf.cc:69-79) for every cell the varblock covers
+  // sigma_quant of each varblock, scattered to the cells it covers
   if (with_sigma && first) {
     const float kInvSigmaNum = -1.1715728752538099024f;
     const int q = f.raw_quant[(size_t)aby * f.xsb + abx];
     const float sigma_quant = epf_quant_mul / (f.quant_scale * (float)q * kInvSigmaNum);
     for (uint32_t iy = 0; iy < cy; iy++)
-      for (uint32_t ix = 0; ix < cx; ix++) {
-        const size_t i = (size_t)(aby + iy) * f.xsb + abx + ix;
-        float sigma = sigma_quant * lut.v[f.sharp[i] & 7];
-        sigma = sigma < -1e-4f ? sigma : -1e-4f;
-        f.inv_sigma[i] = 1.0f / sigma;
-      }
+      for (uint32_t ix = 0; ix < cx; ix++) cell_sq[(by + iy) * gw + bx + ix] = sigma_quant;
+  }
+  __syncthreads();
+  if (in_stripe && group_ok && cls >= 0) {
+    uint32_t pos = wg_base[cls] + rank_in_wave;
+    for (uint32_t w = 0; w < wave; w++) pos += wave_cls[w][cls];
+    WorkItem it;
+    it.pos = (aby << 16) | abx;
+    it.off = g * 1024u + off64;
+    wl.list[cls][pos] = it;
+  }
+  // ComputeSigma (epf.cc:69-79), one cell per thread
+  if (with_sigma && valid) {
+    const size_t i = (size_t)aby * f.xsb + abx;
+    float sigma = cell_sq[tid] * lut.v[f.sharp[i] & 7];
+    sigma = sigma < -1e-4f ? sigma : -1e-4f;
+    f.inv_sigma[i] = 1.0f / sigma;
   }
 }
 
@@ -418,54 +434,26 @@ __global__ __launch_bounds__(64) void k_special(DevFrame f, const WorkItem* __re
 }
 
 // ------------------------------------------------------------------ k_medium
-// LowestFrequenciesFromDC via ReinterpretingDCT (dec_transforms-inl.h:35-64,
-// 691-818) for a CY x CX patch of DC values, in registers; result written
-// into the coefficient matrix m (row stride lp) at its top-left corner.
-template <int CY, int CX>
-__device__ __forceinline__ void LlfFromDcReg(const float* __restrict__ dc, size_t dc_stride,
-                                             float* __restrict__ m, int lp) {
-  float a[CY * CX];  // a[y][x]
+// compile-time-sized select from the resample table with a runtime index
+template <int N>
+__device__ __forceinline__ float ResampleUpSel(int i) {
+  float r = kResampleUpHost[N];
 #pragma unroll
-  for (int y = 0; y < CY; y++)
-#pragma unroll
-    for (int x = 0; x < CX; x++) a[y * CX + x] = dc[(size_t)y * dc_stride + x];
-  // vertical CY-point DCT (scaled 1/CY), then horizontal CX-point (1/CX)
-#pragma unroll
-  for (int x = 0; x < CX; x++) {
-    float v[CY];
-#pragma unroll
-    for (int y = 0; y < CY; y++) v[y] = a[y * CX + x];
-    DctReg<CY>(v);
-#pragma unroll
-    for (int y = 0; y < CY; y++) a[y * CX + x] = (1.0f / CY) * v[y];
-  }
-#pragma unroll
-  for (int y = 0; y < CY; y++) {
-    float v[CX];
-#pragma unroll
-    for (int x = 0; x < CX; x++) v[x] = a[y * CX + x];
-    DctReg<CX>(v);
-#pragma unroll
-    for (int x = 0; x < CX; x++) a[y * CX + x] = (1.0f / CX) * v[x];
-  }
-  // a[u][v]; stored transposed when CY >= CX
-#pragma unroll
-  for (int y = 0; y < CY; y++)
-#pragma unroll
-    for (int x = 0; x < CX; x++) {
-      const float val = a[y * CX + x];
-      if constexpr (CY < CX) {
-        m[y * lp + x] = val * kResampleUpHost[CY + y] * kResampleUpHost[CX + x];
-      } else {
-        m[x * lp + y] = val * kResampleUpHost[CX + x] * kResampleUpHost[CY + y];
-      }
-    }
+  for (int j = 1; j < N; j++) r = (i == j) ? kResampleUpHost[N + j] : r;
+  return r;
 }
 
-// R x C pixel varblocks (R rows tall, C cols wide), 16x8 .. 32x32.
+// R x C pixel varblocks (R rows tall, C cols wide), 16x8 .. 64x64.
 // Workgroup = 3 waves, wave w handles channel w in the transform passes; each
 // 1-D transform lives in one lane's registers; LDS holds the coefficient
 // matrix (padded rows) between the passes.
+//   dequant + CfL  : all threads, 4 coefficients per step (DequantLane)
+//   LLF <- DC      : LowestFrequenciesFromDC via ReinterpretingDCT
+//                    (dec_transforms-inl.h:35-64,691-818): CX lanes do the
+//                    vertical CY-point DCTs, then CY lanes the horizontal ones
+//   pass 1 / pass 2: ComputeScaledIDCT (dct-inl.h:376-397): R lanes run the
+//                    C-point IDCT of one row of frequencies, then C lanes the
+//                    R-point IDCT of one pixel column and store it
 template <int R, int C, int STRATEGY, typename CT>
 __global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __restrict__ list,
                                                 const uint32_t* __restrict__ count) {
@@ -479,6 +467,7 @@ __global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __re
   constexpr int SIZE = R * C;
   constexpr uint32_t kTab = DequantOffset(STRATEGY);
   __shared__ float buf[3][NB][BUF];
+  __shared__ float dcp[3][NB][CY * CX];
   __shared__ BlockHdr hdr[NB];
 
   const uint32_t n = *count;
@@ -489,29 +478,48 @@ __global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __re
   if (tid < nb) hdr[tid] = MakeHdr(f, list[first + tid]);
   __syncthreads();
 
+  const int c = tid >> 6, lane = tid & 63;
+  const int b = lane / ML, i = lane % ML;
+  const bool active = b < nb;
+  const int bb = active ? b : 0;
+  float* m = &buf[c][bb][0];
+  float* dp = &dcp[c][bb][0];
+
+  // LLF step 1: lane i < CX takes DC column i, vertical CY-point DCT (x 1/CY)
+  if (active && i < CX) {
+    const BlockHdr& h = hdr[b];
+    const float* dc = f.dc[c] + (size_t)h.aby * f.xsb + h.abx + i;
+    float v[CY];
+#pragma unroll
+    for (int y = 0; y < CY; y++) v[y] = dc[(size_t)y * f.xsb];
+    DctReg<CY>(v);
+#pragma unroll
+    for (int y = 0; y < CY; y++) dp[y * CX + i] = (1.0f / CY) * v[y];
+  }
+
   // dequant + CfL, 4 coefficients per thread and step
   const float* __restrict__ tab = f.dequant + kTab;
-  for (int i = tid * 4; i < nb * SIZE; i += 192 * 4) {
-    const int b = i / SIZE, k = i % SIZE;
-    const BlockHdr& h = hdr[b];
+  for (int k4 = tid * 4; k4 < nb * SIZE; k4 += 192 * 4) {
+    const int vb = k4 / SIZE, k = k4 % SIZE;
+    const BlockHdr& h = hdr[vb];
     int32_t qx[4], qy[4], qb[4];
     if constexpr (sizeof(CT) == 2) {
       const uint2 vx = *(const uint2*)((const int16_t*)f.coeffs[0] + h.coef + k);
       const uint2 vy = *(const uint2*)((const int16_t*)f.coeffs[1] + h.coef + k);
-      const uint2 vb = *(const uint2*)((const int16_t*)f.coeffs[2] + h.coef + k);
+      const uint2 vz = *(const uint2*)((const int16_t*)f.coeffs[2] + h.coef + k);
       qx[0] = (int16_t)(vx.x & 0xffff); qx[1] = (int32_t)vx.x >> 16;
       qx[2] = (int16_t)(vx.y & 0xffff); qx[3] = (int32_t)vx.y >> 16;
       qy[0] = (int16_t)(vy.x & 0xffff); qy[1] = (int32_t)vy.x >> 16;
       qy[2] = (int16_t)(vy.y & 0xffff); qy[3] = (int32_t)vy.y >> 16;
-      qb[0] = (int16_t)(vb.x & 0xffff); qb[1] = (int32_t)vb.x >> 16;
-      qb[2] = (int16_t)(vb.y & 0xffff); qb[3] = (int32_t)vb.y >> 16;
+      qb[0] = (int16_t)(vz.x & 0xffff); qb[1] = (int32_t)vz.x >> 16;
+      qb[2] = (int16_t)(vz.y & 0xffff); qb[3] = (int32_t)vz.y >> 16;
     } else {
       const int4 vx = *(const int4*)((const int32_t*)f.coeffs[0] + h.coef + k);
       const int4 vy = *(const int4*)((const int32_t*)f.coeffs[1] + h.coef + k);
-      const int4 vb = *(const int4*)((const int32_t*)f.coeffs[2] + h.coef + k);
+      const int4 vz = *(const int4*)((const int32_t*)f.coeffs[2] + h.coef + k);
       qx[0] = vx.x; qx[1] = vx.y; qx[2] = vx.z; qx[3] = vx.w;
       qy[0] = vy.x; qy[1] = vy.y; qy[2] = vy.z; qy[3] = vy.w;
-      qb[0] = vb.x; qb[1] = vb.y; qb[2] = vb.z; qb[3] = vb.w;
+      qb[0] = vz.x; qb[1] = vz.y; qb[2] = vz.z; qb[3] = vz.w;
     }
     const float4 tx = *(const float4*)(tab + k);
     const float4 ty = *(const float4*)(tab + SIZE + k);
@@ -520,9 +528,9 @@ __global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __re
     const float my[4] = {ty.x, ty.y, ty.z, ty.w};
     const float mb[4] = {tb.x, tb.y, tb.z, tb.w};
     const int row = k / L, col = k % L;
-    float* ox = &buf[0][b][row * LP + col];
-    float* oy = &buf[1][b][row * LP + col];
-    float* ob = &buf[2][b][row * LP + col];
+    float* ox = &buf[0][vb][row * LP + col];
+    float* oy = &buf[1][vb][row * LP + col];
+    float* ob = &buf[2][vb][row * LP + col];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const float dy = AdjustQuantBias(qy[j], f.biases[1], f.biases[3]) * (my[j] * h.sy);
@@ -534,18 +542,27 @@ __global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __re
     }
   }
   __syncthreads();
-  // LLF <- DC
-  if (tid < nb * 3) {
-    const int b = tid / 3, c = tid % 3;
-    const BlockHdr& h = hdr[b];
-    LlfFromDcReg<CY, CX>(f.dc[c] + (size_t)h.aby * f.xsb + h.abx, f.xsb, &buf[c][b][0], LP);
+  // LLF step 2: lane i < CY takes row i of the half-transformed patch,
+  // horizontal CX-point DCT (x 1/CX), resample scale, store into the LLF corner
+  // (transposed when CY >= CX, like the rest of the coefficient matrix)
+  if (active && i < CY) {
+    float v[CX];
+#pragma unroll
+    for (int x = 0; x < CX; x++) v[x] = dp[i * CX + x];
+    DctReg<CX>(v);
+    const float ry = ResampleUpSel<CY>(i);
+#pragma unroll
+    for (int x = 0; x < CX; x++) {
+      const float val = (1.0f / CX) * v[x];
+      if constexpr (CY < CX) {
+        m[i * LP + x] = val * ry * kResampleUpHost[CX + x];
+      } else {
+        m[x * LP + i] = val * kResampleUpHost[CX + x] * ry;
+      }
+    }
   }
   __syncthreads();
   // pass 1: for each vertical frequency u, C-point IDCT along v -> T[u][x]
-  const int c = tid >> 6, lane = tid & 63;
-  const int b = lane / ML, i = lane % ML;
-  const bool active = b < nb;
-  float* m = &buf[c][active ? b : 0][0];
   {
     float v[C];
     if (active && i < R) {
@@ -574,7 +591,7 @@ __global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __re
 }
 
 // ------------------------------------------------------------------- k_large
-// Strategies 18..26 (64x64 .. 256x256).  One workgroup per varblock; 1-D
+// Strategies 21..26 (128x128 .. 256x256; legal but never emitted by libjxl).  One workgroup per varblock; 1-D
 // transforms of up to 256 points run on per-thread scratch arrays; the
 // intermediate T[u][x] is written into the varblock's own output rectangle.
 template <int N>
@@ -770,6 +787,9 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, const uint32_t
   JXLHIP_MEDIUM(5, 32, 16, 10)
   JXLHIP_MEDIUM(6, 16, 32, 11)
   JXLHIP_MEDIUM(7, 32, 32, 5)
+  JXLHIP_MEDIUM(8, 64, 64, 18)
+  JXLHIP_MEDIUM(9, 64, 32, 19)
+  JXLHIP_MEDIUM(10, 32, 64, 20)
 #undef JXLHIP_MEDIUM
   mark(mark_arg, 1);
   if (max_items[kClsLarge]) {
@@ -781,7 +801,12 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, const uint32_t
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
                    const SharpLut& lut, hipStream_t st) {
-  hipLaunchKernelGGL(k_prepare, dim3(f.xsg * f.group_rows), dim3(1024), 0, st, f, wl,
+  uint32_t lo = f.group_y0, hi = f.group_y0 + f.group_rows;
+  if (with_sigma) {  // one more group row on each side for the halo rows' sigma
+    if (lo > 0) lo--;
+    if (hi < f.ysg) hi++;
+  }
+  hipLaunchKernelGGL(k_prepare, dim3(f.xsg * (hi - lo)), dim3(1024), 0, st, f, wl, lo,
                      with_sigma, epf_quant_mul, lut);
 }
 

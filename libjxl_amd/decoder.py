@@ -31,7 +31,7 @@ class VarDctDecoder:
         _check(self.L, None, self.L.jxlhip_create(self.device, C.byref(self.ctx)), "jxlhip_create")
         if use_torch_stream:
             s = torch.cuda.current_stream(self.device).cuda_stream
-            _check(self.L, self.ctx, self.L.jxlhip_set_stream(self.ctx, C.c_void_p(s)), "set_stream")
+            _check(self.L, self.ctx, self.L.jxlhip_set_stream(self.ctx, C.c_void_p(s), 1), "set_stream")
         self.params = None
         self._keep = None
         self.out = None

@@ -71,7 +71,7 @@ def test_blocks_each_strategy(dec, dq, oracle, strategy):
     ys = max(264, 8 * cy + 8)
     if max(cx, cy) >= 16:
         xs, ys = 8 * cx + 256, 8 * cy
-    params, t, fr = frames.make_case(xs, ys, mix={strategy: 1.0, 0: 0.05}, gab=False,
+    params, t, fr = frames.make_case(xs, ys, mix={strategy: 3.0 * cx * cy, 0: 1.0}, gab=False,
                                      epf_iters=0, seed=1000 + strategy)
     acs = t["ac_strategy"].numpy()
     used = set((acs[(acs & 1) == 1] >> 1).tolist())
@@ -102,7 +102,7 @@ def test_blocks_mixed_sizes(dec, dq, oracle, size):
 
 def test_blocks_int32_coefficients(dec, dq, oracle):
     params, t, fr = frames.make_case(400, 300, mix=synth.MIX_ALL, gab=False, epf_iters=0,
-                                     coeff_type=1, amp=3000.0, decay=3.0, seed=11)
+                                     coeff_type=1, amp=200000.0, decay=3.0, seed=11)
     assert t["coeffs"][1].dtype == torch.int32
     assert int(t["coeffs"][1].abs().max()) > 32767  # really needs 32 bits
     dec.begin_frame(params)
