@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--coeff32", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also gather stripes on rank 0 each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--calib-copy", action="store_true",
+                    help="run one known-size (1 GiB) device copy so PMC passes can be calibrated")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=[4096, 2160])
     args = ap.parse_args()
 
@@ -110,6 +112,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.calib_copy:
+        a = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        del a, b
     for _ in range(args.warmup):
         step()
     dec.sync()  # also surfaces stream errors

@@ -187,15 +187,21 @@ JXLHIP_EXPORT int jxlhip_submit_group(jxlhip_ctx* ctx, uint32_t group_idx,
 JXLHIP_EXPORT int jxlhip_decode_blocks(jxlhip_ctx* ctx);
 
 /* Multi-GPU halo hand-off between phase 1 and 2.  Number of rows a stripe
- * needs from each neighbour = LoopFilter::Padding() (loop_filter.h:26-29). */
+ * needs from each neighbour = LoopFilter::Padding() (loop_filter.h:26-29):
+ * the GPU-side replacement of GroupBorderAssigner / SaveBorders / LoadBorders
+ * (lib/jxl/dec_group_border.cc:68-187, low_memory_render_pipeline.cc:832-934). */
 JXLHIP_EXPORT int jxlhip_halo_rows(const jxlhip_ctx* ctx);
-/* Device pointers to this stripe's rows to SEND (top/bottom `halo` rows of the
- * stripe's own XYB planes) and to the slots to RECEIVE the neighbours' rows
- * into; each region is 3 planes x halo rows, plane c at +c*plane_stride,
- * row stride *row_stride floats.  which: 0 send-up 1 send-down 2 recv-from-up
- * 3 recv-from-down. */
-JXLHIP_EXPORT int jxlhip_halo_region(jxlhip_ctx* ctx, int which, float** base,
-                                     size_t* row_stride, size_t* plane_stride);
+/* The XYB planes are kept block-major (8x8 tiles) in context memory, so halo
+ * rows travel through dense staging buffers: dev points to 3 * halo * xsize
+ * floats (channel-major, then row, then x) in device memory.
+ * export which: 0 = this stripe's first `halo` rows (to send UP),
+ *               1 = its last `halo` rows (to send DOWN);
+ * import which: 0 = rows received from the stripe ABOVE (placed just above
+ *               this stripe), 1 = rows received from BELOW.
+ * Both are asynchronous on the context's stream. */
+JXLHIP_EXPORT int jxlhip_halo_export(jxlhip_ctx* ctx, int which, float* dev);
+JXLHIP_EXPORT int jxlhip_halo_import(jxlhip_ctx* ctx, int which,
+                                     const float* dev);
 
 /* Phase 2, replaces the render pipeline stages Gaborish/EPF0/EPF1/EPF2/XYB
  * (+ float WriteToOutput) run by RenderPipeline::InputReady ->
@@ -216,9 +222,12 @@ JXLHIP_EXPORT int jxlhip_decode_frame(jxlhip_ctx* ctx, void* out,
 
 JXLHIP_EXPORT int jxlhip_sync(jxlhip_ctx* ctx);
 
-/* Debug/test taps on context-owned intermediates (device pointers). */
-JXLHIP_EXPORT int jxlhip_get_xyb_planes(jxlhip_ctx* ctx, float* planes[3],
-                                        size_t* row_stride, size_t* rows);
+/* Debug/test taps on context-owned intermediates (device pointers).
+ * export_xyb: row-major copy of the phase-1 result, rows [first row of the
+ * stripe, + its block-padded height) x xsize_blocks*8 columns, row stride
+ * dst_stride floats. */
+JXLHIP_EXPORT int jxlhip_export_xyb(jxlhip_ctx* ctx, float* const dst[3],
+                                    size_t dst_stride);
 JXLHIP_EXPORT int jxlhip_get_sigma(jxlhip_ctx* ctx, float** inv_sigma,
                                    size_t* row_stride);
 
@@ -228,10 +237,10 @@ JXLHIP_EXPORT int jxlhip_get_sigma(jxlhip_ctx* ctx, float** inv_sigma,
  * counts per kernel slot (see JXLHIP_KERNEL_*), then resets. */
 enum {
   JXLHIP_KERNEL_PREPARE = 0,  /* block-offset scan, work lists, sigma */
-  JXLHIP_KERNEL_BLOCKS_SMALL = 1,  /* dequant+CfL+inverse transform, 8x8 kinds */
-  JXLHIP_KERNEL_BLOCKS_MEDIUM = 2, /* 16x8 .. 32x32 */
-  JXLHIP_KERNEL_BLOCKS_LARGE = 3,  /* 64x32 .. 256x256 */
-  JXLHIP_KERNEL_FILTERS = 4,  /* fused Gaborish/EPF/XYB->RGB */
+  JXLHIP_KERNEL_BLOCKS = 1,   /* dequant+CfL+LLF+inverse transforms: one launch
+                                 per strategy class, overlapped on several
+                                 streams; the span covers all of them */
+  JXLHIP_KERNEL_FILTERS = 2,  /* fused Gaborish/EPF/XYB->RGB */
   JXLHIP_KERNEL_COUNT = 8
 };
 JXLHIP_EXPORT int jxlhip_profile_enable(jxlhip_ctx* ctx, int enable);

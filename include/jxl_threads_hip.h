@@ -1,0 +1,76 @@
+/*
+ * jxl_threads_hip.h -- the JxlParallelRunner of the MI355X back-end
+ * ("jxl_threads -> HIP stream pool").
+ *
+ * libjxl_threads_hip.so exports the SAME four symbols as libjxl_threads
+ * (lib/include/jxl/thread_parallel_runner.h:45-66, implemented in
+ * lib/threads/thread_parallel_runner.cc:68-109), with the same contract
+ * (lib/include/jxl/parallel_runner.h:105-129): init(opaque, num_threads) is
+ * called once on the calling thread and its non-zero result is returned;
+ * func(opaque, i, thread_id) is called exactly once for every i in
+ * [start_range, end_range) with thread_id < num_threads; the call blocks; the
+ * runner is not re-entrant.  An unmodified djxl / JxlDecoder user links it in
+ * place of libjxl_threads.
+ *
+ * What is different is what a worker IS: every worker thread owns one HIP
+ * stream of the pool (plus thread_id 0 = the calling thread), so host-side
+ * group tasks (entropy decode -> jxlhip_submit_group) issue their H2D copies
+ * on independent streams.  The declarations below mirror the reference's so
+ * this header can be used without libjxl's headers.
+ */
+#ifndef JXL_THREADS_HIP_H_
+#define JXL_THREADS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define JXL_THREADS_HIP_EXPORT __attribute__((visibility("default")))
+#else
+#define JXL_THREADS_HIP_EXPORT
+#endif
+
+#ifndef JXL_PARALLEL_RUNNER_H_
+typedef int JxlParallelRetCode;
+#define JXL_PARALLEL_RET_SUCCESS (0)
+#define JXL_PARALLEL_RET_RUNNER_ERROR (-1)
+typedef JxlParallelRetCode (*JxlParallelRunInit)(void* jpegxl_opaque, size_t num_threads);
+typedef void (*JxlParallelRunFunction)(void* jpegxl_opaque, uint32_t value, size_t thread_id);
+#endif
+
+#ifndef JXL_MEMORY_MANAGER_H_
+/* lib/include/jxl/memory_manager.h:45-63 */
+typedef void* (*jpegxl_alloc_func)(void* opaque, size_t size);
+typedef void (*jpegxl_free_func)(void* opaque, void* address);
+typedef struct JxlMemoryManagerStruct {
+  void* opaque;
+  jpegxl_alloc_func alloc;
+  jpegxl_free_func free;
+} JxlMemoryManager;
+#endif
+
+/* lib/threads/thread_parallel_runner.cc:68-75 */
+JXL_THREADS_HIP_EXPORT JxlParallelRetCode JxlThreadParallelRunner(
+    void* runner_opaque, void* jpegxl_opaque, JxlParallelRunInit init,
+    JxlParallelRunFunction func, uint32_t start_range, uint32_t end_range);
+/* :78-97 -- memory_manager: both callbacks NULL => malloc/free, exactly one
+ * NULL => NULL is returned (lib/threads/thread_parallel_runner.cc:37-53) */
+JXL_THREADS_HIP_EXPORT void* JxlThreadParallelRunnerCreate(
+    const JxlMemoryManager* memory_manager, size_t num_worker_threads);
+/* :99-105 */
+JXL_THREADS_HIP_EXPORT void JxlThreadParallelRunnerDestroy(void* runner_opaque);
+/* :107-109 */
+JXL_THREADS_HIP_EXPORT size_t JxlThreadParallelRunnerDefaultNumWorkerThreads(void);
+
+/* Extension: the hipStream_t owned by `thread_id` (0 = caller) of this runner,
+ * or NULL when no device is present (the runner itself works without one). */
+JXL_THREADS_HIP_EXPORT void* JxlHipParallelRunnerStream(void* runner_opaque, size_t thread_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -7,7 +7,7 @@ _SO = os.path.join(_HERE, "csrc", "libjxl_hip.so")
 _RUNNER_SO = os.path.join(_HERE, "csrc", "libjxl_threads_hip.so")
 
 KERNEL_COUNT = 8
-KERNEL_NAMES = ["prepare", "blocks_small", "blocks_medium", "blocks_large", "filters", "k5", "k6", "k7"]
+KERNEL_NAMES = ["prepare", "blocks", "filters", "k3", "k4", "k5", "k6", "k7"]
 
 
 class JxlHipError(RuntimeError):
@@ -89,8 +89,8 @@ EXPORTS = [
     "jxlhip_destroy", "jxlhip_last_error", "jxlhip_set_stream",
     "jxlhip_frame_begin", "jxlhip_frame_set_inputs", "jxlhip_upload_side_info",
     "jxlhip_submit_group", "jxlhip_decode_blocks", "jxlhip_halo_rows",
-    "jxlhip_halo_region", "jxlhip_decode_filters", "jxlhip_decode_frame",
-    "jxlhip_sync", "jxlhip_get_xyb_planes", "jxlhip_get_sigma",
+    "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_frame",
+    "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
     "jxlhip_profile_enable", "jxlhip_profile_read",
     "jxlhip_default_dequant_tables", "jxlhip_dequant_dc",
 ]
@@ -122,11 +122,12 @@ def load_library():
     L.jxlhip_submit_group.argtypes = [vp, u32, vp * 3, sz]
     L.jxlhip_decode_blocks.argtypes = [vp]
     L.jxlhip_halo_rows.argtypes = [vp]
-    L.jxlhip_halo_region.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+    L.jxlhip_halo_export.argtypes = [vp, i32, vp]
+    L.jxlhip_halo_import.argtypes = [vp, i32, vp]
     L.jxlhip_decode_filters.argtypes = [vp, vp, sz, sz]
     L.jxlhip_decode_frame.argtypes = [vp, vp, sz, sz]
     L.jxlhip_sync.argtypes = [vp]
-    L.jxlhip_get_xyb_planes.argtypes = [vp, vp * 3, C.POINTER(sz), C.POINTER(sz)]
+    L.jxlhip_export_xyb.argtypes = [vp, vp * 3, sz]
     L.jxlhip_get_sigma.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlhip_profile_enable.argtypes = [vp, i32]
     L.jxlhip_profile_read.argtypes = [vp, C.c_float * KERNEL_COUNT, u32 * KERNEL_COUNT]

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -17,6 +18,8 @@ using namespace jxlhip;
 namespace {
 
 constexpr int kPoolStreams = 4;
+constexpr int kMaxBlockStreams = 8;
+constexpr int kMaxBands = 64;
 
 struct ProfSpan {
   hipEvent_t a, b;
@@ -63,6 +66,13 @@ struct jxlhip_ctx {
   // dc scratch
   float* dc_tmp = nullptr;
   size_t dc_tmp_floats = 0;
+  // transform-kernel fan-out (JXLHIP_BLOCK_STREAMS, default 6; 1 = serialise on the main stream)
+  int nblock_streams = 6;
+  hipStream_t bstreams[kMaxBlockStreams] = {nullptr};
+  hipEvent_t bev[kMaxBlockStreams] = {nullptr};
+  hipEvent_t fork_ev = nullptr;
+  int band_rows = 4;  // JXLHIP_BAND_ROWS: group rows per band of decode_frame (0 = whole stripe)
+  bool generic_filters = false;  // JXLHIP_FILTERS=generic: LDS kernel for every stage list
   // profiling
   bool profiling = false;
   std::vector<ProfSpan> spans;
@@ -128,11 +138,6 @@ void ProfEnd(jxlhip_ctx* c) {
   c->prof_prev = nullptr;
 }
 
-void BlocksMark(void* arg, int sub) {
-  jxlhip_ctx* c = (jxlhip_ctx*)arg;
-  ProfMark(c, JXLHIP_KERNEL_BLOCKS_SMALL + sub);
-}
-
 }  // namespace
 
 extern "C" {
@@ -181,6 +186,17 @@ int jxlhip_create(int device, jxlhip_ctx** out) {
   jxlhip_ctx* c = new (std::nothrow) jxlhip_ctx();
   if (!c) return JXLHIP_ERR_OUT_OF_MEMORY;
   c->device = device;
+  {
+    const char* e = getenv("JXLHIP_FILTERS");
+    c->generic_filters = e && !strcmp(e, "generic");
+    const char* b = getenv("JXLHIP_BLOCK_STREAMS");
+    if (b) c->nblock_streams = atoi(b);
+    const char* br = getenv("JXLHIP_BAND_ROWS");
+    if (br) c->band_rows = atoi(br);
+    if (c->band_rows < 0) c->band_rows = 0;
+    if (c->nblock_streams < 1) c->nblock_streams = 1;
+    if (c->nblock_streams > kMaxBlockStreams) c->nblock_streams = kMaxBlockStreams;
+  }
   auto fail = [&](int code) {
     jxlhip_destroy(c);
     return code;
@@ -194,7 +210,14 @@ int jxlhip_create(int device, jxlhip_ctx** out) {
         hipEventCreateWithFlags(&c->pool_ev[i], hipEventDisableTiming) != hipSuccess)
       return fail(JXLHIP_ERR_HIP);
   }
-  if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kNumClasses) != hipSuccess ||
+  for (int i = 0; i < c->nblock_streams; i++) {
+    if (hipStreamCreateWithFlags(&c->bstreams[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->bev[i], hipEventDisableTiming) != hipSuccess)
+      return fail(JXLHIP_ERR_HIP);
+  }
+  if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess)
+    return fail(JXLHIP_ERR_HIP);
+  if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kNumClasses * kMaxBands) != hipSuccess ||
       hipMalloc((void**)&c->error_flag, sizeof(int32_t) * 2) != hipSuccess ||
       hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64)) != hipSuccess)
     return fail(JXLHIP_ERR_OUT_OF_MEMORY);
@@ -223,6 +246,14 @@ void jxlhip_destroy(jxlhip_ctx* c) {
     }
     if (c->pool_ev[i]) (void)hipEventDestroy(c->pool_ev[i]);
   }
+  for (int i = 0; i < kMaxBlockStreams; i++) {
+    if (c->bstreams[i]) {
+      (void)hipStreamSynchronize(c->bstreams[i]);
+      (void)hipStreamDestroy(c->bstreams[i]);
+    }
+    if (c->bev[i]) (void)hipEventDestroy(c->bev[i]);
+  }
+  if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_coeffs[1],
                   c->up_coeffs[2], c->up_side, c->dc_tmp};
@@ -269,6 +300,10 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   f.y0 = f.group_y0 * 256;
   f.y1 = (f.group_y0 + f.group_rows) * 256;
   if (f.y1 > f.ysize) f.y1 = f.ysize;
+  f.fy0 = f.y0;
+  f.fy1 = f.y1;
+  f.band_g0 = f.group_y0;
+  f.band_g1 = f.group_y0 + f.group_rows;
   static const uint32_t kEpfPad[4] = {0, 2, 3, 6};  // loop_filter.h:26-29
   f.halo = kEpfPad[p->lf.epf_iters] + p->lf.gab;
   f.coeff_type = p->coeff_type;
@@ -280,31 +315,37 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   f.cfl_base_x = p->cfl_base_x;
   f.cfl_base_b = p->cfl_base_b;
   f.color_scale = 1.0f / (float)p->cfl_color_factor;
-  // XYB planes: stripe rows padded to whole blocks + halo rows on both sides
+  // XYB planes, block-major: the stripe's block rows plus one tile row above
+  // and below for the halo rows (halo <= 7 < 8)
   const uint32_t rows_blocks = (f.group_y0 + f.group_rows) * 32 > f.ysb
                                    ? f.ysb * 8 - f.y0
                                    : f.group_rows * 256;
-  f.plane_stride = (f.xsb * 8 + 63) & ~63u;
-  f.plane_y0 = (int32_t)f.y0 - (int32_t)f.halo;
-  f.plane_rows = rows_blocks + 2 * f.halo;
-  const size_t plane_floats = (size_t)f.plane_rows * f.plane_stride;
+  f.tile_stride = (f.xsb + 1) & ~1u;
+  f.plane_y0 = (int32_t)f.y0 - 8;
+  f.plane_tile_rows = rows_blocks / 8 + 2;
+  const size_t plane_floats = (size_t)f.plane_tile_rows * f.tile_stride * 64;
   int rc;
   if ((rc = Grow(c, &c->planes, &c->planes_floats, 3 * plane_floats))) return rc;
   for (int ch = 0; ch < 3; ch++) f.xyb[ch] = c->planes + ch * plane_floats;
   if ((rc = Grow(c, &c->inv_sigma, &c->sigma_floats, (size_t)f.xsb * f.ysb))) return rc;
   f.inv_sigma = c->inv_sigma;
   f.error_flag = c->error_flag;
+  {
+    const char* e = getenv("JXLHIP_DEBUG");
+    f.debug = e ? (uint32_t)atoi(e) : 0;
+  }
   // work lists, worst case per class
   const size_t cells = (size_t)f.xsg * f.group_rows * 1024;
   size_t total = 0;
   size_t offs[kNumClasses];
   for (int k = 0; k < kNumClasses; k++) {
     offs[k] = total;
-    const size_t m = cells / kClassMinCovered[k];
+    const size_t m = cells / ClassMinCovered(k);
     c->max_items[k] = (uint32_t)m;
     total += m;
   }
-  if ((rc = Grow(c, &c->lists, &c->lists_items, total))) return rc;
+  // +64: transform kernels fetch their list entry before they know the count
+  if ((rc = Grow(c, &c->lists, &c->lists_items, total + 64))) return rc;
   for (int k = 0; k < kNumClasses; k++) c->wl.list[k] = c->lists + offs[k];
   c->wl.count = c->counts;
   // stage parameters, computed as the reference stages do
@@ -485,10 +526,64 @@ int jxlhip_submit_group(jxlhip_ctx* c, uint32_t group_idx, const void* const coe
 }
 
 // ---- decode -------------------------------------------------------------------
-int jxlhip_decode_blocks(jxlhip_ctx* c) {
-  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+namespace {
+
+// k_prepare + the transform kernels for group rows [g0, g1) of the stripe,
+// using counter slot `band`.
+int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band) {
+  hipStream_t st = c->stream;
+  DevFrame f = c->f;
+  f.band_g0 = g0;
+  f.band_g1 = g1;
+  WorkLists wl = c->wl;
+  wl.count = c->counts + (size_t)band * kNumClasses;
+  uint32_t max_items[kNumClasses];
+  const size_t cells = (size_t)f.xsg * (g1 - g0) * 1024;
+  for (int k = 0; k < kNumClasses; k++) max_items[k] = (uint32_t)(cells / ClassMinCovered(k));
+  ProfBegin(c);
+  LaunchPrepare(f, wl, c->p.lf.epf_iters > 0, c->p.lf.epf_quant_mul, c->lut, st);
+  ProfMark(c, JXLHIP_KERNEL_PREPARE);
+  if (c->nblock_streams > 1) {
+    // fork: the class kernels wait for k_prepare, run side by side, and the
+    // main stream joins them all before anything that reads the planes
+    HIPCHK(c, hipEventRecord(c->fork_ev, st));
+    for (int i = 0; i < c->nblock_streams; i++)
+      HIPCHK(c, hipStreamWaitEvent(c->bstreams[i], c->fork_ev, 0));
+    LaunchBlocks(f, wl, max_items, c->tables, c->tables + 512, c->bstreams, c->nblock_streams);
+    for (int i = 0; i < c->nblock_streams; i++) {
+      HIPCHK(c, hipEventRecord(c->bev[i], c->bstreams[i]));
+      HIPCHK(c, hipStreamWaitEvent(st, c->bev[i], 0));
+    }
+  } else {
+    LaunchBlocks(f, wl, max_items, c->tables, c->tables + 512, &st, 1);
+  }
+  ProfMark(c, JXLHIP_KERNEL_BLOCKS);
+  ProfEnd(c);
+  HIPCHK(c, hipGetLastError());
+  return JXLHIP_OK;
+}
+
+// phase 2 for pixel rows [fy0, fy1) of the stripe
+int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint32_t fy1) {
+  DevFrame f = c->f;
+  f.fy0 = fy0;
+  f.fy1 = fy1;
+  ProfBegin(c);
+  const bool fast = !c->generic_filters && fy1 > fy0 &&
+                    LaunchFiltersFast(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters,
+                                      (int)c->p.output_kind, c->stream);
+  if (!fast && LaunchFilters(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters,
+                             (int)c->p.output_kind, c->stream) != 0)
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "unsupported filter configuration");
+  ProfMark(c, JXLHIP_KERNEL_FILTERS);
+  ProfEnd(c);
+  HIPCHK(c, hipGetLastError());
+  return JXLHIP_OK;
+}
+
+int BeginDecode(jxlhip_ctx* c) {
   if (!c->have_frame || !c->have_inputs)
-    return Fail(c, JXLHIP_ERR_STATE, "decode_blocks needs frame_begin + inputs");
+    return Fail(c, JXLHIP_ERR_STATE, "decode needs frame_begin + inputs");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->stream;
   {
@@ -500,13 +595,31 @@ int jxlhip_decode_blocks(jxlhip_ctx* c) {
       c->pool_dirty[i] = false;
     }
   }
-  HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kNumClasses, st));
-  ProfBegin(c);
-  LaunchPrepare(c->f, c->wl, c->p.lf.epf_iters > 0, c->p.lf.epf_quant_mul, c->lut, st);
-  ProfMark(c, JXLHIP_KERNEL_PREPARE);
-  LaunchBlocks(c->f, c->wl, c->max_items, c->tables, c->tables + 512, st, BlocksMark, c);
-  ProfEnd(c);
-  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kNumClasses * kMaxBands, st));
+  return JXLHIP_OK;
+}
+
+int CheckOutArgs(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
+  const DevFrame& f = c->f;
+  if (!out) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "null output");
+  if (c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32) {
+    if (out_stride < (size_t)f.xsize * 12 || (out_stride & 3))
+      return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "RGB row stride %zu too small", out_stride);
+  } else if (out_stride < f.xsize ||
+             out_plane_stride < out_stride * (size_t)(f.y1 - f.y0 - 1) + f.xsize) {
+    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "XYB strides too small");
+  }
+  return JXLHIP_OK;
+}
+
+}  // namespace
+
+int jxlhip_decode_blocks(jxlhip_ctx* c) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  int rc = BeginDecode(c);
+  if (rc) return rc;
+  rc = LaunchBlocksBand(c, c->f.group_y0, c->f.group_y0 + c->f.group_rows, 0);
+  if (rc) return rc;
   c->blocks_done = true;
   return JXLHIP_OK;
 }
@@ -516,58 +629,81 @@ int jxlhip_halo_rows(const jxlhip_ctx* c) {
   return (int)c->f.halo;
 }
 
-int jxlhip_halo_region(jxlhip_ctx* c, int which, float** base, size_t* row_stride,
-                       size_t* plane_stride) {
-  if (!c || !base || !row_stride || !plane_stride || which < 0 || which > 3)
-    return JXLHIP_ERR_INVALID_ARGUMENT;
-  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "halo_region before frame_begin");
+static int HaloCopy(jxlhip_ctx* c, int which, float* dev, bool to_dense) {
+  if (!c || !dev || which < 0 || which > 1) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "halo copy before frame_begin");
   const DevFrame& f = c->f;
   const uint32_t stripe_rows = f.y1 - f.y0;
   if (f.halo > stripe_rows)
     return Fail(c, JXLHIP_ERR_STATE, "stripe of %u rows is shorter than the %u-row halo",
                 stripe_rows, f.halo);
-  uint32_t row;  // plane row index
-  switch (which) {
-    case 0: row = f.halo; break;                          // send up: first rows of the stripe
-    case 1: row = f.halo + stripe_rows - f.halo; break;   // send down: last rows
-    case 2: row = 0; break;                               // recv from above
-    default: row = f.halo + stripe_rows; break;           // recv from below
-  }
-  *base = f.xyb[0] + (size_t)row * f.plane_stride;
-  *row_stride = f.plane_stride;
-  *plane_stride = (size_t)f.plane_rows * f.plane_stride;
+  if (f.halo == 0) return JXLHIP_OK;
+  int y_first;
+  if (to_dense) y_first = which == 0 ? (int)f.y0 : (int)(f.y1 - f.halo);
+  else y_first = which == 0 ? (int)f.y0 - (int)f.halo : (int)f.y1;
+  if (y_first < 0 || y_first + (int)f.halo > (int)f.ysize)
+    return Fail(c, JXLHIP_ERR_STATE, "no neighbouring stripe on that side");
+  HIPCHK(c, hipSetDevice(c->device));
+  LaunchRowsCopy(f, dev, y_first, (int)f.halo, (int)f.xsize, f.xsize,
+                 (size_t)f.halo * f.xsize, 3, to_dense, c->stream);
+  HIPCHK(c, hipGetLastError());
   return JXLHIP_OK;
 }
 
+int jxlhip_halo_export(jxlhip_ctx* c, int which, float* dev) {
+  if (c && !c->blocks_done) return Fail(c, JXLHIP_ERR_STATE, "halo_export before decode_blocks");
+  return HaloCopy(c, which, dev, true);
+}
+
+int jxlhip_halo_import(jxlhip_ctx* c, int which, const float* dev) {
+  return HaloCopy(c, which, const_cast<float*>(dev), false);
+}
+
 int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
-  if (!c || !out) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->blocks_done) return Fail(c, JXLHIP_ERR_STATE, "decode_filters before decode_blocks");
-  const DevFrame& f = c->f;
-  if (c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32) {
-    if (out_stride < (size_t)f.xsize * 12 || (out_stride & 3))
-      return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "RGB row stride %zu too small", out_stride);
-  } else if (out_stride < f.xsize || out_plane_stride < out_stride * (size_t)(f.y1 - f.y0 - 1) + f.xsize) {
-    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "XYB strides too small");
-  }
+  int rc = CheckOutArgs(c, out, out_stride, out_plane_stride);
+  if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
   FilterParams fp = c->fp;
   fp.out = out;
   fp.out_stride = out_stride;
   fp.out_plane_stride = out_plane_stride;
-  ProfBegin(c);
-  if (LaunchFilters(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind,
-                    c->stream) != 0)
-    return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "unsupported filter configuration");
-  ProfMark(c, JXLHIP_KERNEL_FILTERS);
-  ProfEnd(c);
-  HIPCHK(c, hipGetLastError());
-  return JXLHIP_OK;
+  return LaunchFiltersRows(c, fp, c->f.y0, c->f.y1);
 }
 
+// Both phases.  The stripe is walked in bands of `band_rows` group rows:
+// blocks(b) then filters(b-1), so that the XYB planes of a band are consumed
+// while they are still resident in the 256 MB Infinity Cache instead of making
+// a round trip through HBM (JXLHIP_BAND_ROWS, 0 = one band).
 int jxlhip_decode_frame(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
-  int rc = jxlhip_decode_blocks(c);
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  int rc = BeginDecode(c);
   if (rc) return rc;
-  return jxlhip_decode_filters(c, out, out_stride, out_plane_stride);
+  rc = CheckOutArgs(c, out, out_stride, out_plane_stride);
+  if (rc) return rc;
+  const DevFrame& f = c->f;
+  FilterParams fp = c->fp;
+  fp.out = out;
+  fp.out_stride = out_stride;
+  fp.out_plane_stride = out_plane_stride;
+  uint32_t br = c->band_rows ? (uint32_t)c->band_rows : f.group_rows;
+  while ((f.group_rows + br - 1) / br > (uint32_t)kMaxBands) br++;
+  const uint32_t g_end = f.group_y0 + f.group_rows;
+  uint32_t prev_y0 = f.y0;
+  int band = 0;
+  for (uint32_t g0 = f.group_y0; g0 < g_end; g0 += br, band++) {
+    const uint32_t g1 = g0 + br < g_end ? g0 + br : g_end;
+    rc = LaunchBlocksBand(c, g0, g1, band);
+    if (rc) return rc;
+    if (g0 > f.group_y0) {  // rows of the previous band: its lower halo now exists
+      rc = LaunchFiltersRows(c, fp, prev_y0, g0 * 256);
+      if (rc) return rc;
+      prev_y0 = g0 * 256;
+    }
+  }
+  c->blocks_done = true;
+  return LaunchFiltersRows(c, fp, prev_y0, f.y1);
 }
 
 int jxlhip_sync(jxlhip_ctx* c) {
@@ -588,12 +724,20 @@ int jxlhip_sync(jxlhip_ctx* c) {
 }
 
 // ---- taps ------------------------------------------------------------------------
-int jxlhip_get_xyb_planes(jxlhip_ctx* c, float* planes[3], size_t* row_stride, size_t* rows) {
-  if (!c || !planes || !row_stride || !rows) return JXLHIP_ERR_INVALID_ARGUMENT;
+int jxlhip_export_xyb(jxlhip_ctx* c, float* const dst[3], size_t dst_stride) {
+  if (!c || !dst || !dst[0] || !dst[1] || !dst[2]) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "no frame");
-  for (int ch = 0; ch < 3; ch++) planes[ch] = c->f.xyb[ch];
-  *row_stride = c->f.plane_stride;
-  *rows = c->f.plane_rows;
+  const DevFrame& f = c->f;
+  const int rows = (int)(f.plane_tile_rows - 2) * 8;
+  if (dst_stride < (size_t)f.xsb * 8) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "stride too small");
+  HIPCHK(c, hipSetDevice(c->device));
+  // the three destination planes may be separate allocations: one launch each
+  for (int ch = 0; ch < 3; ch++) {
+    DevFrame g = f;
+    g.xyb[0] = f.xyb[ch];
+    LaunchRowsCopy(g, dst[ch], (int)f.y0, rows, (int)f.xsb * 8, dst_stride, 0, 1, true, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
   return JXLHIP_OK;
 }
 

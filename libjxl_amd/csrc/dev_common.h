@@ -37,32 +37,54 @@ __host__ __device__ constexpr uint32_t DequantOffset(int strategy) {
   return pos;
 }
 
-// Work classes: one compacted varblock list per class, built by k_prepare.
+// Work classes: one compacted varblock list per class, built by k_prepare, so
+// that every wave of the transform kernels runs ONE strategy.
+static constexpr int kNumSpecial = 9;
 static constexpr int kNumMedium = 11;
 enum WorkClass : int {
-  kClsDct8 = 0,     // strategy 0
-  kClsSpecial = 1,  // 1,2,3,12..17 (single 8x8 block, non-DCT8)
-  kClsMedium0 = 2,  // kNumMedium medium kinds follow, see kMediumStrategy
-  kClsLarge = kClsMedium0 + kNumMedium,  // 21..26 (any side >= 128)
+  kClsDct8 = 0,      // strategy 0
+  kClsSpecial0 = 1,  // kNumSpecial single-block kinds follow, see kSpecialStrategy
+  kClsMedium0 = kClsSpecial0 + kNumSpecial,  // kNumMedium kinds, see kMediumStrategy
+  kClsLarge = kClsMedium0 + kNumMedium,      // 21..26 (any side >= 128)
   kNumClasses = kClsLarge + 1
 };
+static constexpr uint8_t kSpecialStrategy[kNumSpecial] = {1, 2, 3, 12, 13, 14, 15, 16, 17};
 // medium class index -> strategy (16x8 .. 64x64)
 static constexpr uint8_t kMediumStrategy[kNumMedium] = {6, 7, 4, 8, 9, 10, 11, 5, 18, 19, 20};
 __host__ __device__ constexpr int ClassOfStrategy(int s) {
   if (s == 0) return kClsDct8;
-  if (s <= 3 || (s >= 12 && s <= 17)) return kClsSpecial;
   if (s >= 21) return kClsLarge;
+  for (int i = 0; i < kNumSpecial; i++)
+    if (kSpecialStrategy[i] == s) return kClsSpecial0 + i;
   for (int i = 0; i < kNumMedium; i++)
     if (kMediumStrategy[i] == s) return kClsMedium0 + i;
   return -1;
 }
+// class -> strategy LUT for device code (runtime strategy index)
+struct ClassLut {
+  int8_t v[27];
+};
+__host__ __device__ constexpr ClassLut MakeClassLut() {
+  ClassLut l{};
+  for (int s = 0; s < 27; s++) l.v[s] = (int8_t)ClassOfStrategy(s);
+  return l;
+}
+static constexpr ClassLut kClassLut = MakeClassLut();
 // worst-case entries per block cell of each class = 1/covered_blocks
-static constexpr uint16_t kClassMinCovered[kNumClasses] = {1, 1, 2, 2,  4,  4,  4,
-                                                           8, 8, 16, 64, 32, 32, 128};
+__host__ __device__ constexpr uint32_t ClassMinCovered(int cls) {
+  if (cls < kClsMedium0) return 1;
+  if (cls == kClsLarge) return 128;
+  const int s = kMediumStrategy[cls - kClsMedium0];
+  return (uint32_t)kCoveredX[s] * kCoveredY[s];
+}
 
-struct WorkItem {
+// 16-byte self-contained work item: a transform kernel needs no other per-block
+// side info (one dependent load less on its critical path).
+struct __attribute__((aligned(16))) WorkItem {
   uint32_t pos;  // (aby << 16) | abx : absolute block coordinates
   uint32_t off;  // group*1024 + offset/64 into the coefficient stream
+  uint32_t qc;   // raw_quant | (ytox & 0xff) << 16 | (ytob & 0xff) << 24 (tile of the first block)
+  uint32_t pad;
 };
 
 // Per-frame kernel arguments (by value).
@@ -73,6 +95,8 @@ struct DevFrame {
   uint32_t xtiles;            // colour tiles per row
   uint32_t group_y0, group_rows;  // stripe (in groups)
   uint32_t y0, y1;            // stripe rows [y0, y1) in pixels (y1 clipped to ysize)
+  uint32_t fy0, fy1;          // rows the filter launch writes (a band of the stripe)
+  uint32_t band_g0, band_g1;  // group rows whose work lists k_prepare builds
   uint32_t halo;              // LoopFilter::Padding()
   uint32_t coeff_type;
   float inv_global_scale, quant_scale;
@@ -88,18 +112,33 @@ struct DevFrame {
   const int8_t* ytob;
   const float* dc[3];
   const float* dequant;
-  // intermediates: XYB planes hold rows [plane_y0, plane_y0 + plane_rows)
+  // intermediates: XYB planes in BLOCK-MAJOR layout: 8x8 tiles of 64 floats
+  // (256 bytes = two full cache lines), tiles row-major with `tile_stride`
+  // tiles per tile row.  Every varblock writes whole tiles, whatever its
+  // strategy class, so each cache line / DRAM burst is written by one
+  // workgroup at one time; the filter kernels read tile rows sequentially.
+  // Rows covered: [plane_y0, plane_y0 + 8 * plane_tile_rows), plane_y0 = y0 - 8.
   float* xyb[3];
-  uint32_t plane_stride;  // floats per row (>= xsb*8)
-  int32_t plane_y0;       // pixel row of plane row 0 (= y0 - halo, may be < 0)
-  uint32_t plane_rows;
+  uint32_t tile_stride;      // tiles per tile row (>= xsb)
+  int32_t plane_y0;          // pixel row of the first tile row (multiple of 8; y0 - 8)
+  uint32_t plane_tile_rows;
   float* inv_sigma;       // xsb*ysb, whole frame indexing
   int32_t* error_flag;
+  uint32_t debug;  // JXLHIP_DEBUG ablation bits (1: no block stores, 2: all blocks read stream offset 0)
 };
 
-__device__ __forceinline__ float* PlanePtr(const DevFrame& f, int c, uint32_t y,
-                                           uint32_t x) {
-  return f.xyb[c] + (size_t)((int32_t)y - f.plane_y0) * f.plane_stride + x;
+// address of pixel (y, x) of channel c in the block-major planes
+__device__ __forceinline__ size_t PlaneOffset(const DevFrame& f, int y, int x) {
+  const uint32_t ry = (uint32_t)(y - f.plane_y0);
+  return ((size_t)(ry >> 3) * f.tile_stride + ((uint32_t)x >> 3)) * 64u + ((ry & 7u) << 3) +
+         ((uint32_t)x & 7u);
+}
+__device__ __forceinline__ float* PlanePtr(const DevFrame& f, int c, uint32_t y, uint32_t x) {
+  return f.xyb[c] + PlaneOffset(f, (int)y, (int)x);
+}
+// first float of the tile holding block (aby, abx)
+__device__ __forceinline__ float* TilePtr(const DevFrame& f, int c, uint32_t aby, uint32_t abx) {
+  return f.xyb[c] + ((size_t)((int)aby - (f.plane_y0 >> 3)) * f.tile_stride + abx) * 64u;
 }
 
 // ---- in-register 1-D transforms (lib/jxl/dct-inl.h:158-232) --------------

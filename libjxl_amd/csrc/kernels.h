@@ -31,14 +31,22 @@ struct FilterParams {
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
                    const SharpLut& lut, hipStream_t st);
-// mark(arg, i) is called after the launches of sub-phase i (0 small, 1 medium,
-// 2 large) so the caller can record profiling events.
+// One launch per work class, spread round-robin over `streams`.
 void LaunchBlocks(const DevFrame& f, const WorkLists& wl, const uint32_t* max_items,
-                  const float* wc, const float* resample, hipStream_t st,
-                  void (*mark)(void*, int), void* mark_arg);
+                  const float* wc, const float* resample, hipStream_t* streams, int nstreams);
 // Returns 0, or -1 when the (gab, epf_iters, output_kind) combination is invalid.
 int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                   int output_kind, hipStream_t st);
+
+// Register/DPP kernel for stage lists with at most one EPF pass; returns false
+// when the configuration is not covered (caller falls back to LaunchFilters).
+bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
+                       int output_kind, hipStream_t st);
+
+// block-major plane rows <-> dense row-major staging
+void LaunchRowsCopy(const DevFrame& f, float* dense, int y_first, int nrows, int ncols,
+                    size_t dense_stride, size_t dense_plane, int nch, bool to_dense,
+                    hipStream_t st);
 
 // a5 / a8 helpers
 void LaunchDefaultDequant(float* table, int32_t* status, hipStream_t st);

@@ -3,8 +3,9 @@
 //                 (the block walk of DecodeGroupImpl, lib/jxl/dec_group.cc:275-359,
 //                 turned into a data-parallel scan) and ComputeSigma
 //                 (lib/jxl/epf.cc:39-133)
-//   k_dct8      : dequant + CfL + 8x8 IDCT, one thread per block, in registers
-//   k_special   : IDENTITY / DCT2X2 / DCT4X4 / DCT4X8 / DCT8X4 / AFV0-3
+//   k_block64   : single-block strategies (DCT8 and IDENTITY / DCT2X2 / DCT4X4 /
+//                 DCT4X8 / DCT8X4 / AFV0-3): dequant + CfL + inverse transform, one
+//                 lane per block in registers, wave-cooperative LDS-staged I/O
 //   k_medium    : 16x8 .. 64x64, LDS-staged, one lane per 1-D transform
 //   k_large     : 128x64 .. 256x256, output plane used as scratch
 // replacing DequantBlock + LowestFrequenciesFromDC + TransformToPixels
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   const uint32_t gy = gy_lo + blockIdx.x / f.xsg;
   // groups just outside the stripe only contribute their sigma cells (the EPF
   // stages evaluate halo rows of the neighbouring stripes)
-  const bool in_stripe = gy >= f.group_y0 && gy < f.group_y0 + f.group_rows;
+  const bool in_stripe = gy >= f.band_g0 && gy < f.band_g1;
   const uint32_t g = gy * f.xsg + gx;
   const uint32_t bx0 = gx * 32, by0 = gy * 32;
   const uint32_t gw = min(32u, f.xsb - bx0), gh = min(32u, f.ysb - by0);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   }
   if (lane == 63) wave_tot[wave] = incl;
   // per-wave class histogram
-  const int cls = first ? ClassOfStrategy((int)s) : -1;
+  const int cls = first ? (int)kClassLut.v[s] : -1;
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t rank_in_wave = 0;
 #pragma unroll
@@ -107,6 +108,10 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     WorkItem it;
     it.pos = (aby << 16) | abx;
     it.off = g * 1024u + off64;
+    const size_t tile = (size_t)(aby >> 3) * f.xtiles + (abx >> 3);
+    it.qc = ((uint32_t)f.raw_quant[(size_t)aby * f.xsb + abx] & 0xffffu) |
+            ((uint32_t)(uint8_t)f.ytox[tile] << 16) | ((uint32_t)(uint8_t)f.ytob[tile] << 24);
+    it.pad = 0;
     wl.list[cls][pos] = it;
   }
   // ComputeSigma (epf.cc:69-79), one cell per thread
@@ -129,55 +134,15 @@ __device__ __forceinline__ BlockHdr MakeHdr(const DevFrame& f, const WorkItem it
   BlockHdr h;
   h.abx = it.pos & 0xffffu;
   h.aby = it.pos >> 16;
-  h.coef = (size_t)it.off * 64u;
-  const int quant = f.raw_quant[(size_t)h.aby * f.xsb + h.abx];
+  h.coef = (f.debug & 2) ? 0 : (size_t)it.off * 64u;
+  const int quant = (int)(it.qc & 0xffffu);
   const float s = f.inv_global_scale / (float)quant;  // dec_group.cc:164
   h.sx = s * f.x_dm;
   h.sy = s;
   h.sb = s * f.b_dm;
-  const size_t tile = (size_t)(h.aby >> 3) * f.xtiles + (h.abx >> 3);
-  h.x_cc = f.cfl_base_x + (float)f.ytox[tile] * f.color_scale;
-  h.b_cc = f.cfl_base_b + (float)f.ytob[tile] * f.color_scale;
+  h.x_cc = f.cfl_base_x + (float)(int8_t)((it.qc >> 16) & 0xffu) * f.color_scale;
+  h.b_cc = f.cfl_base_b + (float)(int8_t)(it.qc >> 24) * f.color_scale;
   return h;
-}
-
-// 64 consecutive coefficients of one channel -> registers
-template <typename CT>
-__device__ __forceinline__ void Load64(const void* base, size_t off, int32_t* q) {
-  if constexpr (sizeof(CT) == 2) {
-    const uint4* p = (const uint4*)((const int16_t*)base + off);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const uint4 v = p[i];
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        q[i * 8 + 2 * j] = (int32_t)(int16_t)(w[j] & 0xffffu);
-        q[i * 8 + 2 * j + 1] = (int32_t)w[j] >> 16;
-      }
-    }
-  } else {
-    const int4* p = (const int4*)((const int32_t*)base + off);
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int4 v = p[i];
-      q[i * 4] = v.x;
-      q[i * 4 + 1] = v.y;
-      q[i * 4 + 2] = v.z;
-      q[i * 4 + 3] = v.w;
-    }
-  }
-}
-
-__device__ __forceinline__ void StoreBlock8x8(const DevFrame& f, int c,
-                                              const BlockHdr& h, const float* px) {
-  float* dst = PlanePtr(f, c, h.aby * 8, h.abx * 8);
-#pragma unroll
-  for (int y = 0; y < 8; y++) {
-    float4* d = (float4*)(dst + (size_t)y * f.plane_stride);
-    d[0] = make_float4(px[y * 8], px[y * 8 + 1], px[y * 8 + 2], px[y * 8 + 3]);
-    d[1] = make_float4(px[y * 8 + 4], px[y * 8 + 5], px[y * 8 + 6], px[y * 8 + 7]);
-  }
 }
 
 // ------------------------------------------------- single-block transforms
@@ -359,78 +324,175 @@ __device__ __forceinline__ void Transform64(const float* co, float* px) {
   }
 }
 
-// Dequantises the 64 coefficients of one single-block varblock and runs its
-// transform for the three channels (DequantLane, dec_group.cc:115-153).
+// ---- wave-cooperative staging for the single-block kernels ----------------
+// One lane decodes one 8x8 varblock in registers, but a lane-per-block global
+// access pattern touches 64 different cache lines per instruction.  So the
+// WAVE moves the data: 8 (int16) or 16 (int32) lanes fetch one block's
+// coefficients as whole 128-byte lines into LDS (XOR-swizzled so both sides
+// stay conflict-light), each lane then reads its own block from LDS; the 8x8
+// results go back through LDS so that every store instruction writes 64
+// 16-byte pieces that tile 32 half block-rows of the output.
+template <typename CT>
+struct Stage64 {
+  static constexpr int kChunks = sizeof(CT) * 64 / 16;  // 16-byte chunks per block: 8 / 16
+  static constexpr int kInChunks = 64 * kChunks;        // one channel of 64 blocks
+  // int16: both channels a wave needs are gathered at once (2 x 8 KB); the
+  // 16 KB result staging aliases them.  int32: one channel at a time (16 KB).
+  static constexpr bool kBothInFlight = sizeof(CT) == 2;
+  static constexpr int kLdsChunks = 1024;               // per wave: 16 KB
+};
+
+// issue the gather of channel c of the wave's 64 blocks into `buf`
+template <typename CT>
+__device__ __forceinline__ void WaveGather64(const DevFrame& f, int c, const uint32_t* blk_off,
+                                             uint4* buf, int lane) {
+  using S = Stage64<CT>;
+  constexpr int kBlocksPerInstr = 64 / S::kChunks;
+  const int sub = lane / S::kChunks, chunk = lane % S::kChunks;
+  const char* base = (const char*)f.coeffs[c];
+  uint4 v[S::kChunks];
+#pragma unroll
+  for (int i = 0; i < S::kChunks; i++) {
+    const size_t byte = (size_t)blk_off[i] * (64 * sizeof(CT)) + (size_t)chunk * 16;
+    v[i] = *(const uint4*)(base + byte);
+  }
+#pragma unroll
+  for (int i = 0; i < S::kChunks; i++) {
+    const int blk = i * kBlocksPerInstr + sub;
+    buf[blk * S::kChunks + (chunk ^ (blk & (S::kChunks - 1)))] = v[i];
+  }
+}
+
+// this lane's block of the gathered channel -> q[64]
+template <typename CT>
+__device__ __forceinline__ void WaveFetch64(const uint4* buf, int lane, int32_t* q) {
+  using S = Stage64<CT>;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < S::kChunks; i++) {
+    const uint4 v = buf[lane * S::kChunks + (i ^ (lane & (S::kChunks - 1)))];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (sizeof(CT) == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        q[i * 8 + 2 * j] = (int32_t)(int16_t)(w[j] & 0xffffu);
+        q[i * 8 + 2 * j + 1] = (int32_t)w[j] >> 16;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) q[i * 4 + j] = (int32_t)w[j];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// px[64] of this lane's block -> LDS -> global.  The planes are block-major
+// (one 8x8 tile = 256 contiguous bytes), so store instruction i writes, for
+// lane l, 16-byte part (l & 15) of block i*4 + (l >> 4): four whole tiles =
+// 1 KB of consecutive bytes when the blocks are x-neighbours.  The LDS image
+// is XOR-swizzled per block so both the per-lane writes and the part-major
+// reads stay conflict-free.
+__device__ __forceinline__ void WaveStore64(const DevFrame& f, int c, uint32_t my_pos, int nvalid,
+                                            float4* lds, int lane, const float* px) {
+#pragma unroll
+  for (int j = 0; j < 16; j++)
+    lds[lane * 16 + (j ^ (lane & 15))] =
+        make_float4(px[j * 4], px[j * 4 + 1], px[j * 4 + 2], px[j * 4 + 3]);
+  __builtin_amdgcn_wave_barrier();
+  const int part = lane & 15, sub = lane >> 4;
+  const bool skip = (f.debug & 1) && px[0] != 12345.678f;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int b = i * 4 + sub;
+    const uint32_t pos = __shfl(my_pos, b, 64);
+    const float4 v = lds[b * 16 + (part ^ (b & 15))];
+    if (b < nvalid && !skip)
+      *(float4*)(TilePtr(f, c, pos >> 16, pos & 0xffffu) + part * 4) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Dequantises one CHANNEL of one single-block varblock and runs its transform
+// (DequantLane, dec_group.cc:115-153).  Called by whole waves; the three
+// channels of a block are decoded by three different waves so that no wave
+// ever has to wait for its own stores before issuing its next loads (on gfx9
+// the in-order vmcnt covers stores too).  X and B recompute the luma
+// dequantisation they need for chroma-from-luma instead of sharing registers.
+// Lanes >= nvalid carry a duplicate of the last block.
 template <int STRATEGY, typename CT>
-__device__ __forceinline__ void DecodeBlock64(const DevFrame& f, const BlockHdr& h) {
+__device__ __forceinline__ void DecodeBlock64(const DevFrame& f, const WorkItem it, int lane,
+                                              int nvalid, uint4* lds, int c) {
   constexpr uint32_t kTab = DequantOffset(STRATEGY);
+  using S = Stage64<CT>;
   const float* __restrict__ tab = f.dequant + kTab;
-  const size_t dci = (size_t)h.aby * f.xsb + h.abx;
-  float dy[64], v[64], px[64];
+  const BlockHdr h = MakeHdr(f, it);
+  const float dcv = f.dc[c][(size_t)h.aby * f.xsb + h.abx];
+  // who owns the blocks this lane moves for the wave
+  uint32_t blk_off[S::kChunks];
+  {
+    constexpr int kBlocksPerInstr = 64 / S::kChunks;
+    const uint32_t my = (f.debug & 2) ? 0u : it.off;
+#pragma unroll
+    for (int i = 0; i < S::kChunks; i++)
+      blk_off[i] = __shfl(my, i * kBlocksPerInstr + lane / S::kChunks, 64);
+  }
+  uint4* bufY = lds;
+  uint4* bufC = S::kBothInFlight ? lds + S::kInChunks : lds;
+  WaveGather64<CT>(f, 1, blk_off, bufY, lane);
+  if (S::kBothInFlight && c != 1) WaveGather64<CT>(f, c, blk_off, bufC, lane);
+  float v[64], px[64];
   {
     int32_t q[64];
-    Load64<CT>(f.coeffs[1], h.coef, q);
+    WaveFetch64<CT>(bufY, lane, q);
 #pragma unroll
     for (int k = 0; k < 64; k++)
-      dy[k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tab[64 + k] * h.sy);
+      v[k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tab[64 + k] * h.sy);
   }
-  {
+  if (c != 1) {  // wave-uniform
+    const float sc = c == 0 ? h.sx : h.sb;
+    const float cc = c == 0 ? h.x_cc : h.b_cc;
+    const float bias = c == 0 ? f.biases[0] : f.biases[2];
+    const float* __restrict__ tc = tab + c * 64;
     int32_t q[64];
-    Load64<CT>(f.coeffs[0], h.coef, q);
+    if (!S::kBothInFlight) WaveGather64<CT>(f, c, blk_off, bufC, lane);
+    WaveFetch64<CT>(bufC, lane, q);
 #pragma unroll
     for (int k = 0; k < 64; k++) {
-      const float dx = AdjustQuantBias(q[k], f.biases[0], f.biases[3]) * (tab[k] * h.sx);
-      v[k] = __builtin_fmaf(h.x_cc, dy[k], dx);
+      const float d = AdjustQuantBias(q[k], bias, f.biases[3]) * (tc[k] * sc);
+      v[k] = __builtin_fmaf(cc, v[k], d);
     }
-    v[0] = f.dc[0][dci];
-    Transform64<STRATEGY>(v, px);
-    StoreBlock8x8(f, 0, h, px);
   }
-  {
-    int32_t q[64];
-    Load64<CT>(f.coeffs[2], h.coef, q);
-#pragma unroll
-    for (int k = 0; k < 64; k++) {
-      const float db = AdjustQuantBias(q[k], f.biases[2], f.biases[3]) * (tab[128 + k] * h.sb);
-      v[k] = __builtin_fmaf(h.b_cc, dy[k], db);
-    }
-    v[0] = f.dc[2][dci];
-    Transform64<STRATEGY>(v, px);
-    StoreBlock8x8(f, 2, h, px);
-  }
-  dy[0] = f.dc[1][dci];
-  Transform64<STRATEGY>(dy, px);
-  StoreBlock8x8(f, 1, h, px);
+  v[0] = dcv;
+  Transform64<STRATEGY>(v, px);
+  WaveStore64(f, c, it.pos, nvalid, (float4*)lds, lane, px);
 }
 
-template <typename CT>
-__global__ __launch_bounds__(256) void k_dct8(DevFrame f, const WorkItem* __restrict__ list,
-                                              const uint32_t* __restrict__ count) {
-  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-  if (idx >= *count) return;
-  const BlockHdr h = MakeHdr(f, list[idx]);
-  DecodeBlock64<0, CT>(f, h);
-}
-
-template <typename CT>
-__global__ __launch_bounds__(64) void k_special(DevFrame f, const WorkItem* __restrict__ list,
-                                                const uint32_t* __restrict__ count) {
-  const uint32_t idx = blockIdx.x * 64u + threadIdx.x;
-  if (idx >= *count) return;
-  const BlockHdr h = MakeHdr(f, list[idx]);
-  const int s = f.acs[(size_t)h.aby * f.xsb + h.abx] >> 1;
-  switch (s) {
-    case 1: DecodeBlock64<1, CT>(f, h); break;
-    case 2: DecodeBlock64<2, CT>(f, h); break;
-    case 3: DecodeBlock64<3, CT>(f, h); break;
-    case 12: DecodeBlock64<12, CT>(f, h); break;
-    case 13: DecodeBlock64<13, CT>(f, h); break;
-    case 14: DecodeBlock64<14, CT>(f, h); break;
-    case 15: DecodeBlock64<15, CT>(f, h); break;
-    case 16: DecodeBlock64<16, CT>(f, h); break;
-    case 17: DecodeBlock64<17, CT>(f, h); break;
-    default: break;
+// One kernel per single-block strategy (0 = DCT8, the bulk; the 9 special
+// kinds).  Workgroup = 3 waves = the 3 channels of the same 64 blocks; every
+// wave is independent (own LDS slice, no barrier).
+template <int STRATEGY, typename CT>
+__global__ __launch_bounds__(192) void k_block64(DevFrame f, const WorkItem* __restrict__ list,
+                                                 const uint32_t* __restrict__ count) {
+  __shared__ uint4 lds[3][Stage64<CT>::kLdsChunks];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t first = blockIdx.x * 64u;
+  // the list is allocated for the worst case (+64 entries of slack), so the
+  // entry can be fetched before the count is known (both loads in flight)
+  WorkItem it = list[first + lane];
+  const uint32_t n = *count;
+  if (first >= n) return;
+  const int nvalid = (int)min(64u, n - first);
+  {  // lanes past the end duplicate the last valid block
+    const uint32_t lp = __shfl(it.pos, nvalid - 1, 64), lo = __shfl(it.off, nvalid - 1, 64),
+                   lq = __shfl(it.qc, nvalid - 1, 64);
+    if (lane >= nvalid) {
+      it.pos = lp;
+      it.off = lo;
+      it.qc = lq;
+    }
   }
+  const int c = wave == 0 ? 1 : (wave == 1 ? 0 : 2);
+  DecodeBlock64<STRATEGY, CT>(f, it, lane, nvalid, lds[wave], c);
 }
 
 // ------------------------------------------------------------------ k_medium
@@ -583,10 +645,13 @@ __global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __re
 #pragma unroll
     for (int j = 0; j < R; j++) v[j] = m[j * TP + i];
     IdctReg<R>(v);
+    // column i of the varblock: tile column i/8, 8 rows per tile, tiles of the
+    // next block row are tile_stride tiles further
     const BlockHdr& h = hdr[b];
-    float* dst = PlanePtr(f, c, h.aby * 8, h.abx * 8 + i);
+    float* dst = TilePtr(f, c, h.aby, h.abx + (i >> 3)) + (i & 7);
 #pragma unroll
-    for (int j = 0; j < R; j++) dst[(size_t)j * f.plane_stride] = v[j];
+    for (int j = 0; j < R; j++)
+      dst[(size_t)(j >> 3) * f.tile_stride * 64 + (j & 7) * 8] = v[j];
   }
 }
 
@@ -742,43 +807,46 @@ __global__ __launch_bounds__(256) void k_large(DevFrame f, const WorkItem* __res
         v[j] = val;
       }
       IdctMem(C, v, tmp, wc);
-      float* dst = PlanePtr(f, c, h.aby * 8 + u, h.abx * 8);
-      for (int j = 0; j < C; j++) dst[j] = v[j];
+      for (int j = 0; j < C; j++) *PlanePtr(f, c, h.aby * 8 + u, h.abx * 8 + j) = v[j];
     }
     __threadfence_block();
     __syncthreads();
     // ---- pass 2: thread x, R-point IDCT along u, in place in the plane
     for (int x = tid; x < C; x += 256) {
-      float* col = PlanePtr(f, c, h.aby * 8, h.abx * 8 + x);
-      for (int j = 0; j < R; j++) v[j] = col[(size_t)j * f.plane_stride];
+      for (int j = 0; j < R; j++) v[j] = *PlanePtr(f, c, h.aby * 8 + j, h.abx * 8 + x);
       IdctMem(R, v, tmp, wc);
-      for (int j = 0; j < R; j++) col[(size_t)j * f.plane_stride] = v[j];
+      for (int j = 0; j < R; j++) *PlanePtr(f, c, h.aby * 8 + j, h.abx * 8 + x) = v[j];
     }
     __syncthreads();
   }
 }
 
 // --------------------------------------------------------------- launchers
+// Every class is its own launch; `streams` lets the caller spread the launches
+// over several HIP streams so the small grids (a few hundred workgroups for
+// the rare kinds) overlap instead of each under-filling the 256 CUs in turn.
 template <typename CT>
 static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, const uint32_t* max_items,
-                          const float* wc, const float* resample, hipStream_t st,
-                          void (*mark)(void*, int), void* mark_arg) {
+                          const float* wc, const float* resample, hipStream_t* streams,
+                          int nstreams) {
+  int next = 0;
+  auto pick = [&]() { return streams[(next++) % nstreams]; };
   if (max_items[kClsDct8]) {
-    hipLaunchKernelGGL(k_dct8<CT>, dim3((max_items[kClsDct8] + 255) / 256), dim3(256), 0, st, f,
-                       wl.list[kClsDct8], wl.count + kClsDct8);
+    hipLaunchKernelGGL((k_block64<0, CT>), dim3((max_items[kClsDct8] + 63) / 64), dim3(192), 0,
+                       pick(), f, wl.list[kClsDct8], wl.count + kClsDct8);
   }
-  if (max_items[kClsSpecial]) {
-    hipLaunchKernelGGL(k_special<CT>, dim3((max_items[kClsSpecial] + 63) / 64), dim3(64), 0, st,
-                       f, wl.list[kClsSpecial], wl.count + kClsSpecial);
-  }
-  mark(mark_arg, 0);
 #define JXLHIP_MEDIUM(IDX, RR, CC, STRAT)                                                   \
   if (max_items[kClsMedium0 + IDX]) {                                                       \
     constexpr int NB = 64 / ((RR) > (CC) ? (RR) : (CC));                                    \
+    static_assert(kMediumStrategy[IDX] == STRAT, "class table mismatch");                   \
     hipLaunchKernelGGL((k_medium<RR, CC, STRAT, CT>),                                       \
                        dim3((max_items[kClsMedium0 + IDX] + NB - 1) / NB), dim3(192), 0,    \
-                       st, f, wl.list[kClsMedium0 + IDX], wl.count + kClsMedium0 + IDX);    \
+                       pick(), f, wl.list[kClsMedium0 + IDX], wl.count + kClsMedium0 + IDX); \
   }
+  // big-latency kinds first so they overlap with the bulk
+  JXLHIP_MEDIUM(8, 64, 64, 18)
+  JXLHIP_MEDIUM(9, 64, 32, 19)
+  JXLHIP_MEDIUM(10, 32, 64, 20)
   JXLHIP_MEDIUM(0, 16, 8, 6)
   JXLHIP_MEDIUM(1, 8, 16, 7)
   JXLHIP_MEDIUM(2, 16, 16, 4)
@@ -787,36 +855,51 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, const uint32_t
   JXLHIP_MEDIUM(5, 32, 16, 10)
   JXLHIP_MEDIUM(6, 16, 32, 11)
   JXLHIP_MEDIUM(7, 32, 32, 5)
-  JXLHIP_MEDIUM(8, 64, 64, 18)
-  JXLHIP_MEDIUM(9, 64, 32, 19)
-  JXLHIP_MEDIUM(10, 32, 64, 20)
 #undef JXLHIP_MEDIUM
-  mark(mark_arg, 1);
+#define JXLHIP_SPECIAL(IDX, STRAT)                                                          \
+  if (max_items[kClsSpecial0 + IDX]) {                                                      \
+    static_assert(kSpecialStrategy[IDX] == STRAT, "class table mismatch");                  \
+    hipLaunchKernelGGL((k_block64<STRAT, CT>),                                              \
+                       dim3((max_items[kClsSpecial0 + IDX] + 63) / 64), dim3(192), 0, pick(), \
+                       f, wl.list[kClsSpecial0 + IDX], wl.count + kClsSpecial0 + IDX);      \
+  }
+  JXLHIP_SPECIAL(0, 1)
+  JXLHIP_SPECIAL(1, 2)
+  JXLHIP_SPECIAL(2, 3)
+  JXLHIP_SPECIAL(3, 12)
+  JXLHIP_SPECIAL(4, 13)
+  JXLHIP_SPECIAL(5, 14)
+  JXLHIP_SPECIAL(6, 15)
+  JXLHIP_SPECIAL(7, 16)
+  JXLHIP_SPECIAL(8, 17)
+#undef JXLHIP_SPECIAL
   if (max_items[kClsLarge]) {
-    hipLaunchKernelGGL(k_large<CT>, dim3(max_items[kClsLarge]), dim3(256), 0, st, f,
+    hipLaunchKernelGGL(k_large<CT>, dim3(max_items[kClsLarge]), dim3(256), 0, pick(), f,
                        wl.list[kClsLarge], wl.count + kClsLarge, wc, resample);
   }
-  mark(mark_arg, 2);
 }
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
                    const SharpLut& lut, hipStream_t st) {
-  uint32_t lo = f.group_y0, hi = f.group_y0 + f.group_rows;
-  if (with_sigma) {  // one more group row on each side for the halo rows' sigma
-    if (lo > 0) lo--;
-    if (hi < f.ysg) hi++;
+  // lists for the band's group rows; sigma additionally for the group row just
+  // outside the STRIPE when the band touches its first / last row (the EPF
+  // stages evaluate halo rows there; inside the stripe the neighbouring bands
+  // provide their own sigma before any filter launch needs it)
+  uint32_t lo = f.band_g0, hi = f.band_g1;
+  if (with_sigma) {
+    if (lo == f.group_y0 && lo > 0) lo--;
+    if (hi == f.group_y0 + f.group_rows && hi < f.ysg) hi++;
   }
   hipLaunchKernelGGL(k_prepare, dim3(f.xsg * (hi - lo)), dim3(1024), 0, st, f, wl, lo,
                      with_sigma, epf_quant_mul, lut);
 }
 
 void LaunchBlocks(const DevFrame& f, const WorkLists& wl, const uint32_t* max_items,
-                  const float* wc, const float* resample, hipStream_t st,
-                  void (*mark)(void*, int), void* mark_arg) {
+                  const float* wc, const float* resample, hipStream_t* streams, int nstreams) {
   if (f.coeff_type == JXLHIP_COEFF_I16)
-    LaunchBlocksT<int16_t>(f, wl, max_items, wc, resample, st, mark, mark_arg);
+    LaunchBlocksT<int16_t>(f, wl, max_items, wc, resample, streams, nstreams);
   else
-    LaunchBlocksT<int32_t>(f, wl, max_items, wc, resample, st, mark, mark_arg);
+    LaunchBlocksT<int32_t>(f, wl, max_items, wc, resample, streams, nstreams);
 }
 
 }  // namespace jxlhip

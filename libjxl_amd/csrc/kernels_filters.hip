@@ -235,7 +235,7 @@ __device__ __forceinline__ void RunStages(const DevFrame& f, const FilterParams&
       const int ry = i / OW, rx = i % OW;
       const int gx = tx0 - OH + rx, gy = ty0 - OH + ry;
       if (gx < 0 || gx >= W || gy < 0 || gy >= H) continue;
-      if (kLast && gy >= (int)f.y1) continue;
+      if (kLast && gy >= (int)f.fy1) continue;
       const int ci = (ry + OFF) * IW + rx + OFF;
       float o[3];
       StagePixel<ID>(in + ci, in + IW * IHt + ci, in + 2 * IW * IHt + ci, IW, gx, gy, f, P, o);
@@ -278,15 +278,16 @@ __global__ __launch_bounds__(NT) void k_filters(DevFrame f, FilterParams P) {
   float* A = smem;
   float* Bf = smem + 3 * AW * AH;
   const int tx0 = blockIdx.x * TW;
-  const int ty0 = (int)f.y0 + blockIdx.y * TH;
+  const int ty0 = (int)f.fy0 + blockIdx.y * TH;
   const int W = (int)f.xsize, H = (int)f.ysize;
   for (int i = threadIdx.x; i < AW * AH; i += NT) {
     const int ry = i / AW, rx = i % AW;
     const int mx = Mirror(tx0 - HT + rx, W);
-    const int prow = Mirror(ty0 - HT + ry, H) - f.plane_y0;
+    const int my = Mirror(ty0 - HT + ry, H);
+    const int prow = my - f.plane_y0;
     float v0 = 0, v1 = 0, v2 = 0;
-    if (prow >= 0 && prow < (int)f.plane_rows) {
-      const size_t o = (size_t)prow * f.plane_stride + mx;
+    if (prow >= 0 && prow < (int)f.plane_tile_rows * 8) {
+      const size_t o = PlaneOffset(f, my, mx);
       v0 = f.xyb[0][o];
       v1 = f.xyb[1][o];
       v2 = f.xyb[2][o];
@@ -304,9 +305,9 @@ __global__ __launch_bounds__(NT) void k_filters(DevFrame f, FilterParams P) {
 template <int OUTK>
 __global__ __launch_bounds__(256) void k_xyb_only(DevFrame f, FilterParams P) {
   const int gx = blockIdx.x * 256 + threadIdx.x;
-  const int gy = (int)f.y0 + blockIdx.y;
-  if (gx >= (int)f.xsize || gy >= (int)f.y1) return;
-  const size_t o = (size_t)(gy - f.plane_y0) * f.plane_stride + gx;
+  const int gy = (int)f.fy0 + blockIdx.y;
+  if (gx >= (int)f.xsize || gy >= (int)f.fy1) return;
+  const size_t o = PlaneOffset(f, gy, gx);
   const float v[3] = {f.xyb[0][o], f.xyb[1][o], f.xyb[2][o]};
   EmitPixel<OUTK>(v, gx, gy - (int)f.y0, P);
 }
@@ -324,7 +325,7 @@ static void LaunchFiltersT(const DevFrame& f, const FilterParams& p, hipStream_t
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  const dim3 grid((f.xsize + TW - 1) / TW, (f.y1 - f.y0 + TH - 1) / TH);
+  const dim3 grid((f.xsize + TW - 1) / TW, (f.fy1 - f.fy0 + TH - 1) / TH);
   hipLaunchKernelGGL((k_filters<GAB, EPF, OUTK, TW, TH, NT>), grid, dim3(NT), lds, st, f, p);
 }
 
@@ -332,9 +333,9 @@ int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_ite
                   int output_kind, hipStream_t st) {
   if (gab < 0 || gab > 1 || epf_iters < 0 || epf_iters > 3 || output_kind < 0 || output_kind > 1)
     return -1;
-  if (f.y1 <= f.y0) return 0;
+  if (f.fy1 <= f.fy0) return 0;
   if (gab == 0 && epf_iters == 0) {
-    const dim3 grid((f.xsize + 255) / 256, f.y1 - f.y0);
+    const dim3 grid((f.xsize + 255) / 256, f.fy1 - f.fy0);
     if (output_kind == 0)
       hipLaunchKernelGGL(k_xyb_only<0>, grid, dim3(256), 0, st, f, p);
     else

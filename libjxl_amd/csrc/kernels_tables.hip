@@ -222,6 +222,29 @@ __global__ __launch_bounds__(256) void k_smooth_dc(uint32_t xs, uint32_t ys, DcP
     p.out[c][o] = __builtin_fmaf(smv[c] - mcv[c], factor, mcv[c]);
 }
 
+// rows [y_first, y_first + nrows) x columns [0, ncols) of the block-major
+// planes <-> dense row-major staging (halo exchange, test export)
+__global__ __launch_bounds__(256) void k_rows_copy(DevFrame f, float* dense, int y_first,
+                                                   int nrows, int ncols, int to_dense,
+                                                   size_t dense_stride, size_t dense_plane) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.y, c = blockIdx.z;
+  if (x >= ncols || r >= nrows) return;
+  float* src = f.xyb[c] + PlaneOffset(f, y_first + r, x);
+  float* d = dense + (size_t)c * dense_plane + (size_t)r * dense_stride + x;
+  if (to_dense) *d = *src;
+  else *src = *d;
+}
+
+void LaunchRowsCopy(const DevFrame& f, float* dense, int y_first, int nrows, int ncols,
+                    size_t dense_stride, size_t dense_plane, int nch, bool to_dense,
+                    hipStream_t st) {
+  if (nrows <= 0 || ncols <= 0) return;
+  hipLaunchKernelGGL(k_rows_copy, dim3((unsigned)((ncols + 255) / 256), (unsigned)nrows, nch),
+                     dim3(256), 0, st, f, dense, y_first, nrows, ncols, to_dense ? 1 : 0,
+                     dense_stride, dense_plane);
+}
+
 void LaunchDefaultDequant(float* table, int32_t* status, hipStream_t st) {
   hipLaunchKernelGGL(k_default_dequant, dim3((JXLHIP_DEQUANT_TABLE_FLOATS + 255) / 256), dim3(256),
                      0, st, table, status);

@@ -1,0 +1,176 @@
+// runner.cc -- libjxl_threads_hip.so: a JxlParallelRunner whose workers each own
+// a HIP stream (see include/jxl_threads_hip.h).  Replaces lib/threads/
+// thread_parallel_runner{.cc,_internal.cc} behind the same four C symbols.
+//
+// Scheduling: one shared atomic cursor over [begin, end); every participant
+// claims a chunk of max(1, remaining / (4 * threads)) tasks per grab, so early
+// chunks are large and the tail is fine-grained.  With zero workers the calling
+// thread runs everything as thread 0.
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/jxl_threads_hip.h"
+
+namespace {
+
+struct Runner {
+  JxlMemoryManager mm{};
+  size_t num_workers = 0;
+  std::vector<std::thread> threads;
+  std::vector<hipStream_t> streams;  // [max(1, num_workers)]
+  bool have_device = false;
+
+  std::mutex mu;
+  std::condition_variable cv_start, cv_done;
+  uint64_t epoch = 0;  // bumped for every Run
+  bool quit = false;
+  size_t running = 0;  // workers still inside the current epoch
+
+  // current job
+  void* opaque = nullptr;
+  JxlParallelRunFunction func = nullptr;
+  uint32_t end = 0;
+  std::atomic<uint32_t> next{0};
+  std::atomic<bool> in_run{false};
+
+  void Drain(size_t thread_id) {
+    const size_t nthreads = num_workers ? num_workers : 1;
+    for (;;) {
+      uint32_t cur = next.load(std::memory_order_relaxed);
+      uint32_t take;
+      do {
+        if (cur >= end) return;
+        const uint32_t remaining = end - cur;
+        take = remaining / (uint32_t)(4 * nthreads);
+        if (take < 1) take = 1;
+      } while (!next.compare_exchange_weak(cur, cur + take, std::memory_order_relaxed));
+      for (uint32_t i = cur; i < cur + take; i++) func(opaque, i, thread_id);
+    }
+  }
+
+  void WorkerMain(size_t thread_id) {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        cv_start.wait(lock, [&] { return quit || epoch != seen; });
+        if (quit) return;
+        seen = epoch;
+      }
+      Drain(thread_id);
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        if (--running == 0) cv_done.notify_all();
+      }
+    }
+  }
+};
+
+void* MMAlloc(const JxlMemoryManager& mm, size_t n) {
+  return mm.alloc ? mm.alloc(mm.opaque, n) : malloc(n);
+}
+void MMFree(const JxlMemoryManager& mm, void* p) {
+  if (mm.free) mm.free(mm.opaque, p);
+  else free(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+JxlParallelRetCode JxlThreadParallelRunner(void* runner_opaque, void* jpegxl_opaque,
+                                           JxlParallelRunInit init, JxlParallelRunFunction func,
+                                           uint32_t start_range, uint32_t end_range) {
+  Runner* r = static_cast<Runner*>(runner_opaque);
+  if (!r || start_range > end_range) return JXL_PARALLEL_RET_RUNNER_ERROR;
+  if (start_range == end_range) return JXL_PARALLEL_RET_SUCCESS;
+  bool expected = false;
+  if (!r->in_run.compare_exchange_strong(expected, true))
+    return JXL_PARALLEL_RET_RUNNER_ERROR;  // not re-entrant
+  const size_t nthreads = r->num_workers ? r->num_workers : 1;
+  const JxlParallelRetCode rc = init(jpegxl_opaque, nthreads);
+  if (rc != 0) {
+    r->in_run.store(false);
+    return rc;
+  }
+  r->opaque = jpegxl_opaque;
+  r->func = func;
+  r->end = end_range;
+  r->next.store(start_range, std::memory_order_relaxed);
+  if (r->num_workers == 0) {
+    r->Drain(0);
+  } else {
+    {
+      std::lock_guard<std::mutex> lock(r->mu);
+      r->running = r->num_workers;
+      r->epoch++;
+    }
+    r->cv_start.notify_all();
+    std::unique_lock<std::mutex> lock(r->mu);
+    r->cv_done.wait(lock, [&] { return r->running == 0; });
+  }
+  r->in_run.store(false);
+  return JXL_PARALLEL_RET_SUCCESS;
+}
+
+void* JxlThreadParallelRunnerCreate(const JxlMemoryManager* memory_manager,
+                                    size_t num_worker_threads) {
+  JxlMemoryManager mm{};
+  if (memory_manager) {
+    mm = *memory_manager;
+    if ((mm.alloc == nullptr) != (mm.free == nullptr)) return nullptr;
+  }
+  void* mem = MMAlloc(mm, sizeof(Runner));
+  if (!mem) return nullptr;
+  Runner* r = new (mem) Runner();
+  r->mm = mm;
+  r->num_workers = num_worker_threads;
+  int ndev = 0;
+  r->have_device = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+  const size_t nstreams = num_worker_threads ? num_worker_threads : 1;
+  r->streams.assign(nstreams, nullptr);
+  if (r->have_device) {
+    for (size_t i = 0; i < nstreams; i++)
+      if (hipStreamCreateWithFlags(&r->streams[i], hipStreamNonBlocking) != hipSuccess)
+        r->streams[i] = nullptr;
+  }
+  r->threads.reserve(num_worker_threads);
+  for (size_t i = 0; i < num_worker_threads; i++)
+    r->threads.emplace_back([r, i] { r->WorkerMain(i); });
+  return r;
+}
+
+void JxlThreadParallelRunnerDestroy(void* runner_opaque) {
+  Runner* r = static_cast<Runner*>(runner_opaque);
+  if (!r) return;
+  {
+    std::lock_guard<std::mutex> lock(r->mu);
+    r->quit = true;
+  }
+  r->cv_start.notify_all();
+  for (auto& t : r->threads) t.join();
+  for (hipStream_t s : r->streams)
+    if (s) (void)hipStreamDestroy(s);
+  const JxlMemoryManager mm = r->mm;
+  r->~Runner();
+  MMFree(mm, r);
+}
+
+size_t JxlThreadParallelRunnerDefaultNumWorkerThreads(void) {
+  return std::thread::hardware_concurrency();
+}
+
+void* JxlHipParallelRunnerStream(void* runner_opaque, size_t thread_id) {
+  Runner* r = static_cast<Runner*>(runner_opaque);
+  if (!r || thread_id >= r->streams.size()) return nullptr;
+  return r->streams[thread_id];
+}
+
+}  // extern "C"

@@ -122,13 +122,19 @@ class VarDctDecoder:
         _check(self.L, self.ctx, self.L.jxlhip_sync(self.ctx), "sync")
 
     # -- taps / profiling --------------------------------------------------------
-    def xyb_planes(self):
-        """Copies of the phase-1 XYB planes (rows of the stripe incl. halo)."""
-        ptrs = (C.c_void_p * 3)()
-        stride, rows = C.c_size_t(), C.c_size_t()
-        _check(self.L, self.ctx, self.L.jxlhip_get_xyb_planes(self.ctx, ptrs, C.byref(stride), C.byref(rows)), "get_xyb_planes")
-        return [_as_tensor(ptrs[c], rows.value * stride.value, torch.float32, self.device).reshape(rows.value, stride.value).clone()
-                for c in range(3)]
+    def export_xyb(self):
+        """Row-major copies of the phase-1 XYB planes (the stripe's block-padded
+        rows x padded width), as numpy arrays."""
+        p = self.params
+        xsb = (p.xsize + 7) // 8
+        y0, y1 = self.stripe_rows()
+        rows = (y1 - y0 + 7) // 8 * 8
+        outs = [torch.empty((rows, xsb * 8), dtype=torch.float32, device=f"cuda:{self.device}")
+                for _ in range(3)]
+        ptrs = (C.c_void_p * 3)(*[o.data_ptr() for o in outs])
+        _check(self.L, self.ctx, self.L.jxlhip_export_xyb(self.ctx, ptrs, xsb * 8), "export_xyb")
+        self.sync()
+        return [o.cpu().numpy() for o in outs]
 
     def sigma(self):
         ptr, stride = C.c_void_p(), C.c_size_t()
@@ -140,14 +146,20 @@ class VarDctDecoder:
     def halo_rows(self):
         return self.L.jxlhip_halo_rows(self.ctx)
 
-    def halo_region(self, which):
-        """Zero-copy torch view [3, halo, xsize_padded] of a halo region."""
-        base, rs, ps = C.c_void_p(), C.c_size_t(), C.c_size_t()
-        _check(self.L, self.ctx, self.L.jxlhip_halo_region(self.ctx, which, C.byref(base), C.byref(rs), C.byref(ps)), "halo_region")
-        h = self.halo_rows()
-        n = 2 * ps.value + h * rs.value
-        flat = _as_tensor(base.value, n, torch.float32, self.device)
-        return torch.as_strided(flat, (3, h, rs.value), (ps.value, rs.value, 1))
+    def halo_export(self, which):
+        """Dense [3, halo, xsize] tensor with this stripe's first (which=0) or
+        last (which=1) halo rows."""
+        p = self.params
+        buf = torch.empty((3, self.halo_rows(), p.xsize), dtype=torch.float32,
+                          device=f"cuda:{self.device}")
+        _check(self.L, self.ctx, self.L.jxlhip_halo_export(self.ctx, which, C.c_void_p(buf.data_ptr())), "halo_export")
+        return buf
+
+    def halo_import(self, which, buf):
+        """Installs rows received from the stripe above (which=0) / below (1)."""
+        assert buf.is_cuda and buf.is_contiguous() and buf.dtype == torch.float32
+        assert tuple(buf.shape) == (3, self.halo_rows(), self.params.xsize)
+        _check(self.L, self.ctx, self.L.jxlhip_halo_import(self.ctx, which, C.c_void_p(buf.data_ptr())), "halo_import")
 
     def profile(self, enable=True):
         _check(self.L, self.ctx, self.L.jxlhip_profile_enable(self.ctx, int(enable)), "profile_enable")

@@ -92,10 +92,18 @@ class StripeDecoder:
     def decode(self, out):
         d = self.dec
         d.decode_blocks()
-        if self.world > 1 and d.halo_rows() > 0:
-            w = self.params["xsize"]
-            exchange_halos(d.halo_region(0)[:, :, :w], d.halo_region(1)[:, :, :w],
-                           d.halo_region(2)[:, :, :w], d.halo_region(3)[:, :, :w],
-                           self.rank, self.world, self.group)
+        h = d.halo_rows()
+        if self.world > 1 and h > 0:
+            up_send = d.halo_export(0) if self.rank > 0 else None
+            dn_send = d.halo_export(1) if self.rank + 1 < self.world else None
+            ref = up_send if up_send is not None else dn_send
+            up_recv, dn_recv = torch.empty_like(ref), torch.empty_like(ref)
+            exchange_halos(up_send if up_send is not None else ref,
+                           dn_send if dn_send is not None else ref,
+                           up_recv, dn_recv, self.rank, self.world, self.group)
+            if self.rank > 0:
+                d.halo_import(0, up_recv)
+            if self.rank + 1 < self.world:
+                d.halo_import(1, dn_recv)
         d.decode_filters(out)
         return out

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz: small seeded VarDCT frames (inputs in the
+jxlhip_frame_inputs layout) together with the CPU oracle's outputs (XYB planes
+after phase 1, sigma, final linear RGB).  The reference decoder itself cannot
+run here (Highway is not vendored), so these vectors pin the ORACLE, which is
+in turn pinned by the reference's fixture-free known-answer tests
+(tests/test_oracle_kat.py).  Re-run only when the oracle is deliberately
+changed:  python tests/golden/make_golden.py"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import frames  # noqa: E402
+from libjxl_amd import synth  # noqa: E402
+
+CASES = {
+    # name: (xsize, ysize, kwargs)
+    "small_d1_gab_epf1": (96, 72, dict(mix={0: 30, 6: 10, 7: 10, 4: 10, 5: 10, 1: 2, 2: 2, 3: 2,
+                                             12: 2, 13: 2, 14: 1, 15: 1, 16: 1, 17: 1},
+                                       gab=True, epf_iters=1, seed=101)),
+    "small_all_filters": (72, 56, dict(mix=synth.MIX_D1, gab=True, epf_iters=3, seed=102,
+                                       custom_lf=True)),
+    "tiny_3x8": (3, 8, dict(mix=synth.MIX_DCT8, gab=True, epf_iters=2, seed=103)),
+}
+
+
+def build(name):
+    xs, ys, kw = CASES[name]
+    params, t, fr = frames.make_case(xs, ys, **kw)
+    planes = fr.decode_groups()
+    out = dict(
+        coeffs=np.stack([c.numpy() for c in t["coeffs"]]),
+        ac_strategy=t["ac_strategy"].numpy(), raw_quant=t["raw_quant"].numpy(),
+        epf_sharpness=t["epf_sharpness"].numpy(), ytox_map=t["ytox_map"].numpy(),
+        ytob_map=t["ytob_map"].numpy(), dc=np.stack([d.numpy() for d in t["dc"]]),
+        xyb=np.stack(planes), sigma=fr.compute_sigma(), rgb=fr.decode(threads=1))
+    return params, out
+
+
+def main():
+    for name in CASES:
+        params, out = build(name)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        h = hashlib.sha256(out["rgb"].tobytes()).hexdigest()[:16]
+        print(name, {k: v.shape for k, v in out.items() if k in ("coeffs", "rgb")}, "rgb sha", h)
+
+
+if __name__ == "__main__":
+    main()

@@ -45,9 +45,7 @@ def dq(dec):
 
 
 def crop_planes(dec, params):
-    xsb, ysb = (params["xsize"] + 7) // 8, (params["ysize"] + 7) // 8
-    h = dec.halo_rows()
-    return [p[h:h + ysb * 8, :xsb * 8].cpu().numpy() for p in dec.xyb_planes()]
+    return dec.export_xyb()
 
 
 def rel_err(got, ref):
@@ -149,6 +147,24 @@ def test_full_pipeline_rgb(dec, dq, oracle, gab, epf, size):
     assert e <= TIGHT, e
 
 
+@pytest.mark.parametrize("gab,epf", [(1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("size", [(533, 401), (61, 70), (1000, 130)])
+def test_generic_lds_filter_kernel_also_matches(dq, oracle, monkeypatch, gab, epf, size):
+    """Stage lists with <= 1 EPF pass normally take the register/DPP kernel; the
+    generic LDS kernel (used for epf_iters >= 2) must agree on them too."""
+    monkeypatch.setenv("JXLHIP_FILTERS", "generic")
+    d = VarDctDecoder(0)
+    monkeypatch.delenv("JXLHIP_FILTERS")
+    params, t, fr = frames.make_case(*size, mix=synth.MIX_D1, gab=bool(gab), epf_iters=epf,
+                                     seed=77)
+    d.begin_frame(params)
+    d.set_inputs(to_dev(t), dq)
+    out = d.decode_frame()
+    d.sync()
+    assert rel_err(out.cpu().numpy(), fr.decode(threads=4)) <= TIGHT
+    d.close()
+
+
 @pytest.mark.parametrize("gab,epf", [(1, 1), (1, 3)])
 def test_full_pipeline_xyb_output_and_custom_lf(dec, dq, oracle, gab, epf):
     params, t, fr = frames.make_case(300, 270, mix=synth.MIX_D1, gab=bool(gab), epf_iters=epf,
@@ -194,8 +210,8 @@ def test_stripes_with_halo_exchange_equal_whole_frame(dec, dq, oracle):
         decs.append(d)
     torch.cuda.synchronize()
     # stripe 0 sends its last rows down, stripe 1 sends its first rows up
-    decs[1].halo_region(2).copy_(decs[0].halo_region(1))
-    decs[0].halo_region(3).copy_(decs[1].halo_region(0))
+    decs[1].halo_import(0, decs[0].halo_export(1))
+    decs[0].halo_import(1, decs[1].halo_export(0))
     for d in decs:
         out = d.alloc_output()
         d.decode_filters(out)

@@ -1,0 +1,111 @@
+"""libjxl_threads_hip.so honours the JxlParallelRunner contract
+(lib/include/jxl/parallel_runner.h:105-129; the reference's own checks are in
+lib/threads/thread_parallel_runner_test.cc: every task exactly once, thread ids
+in range, init failure propagates, re-entry is refused)."""
+import ctypes as C
+import threading
+
+import pytest
+
+from libjxl_amd import abi
+
+INIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t)
+FUNC = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_size_t)
+ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+class MemoryManager(C.Structure):
+    _fields_ = [("opaque", C.c_void_p), ("alloc", ALLOC), ("free", FREE)]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from libjxl_amd import build
+    build.build()
+    L = C.CDLL(abi.runner_library_path())
+    L.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    L.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    L.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    L.JxlThreadParallelRunnerDestroy.restype = None
+    L.JxlThreadParallelRunner.argtypes = [C.c_void_p, C.c_void_p, INIT, FUNC, C.c_uint32, C.c_uint32]
+    L.JxlThreadParallelRunnerDefaultNumWorkerThreads.restype = C.c_size_t
+    L.JxlHipParallelRunnerStream.restype = C.c_void_p
+    L.JxlHipParallelRunnerStream.argtypes = [C.c_void_p, C.c_size_t]
+    return L
+
+
+@pytest.mark.parametrize("workers", [0, 1, 3, 8])
+def test_every_task_once_and_thread_ids_in_range(lib, workers):
+    r = lib.JxlThreadParallelRunnerCreate(None, workers)
+    assert r
+    seen, tids, nthreads = [], set(), []
+    lock = threading.Lock()
+
+    def init(opaque, n):
+        nthreads.append(n)
+        return 0
+
+    def func(opaque, value, tid):
+        with lock:
+            seen.append(value)
+            tids.add(tid)
+
+    for (a, b) in [(0, 1), (5, 5), (3, 1000), (0, 17)]:
+        seen.clear()
+        rc = lib.JxlThreadParallelRunner(r, None, INIT(init), FUNC(func), a, b)
+        assert rc == 0
+        assert sorted(seen) == list(range(a, b))
+    assert all(n == max(workers, 1) for n in nthreads)
+    assert all(t < max(workers, 1) for t in tids)
+    lib.JxlThreadParallelRunnerDestroy(r)
+
+
+def test_init_failure_and_bad_range(lib):
+    r = lib.JxlThreadParallelRunnerCreate(None, 2)
+    calls = []
+    rc = lib.JxlThreadParallelRunner(r, None, INIT(lambda o, n: -7), FUNC(lambda o, v, t: calls.append(v)), 0, 10)
+    assert rc == -7 and not calls
+    rc = lib.JxlThreadParallelRunner(r, None, INIT(lambda o, n: 0), FUNC(lambda o, v, t: None), 5, 3)
+    assert rc == -1
+    lib.JxlThreadParallelRunnerDestroy(r)
+
+
+def test_not_reentrant(lib):
+    r = lib.JxlThreadParallelRunnerCreate(None, 2)
+    inner = []
+    init_cb = INIT(lambda o, n: 0)
+    noop = FUNC(lambda o, v, t: None)
+
+    def func(opaque, value, tid):
+        inner.append(lib.JxlThreadParallelRunner(r, None, init_cb, noop, 0, 4))
+
+    assert lib.JxlThreadParallelRunner(r, None, init_cb, FUNC(func), 0, 3) == 0
+    assert inner == [-1, -1, -1]
+    lib.JxlThreadParallelRunnerDestroy(r)
+
+
+def test_memory_manager_rules(lib):
+    # both callbacks or none (thread_parallel_runner.cc:37-53)
+    count = {"alloc": 0, "free": 0}
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+
+    def alloc(opaque, n):
+        count["alloc"] += 1
+        return libc.malloc(n)
+
+    def free(opaque, p):
+        count["free"] += 1
+        libc.free(p)
+
+    mm = MemoryManager(None, ALLOC(alloc), FREE(free))
+    r = lib.JxlThreadParallelRunnerCreate(C.byref(mm), 1)
+    assert r and count["alloc"] == 1
+    lib.JxlThreadParallelRunnerDestroy(r)
+    assert count["free"] == 1
+    bad = MemoryManager(None, ALLOC(alloc), FREE())
+    assert not lib.JxlThreadParallelRunnerCreate(C.byref(bad), 1)
+    assert lib.JxlThreadParallelRunnerDefaultNumWorkerThreads() >= 1

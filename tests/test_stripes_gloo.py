@@ -1,0 +1,96 @@
+"""N>1 path on CPU: world_size-2 gloo run of the product's stripe partition,
+halo exchange and gather (libjxl_amd/stripes.py).  The per-stripe compute is
+done by the CPU oracle here (no GPU in this test); what is under test is that
+"decode your groups, swap LoopFilter::Padding() rows with the neighbours,
+filter your rows, gather" reproduces the whole-frame result bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, xs, ys, result_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
+    import frames
+    import oracle as O
+    from libjxl_amd import stripes, synth
+    params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=True, epf_iters=1, seed=31)
+    parts = stripes.stripe_partition(ys, world)
+    g0, gr = parts[rank]
+    y0, y1 = stripes.stripe_pixel_rows(ys, g0, gr)
+    halo = 3  # gab 1 + epf1 2
+    xsb, ysb = fr.dims
+    xsg = (xs + 255) // 256
+    L = O.lib()
+    # phase 1 for this rank's groups only
+    planes = [np.zeros((ysb * 8, xsb * 8), np.float32) for _ in range(3)]
+    rc = L.jxo_decode_groups(C.byref(fr.c), O._p3(planes), xsb * 8, g0 * xsg, (g0 + gr) * xsg)
+    assert rc == 0
+    tp = [torch.from_numpy(p) for p in planes]
+
+    def rows(a, b):
+        return torch.stack([p[a:b, :xs] for p in tp])  # [3, rows, xs] (a view per plane)
+
+    # product code under test: halo exchange on strided views
+    up_send, dn_send = rows(y0, y0 + halo), rows(y1 - halo, y1)
+    up_recv = torch.zeros_like(up_send)
+    dn_recv = torch.zeros_like(dn_send)
+    stripes.exchange_halos(up_send, dn_send, up_recv, dn_recv, rank, world)
+    if rank > 0:
+        for c in range(3):
+            tp[c][y0 - halo:y0, :xs] = up_recv[c]
+    if rank + 1 < world:
+        for c in range(3):
+            tp[c][y1:y1 + halo, :xs] = dn_recv[c]
+    # phase 2 on own rows (+2 rows of Gaborish output for EPF1)
+    sigma = fr.compute_sigma()
+    gab = [np.zeros_like(p) for p in planes]
+    a, b = max(0, y0 - 2), min(ys, y1 + 2)
+    L.jxo_gaborish(C.byref(fr.c), O._p3(planes), O._p3(gab), planes[0].shape[1], a, b)
+    epf = [np.zeros_like(p) for p in planes]
+    L.jxo_epf(C.byref(fr.c), 1, O._p(sigma), O._p3(gab), O._p3(epf), planes[0].shape[1], y0, y1)
+    rgb = np.zeros((ys, xs, 3), np.float32)
+    L.jxo_xyb_to_linear_rgb(C.byref(fr.c), O._p3(epf), planes[0].shape[1], O._p(rgb), xs * 3, y0, y1)
+    stripe = torch.from_numpy(rgb[y0:y1].copy())
+    rows_per_rank = [stripes.stripe_pixel_rows(ys, *p)[1] - stripes.stripe_pixel_rows(ys, *p)[0]
+                     for p in parts]
+    full = stripes.gather_stripes(stripe, rows_per_rank, rank, world)
+    if rank == 0:
+        ref = fr.decode(threads=2)
+        ok = bool(np.array_equal(full.numpy(), ref))
+        open(result_path, "w").write("ok" if ok else "mismatch %g" % np.abs(full.numpy() - ref).max())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stripe_partition():
+    from libjxl_amd import stripes
+    assert stripes.stripe_partition(8640, 8) == [(0, 5), (5, 5), (10, 4), (14, 4), (18, 4), (22, 4),
+                                                 (26, 4), (30, 4)]
+    assert stripes.stripe_partition(4320, 1) == [(0, 17)]
+    parts = stripes.stripe_partition(4320 * 8, 8)
+    assert sum(n for _, n in parts) == (4320 * 8 + 255) // 256
+    assert all(b[0] == a[0] + a[1] for a, b in zip(parts, parts[1:]))
+    with pytest.raises(ValueError):
+        stripes.stripe_partition(300, 3)
+    assert stripes.stripe_pixel_rows(700, 2, 1) == (512, 700)
+
+
+def test_two_rank_stripes_halo_exchange_and_gather(tmp_path, oracle):
+    port = 29500 + os.getpid() % 2000
+    result = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(2, port, 300, 600, str(result)), nprocs=2, join=True)
+    assert result.read_text() == "ok"
