@@ -21,8 +21,7 @@ def load(path):
 
 
 def short(name):
-    for key, tag in (("k_filters", "filters"), ("k_xyb_only", "filters"), ("k_dct8", "blocks_small:dct8"),
-                     ("k_special", "blocks_small:special"), ("k_medium", "blocks_medium"),
+    for key, tag in (("k_filters", "filters"), ("k_xyb_only", "filters"), ("k_block64", "blocks_small"), ("k_medium", "blocks_medium"),
                      ("k_large", "blocks_large"), ("k_prepare", "prepare")):
         if key in name:
             return tag
