@@ -226,3 +226,73 @@ class Frame:
         if rc != 0:
             raise ValueError("oracle decode failed")
         return out
+
+
+# ---- oracle/_ref: the libjxl reference itself (compiled in place) ----------
+_REF_SO = os.path.join(_HERE, "_ref", "libjxl_ref.so")
+_ref = None
+
+
+def ref_available():
+    """True when oracle/_ref/libjxl_ref.so exists or can be built here."""
+    from . import build_ref
+    return os.path.exists(_REF_SO) or build_ref.available()
+
+
+def build_reference():
+    """Compile the reference decoder sources in place (needs /root/reference;
+    on the GPU box the prebuilt .so is used)."""
+    from . import build_ref
+    return build_ref.build()
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        lib()  # the restatement exports the shared POD helpers
+        build_reference()
+        L = C.CDLL(_REF_SO)
+        L.jxr_decode_frame.argtypes = [C.POINTER(OracleFrame), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+        L.jxr_default_dequant_tables.argtypes = [C.c_void_p]
+        L.jxr_dequant_dc.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p * 3, C.c_void_p * 3, C.c_void_p,
+                                     C.c_float, C.c_float, C.c_int]
+        L.jxr_describe.restype = C.c_char_p
+        _ref = L
+    return _ref
+
+
+def ref_default_dequant_tables():
+    t = np.zeros(DEQUANT_TABLE_FLOATS, np.float32)
+    assert ref_lib().jxr_default_dequant_tables(_p(t)) == 0
+    return t
+
+
+def ref_dequant_dc(quant_dc, mul_dc, cfl_x_dc, cfl_b_dc, smooth):
+    """DequantDC (+AdaptiveDCSmoothing) by the reference; quant_dc: 3 int32 planes."""
+    ysb, xsb = quant_dc[0].shape
+    q = [np.ascontiguousarray(a, np.int32) for a in quant_dc]
+    out = [np.zeros((ysb, xsb), np.float32) for _ in range(3)]
+    m = np.ascontiguousarray(mul_dc, np.float32)
+    rc = ref_lib().jxr_dequant_dc(xsb, ysb, _p3(q), _p3(out), _p(m), cfl_x_dc, cfl_b_dc, int(smooth))
+    assert rc == 0
+    return out
+
+
+def _decode_ref(self, threads=1, simple_pipeline=False):
+    """The same frame through the REFERENCE's DecodeGroupForRoundtrip + render
+    pipeline (LowMemory executor by default, as djxl; simple_pipeline=True for
+    SimpleRenderPipeline)."""
+    p = self.params
+    if p.output_kind == 1:
+        out = np.zeros((p.ysize, p.xsize, 3), np.float32)
+        rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), p.xsize * 3, 0, threads, int(simple_pipeline))
+    else:
+        out = np.zeros((3, p.ysize, p.xsize), np.float32)
+        rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), p.xsize, p.xsize * p.ysize, threads,
+                                        int(simple_pipeline))
+    if rc != 0:
+        raise ValueError("reference decode failed")
+    return out
+
+
+Frame.decode_ref = _decode_ref

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY.  Builds oracle/_ref/libjxl_ref.so: the libjxl
+REFERENCE decoder sources compiled IN PLACE from /root/reference (never copied)
+with g++, against oracle/hwy_shim (a from-scratch single-lane stand-in for the
+un-vendored Highway submodule) -- no cmake, no reference build system.  The
+driver oracle/ref_driver.cc calls the reference's own internals
+(DecodeGroupForRoundtrip + the real render pipeline, dec_group.cc:820-841,
+enc_adaptive_quantization.cc:840-919) on in-memory coefficients.
+
+Used only by tests/ and bench.py's cpu_baseline as a checker.  /root/reference
+exists only in the build container: on the GPU box the prebuilt .so travels.
+"""
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("JXL_REFERENCE", "/root/reference")
+OUT = os.path.join(HERE, "_ref")
+OBJ = os.path.join(OUT, "obj")
+SHIM = os.path.join(HERE, "hwy_shim")
+CXX = os.environ.get("CXX", "g++")
+FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fno-lto", "-ffunction-sections", "-fdata-sections",
+         "-ffp-contract=off", "-fvisibility=hidden", "-w",
+         "-I" + SHIM, "-I" + REF, "-I" + os.path.join(REF, "lib", "include"),
+         "-DJPEGXL_ENABLE_SKCMS=0", "-DJXL_DEBUG_ON_ERROR=0", "-DJXL_CRASH_ON_ERROR=0"]
+# reference translation units that are not needed by (or not linkable into) the
+# VarDCT back-end harness: public API front-end, JPEG reconstruction, ICC codec
+SKIP = re.compile(r"(decode\.cc|decode_to_jpeg\.cc|jpeg/|icc_codec\.cc|_test\.cc|_gbench\.cc|test_)")
+
+
+def source_list():
+    txt = open(os.path.join(REF, "lib", "jxl_lists.cmake")).read()
+
+    def lst(name):
+        m = re.search(r"set\(%s\n(.*?)\n\)" % name, txt, re.S)
+        return m.group(1).split()
+    files = lst("JPEGXL_INTERNAL_BASE_SOURCES") + lst("JPEGXL_INTERNAL_DEC_SOURCES")
+    return [f for f in files if f.endswith(".cc") and not SKIP.search(f)]
+
+
+def available():
+    return os.path.isdir(os.path.join(REF, "lib", "jxl"))
+
+
+def _compile(job):
+    src, obj = job
+    deps = [src] + ([os.path.join(SHIM, "hwy", h) for h in os.listdir(os.path.join(SHIM, "hwy"))])
+    if os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):
+        return obj, ""
+    extra = ["-I" + HERE] if src.startswith(HERE) else []
+    r = subprocess.run([CXX] + FLAGS + extra + ["-c", src, "-o", obj], capture_output=True, text=True)
+    return (obj if r.returncode == 0 else None), r.stderr
+
+
+def build(verbose=False, only_compile=False):
+    lib = os.path.join(OUT, "libjxl_ref.so")
+    if not available():
+        if os.path.exists(lib):
+            return lib  # prebuilt, travelled with the snapshot
+        raise RuntimeError("reference tree not present and no prebuilt oracle/_ref/libjxl_ref.so")
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for f in source_list():
+        jobs.append((os.path.join(REF, "lib", f), os.path.join(OBJ, f.replace("/", "__")[:-3] + ".o")))
+    if not only_compile:
+        jobs.append((os.path.join(HERE, "ref_driver.cc"), os.path.join(OBJ, "ref_driver.o")))
+    objs, failed = [], []
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        for (src, _), (obj, err) in zip(jobs, ex.map(_compile, jobs)):
+            if obj is None:
+                failed.append((src, err))
+            else:
+                objs.append(obj)
+    if failed:
+        msg = "\n".join("== %s\n%s" % (s, e[:3000]) for s, e in failed[:8])
+        raise RuntimeError("%d reference TUs failed to compile: %s\n%s" % (
+            len(failed), [os.path.basename(s) for s, _ in failed], msg))
+    if only_compile:
+        return objs
+    cmd = [CXX, "-shared", "-fPIC", "-o", lib] + objs + ["-Wl,--gc-sections", "-Wl,--no-undefined",
+                                                         "-lpthread", "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stderr[-6000:])
+    if verbose:
+        print("built", lib)
+    return lib
+
+
+if __name__ == "__main__":
+    build(verbose=True, only_compile="--compile-only" in sys.argv)
+    sys.exit(0)

@@ -6,18 +6,28 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it, and only
  * as the checker / reported baseline.
  *
- * Parity status: the reference decoder cannot be built in this environment
- * (every hot-path translation unit includes Google Highway, an un-vendored
- * submodule: third_party/highway is empty, deps.sh:20), and testdata/ is empty.
- * The oracle is therefore pinned against the reference's own fixture-free
- * known-answer tests (tests/test_oracle_kat.py):
+ * Parity status: PINNED AGAINST THE REFERENCE ITSELF.  The reference's hot path
+ * is compiled in place from /root/reference/lib/jxl (73 decoder translation
+ * units, unmodified) by oracle/build_ref.py into oracle/_ref/libjxl_ref.so; the
+ * only stand-in is oracle/hwy_shim, a from-scratch single-lane implementation of
+ * the Highway API subset libjxl uses (third_party/highway is an un-vendored
+ * submodule, deps.sh:20).  oracle/ref_driver.cc feeds the same in-memory inputs
+ * to the reference's DecodeGroupForRoundtrip + ComputeSigma + real render
+ * pipeline (both executors).  tests/test_reference_parity.py holds this
+ * restatement to BIT-EXACT equality with that library (all 27 strategies, all 8
+ * stage lists, ragged sizes, int32 coefficients, custom LoopFilter fields, DC
+ * dequant + adaptive smoothing, dequant tables), and tests/golden/*.npz are the
+ * reference's own outputs.  In addition the reference's fixture-free
+ * known-answer tests are restated in tests/test_oracle_kat.py:
  *   lib/jxl/dct_test.cc:165-214,251-300,314-475   (DCT/IDCT vs f64 matrix)
  *   lib/jxl/ac_strategy_test.cc:28-245            (27 strategies: roundtrip,
  *        DC = mean, LLF<->DC, 8x8-mean(IDCT(LLF)) = DC, AFV orthonormal)
  *   lib/jxl/quant_weights_test.cc:185-271         (dequant tables)
  *   lib/jxl/opsin_inverse_test.cc:27-49           (XYB inverse of forward)
- * Gaborish/EPF have no fixture-free numeric KAT in the reference:
- * for those two stages parity is "restatement-pinned" only.
+ * Caveat stated once: the shim is scalar with MulAdd = fmaf and exact
+ * reciprocals, i.e. the reference as built for an FMA target with
+ * JXL_HIGH_PRECISION=1; an AVX2 build differs from it in the last bits only where
+ * libjxl uses ApproximateReciprocal (within the reference's own 2e-4 bar).
  *
  * Every function cites the reference lines it restates (paths relative to the
  * libjxl tree).  Arithmetic is fp32 with the reference's operation order;

@@ -1,0 +1,347 @@
+// TEST INFRASTRUCTURE ONLY (part of oracle/).
+//
+// Harness around the UNMODIFIED libjxl reference sources (compiled in place
+// from /root/reference by oracle/build_ref.py into oracle/_ref/libjxl_ref.so).
+// It feeds in-memory quantized coefficients + side info -- exactly the inputs
+// of the product's C ABI (include/jxl_hip.h) -- to the reference's own hot path:
+//
+//   DecodeGroupForRoundtrip (lib/jxl/dec_group.cc:820-841)
+//     -> DecodeGroupImpl -> DequantBlock / LowestFrequenciesFromDC /
+//        TransformToPixels (dec_group.cc:183-457)
+//   ComputeSigma (lib/jxl/epf.cc:39-133)
+//   the real RenderPipeline (LowMemory or Simple executor) built by
+//   PassesDecoderState::PreparePipeline (lib/jxl/dec_cache.cc:117-371):
+//     GaborishStage, EPF0/1/2Stage, XYBStage, FromLinear(identity),
+//     WriteToOutputStage(float)
+//
+// following the reference's bitstream-free precedent RoundtripImage
+// (lib/jxl/enc_adaptive_quantization.cc:840-919).  All arithmetic on the path is
+// the reference's; this file only builds the state objects.
+//
+// Nothing here is linked into or called by the product (libjxl_amd/).
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cmath>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+// The harness must set a handful of private members that the reference only
+// fills from a bitstream (ColorCorrelation base correlations).
+#define private public
+#include "lib/jxl/chroma_from_luma.h"
+#undef private
+
+#include "lib/jxl/ac_strategy.h"
+#include "lib/jxl/base/status.h"
+#include "lib/jxl/compressed_dc.h"
+#include "lib/jxl/dct_util.h"
+#include "lib/jxl/dec_cache.h"
+#include "lib/jxl/dec_group.h"
+#include "lib/jxl/dec_xyb.h"
+#include "lib/jxl/epf.h"
+#include "lib/jxl/frame_header.h"
+#include "lib/jxl/image.h"
+#include "lib/jxl/image_bundle.h"
+#include "lib/jxl/image_metadata.h"
+#include "lib/jxl/loop_filter.h"
+#include "lib/jxl/memory_manager_internal.h"
+#include "lib/jxl/modular/modular_image.h"
+#include "lib/jxl/modular/transform/transform.h"
+#include "lib/jxl/ac_context.h"
+#include "lib/jxl/passes_state.h"
+#include "lib/jxl/quant_weights.h"
+#include "lib/jxl/quantizer.h"
+#include "lib/jxl/render_pipeline/render_pipeline.h"
+
+#include "jxl_oracle.h"  // jxo_frame (POD mirror of the C ABI inputs)
+
+#define JXR_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+using namespace jxl;  // NOLINT
+
+struct Ref {
+  JxlMemoryManager mm;
+  Ref() { (void)MemoryManagerInit(&mm, nullptr); }
+};
+
+Status FillState(const jxo_frame* f, CodecMetadata* metadata, FrameHeader* fh,
+                 PassesDecoderState* dec_state, bool xyb_out) {
+  const jxlhip_frame_params& p = f->p;
+  // ---- image-level metadata: XYB-encoded, float samples, linear sRGB target
+  metadata->m.SetFloat32Samples();
+  metadata->m.xyb_encoded = !xyb_out;
+  metadata->m.color_encoding = ColorEncoding::LinearSRGB(/*is_gray=*/false);
+  JXL_RETURN_IF_ERROR(metadata->size.Set(p.xsize, p.ysize));
+
+  // ---- frame header: one VarDCT frame covering the image
+  fh->nonserialized_metadata = metadata;
+  fh->encoding = FrameEncoding::kVarDCT;
+  fh->frame_type = FrameType::kRegularFrame;
+  fh->color_transform = xyb_out ? ColorTransform::kNone : ColorTransform::kXYB;
+  fh->is_last = true;
+  fh->flags = 0;
+  fh->upsampling = 1;
+  LoopFilter& lf = fh->loop_filter;
+  lf.all_default = false;
+  lf.gab = p.lf.gab != 0;
+  lf.gab_custom = true;
+  lf.gab_x_weight1 = p.lf.gab_weights[0];
+  lf.gab_x_weight2 = p.lf.gab_weights[1];
+  lf.gab_y_weight1 = p.lf.gab_weights[2];
+  lf.gab_y_weight2 = p.lf.gab_weights[3];
+  lf.gab_b_weight1 = p.lf.gab_weights[4];
+  lf.gab_b_weight2 = p.lf.gab_weights[5];
+  lf.epf_iters = p.lf.epf_iters;
+  lf.epf_sharp_custom = true;
+  for (int i = 0; i < 8; i++) lf.epf_sharp_lut[i] = p.lf.epf_sharp_lut[i];
+  lf.epf_weight_custom = true;
+  for (int i = 0; i < 3; i++) lf.epf_channel_scale[i] = p.lf.epf_channel_scale[i];
+  lf.epf_sigma_custom = true;
+  lf.epf_quant_mul = p.lf.epf_quant_mul;
+  lf.epf_pass0_sigma_scale = p.lf.epf_pass0_sigma_scale;
+  lf.epf_pass2_sigma_scale = p.lf.epf_pass2_sigma_scale;
+  lf.epf_border_sad_mul = p.lf.epf_border_sad_mul;
+
+  // ---- shared state (what the DC-group / AC-global sections would decode)
+  PassesSharedState& sh = dec_state->shared_storage;
+  JXL_RETURN_IF_ERROR(InitializePassesSharedState(*fh, &sh, /*encoder=*/false));
+  const FrameDimensions& fd = sh.frame_dim;
+  const size_t xsb = fd.xsize_blocks, ysb = fd.ysize_blocks;
+
+  JXL_RETURN_IF_ERROR(sh.matrices.EnsureComputed(sh.memory_manager, ~0u));
+  sh.quantizer.~Quantizer();
+  new (&sh.quantizer) Quantizer(sh.matrices, p.quant_dc, p.global_scale);
+
+  for (size_t by = 0; by < ysb; by++) {
+    const uint8_t* acs = f->ac_strategy + by * xsb;
+    const int32_t* q = f->raw_quant + by * xsb;
+    const uint8_t* sp = f->epf_sharpness + by * xsb;
+    int32_t* qrow = sh.raw_quant_field.Row(by);
+    uint8_t* srow = sh.epf_sharpness.Row(by);
+    for (size_t bx = 0; bx < xsb; bx++) {
+      qrow[bx] = q[bx];
+      srow[bx] = sp[bx];
+      if (acs[bx] & 1) {
+        const int raw = acs[bx] >> 1;
+        if (raw >= static_cast<int>(AcStrategy::kNumValidStrategies)) {
+          return JXL_FAILURE("invalid strategy");
+        }
+        // Set() validates that the varblock fits and fills the covered cells
+        JXL_RETURN_IF_ERROR(sh.ac_strategy.Set(bx, by, static_cast<AcStrategyType>(raw)));
+      }
+    }
+  }
+  const size_t xst = DivCeil(xsb, kColorTileDimInBlocks), yst = DivCeil(ysb, kColorTileDimInBlocks);
+  for (size_t ty = 0; ty < yst; ty++) {
+    int8_t* rx = sh.cmap.ytox_map.Row(ty);
+    int8_t* rb = sh.cmap.ytob_map.Row(ty);
+    for (size_t tx = 0; tx < xst; tx++) {
+      rx[tx] = f->ytox_map[ty * xst + tx];
+      rb[tx] = f->ytob_map[ty * xst + tx];
+    }
+  }
+  sh.cmap.base_.base_correlation_x_ = p.cfl_base_x;
+  sh.cmap.base_.base_correlation_b_ = p.cfl_base_b;
+  sh.cmap.base_.SetColorFactor(p.cfl_color_factor);
+  for (size_t c = 0; c < 3; c++) {
+    for (size_t by = 0; by < ysb; by++) {
+      memcpy(sh.dc_storage.PlaneRow(c, by), f->dc[c] + by * xsb, xsb * sizeof(float));
+    }
+  }
+
+  // ---- decoder state
+  JXL_RETURN_IF_ERROR(dec_state->output_encoding_info.SetFromMetadata(*metadata));
+  OpsinParams& op = dec_state->output_encoding_info.opsin_params;
+  for (int i = 0; i < 9; i++) {
+    for (int k = 0; k < 4; k++) op.inverse_opsin_matrix[i * 4 + k] = p.inverse_opsin_matrix[i];
+  }
+  for (int i = 0; i < 3; i++) op.opsin_biases[i] = p.opsin_biases[i];
+  op.opsin_biases[3] = 1.0f;  // OpsinParams::Init copies 4 floats; lane 3 unused by XybToRgb
+  for (int i = 0; i < 4; i++) op.opsin_biases_cbrt[i] = cbrtf(op.opsin_biases[i]);  // dec_xyb.cc:122-124
+  for (int i = 0; i < 4; i++) op.quant_biases[i] = p.quant_biases[i];
+
+  JXL_RETURN_IF_ERROR(dec_state->Init(*fh));
+  dec_state->x_dm_multiplier = p.x_dm_multiplier;
+  dec_state->b_dm_multiplier = p.b_dm_multiplier;
+  JXL_RETURN_IF_ERROR(dec_state->InitForAC(/*num_passes=*/1, /*pool=*/nullptr));
+  return true;
+}
+
+Status DecodeFrame(const jxo_frame* f, float* out, size_t out_stride_floats, size_t out_plane_stride,
+                   int threads, int simple_pipeline) {
+  Ref ref;
+  const jxlhip_frame_params& p = f->p;
+  const bool xyb_out = p.output_kind == JXLHIP_OUT_XYB_PLANAR;
+  CodecMetadata metadata;
+  FrameHeader fh(&metadata);
+  auto dec_state = jxl::make_unique<PassesDecoderState>(&ref.mm);
+  JXL_RETURN_IF_ERROR(FillState(f, &metadata, &fh, dec_state.get(), xyb_out));
+  const FrameDimensions& fd = dec_state->shared->frame_dim;
+  const size_t num_groups = fd.num_groups;
+
+  // coefficients: the layout GetBlockFromEncoder reads (dec_group.cc:662-700):
+  // one row of kGroupDim^2 int32 per group and channel
+  std::vector<std::unique_ptr<ACImage>> ac;
+  {
+    JXL_ASSIGN_OR_RETURN(std::unique_ptr<ACImageT<int32_t>> img,
+                         ACImageT<int32_t>::Make(&ref.mm, kGroupDim * kGroupDim, num_groups));
+    for (size_t c = 0; c < 3; c++) {
+      for (size_t g = 0; g < num_groups; g++) {
+        int32_t* row = img->PlaneRow(c, g, 0).ptr32;
+        if (p.coeff_type == JXLHIP_COEFF_I16) {
+          const int16_t* src = static_cast<const int16_t*>(f->coeffs[c]) + g * (kGroupDim * kGroupDim);
+          for (size_t k = 0; k < kGroupDim * kGroupDim; k++) row[k] = src[k];
+        } else {
+          memcpy(row, static_cast<const int32_t*>(f->coeffs[c]) + g * (kGroupDim * kGroupDim),
+                 sizeof(int32_t) * kGroupDim * kGroupDim);
+        }
+      }
+    }
+    ac.emplace_back(std::move(img));
+  }
+
+  // output: interleaved float RGB through the reference's WriteToOutputStage
+  std::vector<float> tmp;
+  float* rgb = out;
+  size_t rgb_stride = out_stride_floats;
+  if (xyb_out) {
+    tmp.resize(static_cast<size_t>(p.xsize) * p.ysize * 3);
+    rgb = tmp.data();
+    rgb_stride = static_cast<size_t>(p.xsize) * 3;
+  }
+  dec_state->width = p.xsize;
+  dec_state->height = p.ysize;
+  dec_state->main_output.format = JxlPixelFormat{3, JXL_TYPE_FLOAT, JXL_NATIVE_ENDIAN, 0};
+  dec_state->main_output.bits_per_sample = 32;
+  dec_state->main_output.buffer = rgb;
+  dec_state->main_output.stride = rgb_stride * sizeof(float);
+  dec_state->main_output.buffer_size = dec_state->main_output.stride * p.ysize;
+
+  ImageBundle decoded(&ref.mm, &metadata.m);
+  PassesDecoderState::PipelineOptions options;
+  options.use_slow_render_pipeline = simple_pipeline != 0;
+  options.coalescing = false;
+  options.render_spotcolors = false;
+  options.render_noise = false;
+  JXL_RETURN_IF_ERROR(dec_state->PreparePipeline(fh, &metadata.m, &decoded, options));
+
+  const size_t nthreads = std::max(1, std::min<int>(threads, static_cast<int>(num_groups)));
+  JXL_RETURN_IF_ERROR(dec_state->render_pipeline->PrepareForThreads(nthreads, /*use_group_ids=*/false));
+  JXL_ASSIGN_OR_RETURN(AlignedArray<GroupDecCache> caches,
+                       AlignedArray<GroupDecCache>::Create(&ref.mm, nthreads));
+
+  std::atomic<size_t> next{0};
+  std::atomic<bool> failed{false};
+  auto worker = [&](size_t thread) {
+    for (;;) {
+      const size_t g = next.fetch_add(1);
+      if (g >= num_groups || failed.load()) return;
+      Status ok = [&]() -> Status {
+        if (fh.loop_filter.epf_iters > 0) {
+          JXL_RETURN_IF_ERROR(ComputeSigma(fh.loop_filter, fd.BlockGroupRect(g), dec_state.get()));
+        }
+        RenderPipelineInput input = dec_state->render_pipeline->GetInputBuffers(g, thread);
+        JXL_RETURN_IF_ERROR(DecodeGroupForRoundtrip(fh, ac, g, dec_state.get(), &caches[thread], thread,
+                                                    input, nullptr, nullptr));
+        JXL_RETURN_IF_ERROR(input.Done());
+        return true;
+      }();
+      if (!ok) failed.store(true);
+    }
+  };
+  if (nthreads == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nthreads; t++) pool.emplace_back(worker, t);
+    for (auto& t : pool) t.join();
+  }
+  if (failed.load()) return JXL_FAILURE("group decode failed");
+
+  if (xyb_out) {
+    for (size_t c = 0; c < 3; c++) {
+      for (size_t y = 0; y < p.ysize; y++) {
+        float* dst = out + c * out_plane_stride + y * out_stride_floats;
+        const float* src = tmp.data() + y * rgb_stride + c;
+        for (size_t x = 0; x < p.xsize; x++) dst[x] = src[3 * x];
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+// Whole path through the reference.  out per p.output_kind, as
+// jxo_decode_frame / jxlhip_decode_frame.  simple_pipeline: 1 =
+// SimpleRenderPipeline, 0 = LowMemoryRenderPipeline (what djxl uses).
+// Returns 0 on success.
+JXR_EXPORT int jxr_decode_frame(const jxo_frame* f, float* out, size_t out_stride_floats,
+                                size_t out_plane_stride, int threads, int simple_pipeline) {
+  Status s = DecodeFrame(f, out, out_stride_floats, out_plane_stride, threads, simple_pipeline);
+  return s ? 0 : -1;
+}
+
+// DequantMatrices::EnsureComputed for the default library
+// (lib/jxl/quant_weights.cc:1211-1271); table: JXLHIP_DEQUANT_TABLE_FLOATS.
+JXR_EXPORT int jxr_default_dequant_tables(float* table) {
+  Ref ref;
+  DequantMatrices m;
+  if (!m.EnsureComputed(&ref.mm, ~0u)) return -1;
+  // table_ is one contiguous block of kTotalTableSize floats starting at the
+  // DCT8 X matrix (table_offsets_[0] == 0, quant_weights.cc:1247-1262)
+  memcpy(table, m.Matrix(AcStrategyType::DCT, 0), sizeof(float) * JXLHIP_DEQUANT_TABLE_FLOATS);
+  return 0;
+}
+
+// DequantDC + AdaptiveDCSmoothing (lib/jxl/compressed_dc.cc:128-250), 4:4:4.
+JXR_EXPORT int jxr_dequant_dc(uint32_t xsb, uint32_t ysb, const int32_t* const quant_dc[3], float* const dc[3],
+                              const float mul_dc[3], float cfl_x_dc, float cfl_b_dc, int smooth) {
+  Ref ref;
+  auto run = [&]() -> Status {
+    JXL_ASSIGN_OR_RETURN(Image3F out, Image3F::Create(&ref.mm, xsb, ysb));
+    JXL_ASSIGN_OR_RETURN(Image im, Image::Create(&ref.mm, xsb, ysb, 32, 3));
+    for (size_t c = 0; c < 3; c++) {
+      // modular channel order for VarDCT DC is Y, X, B (compressed_dc.cc:213-221)
+      const size_t src = c < 2 ? (c ^ 1) : c;
+      for (size_t y = 0; y < ysb; y++) {
+        memcpy(im.channel[c].Row(y), quant_dc[src] + static_cast<size_t>(y) * xsb, xsb * sizeof(int32_t));
+      }
+    }
+    const float dc_factors[3] = {mul_dc[0], mul_dc[1], mul_dc[2]};
+    const float cfl[4] = {cfl_x_dc, 0.0f, cfl_b_dc, 0.0f};
+    BlockCtxMap bctx;
+    JXL_ASSIGN_OR_RETURN(ImageB qdc, ImageB::Create(&ref.mm, xsb, ysb));
+    DequantDC(Rect(0, 0, xsb, ysb), &out, &qdc, im, dc_factors, 1.0f, cfl, YCbCrChromaSubsampling(), bctx);
+    if (smooth) {
+      JXL_RETURN_IF_ERROR(AdaptiveDCSmoothing(&ref.mm, dc_factors, &out, nullptr));
+    }
+    for (size_t c = 0; c < 3; c++) {
+      for (size_t y = 0; y < ysb; y++) {
+        memcpy(dc[c] + static_cast<size_t>(y) * xsb, out.ConstPlaneRow(c, y), xsb * sizeof(float));
+      }
+    }
+    return true;
+  };
+  return run() ? 0 : -1;
+}
+
+JXR_EXPORT const char* jxr_describe(void) {
+  return "libjxl reference (lib/jxl decoder sources compiled in place) with the single-lane Highway shim "
+         "oracle/hwy_shim: MulAdd=fmaf, exact reciprocals, JXL_HIGH_PRECISION=1";
+}

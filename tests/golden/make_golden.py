@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Generates tests/golden/*.npz: small seeded VarDCT frames (inputs in the
-jxlhip_frame_inputs layout) together with the CPU oracle's outputs (XYB planes
-after phase 1, sigma, final linear RGB).  The reference decoder itself cannot
-run here (Highway is not vendored), so these vectors pin the ORACLE, which is
-in turn pinned by the reference's fixture-free known-answer tests
-(tests/test_oracle_kat.py).  Re-run only when the oracle is deliberately
-changed:  python tests/golden/make_golden.py"""
+jxlhip_frame_inputs layout) together with the outputs of the libjxl REFERENCE
+run in this container (oracle/_ref: lib/jxl's decoder sources compiled in place,
+oracle/build_ref.py + oracle/ref_driver.cc): `rgb` = final linear RGB of the
+full path, `xyb` = the planes after dequant + inverse transforms (the reference
+run with the filters off and XYB output).  `sigma` comes from the oracle
+(ComputeSigma has no output tap in the reference; it is covered through `rgb`).
+main() also asserts that the CPU oracle reproduces the reference bit for bit.
+Re-run only on purpose:  python tests/golden/make_golden.py"""
 import hashlib
 import os
 import sys
@@ -44,9 +46,25 @@ def build(name):
     return params, out
 
 
+def reference_outputs(name):
+    """rgb and (cropped) xyb planes by the reference itself."""
+    xs, ys, kw = CASES[name]
+    _, _, fr = frames.make_case(xs, ys, **kw)
+    rgb = fr.decode_ref(threads=1)
+    kw1 = dict(kw, gab=False, epf_iters=0, output_kind=0)
+    _, _, fr1 = frames.make_case(xs, ys, **kw1)
+    return rgb, fr1.decode_ref(threads=1)
+
+
 def main():
     for name in CASES:
         params, out = build(name)
+        xs, ys, _ = CASES[name]
+        rgb, xyb = reference_outputs(name)
+        assert np.array_equal(rgb.view(np.uint32), out["rgb"].view(np.uint32)), "oracle != reference (rgb)"
+        assert np.array_equal(xyb.view(np.uint32), out["xyb"][:, :ys, :xs].view(np.uint32)), \
+            "oracle != reference (xyb)"
+        out["rgb"] = rgb  # the committed vector is the reference's own output
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         h = hashlib.sha256(out["rgb"].tobytes()).hexdigest()[:16]
         print(name, {k: v.shape for k, v in out.items() if k in ("coeffs", "rgb")}, "rgb sha", h)

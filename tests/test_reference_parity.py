@@ -1,0 +1,108 @@
+"""Pins the CPU oracle (oracle/*.c, a restatement) against the libjxl REFERENCE
+ITSELF: oracle/_ref/libjxl_ref.so is lib/jxl's decoder sources compiled in place
+(oracle/build_ref.py, single-lane Highway shim) and driven through the
+reference's own DecodeGroupForRoundtrip + ComputeSigma + render pipeline
+(oracle/ref_driver.cc).  Same in-memory inputs as the product's C ABI.
+
+The restatement follows the reference's operation order (explicit fmaf where
+the reference uses MulAdd), so the bar here is BIT-EXACT equality, for both of
+the reference's executors (LowMemoryRenderPipeline = what djxl runs, and
+SimpleRenderPipeline)."""
+import numpy as np
+import pytest
+
+import frames
+from libjxl_amd import synth
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built and /root/reference absent")
+    oracle.ref_lib()
+    return oracle
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_dequant_tables_bit_identical(ref):
+    # DequantMatrices::EnsureComputed, lib/jxl/quant_weights.cc:1211-1271
+    a, b = ref.default_dequant_tables(), ref.ref_default_dequant_tables()
+    assert np.array_equal(bits(a), bits(b))
+
+
+STAGE_LISTS = [(g, e) for g in (False, True) for e in (0, 1, 2, 3)]
+
+
+@pytest.mark.parametrize("gab,epf", STAGE_LISTS)
+def test_all_strategies_every_stage_list(ref, gab, epf):
+    _, _, fr = frames.make_case(328, 264, mix=synth.MIX_ALL, gab=gab, epf_iters=epf, seed=7 + epf)
+    o = fr.decode(threads=4)
+    assert np.array_equal(bits(o), bits(fr.decode_ref(threads=4)))
+    assert np.array_equal(bits(o), bits(fr.decode_ref(threads=1, simple_pipeline=True)))
+
+
+@pytest.mark.parametrize("xs,ys", [(1, 1), (3, 8), (8, 8), (9, 17), (255, 257), (256, 256), (257, 255),
+                                   (513, 64), (64, 520)])
+def test_ragged_sizes(ref, xs, ys):
+    _, _, fr = frames.make_case(xs, ys, mix=synth.MIX_ALL, gab=True, epf_iters=3, seed=xs * 31 + ys)
+    assert np.array_equal(bits(fr.decode(threads=2)), bits(fr.decode_ref(threads=2)))
+
+
+def test_each_strategy_alone(ref):
+    for s in range(27):
+        cx, cy = ref.covered_blocks(s)
+        _, _, fr = frames.make_case(max(64, 16 * cx), max(64, 16 * cy), mix={s: 1}, gab=True, epf_iters=1,
+                                    seed=100 + s)
+        assert np.array_equal(bits(fr.decode()), bits(fr.decode_ref())), f"strategy {s}"
+
+
+def test_int32_coefficients_and_hdr_intensity(ref):
+    # BASELINE configs[4]: DCT32x32 forced, int32 coefficients, intensity_target > 255
+    _, _, fr = frames.make_case(520, 264, mix=synth.MIX_DCT32, gab=False, epf_iters=0, coeff_type=1,
+                                intensity_target=4000.0, quant_mul=2.0)
+    assert np.array_equal(bits(fr.decode(threads=2)), bits(fr.decode_ref(threads=2)))
+
+
+def test_custom_loop_filter_fields(ref):
+    _, _, fr = frames.make_case(300, 200, mix=synth.MIX_D1, gab=True, epf_iters=3, custom_lf=True, seed=5)
+    assert np.array_equal(bits(fr.decode(threads=2)), bits(fr.decode_ref(threads=2)))
+
+
+def test_xyb_planar_output(ref):
+    # phase 1 only (no filters): the IDCT planes as the render pipeline receives them
+    _, _, fr = frames.make_case(264, 136, mix=synth.MIX_ALL, gab=False, epf_iters=0, output_kind=0)
+    o, r = fr.decode(), fr.decode_ref()
+    assert o.shape == r.shape == (3, 136, 264)
+    assert np.array_equal(bits(o), bits(r))
+    _, _, fr = frames.make_case(264, 136, mix=synth.MIX_D1, gab=True, epf_iters=2, output_kind=0)
+    assert np.array_equal(bits(fr.decode()), bits(fr.decode_ref()))
+
+
+def test_d1_mix_1024_plumbing_config(ref):
+    # BASELINE configs[0]: 1024x1024 d1.0 full pipeline on the CPU
+    _, _, fr = frames.make_case(1024, 1024, mix=synth.MIX_D1, gab=True, epf_iters=1)
+    assert np.array_equal(bits(fr.decode(threads=8)), bits(fr.decode_ref(threads=8)))
+
+
+@pytest.mark.parametrize("smooth", [0, 1])
+def test_dequant_dc_and_smoothing(ref, smooth):
+    # DequantDC + AdaptiveDCSmoothing, lib/jxl/compressed_dc.cc:128-250
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    ysb, xsb = 37, 53
+    base = rng.integers(-40, 40, size=(3, ysb, xsb))
+    base[:, 10:20, 10:30] = base[:, 10:11, 10:11]  # flat areas exercise the smoothing gate
+    q = [np.ascontiguousarray(base[c], np.int32) for c in range(3)]
+    mul = np.array([1.0 / 4096 * 3.1, 1.0 / 512 * 3.1, 1.0 / 256 * 3.1], np.float32)
+    want = ref.ref_dequant_dc(q, mul, 0.0357, 1.0119, smooth)
+    got = [np.zeros((ysb, xsb), np.float32) for _ in range(3)]
+    L = ref.lib()
+    p3 = lambda a: (C.c_void_p * 3)(*[x.ctypes.data for x in a])  # noqa: E731
+    L.jxo_dequant_dc(xsb, ysb, p3(q), p3(got), mul.ctypes.data_as(C.c_void_p), 0.0357, 1.0119)
+    if smooth:
+        L.jxo_adaptive_dc_smoothing(xsb, ysb, mul.ctypes.data_as(C.c_void_p), p3(got))
+    for c in range(3):
+        assert np.array_equal(bits(got[c]), bits(want[c])), c
