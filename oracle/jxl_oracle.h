@@ -16,7 +16,7 @@
  * pipeline (both executors).  tests/test_reference_parity.py holds this
  * restatement to BIT-EXACT equality with that library (all 27 strategies, all 8
  * stage lists, ragged sizes, int32 coefficients, custom LoopFilter fields, DC
- * dequant + adaptive smoothing, dequant tables), and tests/golden/*.npz are the
+ * dequant + adaptive smoothing, dequant tables), and tests/golden/ (npz files) are the
  * reference's own outputs.  In addition the reference's fixture-free
  * known-answer tests are restated in tests/test_oracle_kat.py:
  *   lib/jxl/dct_test.cc:165-214,251-300,314-475   (DCT/IDCT vs f64 matrix)
