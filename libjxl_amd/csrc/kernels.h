@@ -8,7 +8,7 @@ namespace jxlhip {
 
 struct WorkLists {
   WorkItem* list[kNumClasses];
-  uint32_t* count;  // kNumClasses counters, zeroed before k_prepare
+  uint32_t* count;  // kCountStride counters (classes + unit tickets), zeroed before k_prepare
 };
 
 struct SharpLut {
@@ -31,9 +31,10 @@ struct FilterParams {
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
                    const SharpLut& lut, hipStream_t st);
-// One launch per work class, spread round-robin over `streams`.
-void LaunchBlocks(const DevFrame& f, const WorkLists& wl, const uint32_t* max_items,
-                  const float* wc, const float* resample, hipStream_t* streams, int nstreams);
+// Three persistent launches (class families A, B and the large kinds) spread
+// over `streams`; `cells` = block cells of the band (bounds the unit count).
+void LaunchBlocks(const DevFrame& f, const WorkLists& wl, uint32_t cells, const float* wc,
+                  const float* resample, hipStream_t* streams, int nstreams);
 // Returns 0, or -1 when the (gab, epf_iters, output_kind) combination is invalid.
 int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                   int output_kind, hipStream_t st);

@@ -324,6 +324,16 @@ __device__ __forceinline__ void Transform64(const float* co, float* px) {
   }
 }
 
+struct TabOffsets {
+  uint32_t v[27];
+};
+__host__ __device__ constexpr TabOffsets MakeTabOffsets() {
+  TabOffsets t{};
+  for (int s = 0; s < 27; s++) t.v[s] = DequantOffset(s);
+  return t;
+}
+static constexpr TabOffsets kSingleTabOffset = MakeTabOffsets();
+
 // ---- wave-cooperative staging for the single-block kernels ----------------
 // One lane decodes one 8x8 varblock in registers, but a lane-per-block global
 // access pattern touches 64 different cache lines per instruction.  So the
@@ -350,16 +360,13 @@ __device__ __forceinline__ void WaveGather64(const DevFrame& f, int c, const uin
   constexpr int kBlocksPerInstr = 64 / S::kChunks;
   const int sub = lane / S::kChunks, chunk = lane % S::kChunks;
   const char* base = (const char*)f.coeffs[c];
-  uint4 v[S::kChunks];
+  // (no staging array: global loads and LDS stores do not alias, the scheduler
+  // issues all the loads before the first store)
 #pragma unroll
   for (int i = 0; i < S::kChunks; i++) {
     const size_t byte = (size_t)blk_off[i] * (64 * sizeof(CT)) + (size_t)chunk * 16;
-    v[i] = *(const uint4*)(base + byte);
-  }
-#pragma unroll
-  for (int i = 0; i < S::kChunks; i++) {
     const int blk = i * kBlocksPerInstr + sub;
-    buf[blk * S::kChunks + (chunk ^ (blk & (S::kChunks - 1)))] = v[i];
+    buf[blk * S::kChunks + (chunk ^ (blk & (S::kChunks - 1)))] = *(const uint4*)(base + byte);
   }
 }
 
@@ -419,12 +426,13 @@ __device__ __forceinline__ void WaveStore64(const DevFrame& f, int c, uint32_t m
 // the in-order vmcnt covers stores too).  X and B recompute the luma
 // dequantisation they need for chroma-from-luma instead of sharing registers.
 // Lanes >= nvalid carry a duplicate of the last block.
-template <int STRATEGY, typename CT>
-__device__ __forceinline__ void DecodeBlock64(const DevFrame& f, const WorkItem it, int lane,
-                                              int nvalid, uint4* lds, int c) {
-  constexpr uint32_t kTab = DequantOffset(STRATEGY);
+template <typename CT>
+__device__ __forceinline__ void DecodeBlock64(const DevFrame& f, int strategy, const WorkItem it,
+                                              int lane, int nvalid, uint4* lds, int c) {
   using S = Stage64<CT>;
-  const float* __restrict__ tab = f.dequant + kTab;
+  // the ten single-block kinds share this code; only the transform differs
+  // (their dequant tables are 3 x 64 floats at a strategy-dependent offset)
+  const float* __restrict__ tab = f.dequant + kSingleTabOffset.v[strategy];
   const BlockHdr h = MakeHdr(f, it);
   const float dcv = f.dc[c][(size_t)h.aby * f.xsb + h.abx];
   // who owns the blocks this lane moves for the wave
@@ -463,26 +471,36 @@ __device__ __forceinline__ void DecodeBlock64(const DevFrame& f, const WorkItem 
     }
   }
   v[0] = dcv;
-  Transform64<STRATEGY>(v, px);
+  switch (strategy) {  // wave-uniform
+    case 0: Transform64<0>(v, px); break;
+    case 1: Transform64<1>(v, px); break;
+    case 2: Transform64<2>(v, px); break;
+    case 3: Transform64<3>(v, px); break;
+    case 12: Transform64<12>(v, px); break;
+    case 13: Transform64<13>(v, px); break;
+    case 14: Transform64<14>(v, px); break;
+    case 15: Transform64<15>(v, px); break;
+    case 16: Transform64<16>(v, px); break;
+    default: Transform64<17>(v, px); break;
+  }
   WaveStore64(f, c, it.pos, nvalid, (float4*)lds, lane, px);
 }
 
-// One kernel per single-block strategy (0 = DCT8, the bulk; the 9 special
-// kinds).  Workgroup = 3 waves = the 3 channels of the same 64 blocks; every
-// wave is independent (own LDS slice, no barrier).
-template <int STRATEGY, typename CT>
-__global__ __launch_bounds__(192) void k_block64(DevFrame f, const WorkItem* __restrict__ list,
-                                                 const uint32_t* __restrict__ count) {
-  __shared__ uint4 lds[3][Stage64<CT>::kLdsChunks];
+// One unit of a single-block class (0 = DCT8, the bulk; the 9 special kinds):
+// 64 varblocks starting at list[first].  Workgroup = 3 waves = the 3 channels of
+// the same 64 blocks; every wave is independent (own 16 KB LDS slice, no
+// workgroup barrier inside).
+template <typename CT>
+__device__ __forceinline__ void Single64Unit(const DevFrame& f, int strategy,
+                                             const WorkItem* __restrict__ list, uint32_t first,
+                                             uint32_t n, unsigned char* smem) {
+  uint4* lds = reinterpret_cast<uint4*>(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t first = blockIdx.x * 64u;
-  // the list is allocated for the worst case (+64 entries of slack), so the
-  // entry can be fetched before the count is known (both loads in flight)
+  // the list has 64 entries of slack: lanes past the end read garbage that is
+  // replaced by a duplicate of the last valid block
   WorkItem it = list[first + lane];
-  const uint32_t n = *count;
-  if (first >= n) return;
   const int nvalid = (int)min(64u, n - first);
-  {  // lanes past the end duplicate the last valid block
+  {
     const uint32_t lp = __shfl(it.pos, nvalid - 1, 64), lo = __shfl(it.off, nvalid - 1, 64),
                    lq = __shfl(it.qc, nvalid - 1, 64);
     if (lane >= nvalid) {
@@ -492,7 +510,7 @@ __global__ __launch_bounds__(192) void k_block64(DevFrame f, const WorkItem* __r
     }
   }
   const int c = wave == 0 ? 1 : (wave == 1 ? 0 : 2);
-  DecodeBlock64<STRATEGY, CT>(f, it, lane, nvalid, lds[wave], c);
+  DecodeBlock64<CT>(f, strategy, it, lane, nvalid, lds + wave * Stage64<CT>::kLdsChunks, c);
 }
 
 // ------------------------------------------------------------------ k_medium
@@ -516,29 +534,32 @@ __device__ __forceinline__ float ResampleUpSel(int i) {
 //   pass 1 / pass 2: ComputeScaledIDCT (dct-inl.h:376-397): R lanes run the
 //                    C-point IDCT of one row of frequencies, then C lanes the
 //                    R-point IDCT of one pixel column and store it
+template <int R, int C>
+struct MediumGeom {
+  static constexpr int S = R < C ? R : C, L = R < C ? C : R;
+  static constexpr int ML = L;        // lanes per varblock and channel
+  static constexpr int NB = 64 / ML;  // varblocks per batch
+  static constexpr int LP = L + 1;    // coefficient matrix row stride
+  static constexpr int TP = C + 1;    // intermediate T[u][x] / pixel row stride
+  static constexpr int BUF = (S * LP > R * TP ? S * LP : R * TP);
+  static constexpr int CY = R / 8, CX = C / 8;
+  static constexpr int kUnitVarblocks = (64 / (CY * CX)) > NB ? 64 / (CY * CX) : NB;  // 64 blocks of area
+  static constexpr int kHdrOffset = (12 * NB * (BUF + CY * CX) + 15) & ~15;
+  static constexpr int kLdsBytes = kHdrOffset + kUnitVarblocks * 48;
+};
+
+// One batch of NB varblocks whose headers are hdr[0..nb) (already in LDS).
 template <int R, int C, int STRATEGY, typename CT>
-__global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __restrict__ list,
-                                                const uint32_t* __restrict__ count) {
-  constexpr int S = R < C ? R : C, L = R < C ? C : R;
-  constexpr int ML = L;            // lanes per varblock and channel
-  constexpr int NB = 64 / ML;      // varblocks per workgroup
-  constexpr int LP = L + 1;        // coefficient matrix row stride
-  constexpr int TP = C + 1;        // intermediate T[u][x] row stride
-  constexpr int BUF = (S * LP > R * TP ? S * LP : R * TP);
-  constexpr int CY = R / 8, CX = C / 8;
+__device__ __forceinline__ void MediumBatch(const DevFrame& f, const BlockHdr* hdr, int nb,
+                                            unsigned char* smem) {
+  using G = MediumGeom<R, C>;
+  constexpr int L = G::L, ML = G::ML, NB = G::NB, LP = G::LP, TP = G::TP, BUF = G::BUF;
+  constexpr int CY = G::CY, CX = G::CX;
   constexpr int SIZE = R * C;
   constexpr uint32_t kTab = DequantOffset(STRATEGY);
-  __shared__ float buf[3][NB][BUF];
-  __shared__ float dcp[3][NB][CY * CX];
-  __shared__ BlockHdr hdr[NB];
-
-  const uint32_t n = *count;
-  const uint32_t first = blockIdx.x * NB;
-  if (first >= n) return;
-  const int nb = (int)min((uint32_t)NB, n - first);
+  float(*buf)[NB][BUF] = reinterpret_cast<float(*)[NB][BUF]>(smem);
+  float(*dcp)[NB][CY * CX] = reinterpret_cast<float(*)[NB][CY * CX]>(smem + 12 * NB * BUF);
   const int tid = threadIdx.x;
-  if (tid < nb) hdr[tid] = MakeHdr(f, list[first + tid]);
-  __syncthreads();
 
   const int c = tid >> 6, lane = tid & 63;
   const int b = lane / ML, i = lane % ML;
@@ -639,19 +660,47 @@ __global__ __launch_bounds__(192) void k_medium(DevFrame f, const WorkItem* __re
     }
   }
   __syncthreads();
-  // pass 2: for each pixel column x, R-point IDCT along u -> pixels
+  // pass 2: for each pixel column x, R-point IDCT along u -> pixels, in place
+  // (lane i owns column i of T)
   if (active && i < C) {
     float v[R];
 #pragma unroll
     for (int j = 0; j < R; j++) v[j] = m[j * TP + i];
     IdctReg<R>(v);
-    // column i of the varblock: tile column i/8, 8 rows per tile, tiles of the
-    // next block row are tile_stride tiles further
-    const BlockHdr& h = hdr[b];
-    float* dst = TilePtr(f, c, h.aby, h.abx + (i >> 3)) + (i & 7);
 #pragma unroll
-    for (int j = 0; j < R; j++)
-      dst[(size_t)(j >> 3) * f.tile_stride * 64 + (j & 7) * 8] = v[j];
+    for (int j = 0; j < R; j++) m[j * TP + i] = v[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+  // the wave of channel c moves its NB pixel rectangles to the block-major
+  // planes as whole 16-byte tile parts: 16 consecutive lanes write one 256-byte
+  // tile, the next 16 the tile to its right (contiguous in memory)
+  {
+    constexpr int kParts = SIZE / 4;
+    for (int e = lane; e < nb * kParts; e += 64) {
+      const int vb = e / kParts, r = e % kParts;
+      const int t = r >> 4, part = r & 15;
+      const int ty = t / CX, tx = t % CX;
+      const float* src = &buf[c][vb][(ty * 8 + (part >> 1)) * TP + tx * 8 + (part & 1) * 4];
+      const BlockHdr& h = hdr[vb];
+      *(float4*)(TilePtr(f, c, h.aby + ty, h.abx + tx) + part * 4) =
+          make_float4(src[0], src[1], src[2], src[3]);
+    }
+  }
+}
+
+// One unit = 64 blocks of area of one medium class (kUnitVarblocks varblocks
+// starting at list[first]), decoded batch by batch.
+template <int R, int C, int STRATEGY, typename CT>
+__device__ __forceinline__ void MediumUnit(const DevFrame& f, const WorkItem* __restrict__ list,
+                                           uint32_t first, uint32_t n, unsigned char* smem) {
+  using G = MediumGeom<R, C>;
+  BlockHdr* hdr = reinterpret_cast<BlockHdr*>(smem + G::kHdrOffset);
+  const int nvb = (int)min((uint32_t)G::kUnitVarblocks, n - first);
+  if ((int)threadIdx.x < nvb) hdr[threadIdx.x] = MakeHdr(f, list[first + threadIdx.x]);
+  __syncthreads();
+  for (int b0 = 0; b0 < nvb; b0 += G::NB) {
+    MediumBatch<R, C, STRATEGY, CT>(f, hdr + b0, min(G::NB, nvb - b0), smem);
+    __syncthreads();
   }
 }
 
@@ -744,8 +793,9 @@ __global__ __launch_bounds__(256) void k_large(DevFrame f, const WorkItem* __res
                                                const float* __restrict__ resample) {
   __shared__ float llf[32 * 33];  // LLF corner of the current channel
   __shared__ float dcs[32 * 33];
-  if (blockIdx.x >= *count) return;
-  const BlockHdr h = MakeHdr(f, list[blockIdx.x]);
+  const uint32_t n = *count;
+  for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+  const BlockHdr h = MakeHdr(f, list[item]);
   const int strategy = f.acs[(size_t)h.aby * f.xsb + h.abx] >> 1;
   const int cx = kCoveredX[strategy], cy = kCoveredY[strategy];
   const int R = cy * 8, C = cx * 8;
@@ -819,64 +869,142 @@ __global__ __launch_bounds__(256) void k_large(DevFrame f, const WorkItem* __res
     }
     __syncthreads();
   }
+  }
+}
+
+// ------------------------------------------------------ class-family dispatch
+// Phase 1 is three launches, not one per class: a kernel owns a FAMILY of work
+// classes and workgroup u decodes UNIT u of the family -- 64 blocks of area of
+// one class, found from the class list lengths k_prepare left on the device.
+// The host never learns the list lengths, but the unit count is bounded
+// tightly by cells/64 + N, so there are no worst-case grids, no empty launches
+// and no tail of small kernels.  Family A: 64x64, 64x32, 32x64 and the ten
+// single-block classes (~170 VGPRs, 50 KB LDS); family B: 16x8 .. 32x32 (~75
+// VGPRs, <= 26 KB); k_large (128x128 .. 256x256, never emitted by libjxl) keeps
+// its own launch because of its private scratch.
+struct FamilyEntry {
+  int cls;
+  int unit_varblocks;
+};
+
+struct UnitPick {
+  int index;       // entry of the family, -1 = past the end
+  int cls;         // its work class
+  uint32_t first;  // first varblock of the unit in the class list
+  uint32_t n;      // class list length
+};
+
+template <int N>
+__device__ __forceinline__ UnitPick PickUnit(const FamilyEntry (&fam)[N], const uint32_t* cnt,
+                                             uint32_t u) {
+  UnitPick p{-1, 0, 0, 0};
+  uint32_t base = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const uint32_t units = (cnt[i] + fam[i].unit_varblocks - 1) / fam[i].unit_varblocks;
+    if (p.index < 0 && u < base + units) {
+      p.index = i;
+      p.cls = fam[i].cls;
+      p.first = (u - base) * fam[i].unit_varblocks;
+      p.n = cnt[i];
+    }
+    base += units;
+  }
+  return p;
+}
+
+static constexpr int kLdsFamilyA = MediumGeom<64, 64>::kLdsBytes > 49152 ? MediumGeom<64, 64>::kLdsBytes : 49152;
+static constexpr int kLdsFamilyB = MediumGeom<32, 32>::kLdsBytes;
+static_assert(sizeof(BlockHdr) <= 48, "header slots are 48 bytes");
+static_assert(MediumGeom<64, 32>::kLdsBytes <= kLdsFamilyA && MediumGeom<32, 64>::kLdsBytes <= kLdsFamilyA, "");
+static_assert(MediumGeom<16, 8>::kLdsBytes <= kLdsFamilyB && MediumGeom<8, 16>::kLdsBytes <= kLdsFamilyB &&
+              MediumGeom<16, 16>::kLdsBytes <= kLdsFamilyB && MediumGeom<32, 8>::kLdsBytes <= kLdsFamilyB &&
+              MediumGeom<8, 32>::kLdsBytes <= kLdsFamilyB && MediumGeom<32, 16>::kLdsBytes <= kLdsFamilyB &&
+              MediumGeom<16, 32>::kLdsBytes <= kLdsFamilyB, "");
+
+// long units first so that the drain ends on short ones
+static constexpr FamilyEntry kFamilyA[13] = {
+    {kClsMedium0 + 8, 1},  {kClsMedium0 + 9, 2},  {kClsMedium0 + 10, 2}, {kClsDct8, 64},
+    {kClsSpecial0 + 0, 64}, {kClsSpecial0 + 1, 64}, {kClsSpecial0 + 2, 64}, {kClsSpecial0 + 3, 64},
+    {kClsSpecial0 + 4, 64}, {kClsSpecial0 + 5, 64}, {kClsSpecial0 + 6, 64}, {kClsSpecial0 + 7, 64},
+    {kClsSpecial0 + 8, 64}};
+static constexpr FamilyEntry kFamilyB[8] = {
+    {kClsMedium0 + 7, MediumGeom<32, 32>::kUnitVarblocks}, {kClsMedium0 + 5, MediumGeom<32, 16>::kUnitVarblocks},
+    {kClsMedium0 + 6, MediumGeom<16, 32>::kUnitVarblocks}, {kClsMedium0 + 2, MediumGeom<16, 16>::kUnitVarblocks},
+    {kClsMedium0 + 3, MediumGeom<32, 8>::kUnitVarblocks},  {kClsMedium0 + 4, MediumGeom<8, 32>::kUnitVarblocks},
+    {kClsMedium0 + 0, MediumGeom<16, 8>::kUnitVarblocks},  {kClsMedium0 + 1, MediumGeom<8, 16>::kUnitVarblocks}};
+static_assert(kMediumStrategy[8] == 18 && kMediumStrategy[9] == 19 && kMediumStrategy[10] == 20 &&
+              kMediumStrategy[7] == 5 && kMediumStrategy[5] == 10 && kMediumStrategy[6] == 11 &&
+              kMediumStrategy[2] == 4 && kMediumStrategy[3] == 8 && kMediumStrategy[4] == 9 &&
+              kMediumStrategy[0] == 6 && kMediumStrategy[1] == 7, "class table mismatch");
+static_assert(kSpecialStrategy[0] == 1 && kSpecialStrategy[1] == 2 && kSpecialStrategy[2] == 3 &&
+              kSpecialStrategy[3] == 12 && kSpecialStrategy[4] == 13 && kSpecialStrategy[5] == 14 &&
+              kSpecialStrategy[6] == 15 && kSpecialStrategy[7] == 16 && kSpecialStrategy[8] == 17,
+              "class table mismatch");
+
+// One unit per workgroup: unit blockIdx.x of the family (the grid is the tight
+// upper bound cells/64 + N on the unit count, so at most a handful of
+// workgroups find nothing to do).  Deliberately NOT a persistent loop: with a
+// loop around the class switch the compiler hoists every class's invariants
+// into registers that stay live across all classes (measured: 308 VGPRs).
+template <int N, typename Body>
+__device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const WorkLists& wl,
+                                             Body&& body) {
+  uint32_t cnt[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) cnt[i] = wl.count[fam[i].cls];
+  const UnitPick pick = PickUnit(fam, cnt, blockIdx.x);
+  if (pick.index < 0) return;
+  body(pick.index, wl.list[pick.cls], pick.first, pick.n);
+}
+
+template <typename CT>
+__global__ __launch_bounds__(192, 2) void k_transform_a(DevFrame f, WorkLists wl) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
+  UnitDispatch(kFamilyA, wl,
+           [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
+             switch (index) {
+               case 0: MediumUnit<64, 64, 18, CT>(f, list, first, n, smem); break;
+               case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
+               case 2: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
+               default:
+                 Single64Unit<CT>(f, index == 3 ? 0 : (int)kSpecialStrategy[index - 4], list, first,
+                                  n, smem);
+                 break;
+             }
+           });
+}
+
+template <typename CT>
+__global__ __launch_bounds__(192) void k_transform_b(DevFrame f, WorkLists wl) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyB];
+  UnitDispatch(kFamilyB, wl,
+           [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
+             switch (index) {
+               case 0: MediumUnit<32, 32, 5, CT>(f, list, first, n, smem); break;
+               case 1: MediumUnit<32, 16, 10, CT>(f, list, first, n, smem); break;
+               case 2: MediumUnit<16, 32, 11, CT>(f, list, first, n, smem); break;
+               case 3: MediumUnit<16, 16, 4, CT>(f, list, first, n, smem); break;
+               case 4: MediumUnit<32, 8, 8, CT>(f, list, first, n, smem); break;
+               case 5: MediumUnit<8, 32, 9, CT>(f, list, first, n, smem); break;
+               case 6: MediumUnit<16, 8, 6, CT>(f, list, first, n, smem); break;
+               default: MediumUnit<8, 16, 7, CT>(f, list, first, n, smem); break;
+             }
+           });
 }
 
 // --------------------------------------------------------------- launchers
-// Every class is its own launch; `streams` lets the caller spread the launches
-// over several HIP streams so the small grids (a few hundred workgroups for
-// the rare kinds) overlap instead of each under-filling the 256 CUs in turn.
 template <typename CT>
-static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, const uint32_t* max_items,
-                          const float* wc, const float* resample, hipStream_t* streams,
-                          int nstreams) {
-  int next = 0;
-  auto pick = [&]() { return streams[(next++) % nstreams]; };
-  if (max_items[kClsDct8]) {
-    hipLaunchKernelGGL((k_block64<0, CT>), dim3((max_items[kClsDct8] + 63) / 64), dim3(192), 0,
-                       pick(), f, wl.list[kClsDct8], wl.count + kClsDct8);
-  }
-#define JXLHIP_MEDIUM(IDX, RR, CC, STRAT)                                                   \
-  if (max_items[kClsMedium0 + IDX]) {                                                       \
-    constexpr int NB = 64 / ((RR) > (CC) ? (RR) : (CC));                                    \
-    static_assert(kMediumStrategy[IDX] == STRAT, "class table mismatch");                   \
-    hipLaunchKernelGGL((k_medium<RR, CC, STRAT, CT>),                                       \
-                       dim3((max_items[kClsMedium0 + IDX] + NB - 1) / NB), dim3(192), 0,    \
-                       pick(), f, wl.list[kClsMedium0 + IDX], wl.count + kClsMedium0 + IDX); \
-  }
-  // big-latency kinds first so they overlap with the bulk
-  JXLHIP_MEDIUM(8, 64, 64, 18)
-  JXLHIP_MEDIUM(9, 64, 32, 19)
-  JXLHIP_MEDIUM(10, 32, 64, 20)
-  JXLHIP_MEDIUM(0, 16, 8, 6)
-  JXLHIP_MEDIUM(1, 8, 16, 7)
-  JXLHIP_MEDIUM(2, 16, 16, 4)
-  JXLHIP_MEDIUM(3, 32, 8, 8)
-  JXLHIP_MEDIUM(4, 8, 32, 9)
-  JXLHIP_MEDIUM(5, 32, 16, 10)
-  JXLHIP_MEDIUM(6, 16, 32, 11)
-  JXLHIP_MEDIUM(7, 32, 32, 5)
-#undef JXLHIP_MEDIUM
-#define JXLHIP_SPECIAL(IDX, STRAT)                                                          \
-  if (max_items[kClsSpecial0 + IDX]) {                                                      \
-    static_assert(kSpecialStrategy[IDX] == STRAT, "class table mismatch");                  \
-    hipLaunchKernelGGL((k_block64<STRAT, CT>),                                              \
-                       dim3((max_items[kClsSpecial0 + IDX] + 63) / 64), dim3(192), 0, pick(), \
-                       f, wl.list[kClsSpecial0 + IDX], wl.count + kClsSpecial0 + IDX);      \
-  }
-  JXLHIP_SPECIAL(0, 1)
-  JXLHIP_SPECIAL(1, 2)
-  JXLHIP_SPECIAL(2, 3)
-  JXLHIP_SPECIAL(3, 12)
-  JXLHIP_SPECIAL(4, 13)
-  JXLHIP_SPECIAL(5, 14)
-  JXLHIP_SPECIAL(6, 15)
-  JXLHIP_SPECIAL(7, 16)
-  JXLHIP_SPECIAL(8, 17)
-#undef JXLHIP_SPECIAL
-  if (max_items[kClsLarge]) {
-    hipLaunchKernelGGL(k_large<CT>, dim3(max_items[kClsLarge]), dim3(256), 0, pick(), f,
+static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells, const float* wc,
+                          const float* resample, hipStream_t* streams, int nstreams) {
+  const uint32_t units = cells / 64;
+  const uint32_t grid_l = cells / 128 < 512u ? (cells / 128 ? cells / 128 : 1) : 512u;
+  hipLaunchKernelGGL((k_transform_a<CT>), dim3(units + 13), dim3(192), 0, streams[0], f, wl);
+  hipLaunchKernelGGL((k_transform_b<CT>), dim3(units + 8), dim3(192), 0, streams[1 % nstreams], f,
+                     wl);
+  if (cells >= 256)
+    hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, streams[2 % nstreams], f,
                        wl.list[kClsLarge], wl.count + kClsLarge, wc, resample);
-  }
 }
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
@@ -894,12 +1022,12 @@ void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float
                      with_sigma, epf_quant_mul, lut);
 }
 
-void LaunchBlocks(const DevFrame& f, const WorkLists& wl, const uint32_t* max_items,
-                  const float* wc, const float* resample, hipStream_t* streams, int nstreams) {
+void LaunchBlocks(const DevFrame& f, const WorkLists& wl, uint32_t cells, const float* wc,
+                  const float* resample, hipStream_t* streams, int nstreams) {
   if (f.coeff_type == JXLHIP_COEFF_I16)
-    LaunchBlocksT<int16_t>(f, wl, max_items, wc, resample, streams, nstreams);
+    LaunchBlocksT<int16_t>(f, wl, cells, wc, resample, streams, nstreams);
   else
-    LaunchBlocksT<int32_t>(f, wl, max_items, wc, resample, streams, nstreams);
+    LaunchBlocksT<int32_t>(f, wl, cells, wc, resample, streams, nstreams);
 }
 
 }  // namespace jxlhip

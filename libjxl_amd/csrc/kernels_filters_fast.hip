@@ -2,14 +2,19 @@
 // pass ([Gaborish] [EPF1] XYB->RGB: every stream below distance 1.5, i.e. the
 // BASELINE d1.0 configuration), written for the CDNA4 wavefront instead of LDS:
 //
-//   * one wave = 64 adjacent pixel COLUMNS, marching down the rows of its band;
-//   * horizontal neighbours come from the neighbouring LANE through DPP
-//     wave_shr/wave_shl (full VALU rate, no LDS, no barrier);
+//   * one wave = 128 adjacent pixel COLUMNS (each lane owns an aligned PAIR of
+//     columns), marching down the rows of its band.  Two pixels per lane turn
+//     the filter arithmetic into packed fp32 (v_pk_add/mul/fma_f32: two results
+//     per VALU issue) and halve the cross-lane traffic per pixel;
+//   * horizontal neighbours inside the pair are free, the two outside it come
+//     from the neighbouring LANE through DPP wave_shr/wave_shl (no LDS, no
+//     barrier);
 //   * vertical neighbours come from a sliding window of rows kept in registers
 //     (4-slot rings, slot = row & 3, resolved at compile time by unrolling the
 //     row loop 4x);
-//   * input rows are prefetched 4 rows ahead (one coalesced 256-byte load per
-//     wave, row and channel), output rows leave as 12-byte RGB stores.
+//   * input rows are prefetched 4 rows ahead (one 8-byte load per lane, row
+//     and channel; the row base is scalar), output rows leave as 12-byte RGB
+//     stores.
 //
 // EPF1 (lib/jxl/render_pipeline/stage_epf.cc:225-367) is evaluated through an
 // exact regrouping of the reference's sums: with Du(x,y) = |p(x,y-1) - p(x,y)|
@@ -24,12 +29,16 @@
 // lanes/rows outside the image simply run on mirrored input; this kernel is
 // only used when no stage follows an EPF stage, where that identity is all
 // that is needed.  Other stage lists use the generic kernel (kernels_filters.hip).
+#include <stdlib.h>
+
 #include "dev_common.h"
 #include "kernels.h"
 
 namespace jxlhip {
 
 namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int MirrorF(int x, int n) {
   while (x < 0 || x >= n) x = x < 0 ? -x - 1 : 2 * n - 1 - x;
@@ -42,50 +51,136 @@ __device__ __forceinline__ size_t RowOffset(const DevFrame& f, int y) {
   return (size_t)(ry >> 3) * f.tile_stride * 64u + ((ry & 7u) << 3);
 }
 
-// value of the lane holding column x-1 / x+1
+// value held by the previous / next lane (0 at the wave's ends: those lanes
+// are halo lanes whose results are never stored)
 __device__ __forceinline__ float FromLeft(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float FromRight(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+// For the column pair p = (x, x+1), the left neighbours are (x-1, x) and the
+// right neighbours (x+1, x+2): one of each comes from the adjacent lane.  The
+// helpers keep those operations scalar so that the DPP read folds into the
+// arithmetic instruction (v_add_f32_dpp, v_sub_f32_dpp, v_fmac_f32_dpp);
+// everything that stays inside the lane is written on pairs and becomes packed
+// fp32.
+__device__ __forceinline__ v2f AddLeft(v2f acc, v2f p) {
+  return v2f{acc.x + FromLeft(p.y), acc.y + p.x};
+}
+__device__ __forceinline__ v2f AddRight(v2f acc, v2f p) {
+  return v2f{acc.x + p.y, acc.y + FromRight(p.x)};
 }
 
-__device__ __forceinline__ float EpfW(float sad, float inv_sigma) {
-  const float v = __builtin_fmaf(sad, inv_sigma, 1.0f);
-  return v < 0.0f ? 0.0f : v;
+// |v| materialised by an instruction the optimiser cannot see through: as an
+// fabs it would be folded into its consumers as a source modifier, which forces
+// them into the VOP3 encoding -- no DPP operand, no packed form.
+__device__ __forceinline__ float AbsOpaque(float v) {
+  float r;
+  asm("v_and_b32 %0, 0x7fffffff, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ v2f Abs2(v2f v) { return v2f{AbsOpaque(v.x), AbsOpaque(v.y)}; }
+__device__ __forceinline__ v2f Fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f Fma2(v2f a, float b, v2f c) {
+  return __builtin_elementwise_fma(a, v2f{b, b}, c);
 }
 
-template <int GAB, int EPF>
+__device__ __forceinline__ v2f FmaLeft(v2f w, v2f p, v2f a) {
+  return v2f{__builtin_fmaf(w.x, FromLeft(p.y), a.x), __builtin_fmaf(w.y, p.x, a.y)};
+}
+__device__ __forceinline__ v2f FmaRight(v2f w, v2f p, v2f a) {
+  return v2f{__builtin_fmaf(w.x, p.y, a.x), __builtin_fmaf(w.y, FromRight(p.x), a.y)};
+}
+
+// max(0, 1 + sad * inv_sigma) (stage_epf.cc:62-71).  maxNum semantics on
+// purpose: a block whose sigma is below the filter threshold carries
+// inv_sigma = -inf, which turns every weight into 0 (also 0 * -inf = NaN).
+__device__ __forceinline__ v2f EpfW(v2f sad, v2f inv_sigma) {
+  const v2f v = Fma2(sad, inv_sigma, v2f{1.0f, 1.0f});
+  return v2f{__builtin_fmaxf(v.x, 0.0f), __builtin_fmaxf(v.y, 0.0f)};
+}
+
 struct State {
-  float pre[3][4];  // prefetched input rows
-  float in[3][4];   // GAB: input rows
-  float hs[3][4];   // GAB: left + right of the input rows
-  float g[3][4];    // EPF: rows entering EPF (Gaborish output or input)
-  float gl[3][4], gr[3][4];
-  float du[3][4], dl[3][4];
-  float pv[4], ph[4];
+  v2f pre[3][4];  // prefetched input rows
+  v2f in[3][4];   // GAB: input rows
+  v2f hs[3][4];   // GAB: left + right of the input rows
+  v2f g[3][4];    // EPF: rows entering EPF (Gaborish output or input)
+  v2f du[3][4], dl[3][4];
+  v2f pv[4], ph[4];
 };
 
+// per-lane constants
+struct Lane {
+  uint32_t byte_off;  // byte offset of the lane's aligned column pair inside a plane row
+  bool sel0, sel1;    // edge waves: which half of the loaded pair each column takes
+  bool edge;          // wave-uniform: the strip touches a mirrored image edge
+  int gx;             // first column of the pair (may lie outside the image)
+  bool out0, out1;    // column is written by this wave
+  v2f mul;            // EPF sigma multiplier of the two columns (border columns of an 8x8 block differ)
+  int sx;             // block column of the pair for the sigma look-up (clamped)
+};
+
+__device__ __forceinline__ v2f LoadPair(const float* rowp, const Lane& L) {
+  const v2f v = *(const v2f*)((const char*)rowp + L.byte_off);
+  if (!L.edge) return v;
+  return v2f{L.sel0 ? v.y : v.x, L.sel1 ? v.y : v.x};
+}
+
+// XYB -> linear RGB of one pixel (dec_xyb-inl.h:38-86, stage_xyb.cc:42-98)
+__device__ __forceinline__ void XybToRgb(float x, float y, float b, const FilterParams& P,
+                                         float* rgb) {
+  float gr = y + x, gg = y - x, gb = b;
+  gr = gr - P.cbrt_bias[0];
+  gg = gg - P.cbrt_bias[1];
+  gb = gb - P.cbrt_bias[2];
+  const float mr = __builtin_fmaf(gr * gr, gr, P.opsin_bias[0]);
+  const float mg = __builtin_fmaf(gg * gg, gg, P.opsin_bias[1]);
+  const float mb = __builtin_fmaf(gb * gb, gb, P.opsin_bias[2]);
+  const float* m = P.minv;
+  rgb[0] = __builtin_fmaf(m[2], mb, __builtin_fmaf(m[1], mg, m[0] * mr));
+  rgb[1] = __builtin_fmaf(m[5], mb, __builtin_fmaf(m[4], mg, m[3] * mr));
+  rgb[2] = __builtin_fmaf(m[8], mb, __builtin_fmaf(m[7], mg, m[6] * mr));
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// The output is written once and never read by this pipeline: streaming
+// (non-temporal) stores keep it from displacing the XYB planes in L2 / MALL.
 template <int OUTK>
-__device__ __forceinline__ void Emit(const float* v, int gx, int gy_rel, const FilterParams& P) {
+__device__ __forceinline__ void EmitPair(const v2f* v, const Lane& L, int gy_rel,
+                                         const FilterParams& P) {
   if constexpr (OUTK == JXLHIP_OUT_LINEAR_RGB_F32) {
-    float gr = v[1] + v[0], gg = v[1] - v[0], gb = v[2];
-    gr = gr - P.cbrt_bias[0];
-    gg = gg - P.cbrt_bias[1];
-    gb = gb - P.cbrt_bias[2];
-    const float mr = __builtin_fmaf(gr * gr, gr, P.opsin_bias[0]);
-    const float mg = __builtin_fmaf(gg * gg, gg, P.opsin_bias[1]);
-    const float mb = __builtin_fmaf(gb * gb, gb, P.opsin_bias[2]);
-    const float* m = P.minv;
-    float* dst = (float*)((char*)P.out + (size_t)gy_rel * P.out_stride) + 3 * (size_t)gx;
-    dst[0] = __builtin_fmaf(m[2], mb, __builtin_fmaf(m[1], mg, m[0] * mr));
-    dst[1] = __builtin_fmaf(m[5], mb, __builtin_fmaf(m[4], mg, m[3] * mr));
-    dst[2] = __builtin_fmaf(m[8], mb, __builtin_fmaf(m[7], mg, m[6] * mr));
+    float* dst = (float*)((char*)P.out + (size_t)gy_rel * P.out_stride) + 3 * (size_t)L.gx;
+    float a[3], b[3];
+    XybToRgb(v[0].x, v[1].x, v[2].x, P, a);
+    XybToRgb(v[0].y, v[1].y, v[2].y, P, b);
+    if (L.out0 && L.out1) {  // 24 contiguous bytes
+      __builtin_nontemporal_store(f4u{a[0], a[1], a[2], b[0]}, (f4u*)dst);
+      __builtin_nontemporal_store(f2u{b[1], b[2]}, (f2u*)(dst + 4));
+    } else if (L.out0) {
+      __builtin_nontemporal_store(a[0], dst);
+      __builtin_nontemporal_store(a[1], dst + 1);
+      __builtin_nontemporal_store(a[2], dst + 2);
+    } else if (L.out1) {
+      __builtin_nontemporal_store(b[0], dst + 3);
+      __builtin_nontemporal_store(b[1], dst + 4);
+      __builtin_nontemporal_store(b[2], dst + 5);
+    }
   } else {
-    float* dst = (float*)P.out + (size_t)gy_rel * P.out_stride + gx;
-    dst[0] = v[0];
-    dst[P.out_plane_stride] = v[1];
-    dst[2 * P.out_plane_stride] = v[2];
+    float* dst = (float*)P.out + (size_t)gy_rel * P.out_stride + L.gx;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      float* d = dst + c * P.out_plane_stride;
+      if (L.out0 && L.out1) {
+        __builtin_nontemporal_store(f2u{v[c].x, v[c].y}, (f2u*)d);
+      } else if (L.out0) {
+        __builtin_nontemporal_store(v[c].x, d);
+      } else if (L.out1) {
+        __builtin_nontemporal_store(v[c].y, d + 1);
+      }
+    }
   }
 }
 
@@ -93,13 +188,12 @@ __device__ __forceinline__ void Emit(const float* v, int gx, int gy_rel, const F
 // Row bookkeeping: q = row leaving Gaborish (r-1 with GAB, r without),
 // p = q-1 = row whose plus-sums are completed, o = q-2 = EPF output row.
 template <int GAB, int EPF, int OUTK, int PH>
-__device__ __forceinline__ void Step(State<GAB, EPF>& s, int r, const DevFrame& f,
-                                     const FilterParams& P, const float* const* col,
-                                     int prefetch_last_row, int y_begin, int y_end, int gx,
-                                     bool lane_out, float lane_mul, float& inv_sigma_blk) {
-  constexpr int S0 = PH & 3, S1 = (PH + 3) & 3, S2 = (PH + 2) & 3, S3 = (PH + 1) & 3;  // r, r-1, r-2, r-3
+__device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const FilterParams& P,
+                                     const Lane& L, int prefetch_last_row, int y_begin, int y_end,
+                                     float& inv_sigma_blk) {
+  constexpr int S0 = PH & 3, S1 = (PH + 3) & 3, S2 = (PH + 2) & 3;  // r, r-1, r-2
   const int H = (int)f.ysize;
-  float cur[3];
+  v2f cur[3];
   // 1. take row r from the prefetch ring, refill the slot with row r+4
   {
     int pr = r + 4;
@@ -108,20 +202,19 @@ __device__ __forceinline__ void Step(State<GAB, EPF>& s, int r, const DevFrame& 
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       cur[c] = s.pre[c][S0];
-      s.pre[c][S0] = col[c][off];
+      s.pre[c][S0] = LoadPair(f.xyb[c] + off, L);
     }
   }
   // 2. Gaborish (stage_gaborish.cc:33-99) for row q = r-1
-  float gq[3];
+  v2f gq[3];
   if constexpr (GAB) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       s.in[c][S0] = cur[c];
-      s.hs[c][S0] = FromLeft(cur[c]) + FromRight(cur[c]);
-      const float sum1 = s.hs[c][S1] + (s.in[c][S2] + s.in[c][S0]);
-      const float sum2 = s.hs[c][S2] + s.hs[c][S0];
-      gq[c] = __builtin_fmaf(sum2, P.gab_w[c][2],
-                             __builtin_fmaf(sum1, P.gab_w[c][1], s.in[c][S1] * P.gab_w[c][0]));
+      s.hs[c][S0] = v2f{FromLeft(cur[c].y) + cur[c].y, cur[c].x + FromRight(cur[c].x)};
+      const v2f sum1 = s.hs[c][S1] + (s.in[c][S2] + s.in[c][S0]);
+      const v2f sum2 = s.hs[c][S2] + s.hs[c][S0];
+      gq[c] = Fma2(sum2, P.gab_w[c][2], Fma2(sum1, P.gab_w[c][1], s.in[c][S1] * P.gab_w[c][0]));
     }
   } else {
 #pragma unroll
@@ -130,34 +223,31 @@ __device__ __forceinline__ void Step(State<GAB, EPF>& s, int r, const DevFrame& 
   constexpr int Q0 = GAB ? S1 : S0;  // slot of row q
   constexpr int Q1 = (Q0 + 3) & 3, Q2 = (Q0 + 2) & 3, Q3 = (Q0 + 1) & 3;  // q-1, q-2, q-3
   const int q = GAB ? r - 1 : r;
-  float outv[3];
+  v2f outv[3];
   int o;
   if constexpr (EPF) {
     // 3a. differences of the new row q
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      const float l = FromLeft(gq[c]), rr = FromRight(gq[c]);
       s.g[c][Q0] = gq[c];
-      s.gl[c][Q0] = l;
-      s.gr[c][Q0] = rr;
-      s.du[c][Q0] = __builtin_fabsf(s.g[c][Q1] - gq[c]);
-      s.dl[c][Q0] = __builtin_fabsf(l - gq[c]);
+      s.du[c][Q0] = Abs2(s.g[c][Q1] - gq[c]);
+      s.dl[c][Q0] = Abs2(v2f{FromLeft(gq[c].y) - gq[c].x, gq[c].x - gq[c].y});
     }
     // 3b. plus-sums of row p = q-1 (order: up, left, centre, right, down)
-    float pv = 0.0f, ph = 0.0f;
+    v2f pv = {0.0f, 0.0f}, ph = {0.0f, 0.0f};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      const float du_c = s.du[c][Q1], dl_c = s.dl[c][Q1];
-      float v = s.du[c][Q2] + FromLeft(du_c);
+      const v2f du_c = s.du[c][Q1], dl_c = s.dl[c][Q1];
+      v2f v = AddLeft(s.du[c][Q2], du_c);
       v = v + du_c;
-      v = v + FromRight(du_c);
+      v = AddRight(v, du_c);
       v = v + s.du[c][Q0];
-      float h = s.dl[c][Q2] + FromLeft(dl_c);
+      v2f h = AddLeft(s.dl[c][Q2], dl_c);
       h = h + dl_c;
-      h = h + __builtin_fabsf(s.g[c][Q1] - s.gr[c][Q1]);
+      h = AddRight(h, dl_c);  // |p(x,y) - p(x+1,y)| = Dl(x+1,y)
       h = h + s.dl[c][Q0];
-      pv = __builtin_fmaf(v, P.ch_scale[c], pv);
-      ph = __builtin_fmaf(h, P.ch_scale[c], ph);
+      pv = Fma2(v, P.ch_scale[c], pv);
+      ph = Fma2(h, P.ch_scale[c], ph);
     }
     s.pv[Q1] = pv;
     s.ph[Q1] = ph;
@@ -166,29 +256,32 @@ __device__ __forceinline__ void Step(State<GAB, EPF>& s, int r, const DevFrame& 
     const float kMinSigma = -3.90524291751269967465540850526868f;
     if ((o & 7) == 0 || o == y_begin) {
       const int oc = o < 0 ? 0 : (o >= H ? H - 1 : o);
-      inv_sigma_blk = f.inv_sigma[(size_t)(oc >> 3) * f.xsb + (gx >> 3)];
+      const float is = f.inv_sigma[(size_t)(oc >> 3) * f.xsb + L.sx];
+      // below the threshold the stage copies its input (stage_epf.cc:258-262):
+      // -inf zeroes the four weights, and (c + 0) * rcp(1) == c exactly
+      inv_sigma_blk = is < kMinSigma ? -__builtin_inff() : is;
     }
     const int iy = o & 7;
-    const float mul = (iy == 0 || iy == 7) ? P.bsm[1] : lane_mul;
-    const float inv_sigma = inv_sigma_blk * mul;
-    const float wN = EpfW(s.pv[Q2], inv_sigma);
-    const float wW = EpfW(s.ph[Q2], inv_sigma);
-    const float wE = EpfW(FromRight(s.ph[Q2]), inv_sigma);
-    const float wS = EpfW(s.pv[Q1], inv_sigma);
-    float wsum = 1.0f + wN;
+    const v2f mul = (iy == 0 || iy == 7) ? v2f{P.bsm[1], P.bsm[1]} : L.mul;
+    const v2f inv_sigma = mul * inv_sigma_blk;
+    const v2f wN = EpfW(s.pv[Q2], inv_sigma);
+    const v2f wW = EpfW(s.ph[Q2], inv_sigma);
+    const v2f wE = EpfW(v2f{s.ph[Q2].y, FromRight(s.ph[Q2].x)}, inv_sigma);
+    const v2f wS = EpfW(s.pv[Q1], inv_sigma);
+    v2f wsum = v2f{1.0f, 1.0f} + wN;
     wsum = wsum + wW;
     wsum = wsum + wE;
     wsum = wsum + wS;
-    const float inv_w = __builtin_amdgcn_rcpf(wsum);
-    const bool skip = inv_sigma_blk < kMinSigma;
+    const v2f inv_w = {__builtin_amdgcn_rcpf(wsum.x), __builtin_amdgcn_rcpf(wsum.y)};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      float a = s.g[c][Q2];
-      a = __builtin_fmaf(wN, s.g[c][Q3], a);
-      a = __builtin_fmaf(wW, s.gl[c][Q2], a);
-      a = __builtin_fmaf(wE, s.gr[c][Q2], a);
-      a = __builtin_fmaf(wS, s.g[c][Q1], a);
-      outv[c] = skip ? s.g[c][Q2] : a * inv_w;
+      const v2f ctr = s.g[c][Q2];
+      v2f a = ctr;
+      a = Fma2(wN, s.g[c][Q3], a);
+      a = FmaLeft(wW, ctr, a);
+      a = FmaRight(wE, ctr, a);
+      a = Fma2(wS, s.g[c][Q1], a);
+      outv[c] = a * inv_w;
     }
   } else {
     o = q;
@@ -196,30 +289,52 @@ __device__ __forceinline__ void Step(State<GAB, EPF>& s, int r, const DevFrame& 
     for (int c = 0; c < 3; c++) outv[c] = gq[c];
   }
   // 4. emit
-  if (o >= y_begin && o < y_end && !lane_out) Emit<OUTK>(outv, gx, o - (int)f.y0, P);
+  if (o >= y_begin && o < y_end && !((f.debug & 4) && outv[0].x != 12345.678f)) {
+    EmitPair<OUTK>(outv, L, o - (int)f.y0, P);
+  }
 }
 
-template <int GAB, int EPF, int OUTK, int RH>
-__global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P) {
-  constexpr int HX = GAB + 2 * EPF;  // halo columns/rows on each side
-  constexpr int USE = 64 - 2 * HX;   // output columns per wave
+template <int GAB, int EPF>
+struct FastGeom {
+  static constexpr int HX = GAB + 2 * EPF;        // halo rows / columns each side
+  static constexpr int HXP = (HX + 1) & ~1;       // in whole column pairs
+  static constexpr int USE = 128 - 2 * HXP;       // output columns per wave
+};
+
+template <int GAB, int EPF, int OUTK>
+__global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P, int RH) {
+  using G = FastGeom<GAB, EPF>;
+  constexpr int HX = G::HX, HXP = G::HXP, USE = G::USE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x * 4 + wave;
   const int W = (int)f.xsize, H = (int)f.ysize;
-  const int x_first = strip * USE;  // first output column of the wave
+  const int x_first = strip * USE;  // first output column of the wave (even)
   if (x_first >= W) return;
-  const int gx = x_first - HX + lane;
   const int y_begin = (int)f.fy0 + blockIdx.y * RH;
   const int y_end = min(y_begin + RH, (int)f.fy1);
   if (y_begin >= y_end) return;
-  const bool lane_out = lane < HX || lane >= 64 - HX || gx >= W;
-  const int mx = MirrorF(gx, W);
-  const int gxc = gx < 0 ? 0 : (gx >= W ? W - 1 : gx);
-  // block-major planes: lane part (tile column, column in tile) + row part
-  const size_t lane_off = (size_t)(mx >> 3) * 64 + (mx & 7);
-  const float* col[3] = {f.xyb[0] + lane_off, f.xyb[1] + lane_off, f.xyb[2] + lane_off};
-  const int ix = gxc & 7;
-  const float lane_mul = (ix == 0 || ix == 7) ? P.bsm[1] : P.sm[1];
+  Lane L;
+  L.gx = x_first - HXP + 2 * lane;
+  {
+    // the lane's two columns, mirrored into the image, always fall into one
+    // aligned pair of plane columns (the planes are allocated in whole 8x8
+    // tiles, so column W exists when W is odd)
+    const int m0 = MirrorF(L.gx, W), m1 = MirrorF(L.gx + 1, W);
+    const int base = m0 & ~1;
+    L.sel0 = m0 & 1;
+    L.sel1 = m1 & 1;
+    L.byte_off = ((uint32_t)(base >> 3) * 64u + (uint32_t)(base & 7)) * 4u;
+    L.edge = x_first - HXP < 0 || x_first - HXP + 128 > W;
+    const bool lane_in = lane >= HXP / 2 && lane < 64 - HXP / 2;
+    L.out0 = lane_in && L.gx < W;
+    L.out1 = lane_in && L.gx + 1 < W;
+    const int gxc = L.gx < 0 ? 0 : (L.gx >= W ? W - 1 : L.gx);
+    L.sx = gxc >> 3;
+    const int ix = gxc & 7;
+    // columns gx, gx+1 (gx even inside the image): only gx can be a block's
+    // first column and only gx+1 its last
+    L.mul = v2f{ix == 0 ? P.bsm[1] : P.sm[1], ix == 6 ? P.bsm[1] : P.sm[1]};
+  }
   // rows: input rows r = y_begin - HX .. y_end + HX - 1; the pipeline emits
   // row r - HX at step r.
   const int r_first = y_begin - HX;
@@ -230,7 +345,7 @@ __global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P
   int prefetch_last_row = r_last;
   // mirrored rows always fall inside the plane; direct rows must too
   if (prefetch_last_row > plane_last && prefetch_last_row < H) prefetch_last_row = plane_last;
-  State<GAB, EPF> s;
+  State s;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     int pr = r_first + k;
@@ -238,39 +353,63 @@ __global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P
     const size_t off = RowOffset(f, MirrorF(pr, H));
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      s.pre[c][k] = col[c][off];
-      s.in[c][k] = 0.0f;
-      s.hs[c][k] = 0.0f;
-      s.g[c][k] = 0.0f;
-      s.gl[c][k] = 0.0f;
-      s.gr[c][k] = 0.0f;
-      s.du[c][k] = 0.0f;
-      s.dl[c][k] = 0.0f;
+      s.pre[c][k] = LoadPair(f.xyb[c] + off, L);
+      s.in[c][k] = v2f{0.0f, 0.0f};
+      s.hs[c][k] = v2f{0.0f, 0.0f};
+      s.g[c][k] = v2f{0.0f, 0.0f};
+      s.du[c][k] = v2f{0.0f, 0.0f};
+      s.dl[c][k] = v2f{0.0f, 0.0f};
     }
-    s.pv[k] = 0.0f;
-    s.ph[k] = 0.0f;
+    s.pv[k] = v2f{0.0f, 0.0f};
+    s.ph[k] = v2f{0.0f, 0.0f};
   }
   float inv_sigma_blk = -1.0f;
-  const float* const* cp = col;
   for (int r = r_first; r <= r_last; r += 4) {
-    Step<GAB, EPF, OUTK, 0>(s, r, f, P, cp, prefetch_last_row, y_begin, y_end, gxc, lane_out,
-                            lane_mul, inv_sigma_blk);
-    Step<GAB, EPF, OUTK, 1>(s, r + 1, f, P, cp, prefetch_last_row, y_begin, y_end, gxc, lane_out,
-                            lane_mul, inv_sigma_blk);
-    Step<GAB, EPF, OUTK, 2>(s, r + 2, f, P, cp, prefetch_last_row, y_begin, y_end, gxc, lane_out,
-                            lane_mul, inv_sigma_blk);
-    Step<GAB, EPF, OUTK, 3>(s, r + 3, f, P, cp, prefetch_last_row, y_begin, y_end, gxc, lane_out,
-                            lane_mul, inv_sigma_blk);
+    Step<GAB, EPF, OUTK, 0>(s, r, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
+    Step<GAB, EPF, OUTK, 1>(s, r + 1, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
+    Step<GAB, EPF, OUTK, 2>(s, r + 2, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
+    Step<GAB, EPF, OUTK, 3>(s, r + 3, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
   }
+}
+
+// Rows per wave.  Every wave costs (RH + 2*HX) row steps and all waves of a
+// launch take the same time, so the launch runs in ceil(workgroups / resident
+// workgroups) generations: pick the RH that minimises generations * steps
+// instead of leaving a mostly empty last generation.  Resident capacity: 256
+// CUs x 2 workgroups (2 waves per SIMD at < 256 VGPRs).  JXLHIP_FILTER_RH
+// overrides.
+int FilterRowsPerWave(unsigned wgx, unsigned rows, int hx) {
+  static const int forced = [] {
+    const char* e = getenv("JXLHIP_FILTER_RH");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) return forced;
+  static const unsigned resident = [] {
+    const char* e = getenv("JXLHIP_FILTER_RESIDENT");
+    return e ? (unsigned)atoi(e) : 256u * 2u;
+  }();
+  int best = 64;
+  double best_cost = 1e30;
+  for (int rh = 16; rh <= 512; rh += 1) {
+    const unsigned wgs = wgx * ((rows + rh - 1) / rh);
+    const unsigned gens = (wgs + resident - 1) / resident;
+    const double cost = (double)gens * (rh + 2 * hx + 6);  // +6: per-wave prologue
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = rh;
+    }
+  }
+  return best;
 }
 
 template <int GAB, int EPF, int OUTK>
 void LaunchFastT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
-  constexpr int RH = 64;
-  constexpr int USE = 64 - 2 * (GAB + 2 * EPF);
-  const unsigned strips = (f.xsize + USE - 1) / USE;
-  const dim3 grid((strips + 3) / 4, (f.fy1 - f.fy0 + RH - 1) / RH);
-  hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, RH>), grid, dim3(256), 0, st, f, p);
+  using G = FastGeom<GAB, EPF>;
+  const unsigned strips = (f.xsize + G::USE - 1) / G::USE;
+  const unsigned wgx = (strips + 3) / 4;
+  const int RH = FilterRowsPerWave(wgx, f.fy1 - f.fy0, G::HX);
+  const dim3 grid(wgx, (f.fy1 - f.fy0 + RH - 1) / RH);
+  hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK>), grid, dim3(256), 0, st, f, p, RH);
 }
 
 }  // namespace
@@ -278,6 +417,7 @@ void LaunchFastT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st) {
   if (epf_iters > 1 || (gab == 0 && epf_iters == 0)) return false;
+  if (f.xsize < 16) return false;  // multiply mirrored columns: generic kernel
 #define JXLHIP_FAST(G, E)                                  \
   if (gab == G && epf_iters == E) {                        \
     if (output_kind == 0) LaunchFastT<G, E, 0>(f, p, st);  \

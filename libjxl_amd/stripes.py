@@ -91,6 +91,10 @@ class StripeDecoder:
 
     def decode(self, out):
         d = self.dec
+        if self.world == 1:
+            # no neighbours: both phases in one call, walked in bands so that the
+            # XYB planes of a band are filtered while still cache resident
+            return d.decode_frame(out)
         d.decode_blocks()
         h = d.halo_rows()
         if self.world > 1 and h > 0:
