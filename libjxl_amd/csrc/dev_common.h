@@ -127,7 +127,8 @@ struct DevFrame {
   uint32_t plane_tile_rows;
   float* inv_sigma;       // xsb*ysb, whole frame indexing
   int32_t* error_flag;
-  uint32_t debug;  // JXLHIP_DEBUG ablation bits (1: no block stores, 2: all blocks read stream offset 0)
+  uint32_t debug;  // JXLHIP_DEBUG ablation bits (1: no block stores, 2: all blocks read stream offset 0,
+                   // 4: no filter output stores, 8: filter input rows stay in L1)
 };
 
 // address of pixel (y, x) of channel c in the block-major planes

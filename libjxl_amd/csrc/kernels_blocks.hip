@@ -10,6 +10,11 @@
 //   k_large     : 128x64 .. 256x256, output plane used as scratch
 // replacing DequantBlock + LowestFrequenciesFromDC + TransformToPixels
 // (lib/jxl/dec_group.cc:115-181,431-450, lib/jxl/dec_transforms-inl.h:456-818).
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -545,14 +550,82 @@ struct MediumGeom {
   static constexpr int CY = R / 8, CX = C / 8;
   static constexpr int kUnitVarblocks = (64 / (CY * CX)) > NB ? 64 / (CY * CX) : NB;  // 64 blocks of area
   static constexpr int kHdrOffset = (12 * NB * (BUF + CY * CX) + 15) & ~15;
-  static constexpr int kLdsBytes = kHdrOffset + kUnitVarblocks * 48;
+  // pipelined classes (MediumLoads) keep their dequant table in LDS behind the headers
+  static constexpr bool kPipelined = (NB * R * C + 767) / 768 <= 2;
+  static constexpr int kTabOffset = kHdrOffset + kUnitVarblocks * 48;
+  static constexpr int kLdsBytes = kTabOffset + (kPipelined ? 12 * R * C : 0);
+};
+
+// What one thread fetches from global memory for one batch: its share of the
+// quantized coefficients (4 per step and channel) and, for the few lanes that
+// start LowestFrequenciesFromDC, a column of DC values.  Kept in registers so
+// that the NEXT batch's loads are in flight while the current one is decoded
+// (classes with few steps per batch only; the 64-point classes load in place).
+template <int R, int C, typename CT>
+struct MediumLoads {
+  using G = MediumGeom<R, C>;
+  static constexpr int SIZE = R * C;
+  static constexpr int kSteps = (G::NB * SIZE + 767) / 768;
+  static constexpr bool kPipelined = G::kPipelined;
+  using Raw = typename std::conditional<sizeof(CT) == 2, uint2, int4>::type;
+  Raw x[kSteps], y[kSteps], b[kSteps];
+  float dc[G::CY];
+};
+
+template <typename CT>
+__device__ __forceinline__ void UnpackCoeffs(const uint2 v, int32_t* q) {
+  q[0] = (int16_t)(v.x & 0xffff);
+  q[1] = (int32_t)v.x >> 16;
+  q[2] = (int16_t)(v.y & 0xffff);
+  q[3] = (int32_t)v.y >> 16;
+}
+template <typename CT>
+__device__ __forceinline__ void UnpackCoeffs(const int4 v, int32_t* q) {
+  q[0] = v.x;
+  q[1] = v.y;
+  q[2] = v.z;
+  q[3] = v.w;
+}
+
+template <int R, int C, typename CT>
+__device__ __forceinline__ void MediumFetch(const DevFrame& f, const BlockHdr* hdr, int nb,
+                                            MediumLoads<R, C, CT>& ld) {
+  using G = MediumGeom<R, C>;
+  using LD = MediumLoads<R, C, CT>;
+  using Raw = typename LD::Raw;
+  const int tid = threadIdx.x;
+  const int c = tid >> 6, lane = tid & 63;
+  const int b = lane / G::ML, i = lane % G::ML;
+  if (b < nb && i < G::CX) {
+    const BlockHdr& h = hdr[b];
+    const float* dc = f.dc[c] + (size_t)h.aby * f.xsb + h.abx + i;
+#pragma unroll
+    for (int y = 0; y < G::CY; y++) ld.dc[y] = dc[(size_t)y * f.xsb];
+  }
+#pragma unroll
+  for (int it = 0; it < LD::kSteps; it++) {
+    const int k4 = tid * 4 + it * 768;
+    if (k4 < nb * LD::SIZE) {
+      const int vb = k4 / LD::SIZE, k = k4 % LD::SIZE;
+      const size_t at = hdr[vb].coef + k;
+      ld.x[it] = *(const Raw*)((const CT*)f.coeffs[0] + at);
+      ld.y[it] = *(const Raw*)((const CT*)f.coeffs[1] + at);
+      ld.b[it] = *(const Raw*)((const CT*)f.coeffs[2] + at);
+    }
+  }
+}
+
+// the three dequant-table vectors of one step of one thread
+struct TabStep {
+  float4 x, y, b;
 };
 
 // One batch of NB varblocks whose headers are hdr[0..nb) (already in LDS).
 template <int R, int C, int STRATEGY, typename CT>
 __device__ __forceinline__ void MediumBatch(const DevFrame& f, const BlockHdr* hdr, int nb,
-                                            unsigned char* smem) {
+                                            const MediumLoads<R, C, CT>& ld, unsigned char* smem) {
   using G = MediumGeom<R, C>;
+  using LD = MediumLoads<R, C, CT>;
   constexpr int L = G::L, ML = G::ML, NB = G::NB, LP = G::LP, TP = G::TP, BUF = G::BUF;
   constexpr int CY = G::CY, CX = G::CX;
   constexpr int SIZE = R * C;
@@ -570,11 +643,16 @@ __device__ __forceinline__ void MediumBatch(const DevFrame& f, const BlockHdr* h
 
   // LLF step 1: lane i < CX takes DC column i, vertical CY-point DCT (x 1/CY)
   if (active && i < CX) {
-    const BlockHdr& h = hdr[b];
-    const float* dc = f.dc[c] + (size_t)h.aby * f.xsb + h.abx + i;
     float v[CY];
+    if constexpr (LD::kPipelined) {
 #pragma unroll
-    for (int y = 0; y < CY; y++) v[y] = dc[(size_t)y * f.xsb];
+      for (int y = 0; y < CY; y++) v[y] = ld.dc[y];
+    } else {
+      const BlockHdr& h = hdr[b];
+      const float* dc = f.dc[c] + (size_t)h.aby * f.xsb + h.abx + i;
+#pragma unroll
+      for (int y = 0; y < CY; y++) v[y] = dc[(size_t)y * f.xsb];
+    }
     DctReg<CY>(v);
 #pragma unroll
     for (int y = 0; y < CY; y++) dp[y * CX + i] = (1.0f / CY) * v[y];
@@ -582,34 +660,17 @@ __device__ __forceinline__ void MediumBatch(const DevFrame& f, const BlockHdr* h
 
   // dequant + CfL, 4 coefficients per thread and step
   const float* __restrict__ tab = f.dequant + kTab;
-  for (int k4 = tid * 4; k4 < nb * SIZE; k4 += 192 * 4) {
+  auto dequant_step = [&](int k4, const typename LD::Raw rx, const typename LD::Raw ry,
+                          const typename LD::Raw rb, const TabStep& t) {
     const int vb = k4 / SIZE, k = k4 % SIZE;
     const BlockHdr& h = hdr[vb];
     int32_t qx[4], qy[4], qb[4];
-    if constexpr (sizeof(CT) == 2) {
-      const uint2 vx = *(const uint2*)((const int16_t*)f.coeffs[0] + h.coef + k);
-      const uint2 vy = *(const uint2*)((const int16_t*)f.coeffs[1] + h.coef + k);
-      const uint2 vz = *(const uint2*)((const int16_t*)f.coeffs[2] + h.coef + k);
-      qx[0] = (int16_t)(vx.x & 0xffff); qx[1] = (int32_t)vx.x >> 16;
-      qx[2] = (int16_t)(vx.y & 0xffff); qx[3] = (int32_t)vx.y >> 16;
-      qy[0] = (int16_t)(vy.x & 0xffff); qy[1] = (int32_t)vy.x >> 16;
-      qy[2] = (int16_t)(vy.y & 0xffff); qy[3] = (int32_t)vy.y >> 16;
-      qb[0] = (int16_t)(vz.x & 0xffff); qb[1] = (int32_t)vz.x >> 16;
-      qb[2] = (int16_t)(vz.y & 0xffff); qb[3] = (int32_t)vz.y >> 16;
-    } else {
-      const int4 vx = *(const int4*)((const int32_t*)f.coeffs[0] + h.coef + k);
-      const int4 vy = *(const int4*)((const int32_t*)f.coeffs[1] + h.coef + k);
-      const int4 vz = *(const int4*)((const int32_t*)f.coeffs[2] + h.coef + k);
-      qx[0] = vx.x; qx[1] = vx.y; qx[2] = vx.z; qx[3] = vx.w;
-      qy[0] = vy.x; qy[1] = vy.y; qy[2] = vy.z; qy[3] = vy.w;
-      qb[0] = vz.x; qb[1] = vz.y; qb[2] = vz.z; qb[3] = vz.w;
-    }
-    const float4 tx = *(const float4*)(tab + k);
-    const float4 ty = *(const float4*)(tab + SIZE + k);
-    const float4 tb = *(const float4*)(tab + 2 * SIZE + k);
-    const float mx[4] = {tx.x, tx.y, tx.z, tx.w};
-    const float my[4] = {ty.x, ty.y, ty.z, ty.w};
-    const float mb[4] = {tb.x, tb.y, tb.z, tb.w};
+    UnpackCoeffs<CT>(rx, qx);
+    UnpackCoeffs<CT>(ry, qy);
+    UnpackCoeffs<CT>(rb, qb);
+    const float mx[4] = {t.x.x, t.x.y, t.x.z, t.x.w};
+    const float my[4] = {t.y.x, t.y.y, t.y.z, t.y.w};
+    const float mb[4] = {t.b.x, t.b.y, t.b.z, t.b.w};
     const int row = k / L, col = k % L;
     float* ox = &buf[0][vb][row * LP + col];
     float* oy = &buf[1][vb][row * LP + col];
@@ -622,6 +683,37 @@ __device__ __forceinline__ void MediumBatch(const DevFrame& f, const BlockHdr* h
       ox[j] = __builtin_fmaf(h.x_cc, dy, dx);
       oy[j] = dy;
       ob[j] = __builtin_fmaf(h.b_cc, dy, db);
+    }
+  };
+  if constexpr (LD::kPipelined) {
+    // table from LDS: a global load here would sit behind the next batch's
+    // prefetch in the in-order vmcnt queue and serialise with it
+    const float* lt = reinterpret_cast<const float*>(smem + G::kTabOffset);
+#pragma unroll
+    for (int it = 0; it < LD::kSteps; it++) {
+      const int k4 = tid * 4 + it * 768;
+      if (k4 < nb * SIZE) {
+        const int k = k4 % SIZE;
+        TabStep t;
+        t.x = *(const float4*)(lt + k);
+        t.y = *(const float4*)(lt + SIZE + k);
+        t.b = *(const float4*)(lt + 2 * SIZE + k);
+        dequant_step(k4, ld.x[it], ld.y[it], ld.b[it], t);
+      }
+    }
+  } else {
+    using Raw = typename LD::Raw;
+    for (int k4 = tid * 4; k4 < nb * SIZE; k4 += 192 * 4) {
+      const int vb = k4 / SIZE, k = k4 % SIZE;
+      const size_t at = hdr[vb].coef + k;
+      const Raw rx = *(const Raw*)((const CT*)f.coeffs[0] + at);
+      const Raw ry = *(const Raw*)((const CT*)f.coeffs[1] + at);
+      const Raw rb = *(const Raw*)((const CT*)f.coeffs[2] + at);
+      TabStep t;
+      t.x = *(const float4*)(tab + k);
+      t.y = *(const float4*)(tab + SIZE + k);
+      t.b = *(const float4*)(tab + 2 * SIZE + k);
+      dequant_step(k4, rx, ry, rb, t);
     }
   }
   __syncthreads();
@@ -689,18 +781,32 @@ __device__ __forceinline__ void MediumBatch(const DevFrame& f, const BlockHdr* h
 }
 
 // One unit = 64 blocks of area of one medium class (kUnitVarblocks varblocks
-// starting at list[first]), decoded batch by batch.
+// starting at list[first]), decoded batch by batch; the coefficient loads of
+// batch b+1 are issued before batch b is decoded.
 template <int R, int C, int STRATEGY, typename CT>
 __device__ __forceinline__ void MediumUnit(const DevFrame& f, const WorkItem* __restrict__ list,
                                            uint32_t first, uint32_t n, unsigned char* smem) {
   using G = MediumGeom<R, C>;
+  using LD = MediumLoads<R, C, CT>;
   BlockHdr* hdr = reinterpret_cast<BlockHdr*>(smem + G::kHdrOffset);
   const int nvb = (int)min((uint32_t)G::kUnitVarblocks, n - first);
   if ((int)threadIdx.x < nvb) hdr[threadIdx.x] = MakeHdr(f, list[first + threadIdx.x]);
+  if constexpr (LD::kPipelined) {
+    const float4* __restrict__ tab = (const float4*)(f.dequant + DequantOffset(STRATEGY));
+    float4* lt = reinterpret_cast<float4*>(smem + G::kTabOffset);
+    for (int k = threadIdx.x; k < 3 * LD::SIZE / 4; k += 192) lt[k] = tab[k];
+  }
   __syncthreads();
+  LD cur;
+  if constexpr (LD::kPipelined) MediumFetch<R, C, CT>(f, hdr, min(G::NB, nvb), cur);
   for (int b0 = 0; b0 < nvb; b0 += G::NB) {
-    MediumBatch<R, C, STRATEGY, CT>(f, hdr + b0, min(G::NB, nvb - b0), smem);
+    LD nxt;
+    if constexpr (LD::kPipelined) {
+      if (b0 + G::NB < nvb) MediumFetch<R, C, CT>(f, hdr + b0 + G::NB, min(G::NB, nvb - b0 - G::NB), nxt);
+    }
+    MediumBatch<R, C, STRATEGY, CT>(f, hdr + b0, min(G::NB, nvb - b0), cur, smem);
     __syncthreads();
+    if constexpr (LD::kPipelined) cur = nxt;
   }
 }
 
@@ -879,9 +985,9 @@ __global__ __launch_bounds__(256) void k_large(DevFrame f, const WorkItem* __res
 // The host never learns the list lengths, but the unit count is bounded
 // tightly by cells/64 + N, so there are no worst-case grids, no empty launches
 // and no tail of small kernels.  Family A: 64x64, 64x32, 32x64 and the ten
-// single-block classes (~170 VGPRs, 50 KB LDS); family B: 16x8 .. 32x32 (~75
-// VGPRs, <= 26 KB); k_large (128x128 .. 256x256, never emitted by libjxl) keeps
-// its own launch because of its private scratch.
+// single-block classes (168 VGPRs, 50 KB LDS: three workgroups per CU); family
+// B: 16x8 .. 32x32 (~100 VGPRs, <= 26 KB); k_large (128x128 .. 256x256, never
+// emitted by libjxl) keeps its own launch because of its private scratch.
 struct FamilyEntry {
   int cls;
   int unit_varblocks;
@@ -913,7 +1019,7 @@ __device__ __forceinline__ UnitPick PickUnit(const FamilyEntry (&fam)[N], const 
   return p;
 }
 
-static constexpr int kLdsFamilyA = MediumGeom<64, 64>::kLdsBytes > 49152 ? MediumGeom<64, 64>::kLdsBytes : 49152;
+static constexpr int kLdsFamilyA = MediumGeom<64, 64>::kLdsBytes > 3 * 16384 ? MediumGeom<64, 64>::kLdsBytes : 3 * 16384;
 static constexpr int kLdsFamilyB = MediumGeom<32, 32>::kLdsBytes;
 static_assert(sizeof(BlockHdr) <= 48, "header slots are 48 bytes");
 static_assert(MediumGeom<64, 32>::kLdsBytes <= kLdsFamilyA && MediumGeom<32, 64>::kLdsBytes <= kLdsFamilyA, "");
@@ -922,12 +1028,13 @@ static_assert(MediumGeom<16, 8>::kLdsBytes <= kLdsFamilyB && MediumGeom<8, 16>::
               MediumGeom<8, 32>::kLdsBytes <= kLdsFamilyB && MediumGeom<32, 16>::kLdsBytes <= kLdsFamilyB &&
               MediumGeom<16, 32>::kLdsBytes <= kLdsFamilyB, "");
 
-// long units first so that the drain ends on short ones
+// A: 64x64, 64x32, 32x64 (long units first), then the ten single-block classes
 static constexpr FamilyEntry kFamilyA[13] = {
-    {kClsMedium0 + 8, 1},  {kClsMedium0 + 9, 2},  {kClsMedium0 + 10, 2}, {kClsDct8, 64},
+    {kClsMedium0 + 8, 1},   {kClsMedium0 + 9, 2},   {kClsMedium0 + 10, 2},  {kClsDct8, 64},
     {kClsSpecial0 + 0, 64}, {kClsSpecial0 + 1, 64}, {kClsSpecial0 + 2, 64}, {kClsSpecial0 + 3, 64},
     {kClsSpecial0 + 4, 64}, {kClsSpecial0 + 5, 64}, {kClsSpecial0 + 6, 64}, {kClsSpecial0 + 7, 64},
     {kClsSpecial0 + 8, 64}};
+// B: 16x8 .. 32x32, long units first so that the drain ends on short ones
 static constexpr FamilyEntry kFamilyB[8] = {
     {kClsMedium0 + 7, MediumGeom<32, 32>::kUnitVarblocks}, {kClsMedium0 + 5, MediumGeom<32, 16>::kUnitVarblocks},
     {kClsMedium0 + 6, MediumGeom<16, 32>::kUnitVarblocks}, {kClsMedium0 + 2, MediumGeom<16, 16>::kUnitVarblocks},
@@ -937,10 +1044,6 @@ static_assert(kMediumStrategy[8] == 18 && kMediumStrategy[9] == 19 && kMediumStr
               kMediumStrategy[7] == 5 && kMediumStrategy[5] == 10 && kMediumStrategy[6] == 11 &&
               kMediumStrategy[2] == 4 && kMediumStrategy[3] == 8 && kMediumStrategy[4] == 9 &&
               kMediumStrategy[0] == 6 && kMediumStrategy[1] == 7, "class table mismatch");
-static_assert(kSpecialStrategy[0] == 1 && kSpecialStrategy[1] == 2 && kSpecialStrategy[2] == 3 &&
-              kSpecialStrategy[3] == 12 && kSpecialStrategy[4] == 13 && kSpecialStrategy[5] == 14 &&
-              kSpecialStrategy[6] == 15 && kSpecialStrategy[7] == 16 && kSpecialStrategy[8] == 17,
-              "class table mismatch");
 
 // One unit per workgroup: unit blockIdx.x of the family (the grid is the tight
 // upper bound cells/64 + N on the unit count, so at most a handful of
@@ -958,21 +1061,26 @@ __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const 
   body(pick.index, wl.list[pick.cls], pick.first, pick.n);
 }
 
+// Family A is compiled for three waves per SIMD (168 VGPRs, what its LDS use
+// allows anyway); the 64-point transforms of its three big classes would like
+// ~180 and spill a few values to scratch instead -- they are ~5 % of a d1.0
+// frame, and keeping them in this kernel hides their long single-workgroup
+// latency behind the DCT8 bulk (as a launch of their own: +33 us per 8K frame).
 template <typename CT>
-__global__ __launch_bounds__(192, 2) void k_transform_a(DevFrame f, WorkLists wl) {
+__global__ __launch_bounds__(192, sizeof(CT) == 2 ? 3 : 2) void k_transform_a(DevFrame f, WorkLists wl) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
   UnitDispatch(kFamilyA, wl,
-           [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
-             switch (index) {
-               case 0: MediumUnit<64, 64, 18, CT>(f, list, first, n, smem); break;
-               case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
-               case 2: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
-               default:
-                 Single64Unit<CT>(f, index == 3 ? 0 : (int)kSpecialStrategy[index - 4], list, first,
-                                  n, smem);
-                 break;
-             }
-           });
+               [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
+                 switch (index) {
+                   case 0: MediumUnit<64, 64, 18, CT>(f, list, first, n, smem); break;
+                   case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
+                   case 2: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
+                   default:
+                     Single64Unit<CT>(f, index == 3 ? 0 : (int)kSpecialStrategy[index - 4], list,
+                                      first, n, smem);
+                     break;
+                 }
+               });
 }
 
 template <typename CT>
