@@ -21,7 +21,7 @@ def load(path):
 
 
 def short(name):
-    for key, tag in (("k_filters", "filters"), ("k_xyb_only", "filters"), ("k_block64", "blocks_small"), ("k_medium", "blocks_medium"),
+    for key, tag in (("k_filters", "filters"), ("k_xyb_only", "filters"), ("k_transform_a", "blocks_a"), ("k_transform_b", "blocks_b"),
                      ("k_large", "blocks_large"), ("k_prepare", "prepare")):
         if key in name:
             return tag
