@@ -69,8 +69,40 @@ typedef enum {
   /* interleaved linear RGB float, 3 floats per pixel, row stride in bytes
      given at decode time: what XYBStage + WriteToOutputStage(float) produce
      (lib/jxl/render_pipeline/stage_xyb.cc:42-98, stage_write.cc:334-368) */
-  JXLHIP_OUT_LINEAR_RGB_F32 = 1
+  JXLHIP_OUT_LINEAR_RGB_F32 = 1,
+  /* interleaved RGB / RGBA samples after the colour-encoding and packing
+     stages, as described by jxlhip_frame_params::out_format: what
+     FromLinearStage + WriteToOutputStage produce for a buffer output
+     (lib/jxl/render_pipeline/stage_from_linear.cc:34-155,
+     stage_write.cc:254-700, JxlPixelFormat in include/jxl/types.h).  Row
+     stride in bytes given at decode time. */
+  JXLHIP_OUT_PACKED = 2
 } jxlhip_output_kind;
+
+/* Transfer function FromLinearStage applies (the output ColorEncoding's tf;
+ * lib/jxl/cms/transfer_functions-inl.h). */
+typedef enum jxlhip_transfer {
+  JXLHIP_TF_LINEAR = 0, /* OpLinear: samples stay linear */
+  JXLHIP_TF_SRGB = 1    /* OpRgb: TF_SRGB::EncodedFromDisplay (JXL_HIGH_PRECISION) */
+} jxlhip_transfer;
+
+/* JxlDataType of the output buffer (include/jxl/types.h:40-60). */
+typedef enum jxlhip_sample_type {
+  JXLHIP_SAMPLE_F32 = 0, /* JXL_TYPE_FLOAT */
+  JXLHIP_SAMPLE_U8 = 1,  /* JXL_TYPE_UINT8: x (2^bits-1), ordered dither, clamp, round */
+  JXLHIP_SAMPLE_U16 = 2, /* JXL_TYPE_UINT16: x (2^bits-1), clamp, round */
+  JXLHIP_SAMPLE_F16 = 3  /* JXL_TYPE_FLOAT16 */
+} jxlhip_sample_type;
+
+/* Mirrors the members of jxl::ImageOutput / JxlPixelFormat the write stage
+ * reads (lib/jxl/dec_cache.h:70-82). */
+typedef struct jxlhip_output_format {
+  uint32_t transfer;        /* jxlhip_transfer */
+  uint32_t sample_type;     /* jxlhip_sample_type */
+  uint32_t num_channels;    /* 3 = RGB, 4 = RGBA (alpha = 1.0: the frame has no alpha channel) */
+  uint32_t bits_per_sample; /* U8: 1..8, U16: 1..16; ignored for the float types */
+  uint32_t swap_endianness; /* U16 / F16 / F32: byte-swap every sample (JXL_BIG_ENDIAN on this host) */
+} jxlhip_output_format;
 
 /* Mirrors jxl::LoopFilter (lib/jxl/loop_filter.h:20-70); values as decoded. */
 typedef struct jxlhip_loop_filter {
@@ -108,6 +140,8 @@ typedef struct jxlhip_frame_params {
      stripe_group_y0+stripe_group_rows) of the frame.  0,0 = whole frame. */
   uint32_t stripe_group_y0;
   uint32_t stripe_group_rows;
+  /* output_kind == JXLHIP_OUT_PACKED only */
+  jxlhip_output_format out_format;
 } jxlhip_frame_params;
 
 /* Device pointers of one frame's inputs.  Same content the reference keeps in

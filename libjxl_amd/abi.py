@@ -24,6 +24,18 @@ class LoopFilter(C.Structure):
                 ("epf_border_sad_mul", C.c_float)]
 
 
+class OutputFormat(C.Structure):
+    """jxlhip_output_format: FromLinearStage + WriteToOutputStage parameters."""
+    _fields_ = [("transfer", C.c_uint32), ("sample_type", C.c_uint32),
+                ("num_channels", C.c_uint32), ("bits_per_sample", C.c_uint32),
+                ("swap_endianness", C.c_uint32)]
+
+
+OUT_XYB_PLANAR, OUT_LINEAR_RGB_F32, OUT_PACKED = 0, 1, 2
+TF_LINEAR, TF_SRGB = 0, 1
+SAMPLE_F32, SAMPLE_U8, SAMPLE_U16, SAMPLE_F16 = 0, 1, 2, 3
+
+
 class FrameParams(C.Structure):
     _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32),
                 ("coeff_type", C.c_uint32), ("output_kind", C.c_uint32),
@@ -36,7 +48,8 @@ class FrameParams(C.Structure):
                 ("opsin_biases", C.c_float * 3),
                 ("inverse_opsin_matrix", C.c_float * 9),
                 ("stripe_group_y0", C.c_uint32),
-                ("stripe_group_rows", C.c_uint32)]
+                ("stripe_group_rows", C.c_uint32),
+                ("out_format", OutputFormat)]
 
 
 class FrameInputs(C.Structure):
@@ -68,6 +81,13 @@ def make_params(d):
     p.lf.epf_pass0_sigma_scale = d["epf_pass0_sigma_scale"]
     p.lf.epf_pass2_sigma_scale = d["epf_pass2_sigma_scale"]
     p.lf.epf_border_sad_mul = d["epf_border_sad_mul"]
+    of = d.get("out_format")
+    if of:
+        p.out_format.transfer = of.get("transfer", TF_LINEAR)
+        p.out_format.sample_type = of.get("sample_type", SAMPLE_F32)
+        p.out_format.num_channels = of.get("num_channels", 3)
+        p.out_format.bits_per_sample = of.get("bits_per_sample", 0)
+        p.out_format.swap_endianness = of.get("swap_endianness", 0)
     return p
 
 

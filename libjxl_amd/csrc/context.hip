@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "dither_pattern.inc"
 
 using namespace jxlhip;
 
@@ -221,11 +222,13 @@ int jxlhip_create(int device, jxlhip_ctx** out) {
     return fail(JXLHIP_ERR_HIP);
   if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kCountStride * kMaxBands) != hipSuccess ||
       hipMalloc((void**)&c->error_flag, sizeof(int32_t) * 2) != hipSuccess ||
-      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64)) != hipSuccess)
+      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024)) != hipSuccess)
     return fail(JXLHIP_ERR_OUT_OF_MEMORY);
   if (hipMemset(c->error_flag, 0, sizeof(int32_t) * 2) != hipSuccess ||
       hipMemcpy(c->tables, kWcHost, sizeof(float) * 512, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->tables + 512, kResampleUpHost, sizeof(float) * 64, hipMemcpyHostToDevice) !=
+          hipSuccess ||
+      hipMemcpy(c->tables + 576, kDitherPattern, sizeof(float) * 1024, hipMemcpyHostToDevice) !=
           hipSuccess)
     return fail(JXLHIP_ERR_HIP);
   *out = c;
@@ -279,8 +282,17 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   if (p->xsize == 0 || p->ysize == 0 || p->xsize > (1u << 19) || p->ysize > (1u << 19))
     return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "frame size %ux%u out of range", p->xsize,
                 p->ysize);
-  if (p->coeff_type > JXLHIP_COEFF_I32 || p->output_kind > JXLHIP_OUT_LINEAR_RGB_F32)
+  if (p->coeff_type > JXLHIP_COEFF_I32 || p->output_kind > JXLHIP_OUT_PACKED)
     return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad coeff_type/output_kind");
+  if (p->output_kind == JXLHIP_OUT_PACKED) {
+    const jxlhip_output_format& o = p->out_format;
+    const uint32_t max_bits = o.sample_type == JXLHIP_SAMPLE_U8 ? 8 : 16;
+    if (o.transfer > JXLHIP_TF_SRGB || o.sample_type > JXLHIP_SAMPLE_F16 ||
+        (o.num_channels != 3 && o.num_channels != 4) || o.swap_endianness > 1 ||
+        ((o.sample_type == JXLHIP_SAMPLE_U8 || o.sample_type == JXLHIP_SAMPLE_U16) &&
+         (o.bits_per_sample == 0 || o.bits_per_sample > max_bits)))
+      return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad output format");
+  }
   if (p->global_scale <= 0 || p->quant_dc <= 0 || p->cfl_color_factor == 0)
     return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad quantizer parameters");
   if (p->lf.gab > 1 || p->lf.epf_iters > 3)
@@ -369,6 +381,12 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   fp.sm[2] = (float)(p->lf.epf_pass2_sigma_scale * 1.65);
   for (int i = 0; i < 3; i++) fp.bsm[i] = fp.sm[i] * p->lf.epf_border_sad_mul;
   memcpy(fp.minv, p->inverse_opsin_matrix, sizeof(fp.minv));
+  if (p->output_kind == JXLHIP_OUT_PACKED) {
+    fp.fmt = p->out_format;
+    const bool is_int = fp.fmt.sample_type == JXLHIP_SAMPLE_U8 || fp.fmt.sample_type == JXLHIP_SAMPLE_U16;
+    fp.sample_mul = is_int ? (float)((1u << fp.fmt.bits_per_sample) - 1u) : 1.0f;  // stage_write.cc:528
+    fp.dither = c->tables + 576;
+  }
   memcpy(c->lut.v, p->lf.epf_sharp_lut, sizeof(c->lut.v));
   c->fp = fp;
   c->f = f;
@@ -605,6 +623,12 @@ int CheckOutArgs(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_s
   if (c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32) {
     if (out_stride < (size_t)f.xsize * 12 || (out_stride & 3))
       return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "RGB row stride %zu too small", out_stride);
+  } else if (c->p.output_kind == JXLHIP_OUT_PACKED) {
+    const jxlhip_output_format& o = c->p.out_format;
+    const size_t ssz = o.sample_type == JXLHIP_SAMPLE_U8 ? 1 : (o.sample_type == JXLHIP_SAMPLE_F32 ? 4 : 2);
+    if (out_stride < (size_t)f.xsize * o.num_channels * ssz || (out_stride % ssz) ||
+        ((uintptr_t)out % ssz))
+      return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "packed row stride %zu / alignment invalid", out_stride);
   } else if (out_stride < f.xsize ||
              out_plane_stride < out_stride * (size_t)(f.y1 - f.y0 - 1) + f.xsize) {
     return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "XYB strides too small");

@@ -1,0 +1,206 @@
+// emit.h -- the tail of the render pipeline fused into the filter kernels:
+// XYB -> linear RGB (lib/jxl/dec_xyb-inl.h:38-86, stage_xyb.cc:42-98),
+// FromLinearStage (stage_from_linear.cc:34-155) and WriteToOutputStage's sample
+// conversion + interleaving (stage_write.cc:254-330,524-640).  Operation order
+// follows the reference's scalar (single-lane) evaluation so that results are
+// bit-identical to it: explicit fmaf, IEEE sqrt and division.
+#ifndef JXLHIP_EMIT_H_
+#define JXLHIP_EMIT_H_
+
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace jxlhip {
+
+__device__ __forceinline__ void XybToRgb(float x, float y, float b, const FilterParams& P,
+                                         float* rgb) {
+  float gr = y + x, gg = y - x, gb = b;
+  gr = gr - P.cbrt_bias[0];
+  gg = gg - P.cbrt_bias[1];
+  gb = gb - P.cbrt_bias[2];
+  const float mr = __builtin_fmaf(gr * gr, gr, P.opsin_bias[0]);
+  const float mg = __builtin_fmaf(gg * gg, gg, P.opsin_bias[1]);
+  const float mb = __builtin_fmaf(gb * gb, gb, P.opsin_bias[2]);
+  const float* m = P.minv;
+  rgb[0] = __builtin_fmaf(m[2], mb, __builtin_fmaf(m[1], mg, m[0] * mr));
+  rgb[1] = __builtin_fmaf(m[5], mb, __builtin_fmaf(m[4], mg, m[3] * mr));
+  rgb[2] = __builtin_fmaf(m[8], mb, __builtin_fmaf(m[7], mg, m[6] * mr));
+}
+
+// TF_SRGB::EncodedFromDisplay (lib/jxl/cms/transfer_functions-inl.h:244-268):
+// sign-symmetric; 12.92 x below 0.0031308, else a degree-4/4 rational
+// polynomial in sqrt(x) evaluated by Horner's scheme with fused multiply-adds
+// (base/rational_polynomial-inl.h:59-97) and one division.  The square root and
+// the division are the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 (the correctly
+// rounded sequences cost ~25 VALU operations per sample and doubled the filter
+// kernel's time); the result differs from the reference's by <= 2 ulp, far
+// inside what the float pipeline in front of it already differs by.
+__device__ __forceinline__ float SrgbFromLinear(float v) {
+  const float x = __builtin_fabsf(v);
+  const float s = __builtin_amdgcn_sqrtf(x);
+  float yp = 7.352629620e-01f, yq = 2.424867759e-02f;
+  yp = __builtin_fmaf(yp, s, 1.474205315e+00f);
+  yq = __builtin_fmaf(yq, s, 9.258482155e-01f);
+  yp = __builtin_fmaf(yp, s, 3.903842876e-01f);
+  yq = __builtin_fmaf(yq, s, 1.340816930e+00f);
+  yp = __builtin_fmaf(yp, s, 5.287254571e-03f);
+  yq = __builtin_fmaf(yq, s, 3.036675394e-01f);
+  yp = __builtin_fmaf(yp, s, -5.135152395e-04f);
+  yq = __builtin_fmaf(yq, s, 1.004519624e-02f);
+  const float poly = yp * __builtin_amdgcn_rcpf(yq);
+  const float mag = x > 0.0031308f ? poly : x * 12.92f;
+  return __builtin_copysignf(mag, v);
+}
+
+// Output format as seen by the emit code: FmtSel<-1> reads it from the launch
+// parameters (wave-uniform branches per sample -- correct for every format, but
+// the scalar branches cost as much as the arithmetic); FmtSel<ID> with
+// ID = FormatId(transfer, sample_type, channels) fixes it at compile time for
+// the formats the launchers specialise.
+__host__ __device__ constexpr int FormatId(int transfer, int sample_type, int channels) {
+  return transfer | (sample_type << 1) | ((channels - 3) << 3);
+}
+template <int ID>
+struct FmtSel {
+  static __device__ __forceinline__ uint32_t transfer(const jxlhip_output_format&) { return ID & 1; }
+  static __device__ __forceinline__ uint32_t sample_type(const jxlhip_output_format&) { return (ID >> 1) & 3; }
+  static __device__ __forceinline__ uint32_t channels(const jxlhip_output_format&) { return 3 + ((ID >> 3) & 1); }
+};
+template <>
+struct FmtSel<-1> {
+  static __device__ __forceinline__ uint32_t transfer(const jxlhip_output_format& F) { return F.transfer; }
+  static __device__ __forceinline__ uint32_t sample_type(const jxlhip_output_format& F) { return F.sample_type; }
+  static __device__ __forceinline__ uint32_t channels(const jxlhip_output_format& F) { return F.num_channels; }
+};
+
+// MakeUnsigned (stage_write.cc:263-284): scale, ordered dither for 8-bit types,
+// clamp, round to nearest even.  (x, y) are image coordinates, c the channel.
+__device__ __forceinline__ uint16_t Bswap16(uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); }
+
+template <typename DitherPtr>
+__device__ __forceinline__ uint32_t ToUnsigned(const FilterParams& P, DitherPtr dither, float v, int x,
+                                               int y, int c, bool dithered) {
+  v = v * P.sample_mul;
+  if (dithered) v = v + dither[(((uint32_t)y + 13u * c) & 31u) * 32u + (((uint32_t)x + 23u * c) & 31u)];
+  v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), P.sample_mul);
+  return (uint32_t)(int32_t)__builtin_rintf(v);
+}
+
+__device__ __forceinline__ uint16_t HalfBits(float v) {
+  const _Float16 h = (_Float16)v;  // round to nearest even (DemoteTo)
+  uint16_t q;
+  __builtin_memcpy(&q, &h, 2);
+  return q;
+}
+
+// The samples of one pixel as the integers that go to memory (before the
+// endianness swap): u8 / u16 values, f16 bits or f32 bits.  rgb are LINEAR.
+template <typename Sel, typename DitherPtr>
+__device__ __forceinline__ void PackSamples(const FilterParams& P, DitherPtr dither, int x, int y,
+                                            const float* rgb, uint32_t* q) {
+  const jxlhip_output_format& F = P.fmt;
+  const uint32_t st = Sel::sample_type(F);
+  const bool srgb = Sel::transfer(F) == JXLHIP_TF_SRGB;
+  float v[4];
+#pragma unroll
+  for (int c = 0; c < 3; c++) v[c] = srgb ? SrgbFromLinear(rgb[c]) : rgb[c];
+  v[3] = 1.0f;
+  if (st == JXLHIP_SAMPLE_U8) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = ToUnsigned(P, dither, v[c], x, y, c, true);
+    return;
+  }
+  if (st == JXLHIP_SAMPLE_U16) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = ToUnsigned(P, dither, v[c], x, y, c, false);
+  } else if (st == JXLHIP_SAMPLE_F16) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = HalfBits(v[c]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = __float_as_uint(v[c]);
+  }
+  if (F.swap_endianness) {  // rare: one uniform branch
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      q[c] = st == JXLHIP_SAMPLE_F32 ? __builtin_bswap32(q[c]) : (uint32_t)Bswap16((uint16_t)q[c]);
+  }
+}
+
+// One pixel of the JXLHIP_OUT_PACKED output: rgb are LINEAR samples; alpha (4
+// channels) is the opaque 1.0 the reference substitutes when the frame has no
+// alpha channel (stage_write.cc:355-360).  `row` = first byte of output row y.
+template <typename Sel, typename DitherPtr>
+__device__ __forceinline__ void StorePackedPixel(const FilterParams& P, DitherPtr dither, char* row,
+                                                 int x, int y, const float* rgb) {
+  const jxlhip_output_format& F = P.fmt;
+  const int nc = (int)Sel::channels(F);
+  const uint32_t st = Sel::sample_type(F);
+  uint32_t q[4];
+  PackSamples<Sel>(P, dither, x, y, rgb, q);
+  if (st == JXLHIP_SAMPLE_U8) {
+    uint8_t* d = (uint8_t*)row + (size_t)x * nc;
+    if (nc == 4) {
+      *(uint32_t*)d = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+    } else {
+      d[0] = (uint8_t)q[0];
+      d[1] = (uint8_t)q[1];
+      d[2] = (uint8_t)q[2];
+    }
+  } else if (st == JXLHIP_SAMPLE_F32) {
+    uint32_t* d = (uint32_t*)row + (size_t)x * nc;
+    for (int c = 0; c < nc; c++) d[c] = q[c];
+  } else {
+    uint16_t* d = (uint16_t*)row + (size_t)x * nc;
+    for (int c = 0; c < nc; c++) d[c] = (uint16_t)q[c];
+  }
+}
+
+// Two horizontally adjacent pixels (x even) in as few, as wide stores as the
+// format allows: their samples are contiguous in memory.
+template <typename Sel, typename DitherPtr>
+__device__ __forceinline__ void StorePackedPair(const FilterParams& P, DitherPtr dither, char* row,
+                                                int x, int y, const float* rgb0, const float* rgb1) {
+  typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(4)));
+  typedef uint32_t u4 __attribute__((ext_vector_type(4), aligned(4)));
+  const jxlhip_output_format& F = P.fmt;
+  const bool rgba = Sel::channels(F) == 4;
+  const uint32_t st = Sel::sample_type(F);
+  uint32_t a[4], b[4];
+  PackSamples<Sel>(P, dither, x, y, rgb0, a);
+  PackSamples<Sel>(P, dither, x + 1, y, rgb1, b);
+  if (st == JXLHIP_SAMPLE_U8) {
+    if (rgba) {
+      __builtin_nontemporal_store(u2{a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24),
+                                     b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24)},
+                                  (u2*)(row + (size_t)x * 4));
+    } else {  // 6 bytes at a 2-byte aligned address
+      uint16_t* d = (uint16_t*)(row + (size_t)x * 3);
+      d[0] = (uint16_t)(a[0] | (a[1] << 8));
+      d[1] = (uint16_t)(a[2] | (b[0] << 8));
+      d[2] = (uint16_t)(b[1] | (b[2] << 8));
+    }
+  } else if (st == JXLHIP_SAMPLE_F32) {
+    uint32_t* d = (uint32_t*)row + (size_t)x * Sel::channels(F);
+    if (rgba) {
+      __builtin_nontemporal_store(u4{a[0], a[1], a[2], a[3]}, (u4*)d);
+      __builtin_nontemporal_store(u4{b[0], b[1], b[2], b[3]}, (u4*)(d + 4));
+    } else {
+      __builtin_nontemporal_store(u4{a[0], a[1], a[2], b[0]}, (u4*)d);
+      __builtin_nontemporal_store(u2{b[1], b[2]}, (u2*)(d + 4));
+    }
+  } else {  // 16-bit samples
+    uint32_t* d = (uint32_t*)(row + (size_t)x * Sel::channels(F) * 2);
+    if (rgba) {
+      __builtin_nontemporal_store(u4{a[0] | (a[1] << 16), a[2] | (a[3] << 16), b[0] | (b[1] << 16),
+                                     b[2] | (b[3] << 16)},
+                                  (u4*)d);
+    } else {  // 12 bytes as 8 + 4 (a 12-byte vector store measured 8x slower here)
+      __builtin_nontemporal_store(u2{a[0] | (a[1] << 16), a[2] | (b[0] << 16)}, (u2*)d);
+      __builtin_nontemporal_store(b[1] | (b[2] << 16), d + 2);
+    }
+  }
+}
+
+}  // namespace jxlhip
+#endif

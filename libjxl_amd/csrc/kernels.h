@@ -25,8 +25,12 @@ struct FilterParams {
   float cbrt_bias[3];    // cbrt(opsin_biases)
   float minv[9];         // inverse opsin matrix * 255/intensity_target
   void* out;
-  size_t out_stride;        // RGB: bytes per row; XYB: floats per row
+  size_t out_stride;        // RGB / packed: bytes per row; XYB: floats per row
   size_t out_plane_stride;  // XYB only
+  // JXLHIP_OUT_PACKED: FromLinearStage + WriteToOutputStage parameters
+  jxlhip_output_format fmt;
+  float sample_mul;         // 2^bits_per_sample - 1
+  const float* dither;      // 32x32 pattern (device)
 };
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,

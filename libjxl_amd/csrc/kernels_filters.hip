@@ -10,6 +10,7 @@
 // rule is reproduced exactly: every stage sees its input mirrored at the TRUE
 // image edge (lib/jxl/image_ops.h:184-196).
 #include "dev_common.h"
+#include "emit.h"
 #include "kernels.h"
 
 namespace jxlhip {
@@ -195,23 +196,22 @@ __device__ __forceinline__ void StagePixel(const float* p0, const float* p1, con
   }
 }
 
-// XybToRgb (dec_xyb-inl.h:38-86) + output packing
+// XybToRgb (dec_xyb-inl.h:38-86) + output packing; gy is the image row
 template <int OUTK>
-__device__ __forceinline__ void EmitPixel(const float* v, int gx, int gy_rel,
+__device__ __forceinline__ void EmitPixel(const float* v, int gx, int gy, const DevFrame& f,
                                           const FilterParams& P) {
+  const int gy_rel = gy - (int)f.y0;
   if constexpr (OUTK == JXLHIP_OUT_LINEAR_RGB_F32) {
-    float gr = v[1] + v[0], gg = v[1] - v[0], gb = v[2];
-    gr = gr - P.cbrt_bias[0];
-    gg = gg - P.cbrt_bias[1];
-    gb = gb - P.cbrt_bias[2];
-    const float mr = __builtin_fmaf(gr * gr, gr, P.opsin_bias[0]);
-    const float mg = __builtin_fmaf(gg * gg, gg, P.opsin_bias[1]);
-    const float mb = __builtin_fmaf(gb * gb, gb, P.opsin_bias[2]);
-    const float* m = P.minv;
     float* dst = (float*)((char*)P.out + (size_t)gy_rel * P.out_stride) + 3 * (size_t)gx;
-    dst[0] = __builtin_fmaf(m[2], mb, __builtin_fmaf(m[1], mg, m[0] * mr));
-    dst[1] = __builtin_fmaf(m[5], mb, __builtin_fmaf(m[4], mg, m[3] * mr));
-    dst[2] = __builtin_fmaf(m[8], mb, __builtin_fmaf(m[7], mg, m[6] * mr));
+    float rgb[3];
+    XybToRgb(v[0], v[1], v[2], P, rgb);
+    dst[0] = rgb[0];
+    dst[1] = rgb[1];
+    dst[2] = rgb[2];
+  } else if constexpr (OUTK == JXLHIP_OUT_PACKED) {
+    float rgb[3];
+    XybToRgb(v[0], v[1], v[2], P, rgb);
+    StorePackedPixel<FmtSel<-1>>(P, P.dither, (char*)P.out + (size_t)gy_rel * P.out_stride, gx, gy, rgb);
   } else {
     float* dst = (float*)P.out + (size_t)gy_rel * P.out_stride + gx;
     dst[0] = v[0];
@@ -240,7 +240,7 @@ __device__ __forceinline__ void RunStages(const DevFrame& f, const FilterParams&
       float o[3];
       StagePixel<ID>(in + ci, in + IW * IHt + ci, in + 2 * IW * IHt + ci, IW, gx, gy, f, P, o);
       if constexpr (kLast) {
-        EmitPixel<OUTK>(o, gx, gy - (int)f.y0, P);
+        EmitPixel<OUTK>(o, gx, gy, f, P);
       } else {
         out[i] = o[0];
         out[OW * OHt + i] = o[1];
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_xyb_only(DevFrame f, FilterParams P) {
   if (gx >= (int)f.xsize || gy >= (int)f.fy1) return;
   const size_t o = PlaneOffset(f, gy, gx);
   const float v[3] = {f.xyb[0][o], f.xyb[1][o], f.xyb[2][o]};
-  EmitPixel<OUTK>(v, gx, gy - (int)f.y0, P);
+  EmitPixel<OUTK>(v, gx, gy, f, P);
 }
 
 template <int GAB, int EPF, int OUTK>
@@ -331,21 +331,24 @@ static void LaunchFiltersT(const DevFrame& f, const FilterParams& p, hipStream_t
 
 int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                   int output_kind, hipStream_t st) {
-  if (gab < 0 || gab > 1 || epf_iters < 0 || epf_iters > 3 || output_kind < 0 || output_kind > 1)
+  if (gab < 0 || gab > 1 || epf_iters < 0 || epf_iters > 3 || output_kind < 0 || output_kind > 2)
     return -1;
   if (f.fy1 <= f.fy0) return 0;
   if (gab == 0 && epf_iters == 0) {
     const dim3 grid((f.xsize + 255) / 256, f.fy1 - f.fy0);
     if (output_kind == 0)
       hipLaunchKernelGGL(k_xyb_only<0>, grid, dim3(256), 0, st, f, p);
-    else
+    else if (output_kind == 1)
       hipLaunchKernelGGL(k_xyb_only<1>, grid, dim3(256), 0, st, f, p);
+    else
+      hipLaunchKernelGGL(k_xyb_only<2>, grid, dim3(256), 0, st, f, p);
     return 0;
   }
 #define JXLHIP_CASE(G, E)                                    \
   if (gab == G && epf_iters == E) {                          \
     if (output_kind == 0) LaunchFiltersT<G, E, 0>(f, p, st); \
-    else LaunchFiltersT<G, E, 1>(f, p, st);                  \
+    else if (output_kind == 1) LaunchFiltersT<G, E, 1>(f, p, st); \
+    else LaunchFiltersT<G, E, 2>(f, p, st);                  \
     return 0;                                                \
   }
   JXLHIP_CASE(1, 0)

@@ -40,6 +40,7 @@
 #include <stdlib.h>
 
 #include "dev_common.h"
+#include "emit.h"
 #include "kernels.h"
 
 namespace jxlhip {
@@ -127,6 +128,9 @@ struct Lane {
   bool out0, out1;    // column is written by this wave
   v2f mul;            // EPF sigma multiplier of the two columns (border columns of an 8x8 block differ)
   int sx;             // block column of the pair for the sigma look-up (clamped)
+  // packed 8-bit output: the dither pattern, staged in LDS (a global load per
+  // sample would queue behind the row prefetch in the in-order vmcnt)
+  const float __attribute__((address_space(3))) * dither;
 };
 
 __device__ __forceinline__ v2f LoadPair(const float* rowp, const Lane& L) {
@@ -135,31 +139,71 @@ __device__ __forceinline__ v2f LoadPair(const float* rowp, const Lane& L) {
   return v2f{L.sel0 ? v.y : v.x, L.sel1 ? v.y : v.x};
 }
 
-// XYB -> linear RGB of one pixel (dec_xyb-inl.h:38-86, stage_xyb.cc:42-98)
-__device__ __forceinline__ void XybToRgb(float x, float y, float b, const FilterParams& P,
-                                         float* rgb) {
-  float gr = y + x, gg = y - x, gb = b;
-  gr = gr - P.cbrt_bias[0];
-  gg = gg - P.cbrt_bias[1];
-  gb = gb - P.cbrt_bias[2];
-  const float mr = __builtin_fmaf(gr * gr, gr, P.opsin_bias[0]);
-  const float mg = __builtin_fmaf(gg * gg, gg, P.opsin_bias[1]);
-  const float mb = __builtin_fmaf(gb * gb, gb, P.opsin_bias[2]);
-  const float* m = P.minv;
-  rgb[0] = __builtin_fmaf(m[2], mb, __builtin_fmaf(m[1], mg, m[0] * mr));
-  rgb[1] = __builtin_fmaf(m[5], mb, __builtin_fmaf(m[4], mg, m[3] * mr));
-  rgb[2] = __builtin_fmaf(m[8], mb, __builtin_fmaf(m[7], mg, m[6] * mr));
-}
-
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 // The output is written once and never read by this pipeline: streaming
 // (non-temporal) stores keep it from displacing the XYB planes in L2 / MALL.
-template <int OUTK>
-__device__ __forceinline__ void EmitPair(const v2f* v, const Lane& L, int gy_rel,
+// 8-bit RGB: a lane's two pixels are 6 bytes, and sub-dword stores are slow
+// (measured: three 16-bit stores per lane tripled the frame time).  Two
+// neighbouring lanes own 12 bytes = 3 dwords starting at a multiple of 4
+// columns: the first lane stores dwords 0-1 (borrowing 2 bytes from its right
+// neighbour through DPP), the second lane dword 2.
+template <typename Sel>
+__device__ __forceinline__ void StoreRgb8Pair(const FilterParams& P, const Lane& L, char* row,
+                                              int gy, const float* a, const float* b) {
+  typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(4)));
+  uint32_t qa[4], qb[4];
+  PackSamples<Sel>(P, L.dither, L.gx, gy, a, qa);
+  PackSamples<Sel>(P, L.dither, L.gx + 1, gy, b, qb);
+  const uint32_t lo = qa[0] | (qa[1] << 8) | (qa[2] << 16) | (qb[0] << 24);  // bytes 0..3
+  const uint32_t hi = qb[1] | (qb[2] << 8);                                  // bytes 4..5
+  const uint32_t full = (L.out0 && L.out1) ? 1u : 0u;
+  const uint32_t r_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xf, 0xf, true);
+  const uint32_t r_full = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)full, 0x130, 0xf, 0xf, true);
+  const uint32_t l_full = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)full, 0x138, 0xf, 0xf, true);
+  const bool first = ((L.gx >> 1) & 1) == 0;  // gx multiple of 4
+  uint8_t* d = (uint8_t*)row + (size_t)L.gx * 3;
+  if (first && full && r_full) {
+    __builtin_nontemporal_store(u2{lo, hi | (r_lo << 16)}, (u2*)d);
+  } else if (!first && full && l_full) {
+    __builtin_nontemporal_store((lo >> 16) | (hi << 16), (uint32_t*)(d + 2));
+  } else {
+    if (L.out0) {
+      d[0] = (uint8_t)qa[0];
+      d[1] = (uint8_t)qa[1];
+      d[2] = (uint8_t)qa[2];
+    }
+    if (L.out1) {
+      d[3] = (uint8_t)qb[0];
+      d[4] = (uint8_t)qb[1];
+      d[5] = (uint8_t)qb[2];
+    }
+  }
+}
+
+template <int OUTK, int FMT>
+__device__ __forceinline__ void EmitPair(const v2f* v, const Lane& L, int gy, const DevFrame& f,
                                          const FilterParams& P) {
-  if constexpr (OUTK == JXLHIP_OUT_LINEAR_RGB_F32) {
+  const int gy_rel = gy - (int)f.y0;
+  if constexpr (OUTK == JXLHIP_OUT_PACKED) {
+    // FromLinearStage + WriteToOutputStage (emit.h); the packed formats move
+    // 3..16 bytes per pixel, a fraction of the float output
+    using Sel = FmtSel<FMT>;
+    char* row = (char*)P.out + (size_t)gy_rel * P.out_stride;
+    float a[3], b[3];
+    XybToRgb(v[0].x, v[1].x, v[2].x, P, a);
+    XybToRgb(v[0].y, v[1].y, v[2].y, P, b);
+    if (Sel::sample_type(P.fmt) == JXLHIP_SAMPLE_U8 && Sel::channels(P.fmt) == 3) {
+      StoreRgb8Pair<Sel>(P, L, row, gy, a, b);  // all lanes: uses DPP
+    } else if (L.out0 && L.out1) {
+      StorePackedPair<Sel>(P, L.dither, row, L.gx, gy, a, b);
+    } else if (L.out0) {
+      StorePackedPixel<Sel>(P, L.dither, row, L.gx, gy, a);
+    } else if (L.out1) {
+      StorePackedPixel<Sel>(P, L.dither, row, L.gx + 1, gy, b);
+    }
+  } else if constexpr (OUTK == JXLHIP_OUT_LINEAR_RGB_F32) {
     float* dst = (float*)((char*)P.out + (size_t)gy_rel * P.out_stride) + 3 * (size_t)L.gx;
     float a[3], b[3];
     XybToRgb(v[0].x, v[1].x, v[2].x, P, a);
@@ -195,7 +239,7 @@ __device__ __forceinline__ void EmitPair(const v2f* v, const Lane& L, int gy_rel
 // One row step.  PH = (r - r_first) & 3 is the ring slot of input row r.
 // Row bookkeeping: q = row leaving Gaborish (r-1 with GAB, r without),
 // p = q-1 = row whose plus-sums are completed, o = q-2 = EPF output row.
-template <int GAB, int EPF, int OUTK, int PH>
+template <int GAB, int EPF, int OUTK, int FMT, int PH>
 __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const FilterParams& P,
                                      const Lane& L, int prefetch_last_row, int y_begin, int y_end,
                                      float& inv_sigma_blk) {
@@ -299,7 +343,7 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
   }
   // 4. emit
   if (o >= y_begin && o < y_end && !((f.debug & 4) && outv[0].x != 12345.678f)) {
-    EmitPair<OUTK>(outv, L, o - (int)f.y0, P);
+    EmitPair<OUTK, FMT>(outv, L, o, f, P);
   }
 }
 
@@ -310,11 +354,20 @@ struct FastGeom {
   static constexpr int USE = 128 - 2 * HXP;       // output columns per wave
 };
 
-template <int GAB, int EPF, int OUTK>
+template <int GAB, int EPF, int OUTK, int FMT>
 __global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P, int RH) {
   using G = FastGeom<GAB, EPF>;
   constexpr int HX = G::HX, HXP = G::HXP, USE = G::USE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float __attribute__((address_space(3)))* dither_lds = nullptr;
+  if constexpr (OUTK == JXLHIP_OUT_PACKED) {  // before any wave leaves: whole-workgroup barrier
+    __shared__ float s_dither[1024];
+    if (P.fmt.sample_type == JXLHIP_SAMPLE_U8) {  // uniform
+      for (int i = threadIdx.x; i < 1024; i += 256) s_dither[i] = P.dither[i];
+      __syncthreads();
+    }
+    dither_lds = (const float __attribute__((address_space(3)))*)s_dither;
+  }
   const int strip = blockIdx.x * 4 + wave;
   const int W = (int)f.xsize, H = (int)f.ysize;
   const int x_first = strip * USE;  // first output column of the wave (even)
@@ -324,6 +377,7 @@ __global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P
   if (y_begin >= y_end) return;
   Lane L;
   L.gx = x_first - HXP + 2 * lane;
+  L.dither = dither_lds;
   {
     // the lane's two columns, mirrored into the image, always fall into one
     // aligned pair of plane columns (the planes are allocated in whole 8x8
@@ -374,10 +428,10 @@ __global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P
   }
   float inv_sigma_blk = -1.0f;
   for (int r = r_first; r <= r_last; r += 4) {
-    Step<GAB, EPF, OUTK, 0>(s, r, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
-    Step<GAB, EPF, OUTK, 1>(s, r + 1, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
-    Step<GAB, EPF, OUTK, 2>(s, r + 2, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
-    Step<GAB, EPF, OUTK, 3>(s, r + 3, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
+    Step<GAB, EPF, OUTK, FMT, 0>(s, r, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
+    Step<GAB, EPF, OUTK, FMT, 1>(s, r + 1, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
+    Step<GAB, EPF, OUTK, FMT, 2>(s, r + 2, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
+    Step<GAB, EPF, OUTK, FMT, 3>(s, r + 3, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
   }
 }
 
@@ -411,14 +465,31 @@ int FilterRowsPerWave(unsigned wgx, unsigned rows, int hx) {
   return best;
 }
 
-template <int GAB, int EPF, int OUTK>
+template <int GAB, int EPF, int OUTK, int FMT = -1>
 void LaunchFastT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
   using G = FastGeom<GAB, EPF>;
   const unsigned strips = (f.xsize + G::USE - 1) / G::USE;
   const unsigned wgx = (strips + 3) / 4;
   const int RH = FilterRowsPerWave(wgx, f.fy1 - f.fy0, G::HX);
   const dim3 grid(wgx, (f.fy1 - f.fy0 + RH - 1) / RH);
-  hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK>), grid, dim3(256), 0, st, f, p, RH);
+  hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT>), grid, dim3(256), 0, st, f, p, RH);
+}
+
+// The formats djxl writes most (8-bit sRGB for PNG / PPM / JPEG-like consumers,
+// 16-bit sRGB) get a kernel with the format fixed at compile time; everything
+// else takes the one that reads the format from its launch parameters.
+template <int GAB, int EPF>
+void LaunchPackedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
+  const jxlhip_output_format& o = p.fmt;
+  if (o.transfer == JXLHIP_TF_SRGB && !o.swap_endianness) {
+    if (o.sample_type == JXLHIP_SAMPLE_U8 && o.num_channels == 3)
+      return LaunchFastT<GAB, EPF, 2, FormatId(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U8, 3)>(f, p, st);
+    if (o.sample_type == JXLHIP_SAMPLE_U8 && o.num_channels == 4)
+      return LaunchFastT<GAB, EPF, 2, FormatId(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U8, 4)>(f, p, st);
+    if (o.sample_type == JXLHIP_SAMPLE_U16 && o.num_channels == 3)
+      return LaunchFastT<GAB, EPF, 2, FormatId(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U16, 3)>(f, p, st);
+  }
+  LaunchFastT<GAB, EPF, 2, -1>(f, p, st);
 }
 
 }  // namespace
@@ -430,7 +501,8 @@ bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int ep
 #define JXLHIP_FAST(G, E)                                  \
   if (gab == G && epf_iters == E) {                        \
     if (output_kind == 0) LaunchFastT<G, E, 0>(f, p, st);  \
-    else LaunchFastT<G, E, 1>(f, p, st);                   \
+    else if (output_kind == 1) LaunchFastT<G, E, 1>(f, p, st); \
+    else LaunchPackedT<G, E>(f, p, st);                    \
     return true;                                           \
   }
   JXLHIP_FAST(1, 0)

@@ -95,12 +95,17 @@ class VarDctDecoder:
         dev = f"cuda:{self.device}"
         if p.output_kind == 1:
             return torch.empty((y1 - y0, p.xsize, 3), dtype=torch.float32, device=dev)
+        if p.output_kind == 2:  # packed RGB(A): dtype of the sample type (F16 as raw uint16 bits)
+            dt = {0: torch.float32, 1: torch.uint8, 2: torch.int16, 3: torch.int16}[p.out_format.sample_type]
+            return torch.empty((y1 - y0, p.xsize, p.out_format.num_channels), dtype=dt, device=dev)
         return torch.empty((3, y1 - y0, p.xsize), dtype=torch.float32, device=dev)
 
     def _out_args(self, out):
         p = self.params
         if p.output_kind == 1:
             return C.c_void_p(out.data_ptr()), out.stride(0) * 4, 0
+        if p.output_kind == 2:
+            return C.c_void_p(out.data_ptr()), out.stride(0) * out.element_size(), 0
         return C.c_void_p(out.data_ptr()), out.stride(1), out.stride(0)
 
     # -- decode ----------------------------------------------------------------

@@ -35,6 +35,12 @@ class LoopFilter(C.Structure):
                 ("epf_border_sad_mul", C.c_float)]
 
 
+class OutputFormat(C.Structure):
+    _fields_ = [("transfer", C.c_uint32), ("sample_type", C.c_uint32),
+                ("num_channels", C.c_uint32), ("bits_per_sample", C.c_uint32),
+                ("swap_endianness", C.c_uint32)]
+
+
 class FrameParams(C.Structure):
     """Mirror of jxlhip_frame_params (include/jxl_hip.h)."""
     _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32),
@@ -48,7 +54,8 @@ class FrameParams(C.Structure):
                 ("opsin_biases", C.c_float * 3),
                 ("inverse_opsin_matrix", C.c_float * 9),
                 ("stripe_group_y0", C.c_uint32),
-                ("stripe_group_rows", C.c_uint32)]
+                ("stripe_group_rows", C.c_uint32),
+                ("out_format", OutputFormat)]
 
 
 class OracleFrame(C.Structure):
@@ -216,7 +223,12 @@ class Frame:
 
     def decode(self, threads=1):
         p = self.params
-        if p.output_kind == 1:
+        if p.output_kind == 2:  # packed: stride in bytes; F16 as raw uint16 bits
+            of = p.out_format
+            dt = {0: np.float32, 1: np.uint8, 2: np.uint16, 3: np.uint16}[of.sample_type]
+            out = np.zeros((p.ysize, p.xsize, of.num_channels), dt)
+            rc = lib().jxo_decode_frame(C.byref(self.c), _p(out), out.strides[0], 0, threads)
+        elif p.output_kind == 1:
             out = np.zeros((p.ysize, p.xsize, 3), np.float32)
             rc = lib().jxo_decode_frame(C.byref(self.c), _p(out), p.xsize * 3, 0, threads)
         else:
@@ -283,7 +295,15 @@ def _decode_ref(self, threads=1, simple_pipeline=False):
     pipeline (LowMemory executor by default, as djxl; simple_pipeline=True for
     SimpleRenderPipeline)."""
     p = self.params
-    if p.output_kind == 1:
+    if p.output_kind == 2:
+        # packed RGB(A) through the reference's FromLinearStage + WriteToOutputStage;
+        # out_stride is in BYTES for this kind; F16 comes back as raw uint16 bits
+        of = p.out_format
+        dt = {0: np.float32, 1: np.uint8, 2: np.uint16, 3: np.uint16}[of.sample_type]
+        out = np.zeros((p.ysize, p.xsize, of.num_channels), dt)
+        rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), out.strides[0], 0, threads,
+                                        int(simple_pipeline))
+    elif p.output_kind == 1:
         out = np.zeros((p.ysize, p.xsize, 3), np.float32)
         rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), p.xsize * 3, 0, threads, int(simple_pipeline))
     else:

@@ -116,8 +116,21 @@ int jxo_decode_frame(const jxo_frame* f, float* out, size_t out_stride,
     j.out = out;
     j.out_stride = out_stride;
     j.out_plane_stride = out_plane_stride;
-    j.kind = p->output_kind == JXLHIP_OUT_LINEAR_RGB_F32 ? 5 : 6;
-    parallel(j, p->ysize, threads);
+    j.kind = p->output_kind == JXLHIP_OUT_XYB_PLANAR ? 6 : 5;
+    float* lin = NULL;
+    if (p->output_kind == JXLHIP_OUT_PACKED) {
+      /* linear RGB rows first, then FromLinear + WriteToOutput (output.c);
+       * out_stride is in BYTES for this kind */
+      lin = (float*)calloc((size_t)p->xsize * p->ysize * 3, sizeof(float));
+      if (!lin) rc = -1;
+      j.out = lin;
+      j.out_stride = (size_t)p->xsize * 3;
+    }
+    if (rc == 0) parallel(j, p->ysize, threads);
+    if (lin) {
+      jxo_pack_output(f, lin, (size_t)p->xsize * 3, out, out_stride, 0, p->ysize);
+      free(lin);
+    }
   }
   for (int c = 0; c < 3; c++) {
     free(A[c]);

@@ -134,6 +134,10 @@ void jxo_xyb_to_linear_rgb(const jxo_frame* f, const float* const in[3],
 
 /* Whole path, single thread or `threads` pthreads over groups / rows.
  * out per p.output_kind.  Returns 0 on success. */
+/* FromLinearStage + WriteToOutputStage (output.c) for JXLHIP_OUT_PACKED */
+float jxo_srgb_from_linear(float v);
+void jxo_pack_output(const jxo_frame* f, const float* rgb, size_t rgb_stride, void* out,
+                     size_t out_stride_bytes, uint32_t row_begin, uint32_t row_end);
 int jxo_decode_frame(const jxo_frame* f, float* out, size_t out_stride_floats,
                      size_t out_plane_stride, int threads);
 

@@ -1,0 +1,97 @@
+/* output.c -- TEST INFRASTRUCTURE (oracle): restatement of the colour-encoding
+ * and packing tail of the render pipeline for JXLHIP_OUT_PACKED:
+ *   FromLinearStage   lib/jxl/render_pipeline/stage_from_linear.cc:34-155
+ *     TF_SRGB::EncodedFromDisplay  lib/jxl/cms/transfer_functions-inl.h:244-268
+ *     EvalRationalPolynomial       lib/jxl/base/rational_polynomial-inl.h:59-97
+ *   WriteToOutputStage lib/jxl/render_pipeline/stage_write.cc:254-330,524-640
+ * held bit-exact to the reference library by tests/test_reference_parity.py. */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "jxl_oracle.h"
+#include "dither_pattern.inc"
+
+float jxo_srgb_from_linear(float v) {
+  static const float p[5] = {-5.135152395e-04f, 5.287254571e-03f, 3.903842876e-01f, 1.474205315e+00f,
+                             7.352629620e-01f};
+  static const float q[5] = {1.004519624e-02f, 3.036675394e-01f, 1.340816930e+00f, 9.258482155e-01f,
+                             2.424867759e-02f};
+  const float x = fabsf(v);
+  const float s = sqrtf(x);
+  float yp = p[4], yq = q[4];
+  for (int i = 3; i >= 0; i--) {
+    yp = fmaf(yp, s, p[i]);
+    yq = fmaf(yq, s, q[i]);
+  }
+  const float poly = yp / yq;
+  const float mag = x > 0.0031308f ? poly : x * 12.92f;
+  return copysignf(mag, v);
+}
+
+/* IEEE binary16 bits of v, round to nearest even (hwy DemoteTo(float16)) */
+static uint16_t f16_bits(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const int32_t exp = (int32_t)((u >> 23) & 0xff) - 127;
+  uint32_t man = u & 0x7fffffu;
+  if (exp == 128) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+  if (exp > 15) return (uint16_t)(sign | 0x7c00u);
+  if (exp >= -14) {
+    uint32_t h = ((uint32_t)(exp + 15) << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+    return (uint16_t)(sign | h);
+  }
+  if (exp < -25) return (uint16_t)sign;
+  man |= 0x800000u;
+  const int shift = -exp - 14 + 13;  /* 14..24 */
+  uint32_t h = man >> shift;
+  const uint32_t rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (h & 1))) h++;
+  return (uint16_t)(sign | h);
+}
+
+static uint32_t to_unsigned(float v, float mul, uint32_t x, uint32_t y, int c, int dithered) {
+  v = v * mul;
+  if (dithered) v = v + kDitherPattern[((y + 13u * c) & 31u) * 32u + ((x + 23u * c) & 31u)];
+  v = fminf(fmaxf(v, 0.0f), mul);
+  return (uint32_t)(int32_t)rintf(v);
+}
+
+void jxo_pack_output(const jxo_frame* f, const float* rgb, size_t rgb_stride, void* out,
+                     size_t out_stride_bytes, uint32_t row_begin, uint32_t row_end) {
+  const jxlhip_frame_params* p = &f->p;
+  const jxlhip_output_format* F = &p->out_format;
+  const int nc = (int)F->num_channels;
+  const int is_int = F->sample_type == JXLHIP_SAMPLE_U8 || F->sample_type == JXLHIP_SAMPLE_U16;
+  const float mul = is_int ? (float)((1u << F->bits_per_sample) - 1u) : 1.0f;
+  for (uint32_t y = row_begin; y < row_end; y++) {
+    uint8_t* row = (uint8_t*)out + (size_t)y * out_stride_bytes;
+    for (uint32_t x = 0; x < p->xsize; x++) {
+      float v[4];
+      for (int c = 0; c < 3; c++) {
+        const float lin = rgb[(size_t)y * rgb_stride + 3 * (size_t)x + c];
+        v[c] = F->transfer == JXLHIP_TF_SRGB ? jxo_srgb_from_linear(lin) : lin;
+      }
+      v[3] = 1.0f;
+      for (int c = 0; c < nc; c++) {
+        const size_t i = (size_t)x * nc + c;
+        if (F->sample_type == JXLHIP_SAMPLE_U8) {
+          row[i] = (uint8_t)to_unsigned(v[c], mul, x, y, c, 1);
+        } else if (F->sample_type == JXLHIP_SAMPLE_F32) {
+          uint32_t u;
+          memcpy(&u, &v[c], 4);
+          if (F->swap_endianness) u = __builtin_bswap32(u);
+          memcpy(row + 4 * i, &u, 4);
+        } else {
+          uint16_t q = F->sample_type == JXLHIP_SAMPLE_U16 ? (uint16_t)to_unsigned(v[c], mul, x, y, c, 0)
+                                                           : f16_bits(v[c]);
+          if (F->swap_endianness) q = (uint16_t)((q >> 8) | (q << 8));
+          memcpy(row + 2 * i, &q, 2);
+        }
+      }
+    }
+  }
+}

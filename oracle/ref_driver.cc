@@ -85,7 +85,11 @@ Status FillState(const jxo_frame* f, CodecMetadata* metadata, FrameHeader* fh,
   // ---- image-level metadata: XYB-encoded, float samples, linear sRGB target
   metadata->m.SetFloat32Samples();
   metadata->m.xyb_encoded = !xyb_out;
-  metadata->m.color_encoding = ColorEncoding::LinearSRGB(/*is_gray=*/false);
+  // the output colour encoding decides which FromLinearStage op the reference adds
+  // (dec_cache.cc:256-350, stage_from_linear.cc:159-185)
+  const bool srgb_tf = p.output_kind == JXLHIP_OUT_PACKED && p.out_format.transfer == JXLHIP_TF_SRGB;
+  metadata->m.color_encoding = srgb_tf ? ColorEncoding::SRGB(/*is_gray=*/false)
+                                       : ColorEncoding::LinearSRGB(/*is_gray=*/false);
   JXL_RETURN_IF_ERROR(metadata->size.Set(p.xsize, p.ysize));
 
   // ---- frame header: one VarDCT frame covering the image
@@ -182,6 +186,8 @@ Status FillState(const jxo_frame* f, CodecMetadata* metadata, FrameHeader* fh,
   return true;
 }
 
+// out_stride_floats: row stride in floats (XYB / linear RGB float output) or in BYTES
+// (JXLHIP_OUT_PACKED, where `out` is the packed sample buffer)
 Status DecodeFrame(const jxo_frame* f, float* out, size_t out_stride_floats, size_t out_plane_stride,
                    int threads, int simple_pipeline) {
   Ref ref;
@@ -230,6 +236,17 @@ Status DecodeFrame(const jxo_frame* f, float* out, size_t out_stride_floats, siz
   dec_state->main_output.bits_per_sample = 32;
   dec_state->main_output.buffer = rgb;
   dec_state->main_output.stride = rgb_stride * sizeof(float);
+  if (p.output_kind == JXLHIP_OUT_PACKED) {
+    const jxlhip_output_format& of = p.out_format;
+    static const JxlDataType kTypes[4] = {JXL_TYPE_FLOAT, JXL_TYPE_UINT8, JXL_TYPE_UINT16, JXL_TYPE_FLOAT16};
+    if (of.sample_type > 3) return JXL_FAILURE("bad sample type");
+    // swap_endianness is relative to this (little-endian) host
+    dec_state->main_output.format = JxlPixelFormat{of.num_channels, kTypes[of.sample_type],
+                                                   of.swap_endianness ? JXL_BIG_ENDIAN : JXL_LITTLE_ENDIAN, 0};
+    dec_state->main_output.bits_per_sample =
+        of.sample_type == JXLHIP_SAMPLE_F32 ? 32 : (of.sample_type == JXLHIP_SAMPLE_F16 ? 16 : of.bits_per_sample);
+    dec_state->main_output.stride = out_stride_floats;  // bytes
+  }
   dec_state->main_output.buffer_size = dec_state->main_output.stride * p.ysize;
 
   ImageBundle decoded(&ref.mm, &metadata.m);

@@ -97,3 +97,76 @@ def test_config4_hdr_dct32_int32(dec, ref):
 
 def test_xyb_planar_output(dec, ref):
     run_case(dec, ref, 600, 300, mix=synth.MIX_ALL, gab=True, epf_iters=2, output_kind=0)
+
+
+# ---- f3: colour-encoding + packing stages fused into the last kernel ----------
+def run_packed(dec, ref, xs, ys, fmt, **kw):
+    params, t = synth.synth_frame(xs, ys, device="cuda", output_kind=2, out_format=fmt, **kw)
+    dec.begin_frame(params)
+    dq = dec.default_dequant_tables()
+    dec.set_inputs(t, dq)
+    out = dec.decode_frame()
+    dec.sync()
+    got = out.cpu().numpy()
+    npy = {k: ([x.cpu().numpy() for x in v] if isinstance(v, list) else v.cpu().numpy()) for k, v in t.items()}
+    fr = ref.Frame(frames.to_oracle_params(abi.make_params(params)), npy["coeffs"], npy["ac_strategy"],
+                   npy["raw_quant"], npy["epf_sharpness"], npy["ytox_map"], npy["ytob_map"], npy["dc"],
+                   dq.cpu().numpy())
+    want = fr.decode_ref(threads=THREADS)
+    assert got.shape == want.shape
+    return got, want
+
+
+@pytest.mark.parametrize("gab,epf", [(True, 1), (False, 0), (True, 3)])
+@pytest.mark.parametrize("nc", [3, 4])
+def test_packed_srgb_u8(dec, ref, gab, epf, nc):
+    """What djxl writes by default (8-bit sRGB): the float pipeline differs from the
+    reference by <= 2e-5 of the range, so after x255 + dither + rounding a sample may land on
+    the other side of a rounding boundary: at most 1 LSB, for at most 0.1 % of the samples."""
+    got, want = run_packed(dec, ref, 533, 401, dict(transfer=1, sample_type=1, num_channels=nc, bits_per_sample=8),
+                           mix=synth.MIX_ALL, gab=gab, epf_iters=epf, intensity_target=80.0)
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1
+    assert (d != 0).mean() < 1e-3
+    if nc == 4:
+        assert (got[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("tf,st,bits,nc,sw", [(1, 2, 16, 3, 0), (1, 2, 12, 4, 1), (0, 2, 16, 3, 0)])
+def test_packed_u16(dec, ref, tf, st, bits, nc, sw):
+    got, want = run_packed(dec, ref, 520, 264, dict(transfer=tf, sample_type=st, num_channels=nc,
+                                                    bits_per_sample=bits, swap_endianness=sw),
+                           mix=synth.MIX_D1, gab=True, epf_iters=1, intensity_target=80.0 if tf else 255.0)
+    g, w = got.view(np.uint16), want.view(np.uint16)
+    if sw:
+        g, w = g.byteswap(), w.byteswap()
+    d = np.abs(g.astype(np.int32) - w.astype(np.int32))
+    assert d.max() <= max(2, int(TIGHT * 8 * (1 << bits)))
+
+
+@pytest.mark.parametrize("st,sw", [(3, 0), (3, 1), (0, 0), (0, 1)])
+def test_packed_float_srgb(dec, ref, st, sw):
+    got, want = run_packed(dec, ref, 520, 264, dict(transfer=1, sample_type=st, num_channels=4, swap_endianness=sw),
+                           mix=synth.MIX_D1, gab=True, epf_iters=1, intensity_target=80.0)
+    if st == 3:
+        g, w = got.view(np.uint16), want.view(np.uint16)
+        if sw:
+            g, w = g.byteswap(), w.byteswap()
+        g, w = g.view(np.float16).astype(np.float32), w.view(np.float16).astype(np.float32)
+        tol = 2e-3  # one f16 ulp at 1.0 is 9.8e-4
+    else:
+        g, w = got.view(np.uint32), want.view(np.uint32)
+        if sw:
+            g, w = g.byteswap(), w.byteswap()
+        g, w = g.view(np.float32), w.view(np.float32)
+        tol = 1e-4  # the sRGB curve amplifies dark-end differences (slope 12.92)
+    assert float(np.abs(g - w).max()) <= tol * max(1.0, float(np.abs(w).max()))
+    assert (g[..., 3] == 1.0).all()
+
+
+def test_packed_8k_srgb_u8_rgba_full_size(dec, ref):
+    """The bench workload with djxl's default output: 7680x4320 d1.0 -> sRGB RGBA8."""
+    got, want = run_packed(dec, ref, 7680, 4320, dict(transfer=1, sample_type=1, num_channels=4, bits_per_sample=8),
+                           mix=synth.MIX_D1, gab=True, epf_iters=1, intensity_target=80.0)
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3

@@ -106,3 +106,47 @@ def test_dequant_dc_and_smoothing(ref, smooth):
         L.jxo_adaptive_dc_smoothing(xsb, ysb, mul.ctypes.data_as(C.c_void_p), p3(got))
     for c in range(3):
         assert np.array_equal(bits(got[c]), bits(want[c])), c
+
+
+PACKED_FORMATS = [
+    # (transfer, sample_type, bits, channels, swap)
+    (1, 1, 8, 3, 0),   # sRGB u8 RGB  (djxl -> PPM/PNG default)
+    (1, 1, 8, 4, 0),   # sRGB u8 RGBA
+    (0, 1, 5, 3, 0),   # linear, 5-bit samples in bytes
+    (1, 2, 16, 3, 0),  # sRGB u16
+    (1, 2, 12, 4, 1),  # sRGB 12-bit in u16, big-endian, RGBA
+    (1, 3, 0, 3, 0),   # sRGB f16
+    (0, 3, 0, 4, 1),   # linear f16 RGBA, byte-swapped
+    (1, 0, 0, 3, 0),   # sRGB f32
+    (0, 0, 0, 4, 1),   # linear f32 RGBA, byte-swapped
+]
+
+
+@pytest.mark.parametrize("tf,st,bits_,nc,sw", PACKED_FORMATS)
+def test_packed_output_stages(ref, tf, st, bits_, nc, sw):
+    """f3: FromLinearStage (TF_SRGB) + WriteToOutputStage (scale, ordered dither,
+    clamp, round, interleave, alpha = 1, endianness): restatement == reference, byte for byte."""
+    _, _, fr = frames.make_case(264, 136, mix=synth.MIX_D1, gab=True, epf_iters=1, output_kind=2,
+                                intensity_target=80.0 if tf else 255.0, seed=17 + st,
+                                out_format=dict(transfer=tf, sample_type=st, num_channels=nc,
+                                                bits_per_sample=bits_, swap_endianness=sw))
+    o, r = fr.decode(threads=2), fr.decode_ref(threads=2)
+    assert o.shape == r.shape == (136, 264, nc) and o.dtype == r.dtype
+    assert np.array_equal(o.view(np.uint8), r.view(np.uint8))
+    if st in (1, 2) and tf:  # the frame spans a useful range, not a constant
+        assert int(r.max()) - int(r.min()) > (1 << bits_) // 4
+
+
+def test_srgb_transfer_function_known_values(ref):
+    # TF_SRGB::EncodedFromDisplay: 12.92 x below the threshold, within 5e-7 of the
+    # exact sRGB curve above it (transfer_functions-inl.h:244), odd symmetry
+    import ctypes as C
+    L = ref.lib()
+    L.jxo_srgb_from_linear.restype = C.c_float
+    L.jxo_srgb_from_linear.argtypes = [C.c_float]
+    assert L.jxo_srgb_from_linear(0.0) == 0.0
+    assert L.jxo_srgb_from_linear(0.001) == np.float32(np.float32(0.001) * np.float32(12.92))
+    for x in (0.0031309, 0.01, 0.18, 0.5, 1.0):  # the approximation is fitted on [0, 1]
+        exact = 1.055 * x ** (1 / 2.4) - 0.055
+        assert abs(L.jxo_srgb_from_linear(x) - exact) < 2e-6 * max(1.0, exact)
+        assert L.jxo_srgb_from_linear(-x) == -L.jxo_srgb_from_linear(x)
