@@ -1,0 +1,100 @@
+/* jxl_hip_entropy.h -- host side of the VarDCT back-end's input: the AC entropy
+ * decoder that turns the bytes of a frame's AC-global and AC-group sections
+ * into the quantized coefficient stream jxlhip_submit_group() uploads
+ * (SURVEY.md section 8, row f1).  Plain C ABI, part of libjxl_hip.so; host
+ * code only (ANS / prefix decoding is serial per group and parallel across
+ * groups: it runs on the JxlParallelRunner's threads while the GPU decodes the
+ * previous groups).
+ *
+ * Replaces, behaviour for behaviour (libjxl tree, lib/jxl/):
+ *   DecodeHistograms, ANSSymbolReader      dec_ans.cc:31-421, dec_ans.h:148-470
+ *   DecodeContextMap                        dec_context_map.cc:47-95
+ *   HuffmanDecodingData                     dec_huffman.cc:20-245, huffman_table.cc:55-159
+ *   InitAliasTable / AliasTable::Lookup     ans_common.cc:41-146, ans_common.h:107-149
+ *   DecodeCoeffOrders, natural orders       coeff_order.cc:36-156, ac_strategy.cc:28-79,
+ *                                           lehmer_code.h:60-100
+ *   the per-pass part of ProcessACGlobal    dec_frame.cc:396-416
+ *   GetBlockFromBitstream + DecodeACVarBlock dec_group.cc:466-640
+ * Output layout = the reference's ACImage (dct_util.h:23-96): per group and
+ * channel 65536 slots, varblocks in raster visit order, 64*covered_blocks
+ * coefficients each in dequant-matrix order, LLF slots untouched.
+ */
+#ifndef JXL_HIP_ENTROPY_H_
+#define JXL_HIP_ENTROPY_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "jxl_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors jxl::BlockCtxMap (lib/jxl/ac_context.h:85-150) as decoded from the
+ * DC-global section (DecodeBlockCtxMap, entropy_coder.h:44).  A NULL pointer
+ * wherever this struct is expected means the default map (kDefaultCtxMap, no
+ * thresholds). */
+typedef struct jxlhip_block_ctx_map {
+  uint32_t num_dc_ctxs;          /* product of (dc_thresholds[c].size() + 1) */
+  uint32_t num_qf_thresholds;    /* <= 15 */
+  uint32_t qf_thresholds[15];
+  uint32_t ctx_map_size;         /* 3 * 13 * (num_qf_thresholds + 1) * num_dc_ctxs */
+  const uint8_t* ctx_map;
+} jxlhip_block_ctx_map;
+
+/* One pass of the AC-global section: coefficient orders + entropy code. */
+typedef struct jxlhip_ac_pass jxlhip_ac_pass;
+
+/* Decodes `U32(kOrderEnc) used_orders; DecodeCoeffOrders; DecodeHistograms`
+ * (dec_frame.cc:399-410) starting at bit *bit_pos of data[0..size); *bit_pos is
+ * advanced past what was read.  used_acs: bit mask of the raw AC strategies
+ * present in the frame (PassesDecoderState::used_acs); num_histograms: the
+ * frame's number of histogram sets (dec_frame.cc:383-386).
+ * Returns JXLHIP_OK, JXLHIP_ERR_BAD_STREAM (invalid or truncated data) or
+ * JXLHIP_ERR_INVALID_ARGUMENT / JXLHIP_ERR_OUT_OF_MEMORY. */
+JXLHIP_EXPORT int jxlhip_ac_pass_decode(const uint8_t* data, size_t size, size_t* bit_pos,
+                                        uint32_t used_acs, uint32_t num_histograms,
+                                        const jxlhip_block_ctx_map* block_ctx_map,
+                                        jxlhip_ac_pass** out);
+JXLHIP_EXPORT void jxlhip_ac_pass_destroy(jxlhip_ac_pass* pass);
+/* ANSCode::max_num_bits: the frame can use JXLHIP_COEFF_I16 when, over all its
+ * passes, max + ceil(log2(num_passes)) < 16 (dec_frame.cc:414-421). */
+JXLHIP_EXPORT uint32_t jxlhip_ac_pass_max_num_bits(const jxlhip_ac_pass* pass);
+/* the 13-bit mask of transmitted coefficient orders (debugging / tests) */
+JXLHIP_EXPORT uint32_t jxlhip_ac_pass_used_orders(const jxlhip_ac_pass* pass);
+/* coefficient order of order bucket `ord` (0..12) and channel c: 64 * covered
+ * blocks entries (tests) */
+JXLHIP_EXPORT const uint32_t* jxlhip_ac_pass_order(const jxlhip_ac_pass* pass, uint32_t ord, uint32_t c);
+
+/* Decodes one pass of one AC group (DecodeGroup with GetBlockFromBitstream,
+ * dec_group.cc:560-640,780-815): the histogram-set selector, then per varblock
+ * in raster visit order and per channel (Y, X, B) the number of non-zeros and
+ * the coefficients, ADDED (<< shift) into coeffs[c][...] -- the caller zeroes
+ * the three 65536-slot buffers before the group's first pass.
+ *   xsize_blocks/ysize_blocks: frame size in 8x8 blocks; group_x/y: AC group
+ *   ac_strategy, raw_quant: whole-frame side info as in jxlhip_frame_inputs
+ *   quant_dc: per-block DC context index (PassesSharedState::quant_dc), NULL = 0
+ *   coeff_type: JXLHIP_COEFF_I16 / I32 element type of coeffs[]
+ *   ncoeffs (optional): slots used by the group (what jxlhip_submit_group takes)
+ * 4:4:4 only (the VarDCT back-end does not implement chroma subsampling). */
+JXLHIP_EXPORT int jxlhip_ac_group_decode(const jxlhip_ac_pass* pass, uint32_t xsize_blocks,
+                                         uint32_t ysize_blocks, uint32_t group_x, uint32_t group_y,
+                                         const uint8_t* ac_strategy, const int32_t* raw_quant,
+                                         const uint8_t* quant_dc, const uint8_t* data, size_t size,
+                                         size_t* bit_pos, uint32_t shift, uint32_t coeff_type,
+                                         void* const coeffs[3], size_t* ncoeffs);
+
+/* Entropy-decode a single-pass group straight into a pinned staging buffer of
+ * the context and queue its upload (jxlhip_submit_group): the call a
+ * JxlParallelRunner worker makes per AC group.  Thread-safe.  Side info
+ * pointers are HOST memory (the same arrays given to jxlhip_upload_side_info). */
+JXLHIP_EXPORT int jxlhip_ac_group_decode_submit(jxlhip_ctx* ctx, const jxlhip_ac_pass* pass,
+                                                uint32_t group_idx, const uint8_t* ac_strategy,
+                                                const int32_t* raw_quant, const uint8_t* quant_dc,
+                                                const uint8_t* data, size_t size, size_t* bit_pos);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_HIP_ENTROPY_H_ */

@@ -113,6 +113,10 @@ EXPORTS = [
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
     "jxlhip_profile_enable", "jxlhip_profile_read",
     "jxlhip_default_dequant_tables", "jxlhip_dequant_dc",
+    # include/jxl_hip_entropy.h
+    "jxlhip_ac_pass_decode", "jxlhip_ac_pass_destroy", "jxlhip_ac_pass_max_num_bits",
+    "jxlhip_ac_pass_used_orders", "jxlhip_ac_pass_order", "jxlhip_ac_group_decode",
+    "jxlhip_ac_group_decode_submit",
 ]
 
 
@@ -136,6 +140,16 @@ def load_library():
     L.jxlhip_destroy.argtypes = [vp]
     L.jxlhip_destroy.restype = None
     L.jxlhip_set_stream.argtypes = [vp, vp, i32]
+    L.jxlhip_ac_pass_decode.argtypes = [vp, sz, C.POINTER(sz), u32, u32, vp, C.POINTER(vp)]
+    L.jxlhip_ac_pass_destroy.argtypes = [vp]
+    L.jxlhip_ac_pass_destroy.restype = None
+    L.jxlhip_ac_pass_max_num_bits.argtypes = [vp]
+    L.jxlhip_ac_pass_max_num_bits.restype = u32
+    L.jxlhip_ac_pass_used_orders.argtypes = [vp]
+    L.jxlhip_ac_pass_used_orders.restype = u32
+    L.jxlhip_ac_group_decode.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, vp, sz, C.POINTER(sz), u32, u32,
+                                         vp * 3, C.POINTER(sz)]
+    L.jxlhip_ac_group_decode_submit.argtypes = [vp, vp, u32, vp, vp, vp, vp, sz, C.POINTER(sz)]
     L.jxlhip_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlhip_frame_set_inputs.argtypes = [vp, C.POINTER(FrameInputs)]
     L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]

@@ -12,13 +12,14 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 LIB_SOURCES = ["context.hip", "kernels_blocks.hip", "kernels_filters.hip", "kernels_filters_fast.hip",
-               "kernels_tables.hip"]
+               "kernels_tables.hip", "entropy.cc"]
 RUNNER_SOURCES = ["runner.cc"]
 
 
 def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "jxl_hip.h"))
+    hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "jxl_hip_entropy.h"))
     return hdrs
 
 

@@ -8,9 +8,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 
+#include "../../include/jxl_hip_entropy.h"
 #include "kernels.h"
 #include "dither_pattern.inc"
 
@@ -21,6 +23,7 @@ namespace {
 constexpr int kPoolStreams = 4;
 constexpr int kMaxBlockStreams = 8;
 constexpr int kMaxBands = 64;
+constexpr int kStageSlots = 8;  // pinned staging buffers of jxlhip_ac_group_decode_submit
 
 struct ProfSpan {
   hipEvent_t a, b;
@@ -64,6 +67,14 @@ struct jxlhip_ctx {
   bool pool_dirty[kPoolStreams] = {false};
   std::mutex pool_mu;
   uint32_t pool_next = 0;
+  // entropy-decode staging: pinned host buffers (3 channels x 65536 coefficients
+  // each), reused round-robin; stage_ev[i] fires when slot i's upload is done
+  void* stage[kStageSlots] = {nullptr};
+  hipEvent_t stage_ev[kStageSlots] = {nullptr};
+  int stage_state[kStageSlots] = {0};  // 0 free, 1 owned by a decoding thread, 2 upload queued (stage_ev)
+  size_t stage_bytes = 0;
+  std::mutex stage_mu;
+  std::condition_variable stage_cv;
   // dc scratch
   float* dc_tmp = nullptr;
   size_t dc_tmp_floats = 0;
@@ -259,6 +270,13 @@ void jxlhip_destroy(jxlhip_ctx* c) {
     if (c->bev[i]) (void)hipEventDestroy(c->bev[i]);
   }
   if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+  for (int i = 0; i < kStageSlots; i++) {
+    if (c->stage_ev[i]) {
+      if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
+      (void)hipEventDestroy(c->stage_ev[i]);
+    }
+    if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+  }
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_coeffs[1],
                   c->up_coeffs[2], c->up_side, c->dc_tmp};
@@ -515,8 +533,17 @@ int jxlhip_upload_side_info(jxlhip_ctx* c, const uint8_t* ac_strategy, const int
   return JXLHIP_OK;
 }
 
+static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void* const coeffs[3],
+                                  size_t ncoeffs, hipEvent_t done);
+
 int jxlhip_submit_group(jxlhip_ctx* c, uint32_t group_idx, const void* const coeffs[3],
                         size_t ncoeffs) {
+  return jxlhip_submit_group_ev(c, group_idx, coeffs, ncoeffs, nullptr);
+}
+
+// `done` (optional) is recorded behind the three copies on the slot's stream
+static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void* const coeffs[3],
+                                  size_t ncoeffs, hipEvent_t done) {
   if (!c || !coeffs) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "submit_group before frame_begin");
   const DevFrame& f = c->f;
@@ -541,8 +568,89 @@ int jxlhip_submit_group(jxlhip_ctx* c, uint32_t group_idx, const void* const coe
                                     c->pool[slot]);
       if (e != hipSuccess) return Fail(c, JXLHIP_ERR_HIP, "submit_group: %s", hipGetErrorString(e));
     }
+    if (done && hipEventRecord(done, c->pool[slot]) != hipSuccess)
+      return Fail(c, JXLHIP_ERR_HIP, "submit_group: event record failed");
   }
   return JXLHIP_OK;
+}
+
+// f1: entropy-decode one single-pass AC group into a pinned staging slot and
+// queue its upload.  The slot is reused only after its copies completed.
+int jxlhip_ac_group_decode_submit(jxlhip_ctx* c, const jxlhip_ac_pass* pass, uint32_t group_idx,
+                                  const uint8_t* ac_strategy, const int32_t* raw_quant,
+                                  const uint8_t* quant_dc, const uint8_t* data, size_t size,
+                                  size_t* bit_pos) {
+  if (!c || !pass || !ac_strategy || !raw_quant || !data || !bit_pos) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "ac_group_decode_submit before frame_begin");
+  const DevFrame& f = c->f;
+  if (group_idx >= f.xsg * f.ysg) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad group %u", group_idx);
+  const size_t esz = f.coeff_type == JXLHIP_COEFF_I16 ? 2 : 4;
+  const size_t slot_bytes = 3 * (size_t)JXLHIP_GROUP_COEFFS * esz;
+  int slot = -1;
+  {
+    std::unique_lock<std::mutex> lock(c->stage_mu);
+    if (hipSetDevice(c->device) != hipSuccess) return JXLHIP_ERR_HIP;
+    if (c->stage_bytes < slot_bytes) {
+      // (re)allocation: only when no thread owns a slot
+      c->stage_cv.wait(lock, [&] {
+        for (int i = 0; i < kStageSlots; i++)
+          if (c->stage_state[i] == 1) return false;
+        return true;
+      });
+      if (c->stage_bytes < slot_bytes) {
+        for (int i = 0; i < kStageSlots; i++) {
+          if (c->stage[i]) {
+            if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
+            (void)hipHostFree(c->stage[i]);
+            c->stage[i] = nullptr;
+          }
+          c->stage_state[i] = 0;
+          if (hipHostMalloc(&c->stage[i], slot_bytes, hipHostMallocDefault) != hipSuccess)
+            return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
+          if (!c->stage_ev[i] &&
+              hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess)
+            return Fail(c, JXLHIP_ERR_HIP, "event creation failed");
+        }
+        c->stage_bytes = slot_bytes;
+      }
+    }
+    while (slot < 0) {
+      int pending = -1;
+      for (int i = 0; i < kStageSlots && slot < 0; i++) {
+        if (c->stage_state[i] == 0) slot = i;
+        else if (c->stage_state[i] == 2) {
+          if (hipEventQuery(c->stage_ev[i]) == hipSuccess) slot = i;
+          else if (pending < 0) pending = i;
+        }
+      }
+      if (slot >= 0) break;
+      if (pending >= 0) {  // every slot is in flight: wait for one upload
+        if (hipEventSynchronize(c->stage_ev[pending]) != hipSuccess) return JXLHIP_ERR_HIP;
+        if (c->stage_state[pending] == 2) slot = pending;
+      } else {  // every slot is owned by another decoding thread
+        c->stage_cv.wait(lock);
+      }
+    }
+    c->stage_state[slot] = 1;
+  }
+  char* base = (char*)c->stage[slot];
+  void* const ch[3] = {base, base + (size_t)JXLHIP_GROUP_COEFFS * esz, base + 2 * (size_t)JXLHIP_GROUP_COEFFS * esz};
+  memset(base, 0, slot_bytes);  // coefficients are accumulated (dec_group.cc:527-531)
+  size_t ncoeffs = 0;
+  int rc = jxlhip_ac_group_decode(pass, f.xsb, f.ysb, group_idx % f.xsg, group_idx / f.xsg, ac_strategy,
+                                  raw_quant, quant_dc, data, size, bit_pos, /*shift=*/0, f.coeff_type, ch,
+                                  &ncoeffs);
+  if (rc == JXLHIP_OK) {
+    const void* const src[3] = {ch[0], ch[1], ch[2]};
+    rc = jxlhip_submit_group_ev(c, group_idx, src, ncoeffs, c->stage_ev[slot]);
+  }
+  {
+    std::lock_guard<std::mutex> lock(c->stage_mu);
+    c->stage_state[slot] = rc == JXLHIP_OK ? 2 : 0;
+  }
+  c->stage_cv.notify_all();
+  if (rc == JXLHIP_ERR_BAD_STREAM) return Fail(c, rc, "AC group %u: invalid entropy-coded data", group_idx);
+  return rc;
 }
 
 // ---- decode -------------------------------------------------------------------

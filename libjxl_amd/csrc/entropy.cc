@@ -1,0 +1,1099 @@
+// entropy.cc -- the host half of the back-end's input side (include/jxl_hip_entropy.h):
+// JPEG XL's entropy decoder for the AC coefficient stream, written for this
+// library -- bit reader, prefix codes, ANS with alias tables, hybrid-uint
+// tokens, LZ77, context maps, coefficient orders and the per-varblock token
+// walk that fills the ACImage-layout coefficient buffers the HIP kernels read.
+// Host C++ only; one thread per AC group (the JxlParallelRunner's workers).
+//
+// Behavioural specification: ISO/IEC 18181-1 annexes C (entropy coding) and
+// I.3.5-I.3.7, as implemented by the reference at the lines cited per function.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "../../include/jxl_hip_entropy.h"
+
+namespace {
+
+constexpr int kOk = JXLHIP_OK;
+constexpr int kBad = JXLHIP_ERR_BAD_STREAM;
+
+// ---------------------------------------------------------------- bit reader
+// LSB-first (lib/jxl/dec_bit_reader.h).  Reads past the end return zeros and
+// are detected by Healthy().
+class BitReader {
+ public:
+  BitReader(const uint8_t* data, size_t size, size_t bit_pos)
+      : data_(data), size_(size), pos_(std::min(size, bit_pos / 8)) {
+    if (bit_pos / 8 > size) overrun_ = true;
+    Refill();
+    Consume(bit_pos % 8);
+  }
+  inline void Refill() {
+    if (size_ - pos_ >= 8 && pos_ <= size_) {
+      uint64_t v;
+      memcpy(&v, data_ + pos_, 8);
+      buf_ |= v << nbits_;
+      pos_ += (63 - nbits_) >> 3;
+      nbits_ |= 56;
+    } else {
+      while (nbits_ <= 56) {
+        const uint64_t b = pos_ < size_ ? data_[pos_] : 0;
+        pos_++;
+        buf_ |= b << nbits_;
+        nbits_ += 8;
+      }
+    }
+  }
+  inline uint64_t Peek(uint32_t n) const { return buf_ & ((1ull << n) - 1ull); }
+  inline void Consume(uint32_t n) {
+    buf_ >>= n;
+    nbits_ -= n;
+  }
+  // n <= 32
+  inline uint32_t Read(uint32_t n) {
+    Refill();
+    const uint32_t v = (uint32_t)Peek(n);
+    Consume(n);
+    return v;
+  }
+  size_t BitsConsumed() const { return pos_ * 8 - nbits_; }
+  // nothing beyond the last byte has been CONSUMED (peeking is fine)
+  bool Healthy() const { return !overrun_ && BitsConsumed() <= size_ * 8; }
+
+ private:
+  const uint8_t* data_;
+  size_t size_;
+  size_t pos_;  // bytes loaded into buf_ (may run past size_: zeros)
+  uint64_t buf_ = 0;
+  uint32_t nbits_ = 0;
+  bool overrun_ = false;
+};
+
+inline uint32_t FloorLog2(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+inline uint32_t CeilLog2(uint32_t v) { return v <= 1 ? 0 : FloorLog2(v - 1) + 1; }
+
+// U32 with four (value | bits+offset) choices selected by two bits (fields.h U32Enc)
+struct U32Dist {
+  uint32_t bits[4];
+  uint32_t offset[4];
+};
+uint32_t ReadU32(BitReader* br, const U32Dist& d) {
+  const uint32_t sel = br->Read(2);
+  return d.offset[sel] + (d.bits[sel] ? br->Read(d.bits[sel]) : 0);
+}
+
+// ------------------------------------------------------------- prefix codes
+// Canonical prefix codes read LSB-first (RFC 7932 section 3.2-3.5 as used by
+// JPEG XL; reference: dec_huffman.cc, huffman_table.cc).  Two-level table:
+// 8 root bits, then one sub-table per root slot that has longer codes.
+constexpr int kRootBits = 8;
+constexpr int kMaxCodeLength = 15;
+
+struct PrefixEntry {
+  uint8_t bits;    // root: code length, or kRootBits + sub-table width; sub: length - kRootBits
+  uint16_t value;  // symbol, or offset of the sub-table relative to this root slot
+};
+
+struct PrefixCode {
+  std::vector<PrefixEntry> table;
+
+  inline uint32_t ReadSymbol(BitReader* br) const {
+    const PrefixEntry* e = &table[br->Peek(kRootBits)];
+    uint32_t n = e->bits;
+    if (n > kRootBits) {
+      br->Consume(kRootBits);
+      e += e->value + br->Peek(n - kRootBits);
+    }
+    br->Consume(e->bits);
+    return e->value;
+  }
+
+  void SetSingle(uint16_t symbol) {
+    table.assign(1u << kRootBits, PrefixEntry{0, symbol});
+  }
+
+  // lengths[i] in 0..15.  root_bits <= 8.  Returns false for an over- or
+  // under-subscribed code (except the one-symbol code, which reads 0 bits).
+  bool Build(const uint8_t* lengths, size_t n, int root_bits) {
+    uint32_t count[kMaxCodeLength + 1] = {0};
+    for (size_t i = 0; i < n; i++) count[lengths[i]]++;
+    uint32_t used = 0;
+    for (int l = 1; l <= kMaxCodeLength; l++) used += count[l];
+    const size_t root_size = (size_t)1 << root_bits;
+    if (used == 0) return false;
+    if (used == 1) {
+      for (size_t i = 0; i < n; i++)
+        if (lengths[i]) {
+          table.assign(root_size, PrefixEntry{0, (uint16_t)i});
+          return true;
+        }
+    }
+    // Kraft sum must be exactly 1
+    uint32_t space = 1u << kMaxCodeLength;
+    for (int l = 1; l <= kMaxCodeLength; l++) {
+      const uint32_t need = count[l] << (kMaxCodeLength - l);
+      if (need > space) return false;
+      space -= need;
+    }
+    if (space != 0) return false;
+    // canonical codes: increasing length, then symbol order
+    uint32_t next_code[kMaxCodeLength + 2];
+    {
+      uint32_t code = 0;
+      for (int l = 1; l <= kMaxCodeLength; l++) {
+        next_code[l] = code;
+        code = (code + count[l]) << 1;
+      }
+    }
+    struct Sym {
+      uint32_t rev;  // the code as it appears in the LSB-first stream
+      uint8_t len;
+      uint16_t symbol;
+    };
+    std::vector<Sym> syms;
+    syms.reserve(used);
+    for (size_t i = 0; i < n; i++) {
+      const int l = lengths[i];
+      if (!l) continue;
+      uint32_t c = next_code[l]++, r = 0;
+      for (int b = 0; b < l; b++) r |= ((c >> b) & 1u) << (l - 1 - b);
+      syms.push_back(Sym{r, (uint8_t)l, (uint16_t)i});
+    }
+    // widest code hanging off each root slot
+    std::vector<uint8_t> sub_bits(root_size, 0);
+    for (const Sym& s : syms)
+      if (s.len > root_bits) {
+        uint8_t& w = sub_bits[s.rev & (root_size - 1)];
+        w = std::max<uint8_t>(w, (uint8_t)(s.len - root_bits));
+      }
+    size_t total = root_size;
+    std::vector<uint32_t> sub_at(root_size, 0);
+    for (size_t r = 0; r < root_size; r++)
+      if (sub_bits[r]) {
+        sub_at[r] = (uint32_t)total;
+        total += (size_t)1 << sub_bits[r];
+      }
+    table.assign(total, PrefixEntry{0, 0});
+    for (size_t r = 0; r < root_size; r++)
+      if (sub_bits[r]) {
+        table[r].bits = (uint8_t)(root_bits + sub_bits[r]);
+        table[r].value = (uint16_t)(sub_at[r] - r);
+      }
+    for (const Sym& s : syms) {
+      if (s.len <= root_bits) {
+        for (size_t k = s.rev; k < root_size; k += (size_t)1 << s.len)
+          table[k] = PrefixEntry{s.len, s.symbol};
+      } else {
+        const size_t r = s.rev & (root_size - 1);
+        const uint32_t sl = s.len - root_bits, w = sub_bits[r];
+        for (size_t k = s.rev >> root_bits; k < ((size_t)1 << w); k += (size_t)1 << sl)
+          table[sub_at[r] + k] = PrefixEntry{(uint8_t)sl, s.symbol};
+      }
+    }
+    return true;
+  }
+};
+
+// fixed code of the code-length code lengths (dec_huffman.cc:191-194): symbol, length, LSB-first pattern
+struct FixedCode {
+  uint8_t symbol, len, pattern;
+};
+constexpr FixedCode kCodeLengthLengthCode[6] = {{0, 2, 0}, {4, 2, 1}, {3, 2, 2}, {2, 3, 3}, {1, 4, 7}, {5, 4, 15}};
+constexpr uint8_t kCodeLengthOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+
+// HuffmanDecodingData::ReadFromBitStream (dec_huffman.cc:170-243)
+bool ReadPrefixCode(BitReader* br, size_t alphabet_size, PrefixCode* out) {
+  if (alphabet_size > (1u << kMaxCodeLength)) return false;
+  const uint32_t kind = br->Read(2);
+  if (kind == 1) {  // simple code: 1..4 symbols listed explicitly
+    const uint32_t max_bits = alphabet_size > 1 ? FloorLog2((uint32_t)alphabet_size - 1) + 1 : 0;
+    uint32_t n = br->Read(2) + 1;
+    uint16_t s[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < n; i++) {
+      s[i] = (uint16_t)br->Read(max_bits);
+      if (s[i] >= alphabet_size) return false;
+    }
+    for (uint32_t i = 0; i + 1 < n; i++)
+      for (uint32_t j = i + 1; j < n; j++)
+        if (s[i] == s[j]) return false;
+    if (n == 4) n += br->Read(1);  // two shapes for four symbols
+    std::vector<uint8_t> len(alphabet_size, 0);
+    switch (n) {
+      case 1: out->SetSingle(s[0]); return true;
+      case 2: len[s[0]] = 1; len[s[1]] = 1; break;
+      case 3: len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 2; break;
+      case 4: len[s[0]] = len[s[1]] = len[s[2]] = len[s[3]] = 2; break;
+      default: len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 3; len[s[3]] = 3; break;
+    }
+    return out->Build(len.data(), alphabet_size, kRootBits);
+  }
+  // code lengths coded with a code-length code whose own lengths use a fixed code
+  uint8_t cl_len[18] = {0};
+  int space = 32, num_codes = 0;
+  for (size_t i = kind; i < 18 && space > 0; i++) {
+    br->Refill();
+    const uint32_t idx = (uint32_t)br->Peek(4);
+    uint8_t v = 0;
+    for (const FixedCode& c : kCodeLengthLengthCode)
+      if ((idx & ((1u << c.len) - 1)) == c.pattern) {
+        br->Consume(c.len);
+        v = c.symbol;
+        break;
+      }
+    cl_len[kCodeLengthOrder[i]] = v;
+    if (v) {
+      space -= 32 >> v;
+      num_codes++;
+    }
+  }
+  if (!(num_codes == 1 || space == 0)) return false;
+  PrefixCode cl;
+  if (!cl.Build(cl_len, 18, 5)) return false;
+  // ReadHuffmanCodeLengths (dec_huffman.cc:29-96): run-length coded lengths
+  std::vector<uint8_t> len(alphabet_size, 0);
+  size_t symbol = 0;
+  uint8_t prev_len = 8, repeat_len = 0;
+  int repeat = 0;
+  int left = 32768;
+  while (symbol < alphabet_size && left > 0) {
+    br->Refill();
+    const PrefixEntry e = cl.table[br->Peek(5)];
+    br->Consume(e.bits);
+    const uint8_t code = (uint8_t)e.value;
+    if (code < 16) {
+      repeat = 0;
+      len[symbol++] = code;
+      if (code) {
+        prev_len = code;
+        left -= 32768 >> code;
+      }
+    } else {
+      const int extra = code - 14;  // 16: repeat previous length (2 bits), 17: repeat zero (3 bits)
+      const uint8_t new_len = code == 16 ? prev_len : 0;
+      if (repeat_len != new_len) {
+        repeat = 0;
+        repeat_len = new_len;
+      }
+      const int old = repeat;
+      if (repeat > 0) repeat = (repeat - 2) << extra;
+      repeat += (int)br->Read(extra) + 3;
+      const int delta = repeat - old;
+      if (symbol + delta > alphabet_size) return false;
+      memset(&len[symbol], repeat_len, delta);
+      symbol += delta;
+      if (repeat_len) left -= delta << (15 - repeat_len);
+    }
+  }
+  if (left != 0) return false;
+  return out->Build(len.data(), alphabet_size, kRootBits);
+}
+
+// ---------------------------------------------------------------------- ANS
+constexpr uint32_t kAnsLogTab = 12, kAnsTab = 1u << kAnsLogTab;
+constexpr uint32_t kAnsSignature = 0x13;
+
+// alias table entry: slot i of the 2^log_alpha buckets covers `entry_size`
+// states; the first `cutoff` belong to symbol i, the rest to `right_value`
+struct AliasEntry {
+  uint8_t cutoff;
+  uint8_t right_value;
+  uint16_t freq0;
+  uint16_t offsets1;
+  uint16_t freq1;
+};
+
+// InitAliasTable (ans_common.cc:41-146): the order in which over-full buckets
+// donate to under-full ones is part of the format (the encoder mirrors it)
+bool BuildAliasTable(std::vector<int32_t> dist, uint32_t log_alpha, AliasEntry* a) {
+  const uint32_t table_size = 1u << log_alpha;
+  while (!dist.empty() && dist.back() == 0) dist.pop_back();
+  if (dist.empty()) dist.push_back((int32_t)kAnsTab);
+  if (dist.size() > table_size) return false;
+  const uint32_t entry_size = kAnsTab >> log_alpha;
+  int single = -1;
+  uint32_t sum = 0;
+  for (size_t s = 0; s < dist.size(); s++) {
+    sum += (uint32_t)dist[s];
+    if (dist[s] == (int32_t)kAnsTab) single = (int)s;
+  }
+  if (sum != kAnsTab) return false;
+  if (single >= 0) {  // state-preserving table for one-symbol distributions
+    for (uint32_t i = 0; i < table_size; i++) {
+      a[i].right_value = (uint8_t)single;
+      a[i].cutoff = 0;
+      a[i].offsets1 = (uint16_t)(entry_size * i);
+      a[i].freq0 = 0;
+      a[i].freq1 = (uint16_t)kAnsTab;
+    }
+    return true;
+  }
+  std::vector<uint32_t> under, over, cutoffs(table_size, 0);
+  for (size_t i = 0; i < dist.size(); i++) {
+    cutoffs[i] = (uint32_t)dist[i];
+    if (cutoffs[i] > entry_size) over.push_back((uint32_t)i);
+    else if (cutoffs[i] < entry_size) under.push_back((uint32_t)i);
+  }
+  for (uint32_t i = (uint32_t)dist.size(); i < table_size; i++) under.push_back(i);
+  while (!over.empty()) {
+    const uint32_t o = over.back();
+    over.pop_back();
+    if (under.empty()) return false;
+    const uint32_t u = under.back();
+    under.pop_back();
+    const uint32_t by = entry_size - cutoffs[u];
+    cutoffs[o] -= by;
+    a[u].right_value = (uint8_t)o;
+    a[u].offsets1 = (uint16_t)cutoffs[o];
+    if (cutoffs[o] < entry_size) under.push_back(o);
+    else if (cutoffs[o] > entry_size) over.push_back(o);
+  }
+  for (uint32_t i = 0; i < table_size; i++) {
+    if (cutoffs[i] == entry_size) {
+      a[i].right_value = (uint8_t)i;
+      a[i].offsets1 = 0;
+      a[i].cutoff = 0;
+    } else {
+      a[i].offsets1 = (uint16_t)(a[i].offsets1 - cutoffs[i]);
+      a[i].cutoff = (uint8_t)cutoffs[i];
+    }
+    const uint32_t f0 = i < dist.size() ? (uint32_t)dist[i] : 0;
+    const uint32_t r = a[i].right_value;
+    const uint32_t f1 = r < dist.size() ? (uint32_t)dist[r] : 0;
+    a[i].freq0 = (uint16_t)f0;
+    a[i].freq1 = (uint16_t)f1;
+  }
+  return true;
+}
+
+uint32_t ReadVarLenU8(BitReader* br) {  // dec_ans.cc:33-44
+  if (!br->Read(1)) return 0;
+  const uint32_t n = br->Read(3);
+  return n == 0 ? 1 : br->Read(n) + (1u << n);
+}
+uint32_t ReadVarLenU16(BitReader* br) {  // dec_ans.cc:47-58
+  if (!br->Read(1)) return 0;
+  const uint32_t n = br->Read(4);
+  return n == 0 ? 1 : br->Read(n) + (1u << n);
+}
+
+// fixed code of the log-counts (dec_ans.cc:104-121): symbol, length, LSB-first pattern
+constexpr FixedCode kLogCountCode[14] = {{10, 3, 0},  {7, 3, 2},  {6, 3, 4},  {8, 3, 5},   {9, 3, 6},
+                                         {3, 4, 3},   {5, 4, 7},  {4, 4, 9},  {1, 4, 11},  {2, 4, 15},
+                                         {0, 5, 17},  {11, 6, 33}, {12, 7, 1}, {13, 7, 65}};
+
+// ReadHistogram (dec_ans.cc:60-201): a 12-bit ANS distribution
+bool ReadDistribution(BitReader* br, std::vector<int32_t>* counts) {
+  const int range = 1 << kAnsLogTab;
+  if (br->Read(1)) {  // one or two symbols
+    const uint32_t n = br->Read(1) + 1;
+    uint32_t s[2] = {0, 0};
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      s[i] = ReadVarLenU8(br);
+      mx = std::max(mx, s[i]);
+    }
+    counts->assign(mx + 1, 0);
+    if (n == 1) {
+      (*counts)[s[0]] = range;
+    } else {
+      if (s[0] == s[1]) return false;
+      (*counts)[s[0]] = (int32_t)br->Read(kAnsLogTab);
+      (*counts)[s[1]] = range - (*counts)[s[0]];
+    }
+    return true;
+  }
+  if (br->Read(1)) {  // flat
+    const int n = (int)ReadVarLenU8(br) + 1;
+    if (n > range) return false;
+    counts->assign(n, range / n);
+    for (int i = 0; i < range % n; i++) (*counts)[i]++;
+    return true;
+  }
+  uint32_t shift;
+  {
+    const int upper = (int)FloorLog2(kAnsLogTab + 1);
+    int log = 0;
+    for (; log < upper; log++)
+      if (br->Read(1) == 0) break;
+    shift = (br->Read(log) | (1u << log)) - 1;
+    if (shift > kAnsLogTab + 1) return false;
+  }
+  const size_t length = ReadVarLenU8(br) + 3;
+  counts->assign(length, 0);
+  std::vector<int> logcounts(length, 0), same(length, 0);
+  int omit_log = -1, omit_pos = -1;
+  for (size_t i = 0; i < length; i++) {
+    br->Refill();
+    const uint32_t idx = (uint32_t)br->Peek(7);
+    int sym = 0;
+    for (const FixedCode& c : kLogCountCode)
+      if ((idx & ((1u << c.len) - 1)) == c.pattern) {
+        br->Consume(c.len);
+        sym = c.symbol;
+        break;
+      }
+    logcounts[i] = sym - 1;
+    if (logcounts[i] == (int)kAnsLogTab) {  // run-length symbol
+      const int rle = (int)ReadVarLenU8(br);
+      same[i] = rle + 5;
+      i += rle + 3;
+      continue;
+    }
+    if (logcounts[i] > omit_log) {
+      omit_log = logcounts[i];
+      omit_pos = (int)i;
+    }
+  }
+  if (omit_pos < 0) return false;
+  if ((size_t)omit_pos + 1 < length && logcounts[omit_pos + 1] == (int)kAnsLogTab) return false;
+  int prev = 0, numsame = 0, total = 0;
+  for (size_t i = 0; i < length; i++) {
+    if (same[i]) {
+      numsame = same[i] - 1;
+      prev = i > 0 ? (*counts)[i - 1] : 0;
+    }
+    if (numsame > 0) {
+      (*counts)[i] = prev;
+      numsame--;
+    } else {
+      const int code = logcounts[i];
+      if ((int)i == omit_pos || code < 0) continue;
+      if (shift == 0 || code == 0) {
+        (*counts)[i] = 1 << code;
+      } else {
+        // GetPopulationCountPrecision (ans_common.h:27-34)
+        int bitcount = std::min<int>(code, (int)shift - (int)((kAnsLogTab - code) >> 1));
+        if (bitcount < 0) bitcount = 0;
+        (*counts)[i] = (1 << code) + (int)(br->Read(bitcount) << (code - bitcount));
+      }
+    }
+    total += (*counts)[i];
+  }
+  (*counts)[omit_pos] = range - total;
+  return (*counts)[omit_pos] > 0;
+}
+
+// ---------------------------------------------------------- hybrid integers
+struct HybridUint {  // dec_ans.h:66-112
+  uint32_t split_exponent = 4, split_token = 16, msb_in_token = 2, lsb_in_token = 0;
+};
+
+bool ReadHybridUintConfig(BitReader* br, uint32_t log_alpha, HybridUint* c) {  // dec_ans.cc:291-315
+  const uint32_t split_exponent = br->Read(CeilLog2(log_alpha + 1));
+  uint32_t msb = 0, lsb = 0;
+  if (split_exponent != log_alpha) {
+    msb = br->Read(CeilLog2(split_exponent + 1));
+    if (msb > split_exponent) return false;
+    lsb = br->Read(CeilLog2(split_exponent - msb + 1));
+  }
+  if (lsb + msb > split_exponent) return false;
+  c->split_exponent = split_exponent;
+  c->split_token = 1u << split_exponent;
+  c->msb_in_token = msb;
+  c->lsb_in_token = lsb;
+  return true;
+}
+
+inline uint32_t FinishHybridUint(const HybridUint& c, uint32_t token, BitReader* br) {  // dec_ans.h:221-252
+  if (token < c.split_token) return token;
+  uint32_t nbits = c.split_exponent - (c.msb_in_token + c.lsb_in_token) +
+                   ((token - c.split_token) >> (c.msb_in_token + c.lsb_in_token));
+  nbits &= 31u;
+  const uint32_t low = token & ((1u << c.lsb_in_token) - 1);
+  token >>= c.lsb_in_token;
+  const uint32_t bits = (uint32_t)br->Peek(nbits);
+  br->Consume(nbits);
+  return (((((1u << c.msb_in_token) | (token & ((1u << c.msb_in_token) - 1))) << nbits) | bits)
+          << c.lsb_in_token) |
+         low;
+}
+
+// -------------------------------------------------------------- entropy code
+struct Lz77Params {
+  bool enabled = false;
+  uint32_t min_symbol = 224, min_length = 3;
+  HybridUint length_config;
+  uint32_t distance_context = 0;
+};
+
+struct EntropyCode {  // ANSCode
+  bool use_prefix = false;
+  uint32_t log_alpha = 0;
+  std::vector<uint8_t> context_map;
+  std::vector<HybridUint> configs;
+  std::vector<AliasEntry> alias;  // num_histograms << log_alpha
+  std::vector<PrefixCode> prefix;
+  Lz77Params lz77;
+  uint32_t max_num_bits = 0;
+
+  void UpdateMaxNumBits(size_t ctx, uint32_t symbol) {  // dec_ans.cc:339-362
+    const HybridUint* c = &configs[ctx];
+    if (lz77.enabled && lz77.distance_context != ctx && symbol >= lz77.min_symbol) {
+      symbol -= lz77.min_symbol;
+      c = &lz77.length_config;
+    }
+    if (symbol < c->split_token) {
+      max_num_bits = std::max(max_num_bits, c->split_exponent);
+      return;
+    }
+    const uint32_t extra = c->split_exponent - (c->msb_in_token + c->lsb_in_token) +
+                           ((symbol - c->split_token) >> (c->msb_in_token + c->lsb_in_token));
+    max_num_bits = std::max(max_num_bits, c->msb_in_token + c->lsb_in_token + extra + 1);
+  }
+};
+
+constexpr uint32_t kLz77Window = 1u << 20;
+
+class SymbolReader {  // ANSSymbolReader
+ public:
+  SymbolReader(const EntropyCode* code, BitReader* br) : code_(code) {
+    if (!code->use_prefix) {
+      state_ = br->Read(32);
+      log_entry_ = kAnsLogTab - code->log_alpha;
+      entry_mask_ = (1u << log_entry_) - 1;
+    }
+    if (code->lz77.enabled) window_.reset(new (std::nothrow) uint32_t[kLz77Window]);
+  }
+  bool Ok() const { return !code_->lz77.enabled || window_; }
+  bool FinalStateOk() const { return state_ == (kAnsSignature << 16); }
+
+  inline uint32_t ReadToken(uint32_t histo, BitReader* br) {
+    if (code_->use_prefix) return code_->prefix[histo].ReadSymbol(br);
+    const uint32_t res = state_ & (kAnsTab - 1);
+    const AliasEntry* t = &code_->alias[(size_t)histo << code_->log_alpha];
+    const uint32_t i = res >> log_entry_, pos = res & entry_mask_;
+    const AliasEntry& e = t[i];
+    const bool right = pos >= e.cutoff;
+    const uint32_t value = right ? e.right_value : i;
+    const uint32_t offset = (right ? e.offsets1 : 0u) + pos;
+    const uint32_t freq = right ? e.freq1 : e.freq0;
+    state_ = freq * (state_ >> kAnsLogTab) + offset;
+    if (state_ < (1u << 16)) {
+      state_ = (state_ << 16) | (uint32_t)br->Peek(16);
+      br->Consume(16);
+    }
+    return value;
+  }
+
+  // ReadHybridUintClusteredInlined (dec_ans.h:289-356); ctx is a CLUSTERED context
+  inline uint32_t ReadHybridUint(uint32_t ctx, BitReader* br) {
+    if (window_) {
+      if (num_to_copy_ > 0) return CopyOne();
+      br->Refill();
+      const uint32_t token = ReadToken(ctx, br);
+      const Lz77Params& z = code_->lz77;
+      if (token >= z.min_symbol) {
+        num_to_copy_ = FinishHybridUint(z.length_config, token - z.min_symbol, br) + z.min_length;
+        br->Refill();
+        const uint32_t d_token = ReadToken(z.distance_context, br);
+        uint32_t distance = FinishHybridUint(code_->configs[z.distance_context], d_token, br);
+        distance += 1;  // no special distances for 1-D streams (distance_multiplier == 0)
+        if (distance > num_decoded_) distance = num_decoded_;
+        if (distance > kLz77Window) distance = kLz77Window;
+        copy_pos_ = num_decoded_ - distance;
+        if (distance == 0) memset(window_.get(), 0, std::min<size_t>(num_to_copy_, kLz77Window) * 4);
+        if (num_to_copy_ < z.min_length) {  // length wrapped around
+          num_to_copy_ = 0;
+          corrupt_ = true;
+          return 0;
+        }
+        return CopyOne();
+      }
+      const uint32_t v = FinishHybridUint(code_->configs[ctx], token, br);
+      window_[(num_decoded_++) & (kLz77Window - 1)] = v;
+      return v;
+    }
+    br->Refill();
+    const uint32_t token = ReadToken(ctx, br);
+    return FinishHybridUint(code_->configs[ctx], token, br);
+  }
+  bool Corrupt() const { return corrupt_; }
+
+ private:
+  inline uint32_t CopyOne() {
+    const uint32_t v = window_[(copy_pos_++) & (kLz77Window - 1)];
+    num_to_copy_--;
+    window_[(num_decoded_++) & (kLz77Window - 1)] = v;
+    return v;
+  }
+  const EntropyCode* code_;
+  uint32_t state_ = kAnsSignature << 16;
+  uint32_t log_entry_ = 0, entry_mask_ = 0;
+  std::unique_ptr<uint32_t[]> window_;
+  uint32_t num_decoded_ = 0, num_to_copy_ = 0, copy_pos_ = 0;
+  bool corrupt_ = false;
+};
+
+int DecodeEntropyCode(BitReader* br, size_t num_contexts, EntropyCode* code, bool disallow_lz77, int depth);
+
+// DecodeContextMap (dec_context_map.cc:47-95)
+int DecodeContextMap(BitReader* br, std::vector<uint8_t>* map, size_t* num_histograms, int depth) {
+  if (br->Read(1)) {  // simple: fixed width entries
+    const uint32_t bits = br->Read(2);
+    for (uint8_t& e : *map) e = bits ? (uint8_t)br->Read(bits) : 0;
+  } else {
+    const bool use_mtf = br->Read(1) != 0;
+    if (depth > 1) return kBad;  // a context map's code has exactly one context: no further nesting
+    EntropyCode code;
+    int rc = DecodeEntropyCode(br, 1, &code, /*disallow_lz77=*/map->size() <= 2, depth + 1);
+    if (rc) return rc;
+    SymbolReader reader(&code, br);
+    if (!reader.Ok()) return JXLHIP_ERR_OUT_OF_MEMORY;
+    uint32_t maxsym = 0;
+    for (uint8_t& e : *map) {
+      const uint32_t sym = reader.ReadHybridUint(code.context_map[0], br);
+      maxsym = std::max(maxsym, sym);
+      e = (uint8_t)sym;
+    }
+    if (maxsym >= 256 || reader.Corrupt() || !reader.FinalStateOk()) return kBad;
+    if (use_mtf) {  // inverse move-to-front (inverse_mtf-inl.h)
+      uint8_t mtf[256];
+      for (int i = 0; i < 256; i++) mtf[i] = (uint8_t)i;
+      for (uint8_t& e : *map) {
+        const uint8_t idx = e;
+        const uint8_t v = mtf[idx];
+        e = v;
+        if (idx) {
+          memmove(mtf + 1, mtf, idx);
+          mtf[0] = v;
+        }
+      }
+    }
+  }
+  *num_histograms = (size_t)*std::max_element(map->begin(), map->end()) + 1;
+  std::vector<bool> seen(*num_histograms, false);  // every histogram must be referenced
+  size_t found = 0;
+  for (uint8_t e : *map)
+    if (!seen[e]) {
+      seen[e] = true;
+      found++;
+    }
+  return found == *num_histograms ? kOk : kBad;
+}
+
+// DecodeHistograms (dec_ans.cc:364-395) + DecodeANSCodes (dec_ans.cc:205-290)
+int DecodeEntropyCode(BitReader* br, size_t num_contexts, EntropyCode* code, bool disallow_lz77, int depth) {
+  Lz77Params& z = code->lz77;
+  z.enabled = br->Read(1) != 0;  // LZ77Params::VisitFields (dec_ans.cc:328-337)
+  if (z.enabled) {
+    static const U32Dist kMinSymbol = {{0, 0, 0, 15}, {224, 512, 4096, 8}};
+    static const U32Dist kMinLength = {{0, 0, 2, 8}, {3, 4, 5, 9}};
+    z.min_symbol = ReadU32(br, kMinSymbol);
+    z.min_length = ReadU32(br, kMinLength);
+    num_contexts++;
+    if (!ReadHybridUintConfig(br, 8, &z.length_config)) return kBad;
+    if (disallow_lz77) return kBad;
+  }
+  size_t num_histograms = 1;
+  code->context_map.assign(num_contexts, 0);
+  if (num_contexts > 1) {
+    int rc = DecodeContextMap(br, &code->context_map, &num_histograms, depth);
+    if (rc) return rc;
+  }
+  z.distance_context = code->context_map.back();
+  code->use_prefix = br->Read(1) != 0;
+  code->log_alpha = code->use_prefix ? (uint32_t)kMaxCodeLength : br->Read(2) + 5;
+  code->configs.resize(num_histograms);
+  for (HybridUint& c : code->configs)
+    if (!ReadHybridUintConfig(br, code->log_alpha, &c)) return kBad;
+  const size_t max_alphabet = (size_t)1 << code->log_alpha;
+  if (code->use_prefix) {
+    code->prefix.resize(num_histograms);
+    std::vector<uint32_t> sizes(num_histograms);
+    for (uint32_t& s : sizes) {
+      s = ReadVarLenU16(br) + 1;
+      if (s > max_alphabet) return kBad;
+    }
+    for (size_t h = 0; h < num_histograms; h++) {
+      if (sizes[h] > 1) {
+        if (!ReadPrefixCode(br, sizes[h], &code->prefix[h])) return kBad;
+      } else {
+        code->prefix[h].SetSingle(0);
+      }
+      for (size_t k = 0; k < (1u << kRootBits) && k < code->prefix[h].table.size(); k++) {
+        const PrefixEntry& e = code->prefix[h].table[k];
+        if (e.bits <= kRootBits) code->UpdateMaxNumBits(h, e.value);
+      }
+      if (!br->Healthy()) return kBad;
+    }
+  } else {
+    code->alias.assign(num_histograms << code->log_alpha, AliasEntry{});
+    for (size_t h = 0; h < num_histograms; h++) {
+      std::vector<int32_t> counts;
+      if (!ReadDistribution(br, &counts)) return kBad;
+      if (counts.size() > max_alphabet) return kBad;
+      while (!counts.empty() && counts.back() == 0) counts.pop_back();
+      for (size_t s = 0; s < counts.size(); s++)
+        if (counts[s]) code->UpdateMaxNumBits(h, (uint32_t)s);
+      if (!BuildAliasTable(counts, code->log_alpha, &code->alias[h << code->log_alpha])) return kBad;
+      if (!br->Healthy()) return kBad;
+    }
+  }
+  return br->Healthy() ? kOk : kBad;
+}
+
+// ------------------------------------------------------- strategy geometry
+constexpr uint8_t kCovX[27] = {1, 1, 1, 1, 2, 4, 1, 2, 1, 4, 2, 4, 1, 1, 1, 1, 1, 1, 8, 4, 8, 16, 8, 16, 32, 16, 32};
+constexpr uint8_t kCovY[27] = {1, 1, 1, 1, 2, 4, 2, 1, 4, 1, 4, 2, 1, 1, 1, 1, 1, 1, 8, 8, 4, 16, 16, 8, 32, 32, 16};
+// kStrategyOrder (coeff_order.h:44-47): strategies that share a natural order share a bucket
+constexpr uint8_t kStrategyOrder[27] = {0, 1, 1, 1, 2, 3, 4, 4, 5,  5,  6,  6,  1,  1,
+                                        1, 1, 1, 1, 7, 8, 8, 9, 10, 10, 11, 12, 12};
+constexpr int kNumOrders = 13;
+constexpr uint32_t kPermutationContexts = 8;
+
+struct OrderLayout {
+  uint32_t blocks[kNumOrders];       // covered blocks of the bucket's transforms
+  size_t offset[kNumOrders][3 + 1];  // in coefficients (kCoeffOrderOffset * 64)
+  size_t total;
+  OrderLayout() {
+    for (int o = 0; o < kNumOrders; o++) blocks[o] = 0;
+    for (int s = 0; s < 27; s++) blocks[kStrategyOrder[s]] = (uint32_t)kCovX[s] * kCovY[s];
+    size_t pos = 0;
+    for (int o = 0; o < kNumOrders; o++)
+      for (int c = 0; c < 3; c++) {
+        offset[o][c] = pos;
+        pos += (size_t)blocks[o] * 64;
+        offset[o][c + 1] = pos;
+      }
+    total = pos;
+  }
+};
+const OrderLayout& Layout() {
+  static const OrderLayout l;
+  return l;
+}
+
+// AcStrategy::ComputeNaturalCoeffOrder (ac_strategy.cc:28-79): zig-zag over the
+// cx x cx square, keeping the lines of the cy x cx coefficient rectangle, with
+// the cx*cy LLF coefficients first
+void NaturalOrder(int strategy, uint32_t* out) {
+  size_t cx = kCovX[strategy], cy = kCovY[strategy];
+  if (cy > cx) std::swap(cx, cy);  // CoefficientLayout: rows = the smaller side
+  const size_t ratio = cx / cy, mask = ratio - 1, shift = CeilLog2((uint32_t)ratio);
+  const size_t side = cx * 8;
+  size_t cur = cx * cy;
+  auto emit = [&](size_t x, size_t y) {
+    if (y & mask) return;
+    y >>= shift;
+    const size_t val = (x < cx && y < cy) ? y * cx + x : cur++;
+    out[val] = (uint32_t)(y * side + x);
+  };
+  for (size_t i = 0; i < side; i++)
+    for (size_t j = 0; j <= i; j++) {
+      size_t x = j, y = i - j;
+      if (i & 1) std::swap(x, y);
+      emit(x, y);
+    }
+  for (size_t ip = side - 1; ip > 0; ip--) {
+    const size_t i = ip - 1;
+    for (size_t j = 0; j <= i; j++) {
+      size_t x = side - 1 - (i - j), y = side - 1 - j;
+      if (i & 1) std::swap(x, y);
+      emit(x, y);
+    }
+  }
+}
+
+// DecodeLehmerCode (lehmer_code.h:60-100): i-th unused element via a Fenwick tree
+bool LehmerToPermutation(const uint32_t* code, size_t n, uint32_t* perm) {
+  const uint32_t log2n = CeilLog2((uint32_t)n);
+  const size_t padded = (size_t)1 << log2n;
+  std::vector<uint32_t> tree(padded);
+  for (size_t i = 0; i < padded; i++) tree[i] = (uint32_t)((i + 1) & (~(i + 1) + 1));
+  for (size_t i = 0; i < n; i++) {
+    if (code[i] + i >= n) return false;
+    uint32_t rank = code[i] + 1;
+    size_t bit = padded, next = 0;
+    for (uint32_t b = 0; b <= log2n; b++) {
+      const size_t cand = next + bit;
+      bit >>= 1;
+      if (tree[cand - 1] < rank) {
+        next = cand;
+        rank -= tree[cand - 1];
+      }
+    }
+    perm[i] = (uint32_t)next;
+    next += 1;
+    while (next <= padded) {
+      tree[next - 1] -= 1;
+      next += next & (~next + 1);
+    }
+  }
+  return true;
+}
+
+uint32_t CoeffOrderContext(uint32_t v) {  // coeff_order.cc:30-34: token of HybridUint(0,0,0), capped
+  if (v == 0) return 0;
+  return std::min(FloorLog2(v) + 1, kPermutationContexts - 1);
+}
+
+// ReadPermutation (coeff_order.cc:37-64)
+int ReadPermutation(size_t skip, size_t size, uint32_t* order, BitReader* br, SymbolReader* reader,
+                    const EntropyCode& code) {
+  std::vector<uint32_t> lehmer(size, 0);
+  const uint32_t end = reader->ReadHybridUint(code.context_map[CoeffOrderContext((uint32_t)size)], br) +
+                       (uint32_t)skip;
+  if (end > size) return kBad;
+  uint32_t last = 0;
+  for (size_t i = skip; i < end; i++) {
+    lehmer[i] = reader->ReadHybridUint(code.context_map[CoeffOrderContext(last)], br);
+    last = lehmer[i];
+    if (lehmer[i] >= size - i) return kBad;
+  }
+  if (!order) return kOk;
+  return LehmerToPermutation(lehmer.data(), size, order) ? kOk : kBad;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ the pass
+struct jxlhip_ac_pass {
+  uint32_t used_orders = 0;
+  uint32_t num_histograms = 1;
+  std::vector<uint32_t> orders;  // Layout().total
+  EntropyCode code;
+  // BlockCtxMap (ac_context.h:85-150)
+  uint32_t num_dc_ctxs = 1;
+  std::vector<uint32_t> qf_thresholds;
+  std::vector<uint8_t> block_ctx;
+  uint32_t num_block_ctxs = 0;
+  uint32_t NumAcContexts() const { return num_block_ctxs * (37 + 458); }
+};
+
+namespace {
+
+// kDefaultCtxMap (ac_context.h:91-97)
+constexpr uint8_t kDefaultBlockCtx[39] = {0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 9, 10, 11, 12,
+                                          13, 14, 14, 14, 14, 14, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14};
+
+// DecodeCoeffOrders (coeff_order.cc:97-156)
+int DecodeOrders(BitReader* br, uint32_t used_orders, uint32_t used_acs, uint32_t* order) {
+  EntropyCode code;
+  std::unique_ptr<SymbolReader> reader;
+  if (used_orders) {
+    int rc = DecodeEntropyCode(br, kPermutationContexts, &code, false, 0);
+    if (rc) return rc;
+    reader.reset(new (std::nothrow) SymbolReader(&code, br));
+    if (!reader || !reader->Ok()) return JXLHIP_ERR_OUT_OF_MEMORY;
+  }
+  uint32_t acs_mask = 0;
+  for (int s = 0; s < 27; s++)
+    if (used_acs & (1u << s)) acs_mask |= 1u << kStrategyOrder[s];
+  const OrderLayout& L = Layout();
+  std::vector<uint32_t> natural;
+  uint32_t computed = 0;
+  for (int s = 0; s < 27; s++) {
+    const uint32_t ord = kStrategyOrder[s];
+    if (computed & (1u << ord)) continue;
+    computed |= 1u << ord;
+    const bool used = (acs_mask >> ord) & 1;
+    const size_t llf = L.blocks[ord], size = llf * 64;
+    const bool transmitted = (used_orders >> ord) & 1;
+    if (used || transmitted) {
+      natural.resize(size);
+      NaturalOrder(s, natural.data());
+    }
+    if (!transmitted) {
+      if (used)
+        for (int c = 0; c < 3; c++) memcpy(order + L.offset[ord][c], natural.data(), size * sizeof(uint32_t));
+      continue;
+    }
+    for (int c = 0; c < 3; c++) {
+      uint32_t* dst = used ? order + L.offset[ord][c] : nullptr;
+      int rc = ReadPermutation(llf, size, dst, br, reader.get(), code);
+      if (rc) return rc;
+      if (dst)
+        for (size_t k = 0; k < size; k++) dst[k] = natural[dst[k]];
+    }
+  }
+  if (used_orders && (reader->Corrupt() || !reader->FinalStateOk())) return kBad;
+  return br->Healthy() ? kOk : kBad;
+}
+
+// ZeroDensityContext tables (ac_context.h:32-48), as ranges
+inline uint32_t CoeffFreqContext(uint32_t k) {  // k in 1..63
+  return k < 16 ? k - 1 : (k < 32 ? 15 + (k - 16) / 2 : 23 + (k - 32) / 4);
+}
+inline uint32_t CoeffNumNonzeroContext(uint32_t n) {  // n in 1..63
+  if (n < 2) return 0;
+  if (n < 3) return 31;
+  if (n < 5) return 62;
+  if (n < 9) return 93;
+  if (n < 13) return 123;
+  if (n < 21) return 152;
+  if (n < 33) return 180;
+  return 206;
+}
+
+struct ZeroDensityLut {
+  uint16_t v[64][64];  // [nonzeros_left][k]
+  ZeroDensityLut() {
+    for (int n = 0; n < 64; n++)
+      for (int k = 0; k < 64; k++)
+        v[n][k] = (n && k) ? (uint16_t)((CoeffNumNonzeroContext(n) + CoeffFreqContext(k)) * 2) : 0;
+  }
+};
+const ZeroDensityLut& ZdLut() {
+  static const ZeroDensityLut l;
+  return l;
+}
+
+template <typename T>
+int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
+                 const uint8_t* acs_map, const int32_t* raw_quant, const uint8_t* quant_dc, BitReader* br,
+                 uint32_t shift, T* const coeffs[3], size_t* ncoeffs) {
+  const uint32_t bx0 = gx * 32, by0 = gy * 32;
+  if (bx0 >= xsb || by0 >= ysb) return JXLHIP_ERR_INVALID_ARGUMENT;
+  const uint32_t gw = std::min(32u, xsb - bx0), gh = std::min(32u, ysb - by0);
+  // histogram set of this group (dec_group.cc:606-613)
+  uint32_t selector = 0;
+  if (pass->num_histograms > 1) selector = br->Read(CeilLog2(pass->num_histograms));
+  if (selector >= pass->num_histograms) return kBad;
+  const uint32_t ctx_offset = selector * pass->NumAcContexts();
+  SymbolReader reader(&pass->code, br);
+  if (!reader.Ok()) return JXLHIP_ERR_OUT_OF_MEMORY;
+  const uint8_t* cmap = pass->code.context_map.data();
+  const OrderLayout& L = Layout();
+  const ZeroDensityLut& zd = ZdLut();
+  const uint32_t nb = pass->num_block_ctxs;
+  const uint32_t nqf = (uint32_t)pass->qf_thresholds.size();
+  // number of non-zeros per block, for the context of the next ones (GroupDecCache::num_nzeroes)
+  int32_t nz[3][32][32];
+  size_t offset = 0;
+  for (uint32_t by = 0; by < gh; by++) {
+    for (uint32_t bx = 0; bx < gw; bx++) {
+      const size_t cell = (size_t)(by0 + by) * xsb + bx0 + bx;
+      const uint32_t raw = acs_map[cell];
+      if (!(raw & 1)) continue;  // not the first block of its varblock
+      const uint32_t s = raw >> 1;
+      if (s >= 27) return kBad;
+      const uint32_t cx = kCovX[s], cy = kCovY[s];
+      if (bx + cx > gw || by + cy > gh) return kBad;
+      const uint32_t covered = cx * cy, log2c = FloorLog2(covered), size = covered * 64;
+      if (offset + size > 65536) return kBad;
+      const uint32_t ord = kStrategyOrder[s];
+      const uint32_t qf = (uint32_t)raw_quant[cell];
+      uint32_t qf_idx = 0;
+      for (uint32_t t = 0; t < nqf; t++) qf_idx += qf > pass->qf_thresholds[t];
+      const uint32_t dc_idx = quant_dc ? quant_dc[cell] : 0;
+      if (dc_idx >= pass->num_dc_ctxs) return kBad;
+      for (int c : {1, 0, 2}) {
+        // BlockCtxMap::Context (ac_context.h:102-112)
+        uint32_t idx = c < 2 ? (uint32_t)(c ^ 1) : 2u;
+        idx = idx * kNumOrders + ord;
+        idx = idx * (nqf + 1) + qf_idx;
+        idx = idx * pass->num_dc_ctxs + dc_idx;
+        const uint32_t block_ctx = pass->block_ctx[idx];
+        // PredictFromTopAndLeft (entropy_coder.h:25-35)
+        int32_t predicted;
+        if (bx == 0) predicted = by == 0 ? 32 : nz[c][by - 1][bx];
+        else if (by == 0) predicted = nz[c][by][bx - 1];
+        else predicted = (nz[c][by - 1][bx] + nz[c][by][bx - 1] + 1) / 2;
+        // BlockCtxMap::NonZeroContext (ac_context.h:133-143)
+        uint32_t nzp = predicted >= 64 ? 64u : (uint32_t)predicted;
+        const uint32_t nzc = nzp < 8 ? nzp : 4 + nzp / 2;
+        uint32_t nzeros = reader.ReadHybridUint(cmap[ctx_offset + nzc * nb + block_ctx], br);
+        if (nzeros > size - covered) return kBad;
+        const int32_t per_block = (int32_t)((nzeros + covered - 1) >> log2c);
+        for (uint32_t y = 0; y < cy; y++)
+          for (uint32_t x = 0; x < cx; x++) nz[c][by + y][bx + x] = per_block;
+        // DecodeACVarBlock's coefficient loop (dec_group.cc:510-538)
+        const uint8_t* hmap = cmap + ctx_offset + nb * 37 + 458 * block_ctx;
+        const uint32_t* order = pass->orders.data() + L.offset[ord][c];
+        T* block = coeffs[c] + offset;
+        uint32_t prev = nzeros > size / 16 ? 0 : 1;
+        for (uint32_t k = covered; k < size && nzeros != 0; k++) {
+          const uint32_t left = (nzeros + covered - 1) >> log2c;
+          if (left >= 64) return kBad;  // more non-zeros than positions: invalid stream
+          const uint32_t ctx = zd.v[left][k >> log2c] + prev;
+          const uint32_t u = reader.ReadHybridUint(hmap[ctx], br);
+          const uint32_t magnitude = u >> 1, neg = (~u) & 1;  // UnpackSigned
+          const int32_t coeff = (int32_t)((magnitude ^ (neg - 1)) << shift);
+          block[order[k]] = (T)(block[order[k]] + (T)coeff);
+          prev = u != 0;
+          nzeros -= prev;
+        }
+        if (nzeros != 0) return kBad;
+      }
+      offset += size;
+    }
+  }
+  if (reader.Corrupt() || !reader.FinalStateOk()) return kBad;
+  if (!br->Healthy()) return kBad;
+  if (ncoeffs) *ncoeffs = offset;
+  return kOk;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jxlhip_ac_pass_decode(const uint8_t* data, size_t size, size_t* bit_pos, uint32_t used_acs,
+                          uint32_t num_histograms, const jxlhip_block_ctx_map* bcm, jxlhip_ac_pass** out) {
+  if (!data || !bit_pos || !out || num_histograms == 0 || (used_acs >> 27)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  std::unique_ptr<jxlhip_ac_pass> p(new (std::nothrow) jxlhip_ac_pass());
+  if (!p) return JXLHIP_ERR_OUT_OF_MEMORY;
+  if (bcm) {
+    if (bcm->num_dc_ctxs == 0 || bcm->num_qf_thresholds > 15 || !bcm->ctx_map ||
+        bcm->ctx_map_size != 3u * kNumOrders * (bcm->num_qf_thresholds + 1) * bcm->num_dc_ctxs)
+      return JXLHIP_ERR_INVALID_ARGUMENT;
+    p->num_dc_ctxs = bcm->num_dc_ctxs;
+    p->qf_thresholds.assign(bcm->qf_thresholds, bcm->qf_thresholds + bcm->num_qf_thresholds);
+    p->block_ctx.assign(bcm->ctx_map, bcm->ctx_map + bcm->ctx_map_size);
+  } else {
+    p->block_ctx.assign(kDefaultBlockCtx, kDefaultBlockCtx + 39);
+  }
+  p->num_block_ctxs = (uint32_t)*std::max_element(p->block_ctx.begin(), p->block_ctx.end()) + 1;
+  p->num_histograms = num_histograms;
+  BitReader br(data, size, *bit_pos);
+  static const U32Dist kOrderEnc = {{0, 0, 0, 13}, {0x5F, 0x13, 0, 0}};  // frame_header.h:503-504
+  p->used_orders = ReadU32(&br, kOrderEnc);
+  p->orders.assign(Layout().total, 0);
+  int rc = DecodeOrders(&br, p->used_orders, used_acs, p->orders.data());
+  if (rc) return rc;
+  const size_t num_contexts = (size_t)num_histograms * p->NumAcContexts();
+  rc = DecodeEntropyCode(&br, num_contexts, &p->code, false, 0);
+  if (rc) return rc;
+  // the coefficient loop may look 16 contexts past the last one (dec_frame.cc:411-413)
+  p->code.context_map.resize(num_contexts + (474 - 458), 0);
+  *bit_pos = br.BitsConsumed();
+  *out = p.release();
+  return kOk;
+}
+
+void jxlhip_ac_pass_destroy(jxlhip_ac_pass* pass) { delete pass; }
+
+uint32_t jxlhip_ac_pass_max_num_bits(const jxlhip_ac_pass* pass) { return pass ? pass->code.max_num_bits : 0; }
+uint32_t jxlhip_ac_pass_used_orders(const jxlhip_ac_pass* pass) { return pass ? pass->used_orders : 0; }
+const uint32_t* jxlhip_ac_pass_order(const jxlhip_ac_pass* pass, uint32_t ord, uint32_t c) {
+  if (!pass || ord >= (uint32_t)kNumOrders || c > 2) return nullptr;
+  return pass->orders.data() + Layout().offset[ord][c];
+}
+
+int jxlhip_ac_group_decode(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
+                           const uint8_t* acs, const int32_t* raw_quant, const uint8_t* quant_dc,
+                           const uint8_t* data, size_t size, size_t* bit_pos, uint32_t shift, uint32_t coeff_type,
+                           void* const coeffs[3], size_t* ncoeffs) {
+  if (!pass || !acs || !raw_quant || !data || !bit_pos || !coeffs || !coeffs[0] || !coeffs[1] || !coeffs[2] ||
+      coeff_type > JXLHIP_COEFF_I32 || shift > 24)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  BitReader br(data, size, *bit_pos);
+  int rc;
+  if (coeff_type == JXLHIP_COEFF_I16) {
+    int16_t* const c16[3] = {(int16_t*)coeffs[0], (int16_t*)coeffs[1], (int16_t*)coeffs[2]};
+    rc = DecodeGroupT<int16_t>(pass, xsb, ysb, gx, gy, acs, raw_quant, quant_dc, &br, shift, c16, ncoeffs);
+  } else {
+    int32_t* const c32[3] = {(int32_t*)coeffs[0], (int32_t*)coeffs[1], (int32_t*)coeffs[2]};
+    rc = DecodeGroupT<int32_t>(pass, xsb, ysb, gx, gy, acs, raw_quant, quant_dc, &br, shift, c32, ncoeffs);
+  }
+  if (rc == kOk) *bit_pos = br.BitsConsumed();
+  return rc;
+}
+
+}  // extern "C"

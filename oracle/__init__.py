@@ -316,3 +316,31 @@ def _decode_ref(self, threads=1, simple_pipeline=False):
 
 
 Frame.decode_ref = _decode_ref
+
+
+def _encode_ac_ref(self, force_huffman=False, lz77_method=0, custom_orders=True, histo_sets=1):
+    """The frame's quantized coefficients as AC entropy streams written by the
+    REFERENCE's own encoder (oracle/ref_driver.cc EncodeAc).  Returns
+    (global_bytes, [group_bytes...], used_acs, used_orders)."""
+    p = self.params
+    ng = ((p.xsize + 255) // 256) * ((p.ysize + 255) // 256)
+    gcap, cap = 1 << 22, max(1 << 20, ng * 65536 * 3 * 4)
+    gbuf = np.zeros(gcap, np.uint8)
+    buf = np.zeros(cap, np.uint8)
+    offs = np.zeros(ng + 1, np.uint64)
+    gsize = C.c_size_t(0)
+    used_acs, used_orders = C.c_uint32(0), C.c_uint32(0)
+    L = ref_lib()
+    L.jxr_encode_ac.argtypes = [C.POINTER(OracleFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p,
+                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rc = L.jxr_encode_ac(C.byref(self.c), int(force_huffman), int(lz77_method), int(custom_orders), int(histo_sets),
+                         _p(gbuf), gcap, C.byref(gsize), _p(buf), cap, _p(offs), C.byref(used_acs),
+                         C.byref(used_orders))
+    if rc != 0:
+        raise ValueError("reference AC encode failed (%d)" % rc)
+    groups = [bytes(buf[int(offs[g]):int(offs[g + 1])]) for g in range(ng)]
+    return bytes(gbuf[:gsize.value]), groups, used_acs.value, used_orders.value
+
+
+Frame.encode_ac_ref = _encode_ac_ref

@@ -65,6 +65,15 @@
 #include "lib/jxl/quant_weights.h"
 #include "lib/jxl/quantizer.h"
 #include "lib/jxl/render_pipeline/render_pipeline.h"
+#include "lib/jxl/coeff_order.h"
+#include "lib/jxl/enc_ans.h"
+#include "lib/jxl/enc_ans_params.h"
+#include "lib/jxl/enc_aux_out.h"
+#include "lib/jxl/enc_bit_writer.h"
+#include "lib/jxl/enc_coeff_order.h"
+#include "lib/jxl/enc_entropy_coder.h"
+#include "lib/jxl/enc_params.h"
+#include "lib/jxl/frame_header.h"
 
 #include "jxl_oracle.h"  // jxo_frame (POD mirror of the C ABI inputs)
 
@@ -302,6 +311,120 @@ Status DecodeFrame(const jxo_frame* f, float* out, size_t out_stride_floats, siz
   return true;
 }
 
+// ---- f1 test streams: the reference's OWN entropy encoder (enc_coeff_order.cc,
+// enc_entropy_coder.cc, enc_ans.cc) turns the frame's quantized coefficients into
+// the AC-global pass data (coefficient orders + histograms, enc_frame.cc:1255-1330)
+// and one token stream per AC group (enc_frame.cc:1374-1397, selector bits +
+// WriteTokens).  The product's host entropy decoder must reproduce the coefficient
+// buffers from these bytes exactly.
+Status EncodeAc(const jxo_frame* f, int force_huffman, int lz77_method, int custom_orders, int histo_sets,
+                std::vector<uint8_t>* global, std::vector<std::vector<uint8_t>>* groups, uint32_t* used_acs_out,
+                uint32_t* used_orders_out) {
+  Ref ref;
+  CodecMetadata metadata;
+  FrameHeader fh(&metadata);
+  auto dec_state = jxl::make_unique<PassesDecoderState>(&ref.mm);
+  JXL_RETURN_IF_ERROR(FillState(f, &metadata, &fh, dec_state.get(), /*xyb_out=*/false));
+  PassesSharedState& sh = dec_state->shared_storage;
+  const FrameDimensions& fd = sh.frame_dim;
+  const size_t num_groups = fd.num_groups;
+  const jxlhip_frame_params& p = f->p;
+
+  JXL_ASSIGN_OR_RETURN(std::unique_ptr<ACImageT<int32_t>> ac,
+                       ACImageT<int32_t>::Make(&ref.mm, kGroupDim * kGroupDim, num_groups));
+  for (size_t c = 0; c < 3; c++) {
+    for (size_t g = 0; g < num_groups; g++) {
+      int32_t* row = ac->PlaneRow(c, g, 0).ptr32;
+      if (p.coeff_type == JXLHIP_COEFF_I16) {
+        const int16_t* src = static_cast<const int16_t*>(f->coeffs[c]) + g * (kGroupDim * kGroupDim);
+        for (size_t k = 0; k < kGroupDim * kGroupDim; k++) row[k] = src[k];
+      } else {
+        memcpy(row, static_cast<const int32_t*>(f->coeffs[c]) + g * (kGroupDim * kGroupDim),
+               sizeof(int32_t) * kGroupDim * kGroupDim);
+      }
+    }
+  }
+  // strategies present (the decoder accumulates this while decoding the AC strategy map)
+  uint32_t used_acs = 0;
+  for (size_t by = 0; by < fd.ysize_blocks; by++) {
+    AcStrategyRow row = sh.ac_strategy.ConstRow(by);
+    for (size_t bx = 0; bx < fd.xsize_blocks; bx++) used_acs |= 1u << row[bx].RawStrategy();
+  }
+  if (getenv("JXR_TRACE")) fprintf(stderr, "encode_ac step 0\n");
+  *used_acs_out = used_acs;
+
+  // coefficient orders: natural, or the encoder's zero-count sorted ones
+  // (the decoder-side InitializePassesSharedState leaves the order table unallocated)
+  if (sh.coeff_orders.size() < kCoeffOrderMaxSize) sh.coeff_orders.resize(kCoeffOrderMaxSize);
+  const SpeedTier speed = custom_orders ? SpeedTier::kKitten : SpeedTier::kFalcon;
+  auto used = ComputeUsedOrders(custom_orders ? speed : SpeedTier::kKitten, sh.ac_strategy, Rect(sh.raw_quant_field));
+  uint32_t all_used_orders = 0;
+  JXL_RETURN_IF_ERROR(ComputeCoeffOrder(speed, *ac, sh.ac_strategy, fd, all_used_orders, /*prev_used_acs=*/0,
+                                        used.first, custom_orders ? used.second : 0, sh.coeff_orders.data()));
+  if (getenv("JXR_TRACE")) fprintf(stderr, "encode_ac step 1\n");
+  *used_orders_out = all_used_orders;
+
+  // tokens per group
+  std::vector<std::vector<Token>> tokens(num_groups);
+  JXL_ASSIGN_OR_RETURN(Image3I num_nzeroes, Image3I::Create(&ref.mm, kGroupDimInBlocks, kGroupDimInBlocks));
+  JXL_ASSIGN_OR_RETURN(ImageB quant_dc, ImageB::Create(&ref.mm, fd.xsize_blocks, fd.ysize_blocks));
+  ZeroFillImage(&quant_dc);
+  for (size_t g = 0; g < num_groups; g++) {
+    const int32_t* rows[3] = {ac->PlaneRow(0, g, 0).ptr32, ac->PlaneRow(1, g, 0).ptr32, ac->PlaneRow(2, g, 0).ptr32};
+    JXL_RETURN_IF_ERROR(TokenizeCoefficients(sh.coeff_orders.data(), fd.BlockGroupRect(g), rows, sh.ac_strategy,
+                                             fh.chroma_subsampling, &num_nzeroes, &tokens[g], quant_dc,
+                                             sh.raw_quant_field, sh.block_ctx_map));
+  }
+  if (getenv("JXR_TRACE")) fprintf(stderr, "encode_ac step 2\n");
+  // histogram sets: group g uses set g % histo_sets (context offset = set * NumACContexts)
+  const size_t nctx = sh.block_ctx_map.NumACContexts();
+  if (histo_sets > 1) {
+    for (size_t g = 0; g < num_groups; g++) {
+      const size_t off = (g % histo_sets) * nctx;
+      for (Token& t : tokens[g]) t.context += off;
+    }
+  }
+
+  if (getenv("JXR_TRACE")) fprintf(stderr, "encode_ac step 3\n");
+  BitWriter w{&ref.mm};
+  JXL_RETURN_IF_ERROR(w.WithMaxBits(64, LayerType::Order, nullptr, [&] {
+    return U32Coder::Write(kOrderEnc, all_used_orders, &w);
+  }));
+  JXL_RETURN_IF_ERROR(EncodeCoeffOrders(all_used_orders, sh.coeff_orders.data(), &w, LayerType::Order, nullptr));
+  if (getenv("JXR_TRACE")) fprintf(stderr, "encode_ac step 4\n");
+  HistogramParams hp(SpeedTier::kSquirrel, nctx);
+  hp.force_huffman = force_huffman != 0;
+  hp.lz77_method = static_cast<HistogramParams::LZ77Method>(lz77_method);
+  EntropyEncodingData codes;
+  JXL_ASSIGN_OR_RETURN(size_t cost, BuildAndEncodeHistograms(&ref.mm, hp, histo_sets * nctx, tokens, &codes, &w,
+                                                             LayerType::Ac, nullptr));
+  (void)cost;
+  if (getenv("JXR_TRACE")) fprintf(stderr, "encode_ac step 5\n");
+  w.ZeroPadToByte();
+  {
+    Span<const uint8_t> sp = w.GetSpan();
+    global->assign(sp.data(), sp.data() + sp.size());
+  }
+  const size_t selector_bits = histo_sets > 1 ? CeilLog2Nonzero(static_cast<uint32_t>(histo_sets)) : 0;
+  if (getenv("JXR_TRACE")) fprintf(stderr, "encode_ac step 6\n");
+  groups->resize(num_groups);
+  for (size_t g = 0; g < num_groups; g++) {
+    BitWriter gw{&ref.mm};
+    if (selector_bits) {
+      JXL_RETURN_IF_ERROR(gw.WithMaxBits(selector_bits, LayerType::Ac, nullptr, [&] {
+        gw.Write(selector_bits, g % histo_sets);
+        return true;
+      }));
+    }
+    // the contexts were already offset per set: WriteTokens adds nothing more
+    JXL_RETURN_IF_ERROR(WriteTokens(tokens[g], codes, 0, &gw, LayerType::Ac, nullptr));
+    gw.ZeroPadToByte();
+    Span<const uint8_t> sp = gw.GetSpan();
+    (*groups)[g].assign(sp.data(), sp.data() + sp.size());
+  }
+  return true;
+}
+
 }  // namespace
 
 // Whole path through the reference.  out per p.output_kind, as
@@ -361,4 +484,31 @@ JXR_EXPORT int jxr_dequant_dc(uint32_t xsb, uint32_t ysb, const int32_t* const q
 JXR_EXPORT const char* jxr_describe(void) {
   return "libjxl reference (lib/jxl decoder sources compiled in place) with the single-lane Highway shim "
          "oracle/hwy_shim: MulAdd=fmaf, exact reciprocals, JXL_HIGH_PRECISION=1";
+}
+
+// f1: AC entropy streams made by the reference's own encoder.  global_out /
+// groups_out receive the bytes; group_offsets[num_groups + 1] the byte offsets of
+// every group's stream inside groups_out.  Returns 0, -1 on failure, -2 when a
+// buffer is too small.
+JXR_EXPORT int jxr_encode_ac(const jxo_frame* f, int force_huffman, int lz77_method, int custom_orders,
+                             int histo_sets, uint8_t* global_out, size_t global_cap, size_t* global_size,
+                             uint8_t* groups_out, size_t groups_cap, uint64_t* group_offsets, uint32_t* used_acs,
+                             uint32_t* used_orders) {
+  std::vector<uint8_t> global;
+  std::vector<std::vector<uint8_t>> groups;
+  Status s = EncodeAc(f, force_huffman, lz77_method, custom_orders, histo_sets < 1 ? 1 : histo_sets, &global,
+                      &groups, used_acs, used_orders);
+  if (!s) return -1;
+  if (global.size() > global_cap) return -2;
+  memcpy(global_out, global.data(), global.size());
+  *global_size = global.size();
+  size_t pos = 0;
+  for (size_t g = 0; g < groups.size(); g++) {
+    group_offsets[g] = pos;
+    if (pos + groups[g].size() > groups_cap) return -2;
+    memcpy(groups_out + pos, groups[g].data(), groups[g].size());
+    pos += groups[g].size();
+  }
+  group_offsets[groups.size()] = pos;
+  return 0;
 }

@@ -1,0 +1,193 @@
+"""f1: the host AC entropy decoder (include/jxl_hip_entropy.h,
+libjxl_amd/csrc/entropy.cc) against streams written by the REFERENCE's own
+entropy encoder (oracle/ref_driver.cc EncodeAc: ComputeCoeffOrder,
+TokenizeCoefficients, BuildAndEncodeHistograms, WriteTokens compiled in place
+from lib/jxl).  Entropy coding is lossless: the decoder must give back the
+frame's quantized coefficient buffers bit for bit, consume exactly the bytes the
+encoder wrote, and reject damaged streams.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import frames
+from libjxl_amd import abi, synth
+
+BAD_STREAM = -5  # JXLHIP_ERR_BAD_STREAM
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not available")
+    oracle.ref_lib()
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = C.CDLL(abi.library_path())
+    lib.jxlhip_ac_pass_decode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.jxlhip_ac_pass_destroy.argtypes = [C.c_void_p]
+    lib.jxlhip_ac_pass_destroy.restype = None
+    lib.jxlhip_ac_pass_max_num_bits.argtypes = [C.c_void_p]
+    lib.jxlhip_ac_pass_max_num_bits.restype = C.c_uint32
+    lib.jxlhip_ac_pass_used_orders.argtypes = [C.c_void_p]
+    lib.jxlhip_ac_pass_used_orders.restype = C.c_uint32
+    lib.jxlhip_ac_group_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                           C.c_uint32, C.c_uint32, C.c_void_p * 3, C.POINTER(C.c_size_t)]
+    return lib
+
+
+def open_pass(L, glob, used_acs, histo_sets):
+    g = np.frombuffer(glob, np.uint8)
+    pos, h = C.c_size_t(0), C.c_void_p()
+    rc = L.jxlhip_ac_pass_decode(g.ctypes.data, len(g), C.byref(pos), used_acs, histo_sets, None, C.byref(h))
+    return rc, h, pos.value
+
+
+def decode_group(L, h, npy, xs, ys, gi, data, coeff_type, out):
+    xsb, ysb, xsg = (xs + 7) // 8, (ys + 7) // 8, (xs + 255) // 256
+    d = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+    gp, n = C.c_size_t(0), C.c_size_t(0)
+    ptrs = (C.c_void_p * 3)(*[o[gi * 65536:].ctypes.data for o in out])
+    rc = L.jxlhip_ac_group_decode(h, xsb, ysb, gi % xsg, gi // xsg, npy["ac_strategy"].ctypes.data,
+                                  npy["raw_quant"].ctypes.data, None, d.ctypes.data, len(data), C.byref(gp), 0,
+                                  coeff_type, ptrs, C.byref(n))
+    return rc, gp.value, n.value
+
+
+def decode_all(L, npy, xs, ys, glob, groups, used_acs, histo_sets, coeff_type):
+    rc, h, pos = open_pass(L, glob, used_acs, histo_sets)
+    assert rc == 0, rc
+    # the encoder pads the section to a byte boundary: everything else was consumed
+    assert (pos + 7) // 8 == len(glob), (pos, len(glob))
+    dt = np.int16 if coeff_type == 0 else np.int32
+    ng = ((xs + 255) // 256) * ((ys + 255) // 256)
+    out = [np.zeros(ng * 65536, dt) for _ in range(3)]
+    try:
+        for gi, data in enumerate(groups):
+            rc, gp, n = decode_group(L, h, npy, xs, ys, gi, data, coeff_type, out)
+            assert rc == 0, (gi, rc)
+            assert (gp + 7) // 8 == len(data), (gi, gp, len(data))
+        mx = L.jxlhip_ac_pass_max_num_bits(h)
+    finally:
+        L.jxlhip_ac_pass_destroy(h)
+    return mx, out
+
+
+def case(xs, ys, **kw):
+    params, t, fr = frames.make_case(xs, ys, **kw)
+    npy = dict(ac_strategy=np.ascontiguousarray(t["ac_strategy"].numpy()),
+               raw_quant=np.ascontiguousarray(t["raw_quant"].numpy()),
+               coeffs=[c.numpy() for c in t["coeffs"]])
+    return params, fr, npy
+
+
+@pytest.mark.parametrize("opts", [
+    dict(),                                   # ANS, custom coefficient orders
+    dict(force_huffman=True),                 # prefix codes
+    dict(custom_orders=False),                # natural orders only (used_orders == 0)
+    dict(histo_sets=2),                       # per-group histogram-set selector
+    dict(histo_sets=3, force_huffman=True),
+    dict(lz77_method=1),                      # RLE / LZ77 in the token stream (when the encoder picks it)
+    dict(lz77_method=3),
+])
+def test_roundtrip_reference_streams(L, ref, opts):
+    xs, ys = 520, 300
+    params, fr, npy = case(xs, ys, mix=synth.MIX_ALL, gab=True, epf_iters=1, seed=31)
+    glob, groups, used_acs, used_orders = fr.encode_ac_ref(**opts)
+    mx, out = decode_all(L, npy, xs, ys, glob, groups, used_acs, opts.get("histo_sets", 1), 0)
+    for c in range(3):
+        assert np.array_equal(out[c], npy["coeffs"][c]), c
+    assert 0 < mx < 16  # int16 coefficients are enough for this frame (dec_frame.cc:414-421)
+
+
+def test_roundtrip_d1_mix_1024_int16(L, ref):
+    xs = ys = 1024
+    params, fr, npy = case(xs, ys, mix=synth.MIX_D1, gab=True, epf_iters=1)
+    glob, groups, used_acs, used_orders = fr.encode_ac_ref()
+    assert used_orders != 0
+    _, out = decode_all(L, npy, xs, ys, glob, groups, used_acs, 1, 0)
+    for c in range(3):
+        assert np.array_equal(out[c], npy["coeffs"][c]), c
+
+
+def test_roundtrip_int32_large_values(L, ref):
+    # d0.5-like quantisation with int32 buffers: long hybrid-uint tokens
+    xs, ys = 520, 264
+    params, fr, npy = case(xs, ys, mix=synth.MIX_DCT32, gab=False, epf_iters=0, coeff_type=1, quant_mul=2.0, amp=40.0)
+    glob, groups, used_acs, _ = fr.encode_ac_ref()
+    _, out = decode_all(L, npy, xs, ys, glob, groups, used_acs, 1, 1)
+    for c in range(3):
+        assert np.array_equal(out[c], npy["coeffs"][c]), c
+
+
+def test_ragged_sizes(L, ref):
+    for xs, ys in ((8, 8), (1, 1), (257, 9), (300, 513)):
+        params, fr, npy = case(xs, ys, mix=synth.MIX_D1, gab=False, epf_iters=0, seed=xs)
+        glob, groups, used_acs, _ = fr.encode_ac_ref()
+        _, out = decode_all(L, npy, xs, ys, glob, groups, used_acs, 1, 0)
+        for c in range(3):
+            assert np.array_equal(out[c], npy["coeffs"][c]), (xs, ys, c)
+
+
+def test_damaged_streams_are_rejected(L, ref):
+    xs, ys = 264, 136
+    params, fr, npy = case(xs, ys, mix=synth.MIX_D1, gab=False, epf_iters=0, seed=3)
+    glob, groups, used_acs, _ = fr.encode_ac_ref()
+    rc, h, _ = open_pass(L, glob[:len(glob) // 2], used_acs, 1)  # truncated global section
+    assert rc == BAD_STREAM
+    rc, h, _ = open_pass(L, glob, used_acs, 1)
+    assert rc == 0
+    try:
+        for cut in (len(groups[0]) // 3, len(groups[0]) - 2):  # truncated group
+            out = [np.zeros(65536, np.int16) for _ in range(3)]
+            rc, _, _ = decode_group(L, h, npy, xs, ys, 0, groups[0][:cut], 0, out)
+            assert rc == BAD_STREAM, cut
+        # flipped bits: never a crash; the nzeros checks / ANS final state catch almost all
+        rng = np.random.default_rng(1)
+        detected = 0
+        for _ in range(40):
+            d = bytearray(groups[0])
+            d[int(rng.integers(4, len(d) - 4))] ^= 1 << int(rng.integers(0, 8))
+            out = [np.zeros(65536, np.int16) for _ in range(3)]
+            rc, _, _ = decode_group(L, h, npy, xs, ys, 0, bytes(d), 0, out)
+            detected += rc != 0
+        assert detected >= 36
+    finally:
+        L.jxlhip_ac_pass_destroy(h)
+
+
+@pytest.mark.parametrize("method,huff", [(3, False), (3, True), (5, False), (12, True)])
+def test_lz77_token_streams(L, ref, oracle, method, huff):
+    """A frame whose groups repeat one 8-block pattern: the reference encoder
+    (LZ77Method kLZ77b3w3f / b15 / kOptc1) then codes the tokens as LZ77 copies
+    (streams 50x smaller than without), which exercises the window, the length
+    tokens and the distance context."""
+    xs, ys = 520, 300
+    params, t = synth.synth_frame(xs, ys, mix=synth.MIX_DCT8, gab=False, epf_iters=0, device="cpu")
+    for c in range(3):
+        v = t["coeffs"][c].numpy().reshape(-1, 65536)
+        for g in range(v.shape[0]):
+            pat = v[g, :64 * 8].copy()
+            pat[0::64] = 0  # LLF slots stay empty
+            v[g] = np.tile(pat, 128)
+    npy = dict(ac_strategy=np.ascontiguousarray(t["ac_strategy"].numpy()),
+               raw_quant=np.ascontiguousarray(t["raw_quant"].numpy()),
+               coeffs=[c.numpy() for c in t["coeffs"]])
+    fr = oracle.Frame(frames.to_oracle_params(abi.make_params(params)), npy["coeffs"], npy["ac_strategy"],
+                      npy["raw_quant"], t["epf_sharpness"].numpy(), t["ytox_map"].numpy(), t["ytob_map"].numpy(),
+                      [d.numpy() for d in t["dc"]], oracle.default_dequant_tables())
+    plain = fr.encode_ac_ref(lz77_method=0, force_huffman=huff)
+    glob, groups, used_acs, _ = fr.encode_ac_ref(lz77_method=method, force_huffman=huff)
+    assert sum(map(len, groups)) * 10 < sum(map(len, plain[1]))  # LZ77 really is in use
+    _, out = decode_all(L, npy, xs, ys, glob, groups, used_acs, 1, 0)
+    for c in range(3):
+        # only the blocks the frame really has are coded (the tiling also filled unused slots)
+        nblk = [min(32, (xs + 7) // 8 - 32 * (g % 3)) * min(32, (ys + 7) // 8 - 32 * (g // 3)) for g in range(6)]
+        for g in range(6):
+            n = nblk[g] * 64
+            assert np.array_equal(out[c][g * 65536:g * 65536 + n], npy["coeffs"][c][g * 65536:g * 65536 + n]), (c, g)

@@ -170,3 +170,58 @@ def test_packed_8k_srgb_u8_rgba_full_size(dec, ref):
                            mix=synth.MIX_D1, gab=True, epf_iters=1, intensity_target=80.0)
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 1 and (d != 0).mean() < 1e-3
+
+
+# ---- f1: bytes -> pixels.  The reference's entropy ENCODER writes the AC streams;
+# the product decodes them on host threads into pinned staging, uploads them group
+# by group and renders; the result must equal the decode from device-resident
+# coefficients bit for bit (entropy coding is lossless).
+def test_entropy_decode_submit_end_to_end(dec, ref):
+    import ctypes as C
+    import threading
+    xs, ys = 1000, 700
+    params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=True, epf_iters=1, seed=77)
+    dq = dec.default_dequant_tables()
+    dec.begin_frame(params)
+    dec.set_inputs({k: ([x.cuda() for x in v] if isinstance(v, list) else v.cuda()) for k, v in t.items()}, dq)
+    want = dec.decode_frame().clone()
+    dec.sync()
+
+    glob, groups, used_acs, _ = fr.encode_ac_ref(histo_sets=2)
+    d2 = VarDctDecoder(0)
+    d2.begin_frame(params)
+    L = d2.L
+    npy = {k: ([x.numpy() for x in v] if isinstance(v, list) else v.numpy()) for k, v in t.items()}
+    dqh = dq.cpu().numpy()
+    dc3 = (C.c_void_p * 3)(*[x.ctypes.data for x in npy["dc"]])
+    assert L.jxlhip_upload_side_info(d2.ctx, npy["ac_strategy"].ctypes.data, npy["raw_quant"].ctypes.data,
+                                     npy["epf_sharpness"].ctypes.data, npy["ytox_map"].ctypes.data,
+                                     npy["ytob_map"].ctypes.data, dc3, dqh.ctypes.data) == 0
+    g = np.frombuffer(glob, np.uint8)
+    pos, h = C.c_size_t(0), C.c_void_p()
+    assert L.jxlhip_ac_pass_decode(g.ctypes.data, len(g), C.byref(pos), used_acs, 2, None, C.byref(h)) == 0
+    assert L.jxlhip_ac_pass_max_num_bits(h) < 16  # int16 coefficients, as the frame was set up
+    ng = len(groups)
+    errs = []
+
+    def worker(tid, nthreads):  # the JxlParallelRunner's role: groups in any order, concurrently
+        for gi in range(tid, ng, nthreads):
+            d = np.frombuffer(groups[gi], np.uint8)
+            gp = C.c_size_t(0)
+            rc = L.jxlhip_ac_group_decode_submit(d2.ctx, h, gi, npy["ac_strategy"].ctypes.data,
+                                                 npy["raw_quant"].ctypes.data, None, d.ctypes.data, len(d),
+                                                 C.byref(gp))
+            if rc != 0:
+                errs.append((gi, rc))
+
+    threads = [threading.Thread(target=worker, args=(i, 12)) for i in range(12)]  # more threads than staging slots
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    got = d2.decode_frame()
+    d2.sync()
+    L.jxlhip_ac_pass_destroy(h)
+    assert torch.equal(got, want)
+    d2.close()
