@@ -32,16 +32,29 @@ extern "C" {
 #endif
 
 /* Mirrors jxl::BlockCtxMap (lib/jxl/ac_context.h:85-150) as decoded from the
- * DC-global section (DecodeBlockCtxMap, entropy_coder.h:44).  A NULL pointer
+ * DC-global section (DecodeBlockCtxMap, entropy_coder.cc:25-61).  A NULL pointer
  * wherever this struct is expected means the default map (kDefaultCtxMap, no
- * thresholds). */
+ * thresholds).  Channels of the DC thresholds in X, Y, B order. */
+#define JXLHIP_BLOCK_CTX_MAP_MAX (3 * 13 * 64)
 typedef struct jxlhip_block_ctx_map {
-  uint32_t num_dc_ctxs;          /* product of (dc_thresholds[c].size() + 1) */
+  uint32_t num_dc_thresholds[3]; /* each <= 15 */
+  int32_t dc_thresholds[3][15];
+  uint32_t num_dc_ctxs;          /* product of (num_dc_thresholds[c] + 1) */
   uint32_t num_qf_thresholds;    /* <= 15 */
   uint32_t qf_thresholds[15];
+  uint32_t num_ctxs;             /* distinct block contexts, <= 16 */
   uint32_t ctx_map_size;         /* 3 * 13 * (num_qf_thresholds + 1) * num_dc_ctxs */
-  const uint8_t* ctx_map;
+  uint8_t ctx_map[JXLHIP_BLOCK_CTX_MAP_MAX];
 } jxlhip_block_ctx_map;
+
+/* DecodeBlockCtxMap: reads the map at bit *bit_pos of data (advanced). */
+JXLHIP_EXPORT int jxlhip_block_ctx_map_decode(const uint8_t* data, size_t size, size_t* bit_pos,
+                                              jxlhip_block_ctx_map* out);
+/* The per-block DC context index the AC contexts depend on (what DequantDC
+ * leaves in PassesSharedState::quant_dc, compressed_dc.cc:251-295): n blocks,
+ * quantized DC planes in X, Y, B order; map may be NULL (all zero). */
+JXLHIP_EXPORT int jxlhip_quant_dc_contexts(const jxlhip_block_ctx_map* map, size_t n,
+                                           const int32_t* const quant_dc[3], uint8_t* out);
 
 /* One pass of the AC-global section: coefficient orders + entropy code. */
 typedef struct jxlhip_ac_pass jxlhip_ac_pass;

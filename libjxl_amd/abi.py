@@ -36,6 +36,14 @@ TF_LINEAR, TF_SRGB = 0, 1
 SAMPLE_F32, SAMPLE_U8, SAMPLE_U16, SAMPLE_F16 = 0, 1, 2, 3
 
 
+class BlockCtxMap(C.Structure):
+    """jxlhip_block_ctx_map (include/jxl_hip_entropy.h)."""
+    _fields_ = [("num_dc_thresholds", C.c_uint32 * 3), ("dc_thresholds", (C.c_int32 * 15) * 3),
+                ("num_dc_ctxs", C.c_uint32), ("num_qf_thresholds", C.c_uint32),
+                ("qf_thresholds", C.c_uint32 * 15), ("num_ctxs", C.c_uint32), ("ctx_map_size", C.c_uint32),
+                ("ctx_map", C.c_uint8 * (3 * 13 * 64))]
+
+
 class FrameParams(C.Structure):
     _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32),
                 ("coeff_type", C.c_uint32), ("output_kind", C.c_uint32),
@@ -116,7 +124,7 @@ EXPORTS = [
     # include/jxl_hip_entropy.h
     "jxlhip_ac_pass_decode", "jxlhip_ac_pass_destroy", "jxlhip_ac_pass_max_num_bits",
     "jxlhip_ac_pass_used_orders", "jxlhip_ac_pass_order", "jxlhip_ac_group_decode",
-    "jxlhip_ac_group_decode_submit",
+    "jxlhip_ac_group_decode_submit", "jxlhip_block_ctx_map_decode", "jxlhip_quant_dc_contexts",
 ]
 
 
@@ -141,6 +149,8 @@ def load_library():
     L.jxlhip_destroy.restype = None
     L.jxlhip_set_stream.argtypes = [vp, vp, i32]
     L.jxlhip_ac_pass_decode.argtypes = [vp, sz, C.POINTER(sz), u32, u32, vp, C.POINTER(vp)]
+    L.jxlhip_block_ctx_map_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(BlockCtxMap)]
+    L.jxlhip_quant_dc_contexts.argtypes = [C.POINTER(BlockCtxMap), sz, vp * 3, vp]
     L.jxlhip_ac_pass_destroy.argtypes = [vp]
     L.jxlhip_ac_pass_destroy.restype = None
     L.jxlhip_ac_pass_max_num_bits.argtypes = [vp]

@@ -1040,7 +1040,7 @@ int jxlhip_ac_pass_decode(const uint8_t* data, size_t size, size_t* bit_pos, uin
   std::unique_ptr<jxlhip_ac_pass> p(new (std::nothrow) jxlhip_ac_pass());
   if (!p) return JXLHIP_ERR_OUT_OF_MEMORY;
   if (bcm) {
-    if (bcm->num_dc_ctxs == 0 || bcm->num_qf_thresholds > 15 || !bcm->ctx_map ||
+    if (bcm->num_dc_ctxs == 0 || bcm->num_qf_thresholds > 15 || bcm->ctx_map_size > JXLHIP_BLOCK_CTX_MAP_MAX ||
         bcm->ctx_map_size != 3u * kNumOrders * (bcm->num_qf_thresholds + 1) * bcm->num_dc_ctxs)
       return JXLHIP_ERR_INVALID_ARGUMENT;
     p->num_dc_ctxs = bcm->num_dc_ctxs;
@@ -1068,6 +1068,62 @@ int jxlhip_ac_pass_decode(const uint8_t* data, size_t size, size_t* bit_pos, uin
 }
 
 void jxlhip_ac_pass_destroy(jxlhip_ac_pass* pass) { delete pass; }
+
+int jxlhip_block_ctx_map_decode(const uint8_t* data, size_t size, size_t* bit_pos, jxlhip_block_ctx_map* out) {
+  if (!data || !bit_pos || !out) return JXLHIP_ERR_INVALID_ARGUMENT;
+  memset(out, 0, sizeof(*out));
+  BitReader br(data, size, *bit_pos);
+  out->num_dc_ctxs = 1;
+  if (br.Read(1)) {  // default map
+    out->ctx_map_size = 39;
+    memcpy(out->ctx_map, kDefaultBlockCtx, 39);
+    out->num_ctxs = 15;
+  } else {
+    // kDCThresholdDist / kQFThresholdDist (entropy_coder.h:37-42)
+    static const U32Dist kDcDist = {{4, 8, 16, 32}, {0, 16, 272, 65808}};
+    static const U32Dist kQfDist = {{2, 3, 5, 8}, {0, 4, 12, 44}};
+    for (int c = 0; c < 3; c++) {
+      out->num_dc_thresholds[c] = br.Read(4);
+      out->num_dc_ctxs *= out->num_dc_thresholds[c] + 1;
+      for (uint32_t i = 0; i < out->num_dc_thresholds[c]; i++) {
+        const uint32_t u = ReadU32(&br, kDcDist);
+        out->dc_thresholds[c][i] = (int32_t)((u >> 1) ^ (~(u & 1) + 1));  // UnpackSigned
+      }
+    }
+    out->num_qf_thresholds = br.Read(4);
+    for (uint32_t i = 0; i < out->num_qf_thresholds; i++) out->qf_thresholds[i] = ReadU32(&br, kQfDist) + 1;
+    if (out->num_dc_ctxs * (out->num_qf_thresholds + 1) > 64) return kBad;
+    out->ctx_map_size = 3u * kNumOrders * out->num_dc_ctxs * (out->num_qf_thresholds + 1);
+    std::vector<uint8_t> map(out->ctx_map_size, 0);
+    size_t num = 0;
+    int rc = DecodeContextMap(&br, &map, &num, 0);
+    if (rc) return rc;
+    if (num > 16) return kBad;
+    out->num_ctxs = (uint32_t)num;
+    memcpy(out->ctx_map, map.data(), map.size());
+  }
+  if (!br.Healthy()) return kBad;
+  *bit_pos = br.BitsConsumed();
+  return kOk;
+}
+
+int jxlhip_quant_dc_contexts(const jxlhip_block_ctx_map* map, size_t n, const int32_t* const q[3], uint8_t* out) {
+  if (!out || (map && map->num_dc_ctxs > 1 && (!q || !q[0] || !q[1] || !q[2]))) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!map || map->num_dc_ctxs <= 1) {
+    memset(out, 0, n);
+    return kOk;
+  }
+  for (size_t i = 0; i < n; i++) {
+    uint32_t b[3] = {0, 0, 0};
+    for (int c = 0; c < 3; c++)
+      for (uint32_t t = 0; t < map->num_dc_thresholds[c]; t++) b[c] += q[c][i] > map->dc_thresholds[c][t];
+    uint32_t bucket = b[0];
+    bucket = bucket * (map->num_dc_thresholds[2] + 1) + b[2];
+    bucket = bucket * (map->num_dc_thresholds[1] + 1) + b[1];
+    out[i] = (uint8_t)bucket;
+  }
+  return kOk;
+}
 
 uint32_t jxlhip_ac_pass_max_num_bits(const jxlhip_ac_pass* pass) { return pass ? pass->code.max_num_bits : 0; }
 uint32_t jxlhip_ac_pass_used_orders(const jxlhip_ac_pass* pass) { return pass ? pass->used_orders : 0; }

@@ -318,29 +318,48 @@ def _decode_ref(self, threads=1, simple_pipeline=False):
 Frame.decode_ref = _decode_ref
 
 
-def _encode_ac_ref(self, force_huffman=False, lz77_method=0, custom_orders=True, histo_sets=1):
+def _encode_ac_ref(self, force_huffman=False, lz77_method=0, custom_orders=True, histo_sets=1,
+                   custom_block_ctx=False, quant_dc=None, want_block_ctx=False):
     """The frame's quantized coefficients as AC entropy streams written by the
     REFERENCE's own encoder (oracle/ref_driver.cc EncodeAc).  Returns
-    (global_bytes, [group_bytes...], used_acs, used_orders)."""
+    (global_bytes, [group_bytes...], used_acs, used_orders) and, with
+    want_block_ctx, the EncodeBlockCtxMap bytes as a fifth element."""
     p = self.params
     ng = ((p.xsize + 255) // 256) * ((p.ysize + 255) // 256)
     gcap, cap = 1 << 22, max(1 << 20, ng * 65536 * 3 * 4)
     gbuf = np.zeros(gcap, np.uint8)
+    bbuf = np.zeros(1 << 16, np.uint8)
     buf = np.zeros(cap, np.uint8)
     offs = np.zeros(ng + 1, np.uint64)
-    gsize = C.c_size_t(0)
+    gsize, bsize = C.c_size_t(0), C.c_size_t(0)
     used_acs, used_orders = C.c_uint32(0), C.c_uint32(0)
     L = ref_lib()
-    L.jxr_encode_ac.argtypes = [C.POINTER(OracleFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+    L.jxr_encode_ac.argtypes = [C.POINTER(OracleFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t,
                                 C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.c_void_p,
                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    qdc = None if quant_dc is None else np.ascontiguousarray(quant_dc, np.uint8)
     rc = L.jxr_encode_ac(C.byref(self.c), int(force_huffman), int(lz77_method), int(custom_orders), int(histo_sets),
-                         _p(gbuf), gcap, C.byref(gsize), _p(buf), cap, _p(offs), C.byref(used_acs),
-                         C.byref(used_orders))
+                         int(custom_block_ctx), None if qdc is None else qdc.ctypes.data, _p(bbuf), len(bbuf),
+                         C.byref(bsize), _p(gbuf), gcap, C.byref(gsize), _p(buf), cap, _p(offs),
+                         C.byref(used_acs), C.byref(used_orders))
     if rc != 0:
         raise ValueError("reference AC encode failed (%d)" % rc)
     groups = [bytes(buf[int(offs[g]):int(offs[g + 1])]) for g in range(ng)]
-    return bytes(gbuf[:gsize.value]), groups, used_acs.value, used_orders.value
+    res = (bytes(gbuf[:gsize.value]), groups, used_acs.value, used_orders.value)
+    return res + (bytes(bbuf[:bsize.value]),) if want_block_ctx else res
+
+
+def ref_quant_dc_contexts(quant_dc):
+    """quant_dc context indices by the reference's DequantDC under the test block
+    context map; quant_dc: 3 int32 planes in X, Y, B order."""
+    ysb, xsb = quant_dc[0].shape
+    q = [np.ascontiguousarray(a, np.int32) for a in quant_dc]
+    out = np.zeros((ysb, xsb), np.uint8)
+    L = ref_lib()
+    L.jxr_quant_dc_contexts.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p * 3, C.c_void_p]
+    assert L.jxr_quant_dc_contexts(xsb, ysb, _p3(q), _p(out)) == 0
+    return out
 
 
 Frame.encode_ac_ref = _encode_ac_ref

@@ -71,6 +71,7 @@
 #include "lib/jxl/enc_aux_out.h"
 #include "lib/jxl/enc_bit_writer.h"
 #include "lib/jxl/enc_coeff_order.h"
+#include "lib/jxl/enc_context_map.h"
 #include "lib/jxl/enc_entropy_coder.h"
 #include "lib/jxl/enc_params.h"
 #include "lib/jxl/frame_header.h"
@@ -317,7 +318,21 @@ Status DecodeFrame(const jxo_frame* f, float* out, size_t out_stride_floats, siz
 // and one token stream per AC group (enc_frame.cc:1374-1397, selector bits +
 // WriteTokens).  The product's host entropy decoder must reproduce the coefficient
 // buffers from these bytes exactly.
+// A non-default block context map for tests: two X thresholds, one Y threshold,
+// two quantization-field thresholds, 11 block contexts.
+void CustomBlockCtxMap(BlockCtxMap* m) {
+  m->dc_thresholds[0] = {-3, 2};
+  m->dc_thresholds[1] = {0};
+  m->dc_thresholds[2] = {};
+  m->qf_thresholds = {6, 14};
+  m->num_dc_ctxs = 3 * 2 * 1;
+  m->ctx_map.resize(3 * kNumOrders * m->num_dc_ctxs * 3);
+  for (size_t i = 0; i < m->ctx_map.size(); i++) m->ctx_map[i] = static_cast<uint8_t>((i * 7 + i / 13) % 11);
+  m->num_ctxs = 11;
+}
+
 Status EncodeAc(const jxo_frame* f, int force_huffman, int lz77_method, int custom_orders, int histo_sets,
+                int bctx_mode, const uint8_t* quant_dc_in, std::vector<uint8_t>* bctx_bytes,
                 std::vector<uint8_t>* global, std::vector<std::vector<uint8_t>>* groups, uint32_t* used_acs_out,
                 uint32_t* used_orders_out) {
   Ref ref;
@@ -329,6 +344,14 @@ Status EncodeAc(const jxo_frame* f, int force_huffman, int lz77_method, int cust
   const FrameDimensions& fd = sh.frame_dim;
   const size_t num_groups = fd.num_groups;
   const jxlhip_frame_params& p = f->p;
+  if (bctx_mode) CustomBlockCtxMap(&sh.block_ctx_map);
+  {
+    BitWriter bw{&ref.mm};
+    JXL_RETURN_IF_ERROR(EncodeBlockCtxMap(sh.block_ctx_map, &bw, nullptr));
+    bw.ZeroPadToByte();
+    Span<const uint8_t> sp = bw.GetSpan();
+    bctx_bytes->assign(sp.data(), sp.data() + sp.size());
+  }
 
   JXL_ASSIGN_OR_RETURN(std::unique_ptr<ACImageT<int32_t>> ac,
                        ACImageT<int32_t>::Make(&ref.mm, kGroupDim * kGroupDim, num_groups));
@@ -369,6 +392,10 @@ Status EncodeAc(const jxo_frame* f, int force_huffman, int lz77_method, int cust
   JXL_ASSIGN_OR_RETURN(Image3I num_nzeroes, Image3I::Create(&ref.mm, kGroupDimInBlocks, kGroupDimInBlocks));
   JXL_ASSIGN_OR_RETURN(ImageB quant_dc, ImageB::Create(&ref.mm, fd.xsize_blocks, fd.ysize_blocks));
   ZeroFillImage(&quant_dc);
+  if (quant_dc_in) {
+    for (size_t by = 0; by < fd.ysize_blocks; by++)
+      memcpy(quant_dc.Row(by), quant_dc_in + by * fd.xsize_blocks, fd.xsize_blocks);
+  }
   for (size_t g = 0; g < num_groups; g++) {
     const int32_t* rows[3] = {ac->PlaneRow(0, g, 0).ptr32, ac->PlaneRow(1, g, 0).ptr32, ac->PlaneRow(2, g, 0).ptr32};
     JXL_RETURN_IF_ERROR(TokenizeCoefficients(sh.coeff_orders.data(), fd.BlockGroupRect(g), rows, sh.ac_strategy,
@@ -491,14 +518,18 @@ JXR_EXPORT const char* jxr_describe(void) {
 // every group's stream inside groups_out.  Returns 0, -1 on failure, -2 when a
 // buffer is too small.
 JXR_EXPORT int jxr_encode_ac(const jxo_frame* f, int force_huffman, int lz77_method, int custom_orders,
-                             int histo_sets, uint8_t* global_out, size_t global_cap, size_t* global_size,
-                             uint8_t* groups_out, size_t groups_cap, uint64_t* group_offsets, uint32_t* used_acs,
-                             uint32_t* used_orders) {
-  std::vector<uint8_t> global;
+                             int histo_sets, int bctx_mode, const uint8_t* quant_dc, uint8_t* bctx_out,
+                             size_t bctx_cap, size_t* bctx_size, uint8_t* global_out, size_t global_cap,
+                             size_t* global_size, uint8_t* groups_out, size_t groups_cap, uint64_t* group_offsets,
+                             uint32_t* used_acs, uint32_t* used_orders) {
+  std::vector<uint8_t> global, bctx;
   std::vector<std::vector<uint8_t>> groups;
-  Status s = EncodeAc(f, force_huffman, lz77_method, custom_orders, histo_sets < 1 ? 1 : histo_sets, &global,
-                      &groups, used_acs, used_orders);
+  Status s = EncodeAc(f, force_huffman, lz77_method, custom_orders, histo_sets < 1 ? 1 : histo_sets, bctx_mode,
+                      quant_dc, &bctx, &global, &groups, used_acs, used_orders);
   if (!s) return -1;
+  if (bctx.size() > bctx_cap) return -2;
+  memcpy(bctx_out, bctx.data(), bctx.size());
+  *bctx_size = bctx.size();
   if (global.size() > global_cap) return -2;
   memcpy(global_out, global.data(), global.size());
   *global_size = global.size();
@@ -511,4 +542,29 @@ JXR_EXPORT int jxr_encode_ac(const jxo_frame* f, int force_huffman, int lz77_met
   }
   group_offsets[groups.size()] = pos;
   return 0;
+}
+
+// PassesSharedState::quant_dc as the reference's DequantDC computes it with the
+// test block-context map (compressed_dc.cc:251-295); quant_dc[3] in X, Y, B order.
+JXR_EXPORT int jxr_quant_dc_contexts(uint32_t xsb, uint32_t ysb, const int32_t* const quant_dc[3], uint8_t* out) {
+  Ref ref;
+  auto run = [&]() -> Status {
+    JXL_ASSIGN_OR_RETURN(Image3F dc, Image3F::Create(&ref.mm, xsb, ysb));
+    JXL_ASSIGN_OR_RETURN(Image im, Image::Create(&ref.mm, xsb, ysb, 32, 3));
+    for (size_t c = 0; c < 3; c++) {
+      const size_t src = c < 2 ? (c ^ 1) : c;  // modular channel order Y, X, B
+      for (size_t y = 0; y < ysb; y++) {
+        memcpy(im.channel[c].Row(y), quant_dc[src] + static_cast<size_t>(y) * xsb, xsb * sizeof(int32_t));
+      }
+    }
+    const float dc_factors[3] = {1.0f, 1.0f, 1.0f};
+    const float cfl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    BlockCtxMap bctx;
+    CustomBlockCtxMap(&bctx);
+    JXL_ASSIGN_OR_RETURN(ImageB qdc, ImageB::Create(&ref.mm, xsb, ysb));
+    DequantDC(Rect(0, 0, xsb, ysb), &dc, &qdc, im, dc_factors, 1.0f, cfl, YCbCrChromaSubsampling(), bctx);
+    for (size_t y = 0; y < ysb; y++) memcpy(out + y * xsb, qdc.ConstRow(y), xsb);
+    return true;
+  };
+  return run() ? 0 : -1;
 }

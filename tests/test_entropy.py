@@ -191,3 +191,68 @@ def test_lz77_token_streams(L, ref, oracle, method, huff):
         for g in range(6):
             n = nblk[g] * 64
             assert np.array_equal(out[c][g * 65536:g * 65536 + n], npy["coeffs"][c][g * 65536:g * 65536 + n]), (c, g)
+
+
+def test_block_ctx_map_and_dc_contexts(L, ref, oracle):
+    """A non-default BlockCtxMap (DC thresholds on X and Y, two quantization-field
+    thresholds, 11 block contexts): the map is read back from EncodeBlockCtxMap's
+    bytes, the per-block DC context equals what the reference's DequantDC computes,
+    and the AC streams coded under it round-trip."""
+    xs, ys = 520, 300
+    xsb, ysb = (xs + 7) // 8, (ys + 7) // 8
+    params, fr, npy = case(xs, ys, mix=synth.MIX_ALL, gab=False, epf_iters=0, seed=5)
+    rng = np.random.default_rng(9)
+    qdc3 = [rng.integers(-8, 8, size=(ysb, xsb)).astype(np.int32) for _ in range(3)]
+    want_ctx = oracle.ref_quant_dc_contexts(qdc3)
+    assert want_ctx.max() == 5 and want_ctx.min() == 0  # all 3 x 2 buckets occur
+    glob, groups, used_acs, _, bbytes = fr.encode_ac_ref(custom_block_ctx=True, quant_dc=want_ctx,
+                                                         want_block_ctx=True)
+    lib = abi.load_library()
+    m = abi.BlockCtxMap()
+    b = np.frombuffer(bbytes, np.uint8)
+    pos = C.c_size_t(0)
+    assert lib.jxlhip_block_ctx_map_decode(b.ctypes.data, len(b), C.byref(pos), C.byref(m)) == 0
+    assert (pos.value + 7) // 8 == len(b)
+    assert list(m.num_dc_thresholds) == [2, 1, 0] and list(m.dc_thresholds[0])[:2] == [-3, 2]
+    assert m.dc_thresholds[1][0] == 0 and m.num_dc_ctxs == 6
+    assert m.num_qf_thresholds == 2 and list(m.qf_thresholds)[:2] == [6, 14]
+    assert m.ctx_map_size == 3 * 13 * 6 * 3 and m.num_ctxs == 11
+    assert [m.ctx_map[i] for i in range(m.ctx_map_size)] == [(i * 7 + i // 13) % 11 for i in range(m.ctx_map_size)]
+    # DC contexts
+    got_ctx = np.zeros((ysb, xsb), np.uint8)
+    q3 = (C.c_void_p * 3)(*[q.ctypes.data for q in qdc3])
+    assert lib.jxlhip_quant_dc_contexts(C.byref(m), xsb * ysb, q3, got_ctx.ctypes.data) == 0
+    assert np.array_equal(got_ctx, want_ctx)
+    # AC round trip under the custom map
+    g = np.frombuffer(glob, np.uint8)
+    gpos, h = C.c_size_t(0), C.c_void_p()
+    assert lib.jxlhip_ac_pass_decode(g.ctypes.data, len(g), C.byref(gpos), used_acs, 1, C.byref(m), C.byref(h)) == 0
+    try:
+        out = [np.zeros(len(groups) * 65536, np.int16) for _ in range(3)]
+        xsg = (xs + 255) // 256
+        for gi, data in enumerate(groups):
+            d = np.frombuffer(data, np.uint8)
+            gp = C.c_size_t(0)
+            ptrs = (C.c_void_p * 3)(*[o[gi * 65536:].ctypes.data for o in out])
+            rc = lib.jxlhip_ac_group_decode(h, xsb, ysb, gi % xsg, gi // xsg, npy["ac_strategy"].ctypes.data,
+                                            npy["raw_quant"].ctypes.data, got_ctx.ctypes.data, d.ctypes.data, len(d),
+                                            C.byref(gp), 0, 0, ptrs, None)
+            assert rc == 0, (gi, rc)
+        for c in range(3):
+            assert np.array_equal(out[c], npy["coeffs"][c]), c
+    finally:
+        lib.jxlhip_ac_pass_destroy(h)
+
+
+def test_default_block_ctx_map_bytes(L, ref):
+    params, fr, npy = case(64, 64, mix=synth.MIX_DCT8, gab=False, epf_iters=0)
+    *_, bbytes = fr.encode_ac_ref(want_block_ctx=True)
+    lib = abi.load_library()
+    m = abi.BlockCtxMap()
+    b = np.frombuffer(bbytes, np.uint8)
+    pos = C.c_size_t(0)
+    assert lib.jxlhip_block_ctx_map_decode(b.ctypes.data, len(b), C.byref(pos), C.byref(m)) == 0
+    assert m.num_dc_ctxs == 1 and m.num_qf_thresholds == 0 and m.ctx_map_size == 39 and m.num_ctxs == 15
+    default = [0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14,
+               7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14]
+    assert [m.ctx_map[i] for i in range(39)] == default

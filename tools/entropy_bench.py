@@ -1,0 +1,38 @@
+"""Host AC entropy decoder throughput (include/jxl_hip_entropy.h): Mpixels/s per
+thread and with all cores, on streams written by the reference encoder.  CPU only."""
+import ctypes as C, os, sys, time, threading
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import frames, oracle
+from libjxl_amd import abi, synth
+
+xs, ys = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2048, 2048)
+params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=True, epf_iters=1)
+glob, groups, used_acs, _ = fr.encode_ac_ref()
+L = abi.load_library()
+acs = np.ascontiguousarray(t["ac_strategy"].numpy()); rq = np.ascontiguousarray(t["raw_quant"].numpy())
+g = np.frombuffer(glob, np.uint8); pos, h = C.c_size_t(0), C.c_void_p()
+assert L.jxlhip_ac_pass_decode(g.ctypes.data, len(g), C.byref(pos), used_acs, 1, None, C.byref(h)) == 0
+xsb, ysb, xsg = (xs + 7) // 8, (ys + 7) // 8, (xs + 255) // 256
+bufs = [np.frombuffer(x, np.uint8) for x in groups]
+total_bytes = sum(map(len, groups))
+
+def run(tid, nt, reps):
+    out = [np.zeros(65536, np.int16) for _ in range(3)]
+    ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in out])
+    for _ in range(reps):
+        for gi in range(tid, len(bufs), nt):
+            for o in out: o[:] = 0
+            gp = C.c_size_t(0)
+            rc = L.jxlhip_ac_group_decode(h, xsb, ysb, gi % xsg, gi // xsg, acs.ctypes.data, rq.ctypes.data, None,
+                                          bufs[gi].ctypes.data, len(bufs[gi]), C.byref(gp), 0, 0, ptrs, None)
+            assert rc == 0
+for nt in (1, os.cpu_count() or 1):
+    reps = 3
+    ths = [threading.Thread(target=run, args=(i, nt, reps)) for i in range(nt)]
+    t0 = time.perf_counter()
+    for th in ths: th.start()
+    for th in ths: th.join()
+    dt = (time.perf_counter() - t0) / reps
+    print(f"{xs}x{ys} d1.0-like, {total_bytes / (xs * ys) * 8:.2f} bpp AC: {nt} thread(s): {xs * ys / dt / 1e6:.1f} Mpx/s ({total_bytes / dt / 1e6:.1f} MB/s)")
