@@ -83,7 +83,10 @@ typedef enum {
  * lib/jxl/cms/transfer_functions-inl.h). */
 typedef enum jxlhip_transfer {
   JXLHIP_TF_LINEAR = 0, /* OpLinear: samples stay linear */
-  JXLHIP_TF_SRGB = 1    /* OpRgb: TF_SRGB::EncodedFromDisplay (JXL_HIGH_PRECISION) */
+  JXLHIP_TF_SRGB = 1,   /* OpRgb: TF_SRGB::EncodedFromDisplay (JXL_HIGH_PRECISION) */
+  JXLHIP_TF_PQ = 2,     /* OpPq: TF_PQ(tf_param = intensity target in nits)::EncodedFromDisplay */
+  JXLHIP_TF_709 = 3,    /* Op709: TF_709::EncodedFromDisplay */
+  JXLHIP_TF_GAMMA = 4   /* OpGamma: x <= 1e-5 ? 0 : FastPowf(x, tf_param = inverse gamma; DCI: 1/2.6) */
 } jxlhip_transfer;
 
 /* JxlDataType of the output buffer (include/jxl/types.h:40-60). */
@@ -102,6 +105,7 @@ typedef struct jxlhip_output_format {
   uint32_t num_channels;    /* 3 = RGB, 4 = RGBA (alpha = 1.0: the frame has no alpha channel) */
   uint32_t bits_per_sample; /* U8: 1..8, U16: 1..16; ignored for the float types */
   uint32_t swap_endianness; /* U16 / F16 / F32: byte-swap every sample (JXL_BIG_ENDIAN on this host) */
+  float tf_param;           /* PQ: OutputEncodingInfo::orig_intensity_target; GAMMA: inverse_gamma */
 } jxlhip_output_format;
 
 /* Mirrors jxl::LoopFilter (lib/jxl/loop_filter.h:20-70); values as decoded. */

@@ -28,11 +28,11 @@ class OutputFormat(C.Structure):
     """jxlhip_output_format: FromLinearStage + WriteToOutputStage parameters."""
     _fields_ = [("transfer", C.c_uint32), ("sample_type", C.c_uint32),
                 ("num_channels", C.c_uint32), ("bits_per_sample", C.c_uint32),
-                ("swap_endianness", C.c_uint32)]
+                ("swap_endianness", C.c_uint32), ("tf_param", C.c_float)]
 
 
 OUT_XYB_PLANAR, OUT_LINEAR_RGB_F32, OUT_PACKED = 0, 1, 2
-TF_LINEAR, TF_SRGB = 0, 1
+TF_LINEAR, TF_SRGB, TF_PQ, TF_709, TF_GAMMA = 0, 1, 2, 3, 4
 SAMPLE_F32, SAMPLE_U8, SAMPLE_U16, SAMPLE_F16 = 0, 1, 2, 3
 
 
@@ -96,6 +96,7 @@ def make_params(d):
         p.out_format.num_channels = of.get("num_channels", 3)
         p.out_format.bits_per_sample = of.get("bits_per_sample", 0)
         p.out_format.swap_endianness = of.get("swap_endianness", 0)
+        p.out_format.tf_param = of.get("tf_param", 0.0)
     return p
 
 

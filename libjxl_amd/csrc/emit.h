@@ -52,6 +52,53 @@ __device__ __forceinline__ float SrgbFromLinear(float v) {
   return __builtin_copysignf(mag, v);
 }
 
+// EvalRationalPolynomial of degree 4/4 (base/rational_polynomial-inl.h:59-97) with
+// the hardware reciprocal (see SrgbFromLinear)
+__device__ __forceinline__ float Rational44(float x, const float* p, const float* q) {
+  float yp = p[4], yq = q[4];
+#pragma unroll
+  for (int i = 3; i >= 0; i--) {
+    yp = __builtin_fmaf(yp, x, p[i]);
+    yq = __builtin_fmaf(yq, x, q[i]);
+  }
+  return yp * __builtin_amdgcn_rcpf(yq);
+}
+
+// TF_PQ::EncodedFromDisplay (transfer_functions-inl.h:172-208): rational
+// polynomials in x^(1/4), one below and one above 1e-4; `to_10000` =
+// intensity_target / 10000
+__device__ __forceinline__ float PqFromLinear(float v, float to_10000) {
+  const float kP[5] = {1.351392e-02f, -1.095778e+00f, 5.522776e+01f, 1.492516e+02f, 4.838434e+01f};
+  const float kQ[5] = {1.012416e+00f, 2.016708e+01f, 9.263710e+01f, 1.120607e+02f, 2.590418e+01f};
+  const float kPlo[5] = {9.863406e-06f, 3.881234e-01f, 1.352821e+02f, 6.889862e+04f, -2.864824e+05f};
+  const float kQlo[5] = {3.371868e+01f, 1.477719e+03f, 1.608477e+04f, -4.389884e+04f, -2.072546e+05f};
+  const float x = __builtin_fabsf(v);
+  const float r = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(x * to_10000));
+  const float mag = x < 1e-4f ? Rational44(r, kPlo, kQlo) : Rational44(r, kP, kQ);
+  return __builtin_copysignf(mag, v);
+}
+
+// TF_709::EncodedFromDisplay (transfer_functions-inl.h:104-111)
+__device__ __forceinline__ float Bt709FromLinear(float x) {
+  const float hi = __builtin_fmaf(1.099f, FastPowf(x, 0.45f), -0.099f);
+  return x <= 0.018f ? 4.5f * x : hi;
+}
+
+// OpGamma (stage_from_linear.cc:96-109)
+__device__ __forceinline__ float GammaFromLinear(float x, float inverse_gamma) {
+  return x <= 1e-5f ? 0.0f : FastPowf(x, inverse_gamma);
+}
+
+__device__ __forceinline__ float ApplyTransfer(uint32_t tf, float v, float tf_scale) {
+  switch (tf) {
+    case JXLHIP_TF_SRGB: return SrgbFromLinear(v);
+    case JXLHIP_TF_PQ: return PqFromLinear(v, tf_scale);
+    case JXLHIP_TF_709: return Bt709FromLinear(v);
+    case JXLHIP_TF_GAMMA: return GammaFromLinear(v, tf_scale);
+    default: return v;
+  }
+}
+
 // Output format as seen by the emit code: FmtSel<-1> reads it from the launch
 // parameters (wave-uniform branches per sample -- correct for every format, but
 // the scalar branches cost as much as the arithmetic); FmtSel<ID> with
@@ -62,7 +109,7 @@ __host__ __device__ constexpr int FormatId(int transfer, int sample_type, int ch
 }
 template <int ID>
 struct FmtSel {
-  static __device__ __forceinline__ uint32_t transfer(const jxlhip_output_format&) { return ID & 1; }
+  static __device__ __forceinline__ uint32_t transfer(const jxlhip_output_format&) { return ID & 1; }  // linear / sRGB
   static __device__ __forceinline__ uint32_t sample_type(const jxlhip_output_format&) { return (ID >> 1) & 3; }
   static __device__ __forceinline__ uint32_t channels(const jxlhip_output_format&) { return 3 + ((ID >> 3) & 1); }
 };
@@ -100,10 +147,10 @@ __device__ __forceinline__ void PackSamples(const FilterParams& P, DitherPtr dit
                                             const float* rgb, uint32_t* q) {
   const jxlhip_output_format& F = P.fmt;
   const uint32_t st = Sel::sample_type(F);
-  const bool srgb = Sel::transfer(F) == JXLHIP_TF_SRGB;
+  const uint32_t tf = Sel::transfer(F);
   float v[4];
 #pragma unroll
-  for (int c = 0; c < 3; c++) v[c] = srgb ? SrgbFromLinear(rgb[c]) : rgb[c];
+  for (int c = 0; c < 3; c++) v[c] = ApplyTransfer(tf, rgb[c], P.tf_scale);
   v[3] = 1.0f;
   if (st == JXLHIP_SAMPLE_U8) {
 #pragma unroll

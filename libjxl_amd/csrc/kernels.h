@@ -30,6 +30,7 @@ struct FilterParams {
   // JXLHIP_OUT_PACKED: FromLinearStage + WriteToOutputStage parameters
   jxlhip_output_format fmt;
   float sample_mul;         // 2^bits_per_sample - 1
+  float tf_scale;           // PQ: intensity_target / 10000; GAMMA: inverse gamma
   const float* dither;      // 32x32 pattern (device)
 };
 

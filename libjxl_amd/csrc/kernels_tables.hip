@@ -17,40 +17,6 @@ namespace devlib {
 __device__ const uint8_t dKindShort[17] = {1, 1, 1, 1, 2, 4, 1, 1, 2, 1, 1, 8, 4, 16, 8, 32, 16};
 __device__ const uint8_t dKindLong[17] = {1, 1, 1, 1, 2, 4, 2, 4, 4, 1, 1, 8, 8, 16, 16, 32, 32};
 
-__device__ float FastLog2f(float x) {
-  const float p0 = -1.8503833400518310E-06f, p1 = 1.4287160470083755E+00f,
-              p2 = 7.4245873327820566E-01f;
-  const float q0 = 9.9032814277590719E-01f, q1 = 1.0096718572241148E+00f,
-              q2 = 1.7409343003366853E-01f;
-  const int32_t x_bits = __float_as_int(x);
-  const int32_t exp_bits = x_bits - 0x3f2aaaab;
-  const int32_t exp_shifted = exp_bits >> 23;
-  const float mantissa = __int_as_float(x_bits - (int32_t)((uint32_t)exp_shifted << 23));
-  const float exp_val = (float)exp_shifted;
-  const float m = mantissa - 1.0f;
-  const float yp = __builtin_fmaf(__builtin_fmaf(p2, m, p1), m, p0);
-  const float yq = __builtin_fmaf(__builtin_fmaf(q2, m, q1), m, q0);
-  return yp / yq + exp_val;
-}
-
-__device__ float FastPow2f(float x) {
-  const float floorx = __builtin_floorf(x);
-  const float expf_ = __int_as_float(((int32_t)floorx + 127) << 23);
-  const float frac = x - floorx;
-  float num = frac + 1.01749063e+01f;
-  num = __builtin_fmaf(num, frac, 4.88687798e+01f);
-  num = __builtin_fmaf(num, frac, 9.85506591e+01f);
-  num = num * expf_;
-  float den = __builtin_fmaf(frac, 2.10242958e-01f, -2.22328856e-02f);
-  den = __builtin_fmaf(den, frac, -1.94414990e+01f);
-  den = __builtin_fmaf(den, frac, 9.85506633e+01f);
-  return num / den;
-}
-
-__device__ float FastPowf(float base, float exponent) {
-  return FastPow2f(FastLog2f(base) * exponent);
-}
-
 __device__ float Mult(float v) { return v > 0.0f ? 1.0f + v : 1.0f / (1.0f - v); }
 
 // distance-band weight of coefficient (y, x) of a rows x cols table

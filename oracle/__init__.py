@@ -38,7 +38,7 @@ class LoopFilter(C.Structure):
 class OutputFormat(C.Structure):
     _fields_ = [("transfer", C.c_uint32), ("sample_type", C.c_uint32),
                 ("num_channels", C.c_uint32), ("bits_per_sample", C.c_uint32),
-                ("swap_endianness", C.c_uint32)]
+                ("swap_endianness", C.c_uint32), ("tf_param", C.c_float)]
 
 
 class FrameParams(C.Structure):

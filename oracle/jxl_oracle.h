@@ -136,6 +136,9 @@ void jxo_xyb_to_linear_rgb(const jxo_frame* f, const float* const in[3],
  * out per p.output_kind.  Returns 0 on success. */
 /* FromLinearStage + WriteToOutputStage (output.c) for JXLHIP_OUT_PACKED */
 float jxo_srgb_from_linear(float v);
+float jxo_pq_from_linear(float v, float intensity_target);
+float jxo_709_from_linear(float x);
+float jxo_gamma_from_linear(float x, float inverse_gamma);
 void jxo_pack_output(const jxo_frame* f, const float* rgb, size_t rgb_stride, void* out,
                      size_t out_stride_bytes, uint32_t row_begin, uint32_t row_end);
 int jxo_decode_frame(const jxo_frame* f, float* out, size_t out_stride_floats,

@@ -29,6 +29,49 @@ float jxo_srgb_from_linear(float v) {
   return copysignf(mag, v);
 }
 
+static float rational44(float x, const float* p, const float* q) {
+  float yp = p[4], yq = q[4];
+  for (int i = 3; i >= 0; i--) {
+    yp = fmaf(yp, x, p[i]);
+    yq = fmaf(yq, x, q[i]);
+  }
+  return yp / yq;
+}
+
+/* TF_PQ::EncodedFromDisplay (transfer_functions-inl.h:172-208) */
+float jxo_pq_from_linear(float v, float intensity_target) {
+  static const float p[5] = {1.351392e-02f, -1.095778e+00f, 5.522776e+01f, 1.492516e+02f, 4.838434e+01f};
+  static const float q[5] = {1.012416e+00f, 2.016708e+01f, 9.263710e+01f, 1.120607e+02f, 2.590418e+01f};
+  static const float plo[5] = {9.863406e-06f, 3.881234e-01f, 1.352821e+02f, 6.889862e+04f, -2.864824e+05f};
+  static const float qlo[5] = {3.371868e+01f, 1.477719e+03f, 1.608477e+04f, -4.389884e+04f, -2.072546e+05f};
+  const float to_10000 = intensity_target * (1.0f / 10000.0f);
+  const float x = fabsf(v);
+  const float r = sqrtf(sqrtf(x * to_10000));
+  const float mag = x < 1e-4f ? rational44(r, plo, qlo) : rational44(r, p, q);
+  return copysignf(mag, v);
+}
+
+/* TF_709::EncodedFromDisplay (transfer_functions-inl.h:104-111) */
+float jxo_709_from_linear(float x) {
+  const float hi = fmaf(1.099f, jxo_fast_powf(x, 0.45f), -0.099f);
+  return x <= 0.018f ? 4.5f * x : hi;
+}
+
+/* OpGamma (stage_from_linear.cc:96-109) */
+float jxo_gamma_from_linear(float x, float inverse_gamma) {
+  return x <= 1e-5f ? 0.0f : jxo_fast_powf(x, inverse_gamma);
+}
+
+static float apply_tf(const jxlhip_output_format* F, float v) {
+  switch (F->transfer) {
+    case JXLHIP_TF_SRGB: return jxo_srgb_from_linear(v);
+    case JXLHIP_TF_PQ: return jxo_pq_from_linear(v, F->tf_param);
+    case JXLHIP_TF_709: return jxo_709_from_linear(v);
+    case JXLHIP_TF_GAMMA: return jxo_gamma_from_linear(v, F->tf_param);
+    default: return v;
+  }
+}
+
 /* IEEE binary16 bits of v, round to nearest even (hwy DemoteTo(float16)) */
 static uint16_t f16_bits(float v) {
   uint32_t u;
@@ -73,7 +116,7 @@ void jxo_pack_output(const jxo_frame* f, const float* rgb, size_t rgb_stride, vo
       float v[4];
       for (int c = 0; c < 3; c++) {
         const float lin = rgb[(size_t)y * rgb_stride + 3 * (size_t)x + c];
-        v[c] = F->transfer == JXLHIP_TF_SRGB ? jxo_srgb_from_linear(lin) : lin;
+        v[c] = apply_tf(F, lin);
       }
       v[3] = 1.0f;
       for (int c = 0; c < nc; c++) {

@@ -97,9 +97,17 @@ Status FillState(const jxo_frame* f, CodecMetadata* metadata, FrameHeader* fh,
   metadata->m.xyb_encoded = !xyb_out;
   // the output colour encoding decides which FromLinearStage op the reference adds
   // (dec_cache.cc:256-350, stage_from_linear.cc:159-185)
-  const bool srgb_tf = p.output_kind == JXLHIP_OUT_PACKED && p.out_format.transfer == JXLHIP_TF_SRGB;
-  metadata->m.color_encoding = srgb_tf ? ColorEncoding::SRGB(/*is_gray=*/false)
-                                       : ColorEncoding::LinearSRGB(/*is_gray=*/false);
+  const uint32_t tf = p.output_kind == JXLHIP_OUT_PACKED ? p.out_format.transfer : JXLHIP_TF_LINEAR;
+  metadata->m.color_encoding = tf == JXLHIP_TF_LINEAR ? ColorEncoding::LinearSRGB(/*is_gray=*/false)
+                                                      : ColorEncoding::SRGB(/*is_gray=*/false);
+  if (tf == JXLHIP_TF_PQ) {
+    metadata->m.color_encoding.Tf().SetTransferFunction(TransferFunction::kPQ);
+    metadata->m.SetIntensityTarget(p.out_format.tf_param);  // OutputEncodingInfo::orig_intensity_target
+  } else if (tf == JXLHIP_TF_709) {
+    metadata->m.color_encoding.Tf().SetTransferFunction(TransferFunction::k709);
+  } else if (tf == JXLHIP_TF_GAMMA) {
+    JXL_RETURN_IF_ERROR(metadata->m.color_encoding.Tf().SetGamma(p.out_format.tf_param));
+  }
   JXL_RETURN_IF_ERROR(metadata->size.Set(p.xsize, p.ysize));
 
   // ---- frame header: one VarDCT frame covering the image

@@ -256,3 +256,40 @@ def test_default_block_ctx_map_bytes(L, ref):
     default = [0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14,
                7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14]
     assert [m.ctx_map[i] for i in range(39)] == default
+
+
+def test_random_bytes_never_crash(L):
+    """Garbage in: every call returns (an error, almost always) without crashing,
+    hanging or writing outside the caller's buffers."""
+    rng = np.random.default_rng(123)
+    lib = abi.load_library()
+    acs = np.full((8, 8), 1, np.uint8)  # 64 DCT8 blocks
+    rq = np.full((8, 8), 5, np.int32)
+    ok_pass = 0
+    for it in range(300):
+        n = int(rng.integers(1, 400))
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        if it % 3 == 0:
+            data[: n // 2] = 0  # many zero bits: simple / default branches
+        pos, h = C.c_size_t(int(rng.integers(0, 8))), C.c_void_p()
+        rc = lib.jxlhip_ac_pass_decode(data.ctypes.data, n, C.byref(pos), 1, int(rng.integers(1, 4)), None,
+                                       C.byref(h))
+        assert rc in (0, BAD_STREAM)
+        if rc == 0:
+            ok_pass += 1
+            guard = np.full(3 * 65536 + 64, 0x5a5a, np.int16)
+            ptrs = (C.c_void_p * 3)(*[guard[32 + c * 65536:].ctypes.data for c in range(3)])
+            gp = C.c_size_t(0)
+            d2 = rng.integers(0, 256, 64, dtype=np.uint8)
+            rc2 = lib.jxlhip_ac_group_decode(h, 8, 8, 0, 0, acs.ctypes.data, rq.ctypes.data, None, d2.ctypes.data,
+                                             64, C.byref(gp), 0, 0, ptrs, None)
+            assert rc2 in (0, BAD_STREAM)
+            assert (guard[:32] == 0x5a5a).all() and (guard[-32:] == 0x5a5a).all()
+            # 64 DCT8 blocks use 64 * 64 slots per channel: nothing beyond them is touched
+            for c in range(3):
+                assert (guard[32 + c * 65536 + 4096: 32 + (c + 1) * 65536] == 0x5a5a).all()
+            lib.jxlhip_ac_pass_destroy(h)
+        m = abi.BlockCtxMap()
+        pos = C.c_size_t(0)
+        assert lib.jxlhip_block_ctx_map_decode(data.ctypes.data, n, C.byref(pos), C.byref(m)) in (0, BAD_STREAM)
+    assert ok_pass > 0  # some random headers do parse (one-symbol codes): the group path was exercised

@@ -164,6 +164,26 @@ def test_packed_float_srgb(dec, ref, st, sw):
     assert (g[..., 3] == 1.0).all()
 
 
+@pytest.mark.parametrize("tf,par,it", [(2, 1000.0, 1000.0), (3, 0.0, 255.0), (4, 1 / 2.6, 255.0)])
+@pytest.mark.parametrize("st,bits", [(1, 8), (2, 16), (0, 0)])
+def test_packed_pq_709_gamma(dec, ref, tf, par, it, st, bits):
+    """HDR / video transfer functions (PQ at 1000 nits, BT.709, DCI gamma) through the
+    kernels' general packed path."""
+    got, want = run_packed(dec, ref, 520, 264, dict(transfer=tf, sample_type=st, num_channels=3,
+                                                    bits_per_sample=bits, tf_param=par),
+                           mix=synth.MIX_D1, gab=True, epf_iters=1, intensity_target=it)
+    if st == 0:
+        # steep curves near zero (PQ: slope ~1e3 at 1e-4) amplify the float pipeline's 2e-5
+        assert float(np.abs(got - want).max()) <= 2e-3 * max(1.0, float(np.abs(want).max()))
+        assert float(np.abs(got - want).mean()) <= 2e-5
+    else:
+        if st == 2:
+            got, want = got.view(np.uint16), want.view(np.uint16)
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        assert d.max() <= (1 if st == 1 else 140)
+        assert (d > (0 if st == 1 else 8)).mean() < 2e-3
+
+
 def test_packed_8k_srgb_u8_rgba_full_size(dec, ref):
     """The bench workload with djxl's default output: 7680x4320 d1.0 -> sRGB RGBA8."""
     got, want = run_packed(dec, ref, 7680, 4320, dict(transfer=1, sample_type=1, num_channels=4, bits_per_sample=8),

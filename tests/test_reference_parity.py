@@ -122,6 +122,20 @@ PACKED_FORMATS = [
 ]
 
 
+@pytest.mark.parametrize("tf,par,it", [(2, 1000.0, 1000.0), (2, 255.0, 255.0), (3, 0.0, 255.0), (4, 1 / 2.6, 255.0),
+                                       (4, 0.45455, 80.0)])
+@pytest.mark.parametrize("st,bits_", [(1, 8), (2, 16), (0, 0)])
+def test_packed_output_pq_709_gamma(ref, tf, par, it, st, bits_):
+    """FromLinearStage's OpPq (two rational polynomials in x^(1/4)), Op709 and OpGamma
+    (FastPowf) followed by the write stage: restatement == reference, byte for byte."""
+    _, _, fr = frames.make_case(264, 136, mix=synth.MIX_D1, gab=True, epf_iters=1, output_kind=2,
+                                intensity_target=it, seed=23,
+                                out_format=dict(transfer=tf, sample_type=st, num_channels=3, bits_per_sample=bits_,
+                                                tf_param=par))
+    o, r = fr.decode(threads=2), fr.decode_ref(threads=2)
+    assert np.array_equal(o.view(np.uint8), r.view(np.uint8))
+
+
 @pytest.mark.parametrize("tf,st,bits_,nc,sw", PACKED_FORMATS)
 def test_packed_output_stages(ref, tf, st, bits_, nc, sw):
     """f3: FromLinearStage (TF_SRGB) + WriteToOutputStage (scale, ordered dither,
