@@ -29,10 +29,11 @@ def run(tid, nt, reps):
                                           bufs[gi].ctypes.data, len(bufs[gi]), C.byref(gp), 0, 0, ptrs, None)
             assert rc == 0
 for nt in (1, os.cpu_count() or 1):
-    reps = 3
-    ths = [threading.Thread(target=run, args=(i, nt, reps)) for i in range(nt)]
-    t0 = time.perf_counter()
-    for th in ths: th.start()
-    for th in ths: th.join()
-    dt = (time.perf_counter() - t0) / reps
+    reps, dt = 2, 1e9
+    for trial in range(5):  # best of 5: the build container's cores are shared
+        ths = [threading.Thread(target=run, args=(i, nt, reps)) for i in range(nt)]
+        t0 = time.perf_counter()
+        for th in ths: th.start()
+        for th in ths: th.join()
+        dt = min(dt, (time.perf_counter() - t0) / reps)
     print(f"{xs}x{ys} d1.0-like, {total_bytes / (xs * ys) * 8:.2f} bpp AC: {nt} thread(s): {xs * ys / dt / 1e6:.1f} Mpx/s ({total_bytes / dt / 1e6:.1f} MB/s)")
