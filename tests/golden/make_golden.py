@@ -4,7 +4,10 @@ jxlhip_frame_inputs layout) together with the outputs of the libjxl REFERENCE
 run in this container (oracle/_ref: lib/jxl's decoder sources compiled in place,
 oracle/build_ref.py + oracle/ref_driver.cc): `rgb` = final linear RGB of the
 full path, `xyb` = the planes after dequant + inverse transforms (the reference
-run with the filters off and XYB output).  `sigma` comes from the oracle
+run with the filters off and XYB output), `srgb8` = the same frame through the
+reference's FromLinearStage (sRGB) + WriteToOutputStage as RGBA8, and
+`ac_global` / `ac_groups` / `ac_offsets` / `ac_used_acs` = the frame's AC
+coefficients as entropy-coded by the reference's own encoder (f1 test vectors).  `sigma` comes from the oracle
 (ComputeSigma has no output tap in the reference; it is covered through `rgb`).
 main() also asserts that the CPU oracle reproduces the reference bit for bit.
 Re-run only on purpose:  python tests/golden/make_golden.py"""
@@ -46,25 +49,37 @@ def build(name):
     return params, out
 
 
+SRGB8 = dict(transfer=1, sample_type=1, num_channels=4, bits_per_sample=8)
+
+
 def reference_outputs(name):
-    """rgb and (cropped) xyb planes by the reference itself."""
+    """rgb, (cropped) xyb planes, sRGB RGBA8 and AC entropy streams by the reference itself."""
     xs, ys, kw = CASES[name]
     _, _, fr = frames.make_case(xs, ys, **kw)
     rgb = fr.decode_ref(threads=1)
     kw1 = dict(kw, gab=False, epf_iters=0, output_kind=0)
     _, _, fr1 = frames.make_case(xs, ys, **kw1)
-    return rgb, fr1.decode_ref(threads=1)
+    _, _, fr2 = frames.make_case(xs, ys, **dict(kw, output_kind=2, out_format=SRGB8))
+    srgb8 = fr2.decode_ref(threads=1)
+    assert np.array_equal(srgb8, fr2.decode(threads=1)), "oracle != reference (srgb8)"
+    glob, groups, used_acs, _ = fr.encode_ac_ref()
+    ac = dict(ac_global=np.frombuffer(glob, np.uint8), ac_groups=np.frombuffer(b"".join(groups), np.uint8),
+              ac_offsets=np.cumsum([0] + [len(g) for g in groups]).astype(np.int64),
+              ac_used_acs=np.array([used_acs], np.uint32))
+    return rgb, fr1.decode_ref(threads=1), srgb8, ac
 
 
 def main():
     for name in CASES:
         params, out = build(name)
         xs, ys, _ = CASES[name]
-        rgb, xyb = reference_outputs(name)
+        rgb, xyb, srgb8, ac = reference_outputs(name)
         assert np.array_equal(rgb.view(np.uint32), out["rgb"].view(np.uint32)), "oracle != reference (rgb)"
         assert np.array_equal(xyb.view(np.uint32), out["xyb"][:, :ys, :xs].view(np.uint32)), \
             "oracle != reference (xyb)"
         out["rgb"] = rgb  # the committed vector is the reference's own output
+        out["srgb8"] = srgb8
+        out.update(ac)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         h = hashlib.sha256(out["rgb"].tobytes()).hexdigest()[:16]
         print(name, {k: v.shape for k, v in out.items() if k in ("coeffs", "rgb")}, "rgb sha", h)
