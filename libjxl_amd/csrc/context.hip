@@ -710,7 +710,7 @@ int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint3
   return JXLHIP_OK;
 }
 
-int BeginDecode(jxlhip_ctx* c) {
+int BeginDecode(jxlhip_ctx* c, uint32_t nbands) {
   if (!c->have_frame || !c->have_inputs)
     return Fail(c, JXLHIP_ERR_STATE, "decode needs frame_begin + inputs");
   HIPCHK(c, hipSetDevice(c->device));
@@ -724,7 +724,8 @@ int BeginDecode(jxlhip_ctx* c) {
       c->pool_dirty[i] = false;
     }
   }
-  HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kCountStride * kMaxBands, st));
+  if (nbands > (uint32_t)kMaxBands) nbands = kMaxBands;
+  HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kCountStride * nbands, st));
   return JXLHIP_OK;
 }
 
@@ -751,7 +752,7 @@ int CheckOutArgs(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_s
 
 int jxlhip_decode_blocks(jxlhip_ctx* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
-  int rc = BeginDecode(c);
+  int rc = BeginDecode(c, 1);
   if (rc) return rc;
   rc = LaunchBlocksBand(c, c->f.group_y0, c->f.group_y0 + c->f.group_rows, 0);
   if (rc) return rc;
@@ -807,23 +808,24 @@ int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t ou
   return LaunchFiltersRows(c, fp, c->f.y0, c->f.y1);
 }
 
-// Both phases.  The stripe is walked in bands of `band_rows` group rows:
-// blocks(b) then filters(b-1), so that the XYB planes of a band are consumed
-// while they are still resident in the 256 MB Infinity Cache instead of making
-// a round trip through HBM (JXLHIP_BAND_ROWS, 0 = one band).
+// Both phases.  With JXLHIP_BAND_ROWS = n > 0 the stripe is walked in bands of n
+// group rows -- blocks(b) then filters(b-1) -- which was meant to keep a band's
+// XYB planes in the 256 MB Infinity Cache; measured on MI355X it only loses
+// time, so the default is one band = the whole stripe.
 int jxlhip_decode_frame(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
-  int rc = BeginDecode(c);
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "decode needs frame_begin + inputs");
+  const DevFrame& f = c->f;
+  uint32_t br = c->band_rows ? (uint32_t)c->band_rows : f.group_rows;
+  while ((f.group_rows + br - 1) / br > (uint32_t)kMaxBands) br++;
+  int rc = BeginDecode(c, (f.group_rows + br - 1) / br);
   if (rc) return rc;
   rc = CheckOutArgs(c, out, out_stride, out_plane_stride);
   if (rc) return rc;
-  const DevFrame& f = c->f;
   FilterParams fp = c->fp;
   fp.out = out;
   fp.out_stride = out_stride;
   fp.out_plane_stride = out_plane_stride;
-  uint32_t br = c->band_rows ? (uint32_t)c->band_rows : f.group_rows;
-  while ((f.group_rows + br - 1) / br > (uint32_t)kMaxBands) br++;
   const uint32_t g_end = f.group_y0 + f.group_rows;
   uint32_t prev_y0 = f.y0;
   int band = 0;

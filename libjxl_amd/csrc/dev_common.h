@@ -48,9 +48,12 @@ enum WorkClass : int {
   kClsLarge = kClsMedium0 + kNumMedium,      // 21..26 (any side >= 128)
   kNumClasses = kClsLarge + 1
 };
-// counter block of one band: [0, kNumClasses) list lengths
-static constexpr int kCountStride = 32;
-static_assert(kNumClasses <= kCountStride, "counter block layout");
+// counter block of one band: the list length of class c lives at
+// count[c * kCounterPad] -- one 128-byte line per counter, so that the ~20
+// atomics every k_prepare workgroup issues do not all serialise on one line
+static constexpr int kCounterPad = 32;
+static constexpr int kCountStride = 32 * kCounterPad;
+static_assert(kNumClasses <= 32, "counter block layout");
 static constexpr uint8_t kSpecialStrategy[kNumSpecial] = {1, 2, 3, 12, 13, 14, 15, 16, 17};
 // medium class index -> strategy (16x8 .. 64x64)
 static constexpr uint8_t kMediumStrategy[kNumMedium] = {6, 7, 4, 8, 9, 10, 11, 5, 18, 19, 20};

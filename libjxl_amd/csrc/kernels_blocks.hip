@@ -45,6 +45,13 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   const uint32_t by = valid ? tid / gw : 0, bx = valid ? tid % gw : 0;
   const uint32_t aby = by0 + by, abx = bx0 + bx;
   const uint32_t raw = valid ? f.acs[(size_t)aby * f.xsb + abx] : 0;
+  // side info of the cell, fetched up front: these loads overlap the scan
+  // instead of starting after the two barriers
+  const size_t cell = (size_t)aby * f.xsb + abx;
+  const size_t tile = (size_t)(aby >> 3) * f.xtiles + (abx >> 3);
+  const int cell_q = valid ? f.raw_quant[cell] : 1;
+  const uint32_t cell_cfl = valid ? (((uint32_t)(uint8_t)f.ytox[tile] << 16) | ((uint32_t)(uint8_t)f.ytob[tile] << 24)) : 0;
+  const uint32_t cell_sharp = (with_sigma && valid) ? f.sharp[cell] : 0;
   bool first = raw & 1;
   uint32_t s = raw >> 1;
   bool bad = false;
@@ -96,13 +103,12 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     uint32_t n = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) n += wave_cls[w][tid];
-    wg_base[tid] = (n && in_stripe && group_ok) ? atomicAdd(&wl.count[tid], n) : 0;
+    wg_base[tid] = (n && in_stripe && group_ok) ? atomicAdd(&wl.count[tid * kCounterPad], n) : 0;
   }
   // sigma_quant of each varblock, scattered to the cells it covers
   if (with_sigma && first) {
     const float kInvSigmaNum = -1.1715728752538099024f;
-    const int q = f.raw_quant[(size_t)aby * f.xsb + abx];
-    const float sigma_quant = epf_quant_mul / (f.quant_scale * (float)q * kInvSigmaNum);
+    const float sigma_quant = epf_quant_mul / (f.quant_scale * (float)cell_q * kInvSigmaNum);
     for (uint32_t iy = 0; iy < cy; iy++)
       for (uint32_t ix = 0; ix < cx; ix++) cell_sq[(by + iy) * gw + bx + ix] = sigma_quant;
   }
@@ -113,18 +119,15 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     WorkItem it;
     it.pos = (aby << 16) | abx;
     it.off = g * 1024u + off64;
-    const size_t tile = (size_t)(aby >> 3) * f.xtiles + (abx >> 3);
-    it.qc = ((uint32_t)f.raw_quant[(size_t)aby * f.xsb + abx] & 0xffffu) |
-            ((uint32_t)(uint8_t)f.ytox[tile] << 16) | ((uint32_t)(uint8_t)f.ytob[tile] << 24);
+    it.qc = ((uint32_t)cell_q & 0xffffu) | cell_cfl;
     it.pad = 0;
     wl.list[cls][pos] = it;
   }
   // ComputeSigma (epf.cc:69-79), one cell per thread
   if (with_sigma && valid) {
-    const size_t i = (size_t)aby * f.xsb + abx;
-    float sigma = cell_sq[tid] * lut.v[f.sharp[i] & 7];
+    float sigma = cell_sq[tid] * lut.v[cell_sharp & 7];
     sigma = sigma < -1e-4f ? sigma : -1e-4f;
-    f.inv_sigma[i] = 1.0f / sigma;
+    f.inv_sigma[cell] = 1.0f / sigma;
   }
 }
 
@@ -1055,7 +1058,7 @@ __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const 
                                              Body&& body) {
   uint32_t cnt[N];
 #pragma unroll
-  for (int i = 0; i < N; i++) cnt[i] = wl.count[fam[i].cls];
+  for (int i = 0; i < N; i++) cnt[i] = wl.count[fam[i].cls * kCounterPad];
   const UnitPick pick = PickUnit(fam, cnt, blockIdx.x);
   if (pick.index < 0) return;
   body(pick.index, wl.list[pick.cls], pick.first, pick.n);
@@ -1112,7 +1115,7 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
                      wl);
   if (cells >= 256)
     hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, streams[2 % nstreams], f,
-                       wl.list[kClsLarge], wl.count + kClsLarge, wc, resample);
+                       wl.list[kClsLarge], wl.count + kClsLarge * kCounterPad, wc, resample);
 }
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
