@@ -363,3 +363,62 @@ def ref_quant_dc_contexts(quant_dc):
 
 
 Frame.encode_ac_ref = _encode_ac_ref
+
+
+class RealStream:
+    """A genuine VarDCT codestream written by the REFERENCE's own encoder
+    (jxl::EncodeFrame on a procedural image, oracle/ref_real_stream.cc), the
+    reference FrameDecoder's pixels for it, and the inputs of the product's
+    boundary lifted from that decoder's PassesSharedState.  Test infrastructure."""
+
+    _WHAT = dict(codestream=(0, np.uint8), ac_strategy=(1, np.uint8), raw_quant=(2, np.int32),
+                 epf_sharpness=(3, np.uint8), ytox_map=(4, np.int8), ytob_map=(5, np.int8),
+                 dc_x=(6, np.float32), dc_y=(7, np.float32), dc_b=(8, np.float32), quant_dc=(9, np.uint8),
+                 block_ctx_bytes=(10, np.uint8), rgb=(11, np.float32), section_offset=(12, np.uint64),
+                 section_size=(13, np.uint64), params=(14, np.uint8), dequant_table=(15, np.float32))
+
+    def __init__(self, xsize, ysize, seed=1, distance=1.0, speed_tier=3, epf=-1):
+        L = ref_lib()
+        L.jxr_real_case_create.restype = C.c_void_p
+        L.jxr_real_case_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int]
+        L.jxr_real_case_destroy.argtypes = [C.c_void_p]
+        L.jxr_real_case_data.restype = C.c_void_p
+        L.jxr_real_case_data.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+        L.jxr_real_case_info.restype = C.c_uint64
+        L.jxr_real_case_info.argtypes = [C.c_void_p, C.c_int]
+        h = L.jxr_real_case_create(xsize, ysize, seed, distance, speed_tier, epf)
+        if not h:
+            raise ValueError("reference encode/decode failed")
+        try:
+            for name, (what, dt) in self._WHAT.items():
+                n = C.c_size_t(0)
+                p = L.jxr_real_case_data(h, what, C.byref(n))
+                a = np.frombuffer(C.string_at(p, n.value), dt).copy() if n.value else np.zeros(0, dt)
+                setattr(self, name, a)
+            (self.num_groups, self.num_dc_groups, self.num_histograms, self.used_acs, self.frame_offset,
+             self.sections_offset) = [int(L.jxr_real_case_info(h, i)) for i in range(6)]
+        finally:
+            L.jxr_real_case_destroy(h)
+        self.xsize, self.ysize = xsize, ysize
+        xsb, ysb = (xsize + 7) // 8, (ysize + 7) // 8
+        for name in ("ac_strategy", "raw_quant", "epf_sharpness", "dc_x", "dc_y", "dc_b", "quant_dc"):
+            setattr(self, name, getattr(self, name).reshape(ysb, xsb))
+        self.rgb = self.rgb.reshape(ysize, xsize, 3)
+        self.frame_params = FrameParams.from_buffer_copy(self.params.tobytes())
+
+    def section(self, logical_id):
+        """Bytes of TOC section `logical_id` (0 = DC global, 1.. = DC groups, then AC
+        global, then one per AC group: frame_header.h / dec_frame.cc:655-705)."""
+        o, n = int(self.section_offset[logical_id]), int(self.section_size[logical_id])
+        return self.codestream[o:o + n].tobytes()
+
+    def ac_global(self):
+        return self.section(1 + self.num_dc_groups)
+
+    def ac_group(self, g):
+        return self.section(2 + self.num_dc_groups + g)
+
+    def frame(self, coeffs):
+        """An oracle Frame over this stream's side info and the given coefficient buffers."""
+        return Frame(self.frame_params, coeffs, self.ac_strategy, self.raw_quant, self.epf_sharpness,
+                     self.ytox_map, self.ytob_map, [self.dc_x, self.dc_y, self.dc_b], self.dequant_table)

@@ -31,11 +31,6 @@ FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fno-lto", "-ffunction-sections", "-fdat
 SKIP = re.compile(r"(decode\.cc|decode_to_jpeg\.cc|jpeg/|icc_codec\.cc|_test\.cc|_gbench\.cc|test_)")
 
 
-ENC_ENTROPY = ["enc_ans.cc", "enc_ans_simd.cc", "enc_bit_writer.cc", "enc_cluster.cc", "enc_context_map.cc",
-               "enc_huffman.cc", "enc_huffman_tree.cc", "enc_lz77.cc", "enc_entropy_coder.cc", "enc_coeff_order.cc",
-               "enc_aux_out.cc", "enc_fields.cc"]
-
-
 def source_list():
     txt = open(os.path.join(REF, "lib", "jxl_lists.cmake")).read()
 
@@ -43,9 +38,10 @@ def source_list():
         m = re.search(r"set\(%s\n(.*?)\n\)" % name, txt, re.S)
         return m.group(1).split()
     files = lst("JPEGXL_INTERNAL_BASE_SOURCES") + lst("JPEGXL_INTERNAL_DEC_SOURCES")
-    # the entropy-ENCODER translation units: tests/test_entropy.py lets the reference
-    # write authentic AC streams for the product's host entropy decoder (f1)
-    files += ["jxl/" + f for f in ENC_ENTROPY]
+    # the ENCODER translation units: the tests let the reference write authentic AC
+    # streams for the product's host entropy decoder (f1, tests/test_entropy.py) and whole
+    # VarDCT codestreams of natural-looking images (tests/test_real_streams.py)
+    files += [f for f in lst("JPEGXL_INTERNAL_ENC_SOURCES") if f not in files]
     return [f for f in files if f.endswith(".cc") and not SKIP.search(f)]
 
 
@@ -74,7 +70,8 @@ def build(verbose=False, only_compile=False):
     for f in source_list():
         jobs.append((os.path.join(REF, "lib", f), os.path.join(OBJ, f.replace("/", "__")[:-3] + ".o")))
     if not only_compile:
-        jobs.append((os.path.join(HERE, "ref_driver.cc"), os.path.join(OBJ, "ref_driver.o")))
+        for drv in ("ref_driver", "ref_real_stream"):
+            jobs.append((os.path.join(HERE, drv + ".cc"), os.path.join(OBJ, drv + ".o")))
     objs, failed = [], []
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         for (src, _), (obj, err) in zip(jobs, ex.map(_compile, jobs)):

@@ -1,0 +1,377 @@
+// ref_real_stream.cc -- TEST INFRASTRUCTURE (oracle/_ref).  A whole libjxl round trip
+// on natural-looking content, with taps at the product's C-ABI boundary:
+//   1. a procedural float image -> the reference ENCODER (EncodeFrame: adaptive
+//      quantization, AC-strategy search, chroma-from-luma, EPF sharpness, coefficient
+//      orders, ANS) -> a genuine VarDCT codestream;
+//   2. the reference DECODER (FrameDecoder) decodes it to linear float RGB;
+//   3. everything the back-end's boundary takes is dumped from the decoder's state
+//      (PassesSharedState / PassesDecoderState / FrameHeader) together with the byte
+//      ranges of the AC-global and AC-group sections (TOC).
+// The product then entropy-decodes the REAL AC sections (include/jxl_hip_entropy.h) and
+// renders them (C oracle on the CPU, HIP kernels on the GPU); the pixels must match
+// step 2.  Nothing here is shipped or measured.
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "lib/jxl/ac_strategy.h"
+#include "lib/jxl/base/status.h"
+#include "lib/jxl/chroma_from_luma.h"
+#include "lib/jxl/color_encoding_internal.h"
+#include "lib/jxl/dec_bit_reader.h"
+#include "lib/jxl/dec_cache.h"
+#include "lib/jxl/dec_frame.h"
+#include "lib/jxl/enc_aux_out.h"
+#include "lib/jxl/enc_bit_writer.h"
+#include "lib/jxl/enc_context_map.h"
+#include "lib/jxl/enc_fields.h"
+#include "lib/jxl/enc_frame.h"
+#include "lib/jxl/enc_params.h"
+#include "lib/jxl/frame_header.h"
+#include "lib/jxl/image.h"
+#include "lib/jxl/image_bundle.h"
+#include "lib/jxl/image_metadata.h"
+#include "lib/jxl/memory_manager_internal.h"
+#include "lib/jxl/passes_state.h"
+#include "lib/jxl/quantizer.h"
+
+#include "jxl_oracle.h"
+
+#include <brotli/encode.h>
+
+#include <jxl/cms.h>
+
+#include "lib/jxl/enc_icc_codec.h"
+#include "lib/jxl/jpeg/enc_jpeg_data.h"
+#include "lib/jxl/jpeg/jpeg_data.h"
+
+#define JXR_EXPORT extern "C" __attribute__((visibility("default")))
+
+// Link-time stand-ins for code paths the oracle never takes (see hwy_shim/brotli/encode.h;
+// JPEG transcoding lives in lib/jxl/jpeg/, which is not part of this build).
+extern "C" {
+BrotliEncoderState* BrotliEncoderCreateInstance(brotli_alloc_func, brotli_free_func, void*) { return nullptr; }
+void BrotliEncoderDestroyInstance(BrotliEncoderState*) {}
+BROTLI_BOOL BrotliEncoderSetParameter(BrotliEncoderState*, BrotliEncoderParameter, uint32_t) { return BROTLI_FALSE; }
+BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState*, BrotliEncoderOperation, size_t*, const uint8_t**,
+                                        size_t*, uint8_t**, size_t*) { return BROTLI_FALSE; }
+BROTLI_BOOL BrotliEncoderIsFinished(BrotliEncoderState*) { return BROTLI_TRUE; }
+size_t BrotliEncoderMaxCompressedSize(size_t n) { return n + 1024; }
+}
+extern "C" const JxlCmsInterface* JxlGetDefaultCms() { return nullptr; }
+namespace jxl {
+Status WriteICC(Span<const uint8_t>, BitWriter* JXL_RESTRICT, LayerType, AuxOut* JXL_RESTRICT) {
+  return JXL_FAILURE("ICC profiles are not part of the oracle build");
+}
+namespace jpeg {
+Status EncodeJPEGData(JxlMemoryManager*, JPEGData&, std::vector<uint8_t>*, const CompressParams&) {
+  return JXL_FAILURE("JPEG transcoding is not part of the oracle build");
+}
+Status SetColorEncodingFromJpegData(const jpeg::JPEGData&, ColorEncoding*) {
+  return JXL_FAILURE("JPEG transcoding is not part of the oracle build");
+}
+StatusOr<std::unique_ptr<JPEGData>> ParseJPG(JxlMemoryManager*, Bytes) {
+  return JXL_FAILURE("JPEG transcoding is not part of the oracle build");
+}
+Status SetBlobsFromJpegData(const jpeg::JPEGData&, Blobs*) {
+  return JXL_FAILURE("JPEG transcoding is not part of the oracle build");
+}
+Status SetChromaSubsamplingFromJpegData(const JPEGData&, YCbCrChromaSubsampling*) {
+  return JXL_FAILURE("JPEG transcoding is not part of the oracle build");
+}
+Status SetColorTransformFromJpegData(const JPEGData&, ColorTransform*) {
+  return JXL_FAILURE("JPEG transcoding is not part of the oracle build");
+}
+}  // namespace jpeg
+}  // namespace jxl
+
+namespace {
+using namespace jxl;  // NOLINT
+
+// one frame's worth of results, owned by the handle
+struct RealCase {
+  std::vector<uint8_t> codestream;
+  size_t frame_offset = 0;    // first byte of the frame (header + TOC + sections)
+  size_t sections_offset = 0; // first byte of the first section
+  std::vector<uint64_t> section_offset, section_size;  // indexed by logical section id
+  uint32_t xsize = 0, ysize = 0, num_groups = 0, num_dc_groups = 0, num_histograms = 0, used_acs = 0;
+  jxlhip_frame_params params{};
+  std::vector<uint8_t> acs, sharp, quant_dc, bctx_bytes;
+  std::vector<int32_t> raw_quant;
+  std::vector<int8_t> ytox, ytob;
+  std::vector<float> dc[3];
+  std::vector<float> rgb;     // reference decoder output, interleaved linear RGB
+  std::vector<float> dequant; // the frame's DequantMatrices table (JXLHIP_DEQUANT_TABLE_FLOATS)
+};
+
+// dark gradient + textured disc + noise patch + sharp edges (after test_image.cc's GetSomeTestImage)
+void FillImage(Image3F* img, uint32_t seed) {
+  const size_t xs = img->xsize(), ys = img->ysize();
+  uint32_t s = seed * 2654435761u + 12345u;
+  auto rnd = [&]() {
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return (s & 0xffffff) / 16777216.0f;
+  };
+  float c0[3], c1[3];
+  for (int c = 0; c < 3; c++) {
+    c0[c] = 0.02f + 0.25f * rnd();
+    c1[c] = 0.15f + 0.6f * rnd();
+  }
+  const float cx = xs * (0.3f + 0.4f * rnd()), cy = ys * (0.3f + 0.4f * rnd());
+  const float rad = 0.28f * std::min(xs, ys);
+  for (size_t y = 0; y < ys; y++) {
+    float* rows[3] = {img->PlaneRow(0, y), img->PlaneRow(1, y), img->PlaneRow(2, y)};
+    for (size_t x = 0; x < xs; x++) {
+      const float t = static_cast<float>(y) / ys, u = static_cast<float>(x) / xs;
+      float v[3];
+      for (int c = 0; c < 3; c++) v[c] = c0[c] + (c1[c] - c0[c]) * (0.7f * t + 0.3f * u);
+      const float dx = x - cx, dy = y - cy;
+      if (dx * dx + dy * dy < rad * rad) {  // textured disc
+        const float tex = 0.5f + 0.5f * std::sin(0.11f * x) * std::cos(0.07f * y + 0.013f * x);
+        v[0] = 0.55f * tex + 0.1f;
+        v[1] = 0.35f + 0.3f * tex * t;
+        v[2] = 0.2f + 0.5f * (1.0f - tex);
+      }
+      if (x > xs * 0.62f && x < xs * 0.93f && y > ys * 0.12f && y < ys * 0.38f) {  // noise patch
+        for (int c = 0; c < 3; c++) v[c] = 0.15f + 0.5f * rnd();
+      }
+      if ((x / 24 + y / 24) % 7 == 0 && y > ys * 0.7f) {  // checker edges
+        for (int c = 0; c < 3; c++) v[c] = 0.9f - v[c] * 0.5f;
+      }
+      for (int c = 0; c < 3; c++) rows[c][x] = v[c];
+    }
+  }
+}
+
+Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_tier, int epf, RealCase* out) {
+  JxlMemoryManager mm;
+  JXL_RETURN_IF_ERROR(MemoryManagerInit(&mm, nullptr));
+  // ---- 1. encode
+  CodecMetadata metadata;
+  metadata.m.SetFloat32Samples();
+  metadata.m.xyb_encoded = true;
+  metadata.m.color_encoding = ColorEncoding::LinearSRGB(/*is_gray=*/false);
+  JXL_RETURN_IF_ERROR(metadata.size.Set(xs, ys));
+  ImageBundle ib(&mm, &metadata.m);
+  {
+    JXL_ASSIGN_OR_RETURN(Image3F img, Image3F::Create(&mm, xs, ys));
+    FillImage(&img, seed);
+    JXL_RETURN_IF_ERROR(ib.SetFromImage(std::move(img), metadata.m.color_encoding));
+  }
+  CompressParams cparams;
+  cparams.butteraugli_distance = distance;
+  cparams.speed_tier = static_cast<SpeedTier>(speed_tier);
+  cparams.patches = Override::kOff;
+  cparams.dots = Override::kOff;
+  cparams.noise = Override::kOff;
+  cparams.epf = epf;  // -1 = the encoder's choice
+  cparams.color_transform = ColorTransform::kXYB;
+  JXL_RETURN_IF_ERROR(ParamsPostInit(&cparams));
+  BitWriter writer{&mm};
+  JXL_RETURN_IF_ERROR(WriteCodestreamHeaders(&metadata, &writer, nullptr));
+  JXL_RETURN_IF_ERROR(writer.WithMaxBits(8, LayerType::Header, nullptr, [&] {
+    writer.ZeroPadToByte();
+    return true;
+  }));
+  out->frame_offset = writer.BitsWritten() / 8;
+  FrameInfo info;
+  info.is_last = true;
+  JxlCmsInterface no_cms{};  // never used: the input already is linear sRGB
+  JXL_RETURN_IF_ERROR(EncodeFrame(&mm, cparams, info, &metadata, ib, no_cms, nullptr, &writer, nullptr));
+  {
+    PaddedBytes bytes = std::move(writer).TakeBytes();
+    out->codestream.assign(bytes.data(), bytes.data() + bytes.size());
+  }
+
+  // ---- 2. decode with the reference's FrameDecoder (the body of jxl::DecodeFrame, dec_frame.cc:82-133)
+  auto dec_state = jxl::make_unique<PassesDecoderState>(&mm);
+  JXL_RETURN_IF_ERROR(dec_state->output_encoding_info.SetFromMetadata(metadata));
+  out->rgb.assign(static_cast<size_t>(xs) * ys * 3, 0.0f);
+  ImageBundle decoded(&mm, &metadata.m);
+  FrameDecoder fd(dec_state.get(), metadata, nullptr, /*use_slow_rendering_pipeline=*/false);
+  const uint8_t* in = out->codestream.data() + out->frame_offset;
+  const size_t avail = out->codestream.size() - out->frame_offset;
+  BitReader reader(Bytes(in, avail));
+  JXL_RETURN_IF_ERROR(fd.InitFrame(&reader, &decoded, false));
+  JXL_RETURN_IF_ERROR(fd.InitFrameOutput());
+  // PassesDecoderState::Init (from InitFrameOutput) clears main_output: set it now, as decode.cc:1470 does
+  JXL_RETURN_IF_ERROR(fd.SetImageOutput(PixelCallback(), out->rgb.data(), out->rgb.size() * sizeof(float), xs, ys,
+                                        JxlPixelFormat{3, JXL_TYPE_FLOAT, JXL_NATIVE_ENDIAN, 0}, 32,
+                                        /*unpremul_alpha=*/false, /*undo_orientation=*/false));
+  const size_t header_bytes = reader.TotalBitsConsumed() / kBitsPerByte;
+  JXL_RETURN_IF_ERROR(reader.Close());
+  out->sections_offset = out->frame_offset + header_bytes;
+  const FrameHeader& fh = fd.GetFrameHeader();
+  const FrameDimensions fdim = fh.ToFrameDimensions();
+  out->num_groups = fdim.num_groups;
+  out->num_dc_groups = fdim.num_dc_groups;
+  const size_t num_sections = fd.Toc().size();
+  out->section_offset.assign(num_sections, 0);
+  out->section_size.assign(num_sections, 0);
+  {
+    Status close_ok = true;
+    std::vector<std::unique_ptr<BitReader>> readers;
+    std::vector<std::unique_ptr<BitReaderScopedCloser>> closers;
+    std::vector<FrameDecoder::SectionInfo> infos;
+    size_t pos = header_bytes, index = 0;
+    for (auto e : fd.Toc()) {
+      JXL_RETURN_IF_ERROR(pos + e.size <= avail);
+      out->section_offset[e.id] = out->frame_offset + pos;
+      out->section_size[e.id] = e.size;
+      auto br = make_unique<BitReader>(Bytes(in + pos, e.size));
+      infos.emplace_back(FrameDecoder::SectionInfo{br.get(), e.id, index++});
+      closers.emplace_back(make_unique<BitReaderScopedCloser>(*br, close_ok));
+      readers.emplace_back(std::move(br));
+      pos += e.size;
+    }
+    std::vector<FrameDecoder::SectionStatus> status(infos.size());
+    JXL_RETURN_IF_ERROR(fd.ProcessSections(infos.data(), infos.size(), status.data()));
+    for (auto st : status) JXL_RETURN_IF_ERROR(st == FrameDecoder::kDone);
+    closers.clear();
+    JXL_RETURN_IF_ERROR(close_ok);
+  }
+  JXL_RETURN_IF_ERROR(fd.FinalizeFrame());
+
+  // ---- 3. the inputs of the product's boundary, from the decoder's state
+  if (fh.encoding != FrameEncoding::kVarDCT || fh.passes.num_passes != 1 || fh.upsampling != 1 ||
+      !fh.chroma_subsampling.Is444() || (fh.flags & (FrameHeader::kNoise | FrameHeader::kPatches |
+                                                    FrameHeader::kSplines | FrameHeader::kUseDcFrame))) {
+    return JXL_FAILURE("frame uses features outside the back-end's scope");
+  }
+  const PassesSharedState& sh = dec_state->shared_storage;
+  const size_t xsb = fdim.xsize_blocks, ysb = fdim.ysize_blocks;
+  out->xsize = xs;
+  out->ysize = ys;
+  out->num_histograms = sh.num_histograms;
+  out->used_acs = dec_state->used_acs;
+  out->acs.resize(xsb * ysb);
+  out->sharp.resize(xsb * ysb);
+  out->quant_dc.resize(xsb * ysb);
+  out->raw_quant.resize(xsb * ysb);
+  for (int c = 0; c < 3; c++) out->dc[c].resize(xsb * ysb);
+  for (size_t by = 0; by < ysb; by++) {
+    AcStrategyRow arow = sh.ac_strategy.ConstRow(by);
+    const int32_t* q = sh.raw_quant_field.ConstRow(by);
+    const uint8_t* sp = sh.epf_sharpness.ConstRow(by);
+    const uint8_t* qdc = sh.quant_dc.ConstRow(by);
+    for (size_t bx = 0; bx < xsb; bx++) {
+      const AcStrategy a = arow[bx];
+      out->acs[by * xsb + bx] = static_cast<uint8_t>((a.RawStrategy() << 1) | (a.IsFirstBlock() ? 1 : 0));
+      out->raw_quant[by * xsb + bx] = q[bx];
+      out->sharp[by * xsb + bx] = sp[bx];
+      out->quant_dc[by * xsb + bx] = qdc[bx];
+    }
+    for (int c = 0; c < 3; c++) {
+      memcpy(out->dc[c].data() + by * xsb, sh.dc->ConstPlaneRow(c, by), xsb * sizeof(float));
+    }
+  }
+  const size_t xst = DivCeil(xsb, kColorTileDimInBlocks), yst = DivCeil(ysb, kColorTileDimInBlocks);
+  out->ytox.resize(xst * yst);
+  out->ytob.resize(xst * yst);
+  for (size_t ty = 0; ty < yst; ty++) {
+    memcpy(out->ytox.data() + ty * xst, sh.cmap.ytox_map.ConstRow(ty), xst);
+    memcpy(out->ytob.data() + ty * xst, sh.cmap.ytob_map.ConstRow(ty), xst);
+  }
+  {
+    BitWriter bw{&mm};
+    JXL_RETURN_IF_ERROR(EncodeBlockCtxMap(sh.block_ctx_map, &bw, nullptr));
+    bw.ZeroPadToByte();
+    Span<const uint8_t> sp = bw.GetSpan();
+    out->bctx_bytes.assign(sp.data(), sp.data() + sp.size());
+  }
+  {
+    // table_ is one contiguous block starting at the DCT8 X matrix (quant_weights.cc:1247-1262);
+    // FrameDecoder has computed every matrix in used_acs, the rest of the block is never read
+    JXL_RETURN_IF_ERROR(const_cast<DequantMatrices&>(sh.matrices).EnsureComputed(&mm, ~0u));
+    out->dequant.resize(JXLHIP_DEQUANT_TABLE_FLOATS);
+    memcpy(out->dequant.data(), sh.matrices.Matrix(AcStrategyType::DCT, 0), sizeof(float) * JXLHIP_DEQUANT_TABLE_FLOATS);
+  }
+  jxlhip_frame_params& p = out->params;
+  memset(&p, 0, sizeof(p));
+  p.xsize = xs;
+  p.ysize = ys;
+  p.coeff_type = JXLHIP_COEFF_I16;  // the test checks jxlhip_ac_pass_max_num_bits() < 16
+  p.output_kind = JXLHIP_OUT_LINEAR_RGB_F32;
+  const QuantizerParams qp = sh.quantizer.GetParams();
+  p.global_scale = qp.global_scale;
+  p.quant_dc = qp.quant_dc;
+  p.x_dm_multiplier = dec_state->x_dm_multiplier;
+  p.b_dm_multiplier = dec_state->b_dm_multiplier;
+  const OpsinParams& op = dec_state->output_encoding_info.opsin_params;
+  for (int i = 0; i < 4; i++) p.quant_biases[i] = op.quant_biases[i];
+  for (int i = 0; i < 3; i++) p.opsin_biases[i] = op.opsin_biases[i];
+  for (int i = 0; i < 9; i++) p.inverse_opsin_matrix[i] = op.inverse_opsin_matrix[i * 4];
+  p.cfl_base_x = sh.cmap.base().GetBaseCorrelationX();
+  p.cfl_base_b = sh.cmap.base().GetBaseCorrelationB();
+  p.cfl_color_factor = static_cast<uint32_t>(sh.cmap.base().GetColorFactor());
+  const LoopFilter& lf = fh.loop_filter;
+  p.lf.gab = lf.gab ? 1 : 0;
+  p.lf.gab_weights[0] = lf.gab_x_weight1;
+  p.lf.gab_weights[1] = lf.gab_x_weight2;
+  p.lf.gab_weights[2] = lf.gab_y_weight1;
+  p.lf.gab_weights[3] = lf.gab_y_weight2;
+  p.lf.gab_weights[4] = lf.gab_b_weight1;
+  p.lf.gab_weights[5] = lf.gab_b_weight2;
+  p.lf.epf_iters = lf.epf_iters;
+  for (int i = 0; i < 8; i++) p.lf.epf_sharp_lut[i] = lf.epf_sharp_lut[i];
+  for (int i = 0; i < 3; i++) p.lf.epf_channel_scale[i] = lf.epf_channel_scale[i];
+  p.lf.epf_quant_mul = lf.epf_quant_mul;
+  p.lf.epf_pass0_sigma_scale = lf.epf_pass0_sigma_scale;
+  p.lf.epf_pass2_sigma_scale = lf.epf_pass2_sigma_scale;
+  p.lf.epf_border_sad_mul = lf.epf_border_sad_mul;
+  return true;
+}
+
+}  // namespace
+
+JXR_EXPORT void* jxr_real_case_create(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_tier,
+                                      int epf) {
+  auto c = std::make_unique<RealCase>();
+  if (!Run(xs, ys, seed, distance, speed_tier, epf, c.get())) return nullptr;
+  return c.release();
+}
+JXR_EXPORT void jxr_real_case_destroy(void* h) { delete static_cast<RealCase*>(h); }
+
+// what = 0 codestream, 1 acs, 2 raw_quant, 3 sharpness, 4 ytox, 5 ytob, 6..8 dc x/y/b, 9 quant_dc,
+// 10 block-ctx-map bytes, 11 rgb, 12 section offsets (u64), 13 section sizes (u64), 14 frame params,
+// 15 dequant table
+JXR_EXPORT const void* jxr_real_case_data(void* h, int what, size_t* bytes) {
+  RealCase* c = static_cast<RealCase*>(h);
+  auto ret = [&](const void* p, size_t n) {
+    *bytes = n;
+    return p;
+  };
+  switch (what) {
+    case 0: return ret(c->codestream.data(), c->codestream.size());
+    case 1: return ret(c->acs.data(), c->acs.size());
+    case 2: return ret(c->raw_quant.data(), c->raw_quant.size() * 4);
+    case 3: return ret(c->sharp.data(), c->sharp.size());
+    case 4: return ret(c->ytox.data(), c->ytox.size());
+    case 5: return ret(c->ytob.data(), c->ytob.size());
+    case 6: case 7: case 8: return ret(c->dc[what - 6].data(), c->dc[what - 6].size() * 4);
+    case 9: return ret(c->quant_dc.data(), c->quant_dc.size());
+    case 10: return ret(c->bctx_bytes.data(), c->bctx_bytes.size());
+    case 11: return ret(c->rgb.data(), c->rgb.size() * 4);
+    case 12: return ret(c->section_offset.data(), c->section_offset.size() * 8);
+    case 13: return ret(c->section_size.data(), c->section_size.size() * 8);
+    case 14: return ret(&c->params, sizeof(c->params));
+    case 15: return ret(c->dequant.data(), c->dequant.size() * 4);
+    default: *bytes = 0; return static_cast<const void*>(nullptr);
+  }
+}
+// 0 num_groups, 1 num_dc_groups, 2 num_histograms, 3 used_acs, 4 frame offset, 5 sections offset
+JXR_EXPORT uint64_t jxr_real_case_info(void* h, int what) {
+  RealCase* c = static_cast<RealCase*>(h);
+  switch (what) {
+    case 0: return c->num_groups;
+    case 1: return c->num_dc_groups;
+    case 2: return c->num_histograms;
+    case 3: return c->used_acs;
+    case 4: return c->frame_offset;
+    case 5: return c->sections_offset;
+    default: return 0;
+  }
+}
