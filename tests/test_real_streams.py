@@ -45,7 +45,7 @@ def ceil_log2(n):
 
 def entropy_decode(L, rs):
     """AC global + AC group sections of rs through the product's entropy decoder.
-    Returns the three coefficient buffers (int16)."""
+    Returns (coeff_type, the three coefficient buffers)."""
     bctx = abi.BlockCtxMap()
     pos = C.c_size_t(0)
     b = rs.block_ctx_bytes
@@ -64,8 +64,10 @@ def entropy_decode(L, rs):
     assert rc == 0, rc
     assert (pos.value + 7) // 8 == len(glob), (pos.value, len(glob))
     try:
-        assert L.jxlhip_ac_pass_max_num_bits(h) < 16
-        out = [np.zeros(rs.num_groups * 65536, np.int16) for _ in range(3)]
+        # dec_frame.cc:414-421: 16-bit coefficient buffers only when no token can carry 16 bits
+        # (a flat histogram in the stream is enough to make the reference pick int32)
+        ct = 0 if L.jxlhip_ac_pass_max_num_bits(h) < 16 else 1
+        out = [np.zeros(rs.num_groups * 65536, np.int32 if ct else np.int16) for _ in range(3)]
         xsb, ysb, xsg = (rs.xsize + 7) // 8, (rs.ysize + 7) // 8, (rs.xsize + 255) // 256
         for g in range(rs.num_groups):
             d = np.frombuffer(rs.ac_group(g), np.uint8)
@@ -73,12 +75,12 @@ def entropy_decode(L, rs):
             ptrs = (C.c_void_p * 3)(*[o[g * 65536:].ctypes.data for o in out])
             rc = L.jxlhip_ac_group_decode(h, xsb, ysb, g % xsg, g // xsg, rs.ac_strategy.ctypes.data,
                                           rs.raw_quant.ctypes.data, rs.quant_dc.ctypes.data, d.ctypes.data, len(d),
-                                          C.byref(gp), 0, 0, ptrs, C.byref(n))
+                                          C.byref(gp), 0, ct, ptrs, C.byref(n))
             assert rc == 0, (g, rc)
             assert (gp.value + 7) // 8 == len(d), (g, gp.value, len(d))
     finally:
         L.jxlhip_ac_pass_destroy(h)
-    return out
+    return ct, out
 
 
 @pytest.mark.parametrize("xs,ys,distance,tier,epf", [
@@ -87,14 +89,15 @@ def entropy_decode(L, rs):
     (640, 264, 0.5, 5, -1),   # hare d0.5
     (384, 520, 2.0, 2, 1),    # kitten, EPF forced to 1 iteration
     (300, 300, 1.0, 7, 0),    # falcon (DCT8 only), no EPF
+    (1024, 1280, 1.0, 5, -1), # 20 groups; a flat histogram cluster -> the reference's int32 buffers
 ])
 def test_reference_encoded_stream_decodes_to_reference_pixels(L, ref, xs, ys, distance, tier, epf):
     rs = ref.RealStream(xs, ys, seed=xs + ys, distance=distance, speed_tier=tier, epf=epf)
-    coeffs = entropy_decode(L, rs)
+    ct, coeffs = entropy_decode(L, rs)
     assert any(np.any(c) for c in coeffs)
     fr = rs.frame(coeffs)
-    fr.params.output_kind = 1
     fr.c.p.output_kind = 1
+    fr.c.p.coeff_type = ct
     out = fr.decode(threads=4)
     assert np.array_equal(out, rs.rgb), float(np.abs(out - rs.rgb).max())
 
@@ -121,12 +124,6 @@ def test_reference_encoded_stream_through_hip_path(ref, xs, ys, distance, tier, 
     L = d.L
     params = abi.FrameParams.from_buffer_copy(rs.params.tobytes())
     params.output_kind = 1
-    d.begin_frame(params)
-    dc = [rs.dc_x, rs.dc_y, rs.dc_b]
-    dc3 = (C.c_void_p * 3)(*[x.ctypes.data for x in dc])
-    assert L.jxlhip_upload_side_info(d.ctx, rs.ac_strategy.ctypes.data, rs.raw_quant.ctypes.data,
-                                     rs.epf_sharpness.ctypes.data, rs.ytox_map.ctypes.data,
-                                     rs.ytob_map.ctypes.data, dc3, rs.dequant_table.ctypes.data) == 0
     bctx = abi.BlockCtxMap()
     pos = C.c_size_t(0)
     b = rs.block_ctx_bytes
@@ -139,7 +136,13 @@ def test_reference_encoded_stream_through_hip_path(ref, xs, ys, distance, tier, 
     h = C.c_void_p()
     assert L.jxlhip_ac_pass_decode(glob.ctypes.data, len(glob), C.byref(pos), rs.used_acs, num_histo,
                                    C.byref(bctx), C.byref(h)) == 0
-    assert L.jxlhip_ac_pass_max_num_bits(h) < 16
+    params.coeff_type = 0 if L.jxlhip_ac_pass_max_num_bits(h) < 16 else 1  # dec_frame.cc:414-421
+    d.begin_frame(params)
+    dc = [rs.dc_x, rs.dc_y, rs.dc_b]
+    dc3 = (C.c_void_p * 3)(*[x.ctypes.data for x in dc])
+    assert L.jxlhip_upload_side_info(d.ctx, rs.ac_strategy.ctypes.data, rs.raw_quant.ctypes.data,
+                                     rs.epf_sharpness.ctypes.data, rs.ytox_map.ctypes.data,
+                                     rs.ytob_map.ctypes.data, dc3, rs.dequant_table.ctypes.data) == 0
     errs = []
 
     def worker(tid, nthreads):
