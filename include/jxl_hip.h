@@ -56,7 +56,8 @@ typedef enum {
   JXLHIP_ERR_OUT_OF_MEMORY = -3,
   JXLHIP_ERR_HIP = -4,         /* a HIP runtime call failed; see last_error */
   JXLHIP_ERR_BAD_STREAM = -5,  /* side info violates a format constraint */
-  JXLHIP_ERR_STATE = -6        /* call sequence error */
+  JXLHIP_ERR_STATE = -6,       /* call sequence error */
+  JXLHIP_ERR_UNSUPPORTED = -7  /* valid stream feature outside this back-end */
 } jxlhip_status;
 
 /* ACType, lib/jxl/dct_util.h:23; chosen per frame at lib/jxl/dec_frame.cc:421-431 */
@@ -287,9 +288,47 @@ JXLHIP_EXPORT int jxlhip_profile_read(jxlhip_ctx* ctx,
                                       uint32_t launches[JXLHIP_KERNEL_COUNT]);
 
 /* ---- device-side helpers for rows of SURVEY 8(a) outside the two phases -- */
-/* a5: DequantMatrices::EnsureComputed for the default library
- * (quant_weights.cc:163-358,1211-1271): fills a JXLHIP_DEQUANT_TABLE_FLOATS
- * device buffer with the default dequant tables. */
+/* a5: DequantMatrices (quant_weights.h:350-428).  One parameter set per
+ * quant table (17 of them, QuantTable order: DCT, IDENTITY, DCT2X2, DCT4X4,
+ * DCT16X16, DCT32X32, DCT8X16, DCT8X32, DCT16X32, DCT4X8, AFV0, DCT64X64,
+ * DCT32X64, DCT128X128, DCT64X128, DCT256X256, DCT128X256) mirroring
+ * QuantEncodingInternal (quant_weights.h:57-187) with the values as the
+ * decoder holds them (i.e. after Decode's *64 scalings, quant_weights.cc:373-
+ * 470).  jxlhip_dequant_encodings_decode (jxl_hip_entropy.h) fills it from the
+ * AC-global section. */
+typedef enum {
+  JXLHIP_QUANT_LIBRARY = 0, /* the default parameters of the table's kind */
+  JXLHIP_QUANT_ID = 1,      /* weights[c][0..2] */
+  JXLHIP_QUANT_DCT2 = 2,    /* weights[c][0..5] */
+  JXLHIP_QUANT_DCT4 = 3,    /* weights[c][0..1] multipliers + bands */
+  JXLHIP_QUANT_DCT4X8 = 4,  /* weights[c][0] multiplier + bands */
+  JXLHIP_QUANT_AFV = 5,     /* weights[c][0..8] + bands (4x8) + bands_afv_4x4 */
+  JXLHIP_QUANT_DCT = 6,     /* bands */
+  JXLHIP_QUANT_RAW = 7      /* modular-coded explicit table: NOT supported */
+} jxlhip_quant_mode;
+#define JXLHIP_NUM_QUANT_TABLES 17
+#define JXLHIP_MAX_DISTANCE_BANDS 17
+typedef struct jxlhip_quant_encoding {
+  uint32_t mode;               /* jxlhip_quant_mode */
+  uint32_t num_bands;          /* DctQuantWeightParams::num_distance_bands */
+  uint32_t num_bands_afv_4x4;  /* dct_params_afv_4x4 (AFV only) */
+  uint32_t reserved;
+  float bands[3][JXLHIP_MAX_DISTANCE_BANDS];
+  float bands_afv_4x4[3][JXLHIP_MAX_DISTANCE_BANDS];
+  float weights[3][9];
+} jxlhip_quant_encoding;
+
+/* DequantMatrices::EnsureComputed (quant_weights.cc:163-358,1211-1271): fills a
+ * JXLHIP_DEQUANT_TABLE_FLOATS device buffer with the dequant tables of the 17
+ * encodings (NULL = all JXLHIP_QUANT_LIBRARY).  Asynchronous on the context's
+ * stream like the decode calls; parameters that give a weight outside
+ * [1e-8, 1e8) (the reference's "Invalid quantization table",
+ * quant_weights.cc:329-339) surface as JXLHIP_ERR_BAD_STREAM from the next
+ * jxlhip_sync().  JXLHIP_ERR_UNSUPPORTED for JXLHIP_QUANT_RAW. */
+JXLHIP_EXPORT int jxlhip_dequant_tables(jxlhip_ctx* ctx,
+                                        const jxlhip_quant_encoding* encodings,
+                                        float* table_dev);
+/* = jxlhip_dequant_tables(ctx, NULL, table_dev) */
 JXLHIP_EXPORT int jxlhip_default_dequant_tables(jxlhip_ctx* ctx,
                                                 float* table_dev);
 /* a8: DequantDC + AdaptiveDCSmoothing (compressed_dc.cc:128-250), 4:4:4.

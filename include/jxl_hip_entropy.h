@@ -56,6 +56,16 @@ JXLHIP_EXPORT int jxlhip_block_ctx_map_decode(const uint8_t* data, size_t size, 
 JXLHIP_EXPORT int jxlhip_quant_dc_contexts(const jxlhip_block_ctx_map* map, size_t n,
                                            const int32_t* const quant_dc[3], uint8_t* out);
 
+/* DequantMatrices::Decode (quant_weights.cc:373-511), the first field of the
+ * AC-global section: one "all default" bit, else 17 x (3-bit mode + that mode's
+ * F16 parameters).  Fills enc[JXLHIP_NUM_QUANT_TABLES] for
+ * jxlhip_dequant_tables(); *bit_pos advanced.  JXLHIP_ERR_BAD_STREAM on the
+ * reference's failures (too-small weights, F16 inf/NaN, non-8x8 mode on a larger
+ * table, truncation), JXLHIP_ERR_UNSUPPORTED on kQuantModeRAW (its table is
+ * modular-coded). */
+JXLHIP_EXPORT int jxlhip_dequant_encodings_decode(const uint8_t* data, size_t size, size_t* bit_pos,
+                                                  jxlhip_quant_encoding* enc);
+
 /* One pass of the AC-global section: coefficient orders + entropy code. */
 typedef struct jxlhip_ac_pass jxlhip_ac_pass;
 
@@ -79,6 +89,17 @@ JXLHIP_EXPORT uint32_t jxlhip_ac_pass_used_orders(const jxlhip_ac_pass* pass);
 /* coefficient order of order bucket `ord` (0..12) and channel c: 64 * covered
  * blocks entries (tests) */
 JXLHIP_EXPORT const uint32_t* jxlhip_ac_pass_order(const jxlhip_ac_pass* pass, uint32_t ord, uint32_t c);
+
+/* The whole AC-global section as FrameDecoder::ProcessACGlobal reads it
+ * (dec_frame.cc:372-416): jxlhip_dequant_encodings_decode, then num_histograms
+ * (1 + CeilLog2Nonzero(num_groups) bits), then num_passes x jxlhip_ac_pass_decode.
+ * passes[0..num_passes) receive the pass handles (caller destroys them; all are
+ * NULL on failure).  data/size: the section's bytes, read from bit 0. */
+JXLHIP_EXPORT int jxlhip_ac_global_decode(const uint8_t* data, size_t size, uint32_t num_groups,
+                                          uint32_t num_passes, uint32_t used_acs,
+                                          const jxlhip_block_ctx_map* block_ctx_map,
+                                          jxlhip_quant_encoding* enc, uint32_t* num_histograms,
+                                          jxlhip_ac_pass** passes, size_t* bits_consumed);
 
 /* Decodes one pass of one AC group (DecodeGroup with GetBlockFromBitstream,
  * dec_group.cc:560-640,780-815): the histogram-set selector, then per varblock

@@ -44,6 +44,20 @@ class BlockCtxMap(C.Structure):
                 ("ctx_map", C.c_uint8 * (3 * 13 * 64))]
 
 
+QUANT_LIBRARY, QUANT_ID, QUANT_DCT2, QUANT_DCT4, QUANT_DCT4X8, QUANT_AFV, QUANT_DCT, QUANT_RAW = range(8)
+NUM_QUANT_TABLES, MAX_DISTANCE_BANDS = 17, 17
+
+
+class QuantEncoding(C.Structure):
+    """jxlhip_quant_encoding: one dequant table's parameters (QuantEncodingInternal)."""
+    _fields_ = [("mode", C.c_uint32), ("num_bands", C.c_uint32), ("num_bands_afv_4x4", C.c_uint32),
+                ("reserved", C.c_uint32), ("bands", (C.c_float * 17) * 3), ("bands_afv_4x4", (C.c_float * 17) * 3),
+                ("weights", (C.c_float * 9) * 3)]
+
+
+QuantEncodings = QuantEncoding * NUM_QUANT_TABLES
+
+
 class FrameParams(C.Structure):
     _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32),
                 ("coeff_type", C.c_uint32), ("output_kind", C.c_uint32),
@@ -121,11 +135,12 @@ EXPORTS = [
     "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_frame",
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
     "jxlhip_profile_enable", "jxlhip_profile_read",
-    "jxlhip_default_dequant_tables", "jxlhip_dequant_dc",
+    "jxlhip_dequant_tables", "jxlhip_default_dequant_tables", "jxlhip_dequant_dc",
     # include/jxl_hip_entropy.h
     "jxlhip_ac_pass_decode", "jxlhip_ac_pass_destroy", "jxlhip_ac_pass_max_num_bits",
     "jxlhip_ac_pass_used_orders", "jxlhip_ac_pass_order", "jxlhip_ac_group_decode",
     "jxlhip_ac_group_decode_submit", "jxlhip_block_ctx_map_decode", "jxlhip_quant_dc_contexts",
+    "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode",
 ]
 
 
@@ -177,6 +192,10 @@ def load_library():
     L.jxlhip_profile_enable.argtypes = [vp, i32]
     L.jxlhip_profile_read.argtypes = [vp, C.c_float * KERNEL_COUNT, u32 * KERNEL_COUNT]
     L.jxlhip_default_dequant_tables.argtypes = [vp, vp]
+    L.jxlhip_dequant_tables.argtypes = [vp, vp, vp]
+    L.jxlhip_dequant_encodings_decode.argtypes = [vp, sz, C.POINTER(sz), vp]
+    L.jxlhip_ac_global_decode.argtypes = [vp, sz, u32, u32, u32, vp, vp, C.POINTER(u32), C.POINTER(vp),
+                                          C.POINTER(sz)]
     L.jxlhip_dequant_dc.argtypes = [vp, vp * 3, vp * 3, vp, C.c_float, C.c_float, i32]
     _lib = L
     return L

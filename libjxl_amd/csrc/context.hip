@@ -54,6 +54,8 @@ struct jxlhip_ctx {
   uint32_t* counts = nullptr;    // kNumClasses
   int32_t* error_flag = nullptr; // [0] stream error, [1] table status
   float* tables = nullptr;       // wc[512] + resample[64]
+  jxlhip_quant_encoding* quant_enc = nullptr;  // device: the 17 resolved encodings of the last table build
+  jxlhip_quant_encoding quant_enc_host[JXLHIP_NUM_QUANT_TABLES];
   WorkLists wl{};
   uint32_t max_items[kNumClasses] = {0};
   // upload path
@@ -186,6 +188,7 @@ const char* jxlhip_status_string(int status) {
     case JXLHIP_ERR_HIP: return "HIP runtime error";
     case JXLHIP_ERR_BAD_STREAM: return "side info violates a format constraint";
     case JXLHIP_ERR_STATE: return "call sequence error";
+    case JXLHIP_ERR_UNSUPPORTED: return "stream feature outside this back-end";
     default: return "unknown status";
   }
 }
@@ -233,7 +236,8 @@ int jxlhip_create(int device, jxlhip_ctx** out) {
     return fail(JXLHIP_ERR_HIP);
   if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kCountStride * kMaxBands) != hipSuccess ||
       hipMalloc((void**)&c->error_flag, sizeof(int32_t) * 2) != hipSuccess ||
-      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024)) != hipSuccess)
+      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024)) != hipSuccess ||
+      hipMalloc((void**)&c->quant_enc, sizeof(jxlhip_quant_encoding) * JXLHIP_NUM_QUANT_TABLES) != hipSuccess)
     return fail(JXLHIP_ERR_OUT_OF_MEMORY);
   if (hipMemset(c->error_flag, 0, sizeof(int32_t) * 2) != hipSuccess ||
       hipMemcpy(c->tables, kWcHost, sizeof(float) * 512, hipMemcpyHostToDevice) != hipSuccess ||
@@ -279,7 +283,7 @@ void jxlhip_destroy(jxlhip_ctx* c) {
   }
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_coeffs[1],
-                  c->up_coeffs[2], c->up_side, c->dc_tmp};
+                  c->up_coeffs[2], c->up_side, c->dc_tmp,       c->quant_enc};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -917,12 +921,58 @@ int jxlhip_profile_read(jxlhip_ctx* c, float ms[JXLHIP_KERNEL_COUNT],
 }
 
 // ---- a5 / a8 ------------------------------------------------------------------------
-int jxlhip_default_dequant_tables(jxlhip_ctx* c, float* table_dev) {
+// Library encodings -> the parameters they stand for (DequantMatrices::Library,
+// quant_weights.cc:532-1188; data in format_constants.inc).  The AFV library entry
+// takes its 4x8 and 4x4 band parameters from the DCT4X8 and DCT4X4 entries.
+static void ResolveLibrary(int kind, jxlhip_quant_encoding* e) {
+  static const uint32_t kModeOfLib[6] = {JXLHIP_QUANT_DCT,  JXLHIP_QUANT_ID,     JXLHIP_QUANT_DCT2,
+                                         JXLHIP_QUANT_DCT4, JXLHIP_QUANT_DCT4X8, JXLHIP_QUANT_AFV};
+  const QuantLibEntry& l = kQuantLib[kind];
+  memset(e, 0, sizeof(*e));
+  e->mode = kModeOfLib[l.mode];
+  const QuantLibEntry& b = l.mode == 5 ? kQuantLib[9] : l;
+  e->num_bands = (uint32_t)b.nb;
+  for (int c = 0; c < 3; c++) {
+    for (int i = 0; i < 8; i++) e->bands[c][i] = b.bands[c][i];
+    for (int i = 0; i < 9; i++) e->weights[c][i] = l.w[c][i];
+  }
+  if (l.mode == 5) {
+    e->num_bands_afv_4x4 = (uint32_t)kQuantLib[3].nb;
+    for (int c = 0; c < 3; c++)
+      for (int i = 0; i < 8; i++) e->bands_afv_4x4[c][i] = kQuantLib[3].bands[c][i];
+  }
+}
+
+int jxlhip_dequant_tables(jxlhip_ctx* c, const jxlhip_quant_encoding* enc, float* table_dev) {
   if (!c || !table_dev) return JXLHIP_ERR_INVALID_ARGUMENT;
+  static const uint32_t kSingleBlockKinds = 0x60F;  // kinds whose matrix is one 8x8 block
+  for (int k = 0; k < JXLHIP_NUM_QUANT_TABLES; k++) {
+    jxlhip_quant_encoding* e = &c->quant_enc_host[k];
+    if (!enc || enc[k].mode == JXLHIP_QUANT_LIBRARY) {
+      ResolveLibrary(k, e);
+      continue;
+    }
+    *e = enc[k];
+    if (e->mode == JXLHIP_QUANT_RAW)
+      return Fail(c, JXLHIP_ERR_UNSUPPORTED, "kQuantModeRAW dequant tables are modular-coded");
+    const bool has_bands = e->mode == JXLHIP_QUANT_DCT || e->mode == JXLHIP_QUANT_DCT4 ||
+                           e->mode == JXLHIP_QUANT_DCT4X8 || e->mode == JXLHIP_QUANT_AFV;
+    if (e->mode > JXLHIP_QUANT_RAW || (e->mode != JXLHIP_QUANT_DCT && !((kSingleBlockKinds >> k) & 1)) ||
+        (has_bands && (e->num_bands < 1 || e->num_bands > JXLHIP_MAX_DISTANCE_BANDS)) ||
+        (e->mode == JXLHIP_QUANT_AFV &&
+         (e->num_bands_afv_4x4 < 1 || e->num_bands_afv_4x4 > JXLHIP_MAX_DISTANCE_BANDS)))
+      return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "malformed quant encoding");
+  }
   HIPCHK(c, hipSetDevice(c->device));
-  LaunchDefaultDequant(table_dev, c->error_flag + 1, c->stream);
+  HIPCHK(c, hipMemcpyAsync(c->quant_enc, c->quant_enc_host, sizeof(c->quant_enc_host), hipMemcpyHostToDevice,
+                           c->stream));
+  LaunchDequantTables(table_dev, c->quant_enc, c->error_flag + 1, c->stream);
   HIPCHK(c, hipGetLastError());
   return JXLHIP_OK;
+}
+
+int jxlhip_default_dequant_tables(jxlhip_ctx* c, float* table_dev) {
+  return jxlhip_dequant_tables(c, nullptr, table_dev);
 }
 
 int jxlhip_dequant_dc(jxlhip_ctx* c, const int32_t* const quant_dc[3], float* const dc_out[3],

@@ -7,6 +7,7 @@
 //
 // Behavioural specification: ISO/IEC 18181-1 annexes C (entropy coding) and
 // I.3.5-I.3.7, as implemented by the reference at the lines cited per function.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1068,6 +1069,134 @@ int jxlhip_ac_pass_decode(const uint8_t* data, size_t size, size_t* bit_pos, uin
 }
 
 void jxlhip_ac_pass_destroy(jxlhip_ac_pass* pass) { delete pass; }
+
+// ---- dequant-matrix encodings (quant_weights.cc:373-511) -----------------------
+namespace {
+// F16Coder::Read (fields.cc:550-574)
+bool ReadF16(BitReader* br, float* v) {
+  const uint32_t bits16 = br->Read(16);
+  const uint32_t sign = bits16 >> 15, biased_exp = (bits16 >> 10) & 0x1F, mantissa = bits16 & 0x3FF;
+  if (biased_exp == 31) return false;  // infinity / NaN
+  if (biased_exp == 0) {
+    *v = (1.0f / 16384) * (mantissa * (1.0f / 1024));
+    if (sign) *v = -*v;
+    return true;
+  }
+  const uint32_t bits32 = (sign << 31) | ((biased_exp + (127 - 15)) << 23) | (mantissa << 13);
+  memcpy(v, &bits32, 4);
+  return true;
+}
+
+constexpr float kAlmostZero = 1e-8f;
+
+bool ReadDctParams(BitReader* br, uint32_t* nb, float bands[3][JXLHIP_MAX_DISTANCE_BANDS]) {  // :373-386
+  *nb = br->Read(4) + 1;
+  for (int c = 0; c < 3; c++) {
+    for (uint32_t i = 0; i < *nb; i++)
+      if (!ReadF16(br, &bands[c][i])) return false;
+    if (bands[c][0] < kAlmostZero) return false;
+    bands[c][0] *= 64.0f;
+  }
+  return true;
+}
+
+// table kinds whose matrix is a single 8x8 block (required_size_x * required_size_y == 1)
+constexpr uint32_t kSingleBlockKinds = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 3) | (1u << 9) | (1u << 10);
+
+int ReadQuantEncoding(BitReader* br, uint32_t kind, jxlhip_quant_encoding* e) {  // Decode, :388-470
+  memset(e, 0, sizeof(*e));
+  const uint32_t mode = br->Read(3);
+  const bool single = (kSingleBlockKinds >> kind) & 1;
+  auto weights = [&](int n, int scaled, bool check) {
+    for (int c = 0; c < 3; c++)
+      for (int i = 0; i < n; i++) {
+        if (!ReadF16(br, &e->weights[c][i])) return false;
+        if (check && fabsf(e->weights[c][i]) < kAlmostZero) return false;
+        if (i < scaled) e->weights[c][i] *= 64;
+      }
+    return true;
+  };
+  switch (mode) {
+    case JXLHIP_QUANT_LIBRARY: break;  // kCeilLog2NumPredefinedTables == 0 bits
+    case JXLHIP_QUANT_ID:
+      if (!single || !weights(3, 3, true)) return kBad;
+      break;
+    case JXLHIP_QUANT_DCT2:
+      if (!single || !weights(6, 6, true)) return kBad;
+      break;
+    case JXLHIP_QUANT_DCT4X8:
+      if (!single || !weights(1, 0, true) || !ReadDctParams(br, &e->num_bands, e->bands)) return kBad;
+      break;
+    case JXLHIP_QUANT_DCT4:
+      if (!single || !weights(2, 0, true) || !ReadDctParams(br, &e->num_bands, e->bands)) return kBad;
+      break;
+    case JXLHIP_QUANT_AFV:
+      if (!single || !weights(9, 6, false) || !ReadDctParams(br, &e->num_bands, e->bands) ||
+          !ReadDctParams(br, &e->num_bands_afv_4x4, e->bands_afv_4x4))
+        return kBad;
+      break;
+    case JXLHIP_QUANT_DCT:
+      if (!ReadDctParams(br, &e->num_bands, e->bands)) return kBad;
+      break;
+    default:  // kQuantModeRAW: ModularFrameDecoder::DecodeQuantTable
+      e->mode = mode;
+      return JXLHIP_ERR_UNSUPPORTED;
+  }
+  e->mode = mode;
+  return br->Healthy() ? kOk : kBad;
+}
+
+int ReadQuantEncodings(BitReader* br, jxlhip_quant_encoding* enc) {  // DequantMatrices::Decode, :497-511
+  const bool all_default = br->Read(1);
+  memset(enc, 0, sizeof(*enc) * JXLHIP_NUM_QUANT_TABLES);
+  if (all_default) return br->Healthy() ? kOk : kBad;
+  for (uint32_t k = 0; k < JXLHIP_NUM_QUANT_TABLES; k++) {
+    const int rc = ReadQuantEncoding(br, k, &enc[k]);
+    if (rc) return rc;
+  }
+  return kOk;
+}
+}  // namespace
+
+int jxlhip_dequant_encodings_decode(const uint8_t* data, size_t size, size_t* bit_pos, jxlhip_quant_encoding* enc) {
+  if (!data || !bit_pos || !enc) return JXLHIP_ERR_INVALID_ARGUMENT;
+  BitReader br(data, size, *bit_pos);
+  const int rc = ReadQuantEncodings(&br, enc);
+  if (rc) return rc;
+  *bit_pos = br.BitsConsumed();
+  return kOk;
+}
+
+int jxlhip_ac_global_decode(const uint8_t* data, size_t size, uint32_t num_groups, uint32_t num_passes,
+                            uint32_t used_acs, const jxlhip_block_ctx_map* block_ctx_map, jxlhip_quant_encoding* enc,
+                            uint32_t* num_histograms, jxlhip_ac_pass** passes, size_t* bits_consumed) {
+  if (!data || !enc || !num_histograms || !passes || num_groups == 0 || num_passes == 0 || num_passes > 11)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < num_passes; i++) passes[i] = nullptr;
+  size_t pos = 0;
+  {
+    BitReader br(data, size, 0);
+    const int rc = ReadQuantEncodings(&br, enc);
+    if (rc) return rc;
+    uint32_t bits = 0;  // CeilLog2Nonzero(num_groups)
+    while ((1ull << bits) < num_groups) bits++;
+    *num_histograms = 1 + br.Read(bits);  // dec_frame.cc:383-386
+    if (!br.Healthy()) return kBad;
+    pos = br.BitsConsumed();
+  }
+  for (uint32_t i = 0; i < num_passes; i++) {
+    const int rc = jxlhip_ac_pass_decode(data, size, &pos, used_acs, *num_histograms, block_ctx_map, &passes[i]);
+    if (rc) {
+      for (uint32_t j = 0; j < i; j++) {
+        jxlhip_ac_pass_destroy(passes[j]);
+        passes[j] = nullptr;
+      }
+      return rc;
+    }
+  }
+  if (bits_consumed) *bits_consumed = pos;
+  return kOk;
+}
 
 int jxlhip_block_ctx_map_decode(const uint8_t* data, size_t size, size_t* bit_pos, jxlhip_block_ctx_map* out) {
   if (!data || !bit_pos || !out) return JXLHIP_ERR_INVALID_ARGUMENT;

@@ -55,7 +55,8 @@ void LaunchRowsCopy(const DevFrame& f, float* dense, int y_first, int nrows, int
                     hipStream_t st);
 
 // a5 / a8 helpers
-void LaunchDefaultDequant(float* table, int32_t* status, hipStream_t st);
+void LaunchDequantTables(float* table, const jxlhip_quant_encoding* enc_dev, int32_t* status,
+                         hipStream_t st);
 void LaunchDequantDC(uint32_t xsb, uint32_t ysb, const int32_t* const q[3], float* const dc[3],
                      float* const tmp[3], const float mul_dc[3], float cfl_x, float cfl_b,
                      int smooth, hipStream_t st);

@@ -1,19 +1,14 @@
 // kernels_tables.hip -- SURVEY 8(a) rows a5 and a8 on the device:
-//   k_default_dequant : DequantMatrices::EnsureComputed for the default library
-//                       (lib/jxl/quant_weights.cc:48-160,163-358,1190-1271; FastPowf
-//                       lib/jxl/base/fast_math-inl.h:46-92), one thread per table entry
+//   k_dequant_tables  : DequantMatrices::EnsureComputed / ComputeQuantTable for 17
+//                       resolved QuantEncodings (lib/jxl/quant_weights.cc:48-160,
+//                       163-358,1190-1271; FastPowf lib/jxl/base/fast_math-inl.h:46-92),
+//                       one thread per table entry
 //   k_dequant_dc      : DequantDC, 4:4:4 (lib/jxl/compressed_dc.cc:201-232)
 //   k_smooth_dc       : AdaptiveDCSmoothing (lib/jxl/compressed_dc.cc:63-197)
 #include "dev_common.h"
 #include "kernels.h"
 
 namespace jxlhip {
-namespace devlib {
-#undef JXL_FMT_CONST
-#define JXL_FMT_CONST __device__ const
-#include "format_constants.inc"
-}  // namespace devlib
-
 __device__ const uint8_t dKindShort[17] = {1, 1, 1, 1, 2, 4, 1, 1, 2, 1, 1, 8, 4, 16, 8, 32, 16};
 __device__ const uint8_t dKindLong[17] = {1, 1, 1, 1, 2, 4, 2, 4, 4, 1, 1, 8, 8, 16, 16, 32, 32};
 
@@ -22,7 +17,7 @@ __device__ float Mult(float v) { return v > 0.0f ? 1.0f + v : 1.0f / (1.0f - v);
 // distance-band weight of coefficient (y, x) of a rows x cols table
 __device__ float DctWeight(int rows, int cols, const float* bands_in, int nb, int y, int x,
                            bool* ok) {
-  float bands[8];
+  float bands[JXLHIP_MAX_DISTANCE_BANDS];
   bands[0] = bands_in[0];
   if (bands[0] < 1e-8f) *ok = false;
   for (int i = 1; i < nb; i++) {
@@ -50,8 +45,9 @@ __device__ float Interpolate(float pos, float max, const float* array, int len) 
   return a * FastPowf(b / a, scaled_pos - idx);
 }
 
-__global__ __launch_bounds__(256) void k_default_dequant(float* __restrict__ table,
-                                                         int32_t* __restrict__ status) {
+__global__ __launch_bounds__(256) void k_dequant_tables(float* __restrict__ table,
+                                                        const jxlhip_quant_encoding* __restrict__ enc,
+                                                        int32_t* __restrict__ status) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= JXLHIP_DEQUANT_TABLE_FLOATS) return;
   // locate (kind, c, y, x)
@@ -67,33 +63,34 @@ __global__ __launch_bounds__(256) void k_default_dequant(float* __restrict__ tab
   const int c = (int)(i - pos) / num;
   const int k = (int)(i - pos) % num;
   const int y = k / wcols, x = k % wcols;
-  const devlib::QuantLibEntry& e = devlib::kQuantLib[kind];
+  const jxlhip_quant_encoding& e = enc[kind];
+  const int nb = (int)e.num_bands;
   bool ok = true;
   float w;
   switch (e.mode) {
-    case 1:  // ID
-      w = (k == 1 || k == 8) ? e.w[c][1] : (k == 9 ? e.w[c][2] : e.w[c][0]);
+    case JXLHIP_QUANT_ID:
+      w = (k == 1 || k == 8) ? e.weights[c][1] : (k == 9 ? e.weights[c][2] : e.weights[c][0]);
       break;
-    case 2:  // DCT2
+    case JXLHIP_QUANT_DCT2:
       if (y < 2 && x < 2) {
-        w = k == 0 ? (float)0xBAD : (k == 9 ? e.w[c][1] : e.w[c][0]);
+        w = k == 0 ? (float)0xBAD : (k == 9 ? e.weights[c][1] : e.weights[c][0]);
       } else if (y < 4 && x < 4) {
-        w = (y >= 2 && x >= 2) ? e.w[c][3] : e.w[c][2];
+        w = (y >= 2 && x >= 2) ? e.weights[c][3] : e.weights[c][2];
       } else {
-        w = (y >= 4 && x >= 4) ? e.w[c][5] : e.w[c][4];
+        w = (y >= 4 && x >= 4) ? e.weights[c][5] : e.weights[c][4];
       }
       break;
-    case 3:  // DCT4
-      w = DctWeight(4, 4, e.bands[c], e.nb, y / 2, x / 2, &ok);
-      if (k == 1 || k == 8) w /= e.w[c][0];
-      if (k == 9) w /= e.w[c][1];
+    case JXLHIP_QUANT_DCT4:
+      w = DctWeight(4, 4, e.bands[c], nb, y / 2, x / 2, &ok);
+      if (k == 1 || k == 8) w /= e.weights[c][0];
+      if (k == 9) w /= e.weights[c][1];
       break;
-    case 4:  // DCT4X8
-      w = DctWeight(4, 8, e.bands[c], e.nb, y / 2, x, &ok);
-      if (k == 8) w /= e.w[c][0];
+    case JXLHIP_QUANT_DCT4X8:
+      w = DctWeight(4, 8, e.bands[c], nb, y / 2, x, &ok);
+      if (k == 8) w /= e.weights[c][0];
       break;
-    case 0:
-      w = DctWeight(wrows, wcols, e.bands[c], e.nb, y, x, &ok);
+    case JXLHIP_QUANT_DCT:
+      w = DctWeight(wrows, wcols, e.bands[c], nb, y, x, &ok);
       break;
     default: {  // AFV
       const float kFreqs[16] = {0xBAD, 0xBAD, 0.8517778890324296f, 5.37778436506804f,
@@ -101,32 +98,30 @@ __global__ __launch_bounds__(256) void k_default_dequant(float* __restrict__ tab
                                 1.6598270267479331f, 4.0f, 7.275749096817861f,
                                 10.423227632456525f, 2.662932286148962f, 7.630657783650829f,
                                 8.962388608184032f, 12.97166202570235f};
-      const devlib::QuantLibEntry& e48 = devlib::kQuantLib[9];
-      const devlib::QuantLibEntry& e44 = devlib::kQuantLib[3];
       const float lo = 0.8517778890324296f;
       const float hi = 12.97166202570235f - lo + 1e-6f;
       float bands[4];
-      bands[0] = e.w[c][5];
+      bands[0] = e.weights[c][5];
       if (bands[0] < 1e-8f) ok = false;
       for (int j = 1; j < 4; j++) {
-        bands[j] = bands[j - 1] * Mult(e.w[c][j + 5]);
+        bands[j] = bands[j - 1] * Mult(e.weights[c][j + 5]);
         if (bands[j] < 1e-8f) ok = false;
       }
       if (y & 1) {  // odd rows: the 4x8 DCT part
-        w = DctWeight(4, 8, e48.bands[c], e48.nb, y / 2, x, &ok);
+        w = DctWeight(4, 8, e.bands[c], nb, y / 2, x, &ok);
       } else if (x & 1) {  // even rows, odd columns: the 4x4 DCT part
-        w = DctWeight(4, 4, e44.bands[c], e44.nb, y / 2, x / 2, &ok);
+        w = DctWeight(4, 4, e.bands_afv_4x4[c], (int)e.num_bands_afv_4x4, y / 2, x / 2, &ok);
       } else {  // even rows, even columns: the AFV part
         const int ay = y / 2, ax = x / 2;
         if (ay < 2 && ax < 2) w = 0;  // placeholders, fixed up below
         else w = Interpolate(kFreqs[ay * 4 + ax] - lo, hi, bands, 4);
       }
       if (k == 0) w = 1;
-      if (k == 1 * 8 + 0) w = e.w[c][0];
-      if (k == 0 * 8 + 1) w = e.w[c][1];
-      if (k == 2 * 8 + 0) w = e.w[c][2];
-      if (k == 0 * 8 + 2) w = e.w[c][3];
-      if (k == 2 * 8 + 2) w = e.w[c][4];
+      if (k == 1 * 8 + 0) w = e.weights[c][0];
+      if (k == 0 * 8 + 1) w = e.weights[c][1];
+      if (k == 2 * 8 + 0) w = e.weights[c][2];
+      if (k == 0 * 8 + 2) w = e.weights[c][3];
+      if (k == 2 * 8 + 2) w = e.weights[c][4];
       break;
     }
   }
@@ -211,9 +206,10 @@ void LaunchRowsCopy(const DevFrame& f, float* dense, int y_first, int nrows, int
                      dense_stride, dense_plane);
 }
 
-void LaunchDefaultDequant(float* table, int32_t* status, hipStream_t st) {
-  hipLaunchKernelGGL(k_default_dequant, dim3((JXLHIP_DEQUANT_TABLE_FLOATS + 255) / 256), dim3(256),
-                     0, st, table, status);
+void LaunchDequantTables(float* table, const jxlhip_quant_encoding* enc_dev, int32_t* status,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_dequant_tables, dim3((JXLHIP_DEQUANT_TABLE_FLOATS + 255) / 256), dim3(256),
+                     0, st, table, enc_dev, status);
 }
 
 void LaunchDequantDC(uint32_t xsb, uint32_t ysb, const int32_t* const q[3], float* const dc[3],

@@ -60,6 +60,13 @@ class VarDctDecoder:
         _check(self.L, self.ctx, self.L.jxlhip_default_dequant_tables(self.ctx, C.c_void_p(t.data_ptr())), "default_dequant_tables")
         return t
 
+    def dequant_tables(self, encodings=None):
+        """The 17 dequant tables of abi.QuantEncodings (None = the default library)."""
+        t = torch.empty(2056 * 64 * 3, dtype=torch.float32, device=f"cuda:{self.device}")
+        e = None if encodings is None else C.cast(C.byref(encodings), C.c_void_p)
+        _check(self.L, self.ctx, self.L.jxlhip_dequant_tables(self.ctx, e, C.c_void_p(t.data_ptr())), "dequant_tables")
+        return t
+
     def set_inputs(self, tensors, dequant_table):
         """tensors: dict of CUDA tensors laid out as jxlhip_frame_inputs."""
         dev = f"cuda:{self.device}"

@@ -279,6 +279,40 @@ def ref_default_dequant_tables():
     return t
 
 
+def dequant_tables(encodings):
+    """The C restatement's tables for 17 jxlhip_quant_encoding (a ctypes array, e.g.
+    libjxl_amd.abi.QuantEncodings); None when the reference would reject them."""
+    t = np.zeros(DEQUANT_TABLE_FLOATS, np.float32)
+    L = lib()
+    L.jxo_dequant_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.jxo_dequant_tables(C.cast(C.byref(encodings), C.c_void_p), _p(t), None)
+    return t if rc == 0 else None
+
+
+def ref_dequant_encode(encodings):
+    """The encodings as the reference's DequantMatricesEncode writes them (bytes)."""
+    L = ref_lib()
+    L.jxr_dequant_encode.restype = C.c_int64
+    L.jxr_dequant_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    buf = np.zeros(1 << 16, np.uint8)
+    n = L.jxr_dequant_encode(C.cast(C.byref(encodings), C.c_void_p), _p(buf), len(buf))
+    if n < 0:
+        raise ValueError("reference could not encode the quant encodings")
+    return bytes(buf[:n])
+
+
+def ref_dequant_decode(data):
+    """DequantMatrices::Decode + EnsureComputed by the reference on raw bytes:
+    (status, table, bits_consumed); status 0 ok, 1 Decode failed, 2 compute failed."""
+    L = ref_lib()
+    L.jxr_dequant_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    d = np.frombuffer(data, np.uint8)
+    t = np.zeros(DEQUANT_TABLE_FLOATS, np.float32)
+    bits = C.c_size_t(0)
+    rc = L.jxr_dequant_decode(d.ctypes.data, len(d), _p(t), C.byref(bits))
+    return rc, t, bits.value
+
+
 def ref_dequant_dc(quant_dc, mul_dc, cfl_x_dc, cfl_b_dc, smooth):
     """DequantDC (+AdaptiveDCSmoothing) by the reference; quant_dc: 3 int32 planes."""
     ysb, xsb = quant_dc[0].shape
@@ -290,10 +324,19 @@ def ref_dequant_dc(quant_dc, mul_dc, cfl_x_dc, cfl_b_dc, smooth):
     return out
 
 
-def _decode_ref(self, threads=1, simple_pipeline=False):
+def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None):
     """The same frame through the REFERENCE's DecodeGroupForRoundtrip + render
     pipeline (LowMemory executor by default, as djxl; simple_pipeline=True for
-    SimpleRenderPipeline)."""
+    SimpleRenderPipeline).  The reference computes its own dequant tables: the
+    default library, or quant_encodings (17 jxlhip_quant_encoding) when given."""
+    if quant_encodings is not None:
+        L = ref_lib()
+        L.jxr_set_quant_encodings.argtypes = [C.c_void_p]
+        assert L.jxr_set_quant_encodings(C.cast(C.byref(quant_encodings), C.c_void_p)) == 0
+        try:
+            return _decode_ref(self, threads, simple_pipeline)
+        finally:
+            L.jxr_set_quant_encodings(None)
     p = self.params
     if p.output_kind == 2:
         # packed RGB(A) through the reference's FromLinearStage + WriteToOutputStage;

@@ -25,7 +25,7 @@ CXX = os.environ.get("CXX", "g++")
 FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fno-lto", "-ffunction-sections", "-fdata-sections",
          "-ffp-contract=off", "-fvisibility=hidden", "-w",
          "-I" + SHIM, "-I" + REF, "-I" + os.path.join(REF, "lib", "include"),
-         "-DJPEGXL_ENABLE_SKCMS=0", "-DJXL_DEBUG_ON_ERROR=0", "-DJXL_CRASH_ON_ERROR=0"]
+         "-DJPEGXL_ENABLE_SKCMS=0", "-DJXL_DEBUG_ON_ERROR=0"]  # (defining JXL_CRASH_ON_ERROR at all turns it on)
 # reference translation units that are not needed by (or not linkable into) the
 # VarDCT back-end harness: public API front-end, JPEG reconstruction, ICC codec
 SKIP = re.compile(r"(decode\.cc|decode_to_jpeg\.cc|jpeg/|icc_codec\.cc|_test\.cc|_gbench\.cc|test_)")

@@ -86,6 +86,9 @@ float jxo_fast_powf(float base, float exponent);
 /* Default library, all 17 kinds. table: JXLHIP_DEQUANT_TABLE_FLOATS floats.
  * inv_table may be NULL.  Returns 0 on success. */
 int jxo_default_dequant_tables(float* table, float* inv_table);
+/* ... of 17 jxlhip_quant_encoding (NULL / JXLHIP_QUANT_LIBRARY = default); -1 on the
+ * reference's "Invalid distance bands" / "Invalid quantization table" failures */
+int jxo_dequant_tables(const jxlhip_quant_encoding* encodings, float* table, float* inv_table);
 
 /* ---- dequant (quantizer-inl.h:34-67, dec_group.cc:115-181) -------------- */
 float jxo_adjust_quant_bias(int c, int32_t q, const float biases[4]);

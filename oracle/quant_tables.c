@@ -61,7 +61,8 @@ float jxo_fast_powf(float base, float exponent) {
 static float mult(float v) { return v > 0.0f ? 1.0f + v : 1.0f / (1.0f - v); }
 
 /* GetQuantWeights (quant_weights.cc:129-160): rows x cols, 3 channels */
-static int dct_weights(int rows, int cols, const float bands_in[3][8], int nb,
+static int dct_weights(int rows, int cols,
+                       const float bands_in[3][JXLHIP_MAX_DISTANCE_BANDS], int nb,
                        float* out) {
   const float kSqrt2 = 1.41421356237f;
   for (int c = 0; c < 3; c++) {
@@ -105,11 +106,45 @@ static float interpolate(float pos, float max, const float* array, int len) {
   return a * jxo_fast_powf(b / a, scaled_pos - idx);
 }
 
-/* ComputeQuantTable (quant_weights.cc:163-358) for library entry `kind` */
-static int compute_kind(int kind, float* table, float* inv_table) {
-  const QuantLibEntry* e = &kQuantLib[kind];
+/* Library encodings -> the parameters they stand for (DequantMatrices::Library,
+ * quant_weights.cc:532-1188); the AFV entry's 4x8 / 4x4 band parameters are the
+ * DCT4X8 / DCT4X4 entries'. */
+static void resolve_library(int kind, jxlhip_quant_encoding* e) {
+  static const uint32_t kModeOfLib[6] = {JXLHIP_QUANT_DCT,  JXLHIP_QUANT_ID,
+                                         JXLHIP_QUANT_DCT2, JXLHIP_QUANT_DCT4,
+                                         JXLHIP_QUANT_DCT4X8, JXLHIP_QUANT_AFV};
+  const QuantLibEntry* l = &kQuantLib[kind];
+  const QuantLibEntry* b = l->mode == 5 ? &kQuantLib[9] : l;
+  memset(e, 0, sizeof(*e));
+  e->mode = kModeOfLib[l->mode];
+  e->num_bands = (uint32_t)b->nb;
+  for (int c = 0; c < 3; c++) {
+    for (int i = 0; i < 8; i++) e->bands[c][i] = b->bands[c][i];
+    for (int i = 0; i < 9; i++) e->weights[c][i] = l->w[c][i];
+  }
+  if (l->mode == 5) {
+    e->num_bands_afv_4x4 = (uint32_t)kQuantLib[3].nb;
+    for (int c = 0; c < 3; c++)
+      for (int i = 0; i < 8; i++) e->bands_afv_4x4[c][i] = kQuantLib[3].bands[c][i];
+  }
+}
+
+/* ComputeQuantTable (quant_weights.cc:163-358) for table `kind` under a
+ * resolved (non-library) encoding */
+static int compute_kind(int kind, const jxlhip_quant_encoding* enc, float* table,
+                        float* inv_table) {
+  /* the body below predates jxlhip_quant_encoding: view the encoding through its
+   * old field names */
+  struct { int mode; int nb; const float (*bands)[JXLHIP_MAX_DISTANCE_BANDS]; const float (*w)[9]; } ev, *e = &ev;
+  static const int kOldMode[8] = {-1, 1, 2, 3, 4, 5, 0, -1};
+  ev.mode = enc->mode < 8 ? kOldMode[enc->mode] : -1;
+  ev.nb = (int)enc->num_bands;
+  ev.bands = enc->bands;
+  ev.w = enc->weights;
+  if (ev.mode < 0) return -1;
   const int wrows = 8 * kKindShort[kind], wcols = 8 * kKindLong[kind];
   const int num = wrows * wcols;
+  if (ev.mode != 0 && num != 64) return -1;
   float* w = inv_table; /* build weights in place in inv_table */
   switch (e->mode) {
     case 1: /* ID, :70-80 */
@@ -175,10 +210,8 @@ static int compute_kind(int kind, float* table, float* inv_table) {
           2.662932286148962f, 7.630657783650829f, 8.962388608184032f,
           12.97166202570235f};
       float w48[3 * 32], w44[3 * 16];
-      const QuantLibEntry* e48 = &kQuantLib[9];
-      const QuantLibEntry* e44 = &kQuantLib[3];
-      if (dct_weights(4, 8, e48->bands, e48->nb, w48)) return -1;
-      if (dct_weights(4, 4, e44->bands, e44->nb, w44)) return -1;
+      if (dct_weights(4, 8, enc->bands, (int)enc->num_bands, w48)) return -1;
+      if (dct_weights(4, 4, enc->bands_afv_4x4, (int)enc->num_bands_afv_4x4, w44)) return -1;
       const float lo = 0.8517778890324296f;
       const float hi = 12.97166202570235f - lo + 1e-6f;
       for (int c = 0; c < 3; c++) {
@@ -224,12 +257,16 @@ static int compute_kind(int kind, float* table, float* inv_table) {
   return 0;
 }
 
-int jxo_default_dequant_tables(float* table, float* inv_table) {
+int jxo_dequant_tables(const jxlhip_quant_encoding* encodings, float* table,
+                       float* inv_table) {
   static __thread float scratch_inv[JXLHIP_DEQUANT_TABLE_FLOATS];
   float* inv = inv_table ? inv_table : scratch_inv;
   size_t pos = 0;
   for (int k = 0; k < 17; k++) {
-    if (compute_kind(k, table + pos, inv + pos)) return -1;
+    jxlhip_quant_encoding e;
+    if (!encodings || encodings[k].mode == JXLHIP_QUANT_LIBRARY) resolve_library(k, &e);
+    else e = encodings[k];
+    if (compute_kind(k, &e, table + pos, inv + pos)) return -1;
     /* lowest frequencies get a 0 inverse table (quant_weights.cc:343-356) */
     const int xs = kKindShort[k], ys = kKindLong[k]; /* CoefficientLayout: ys>=xs */
     for (int c = 0; c < 3; c++)
@@ -239,4 +276,8 @@ int jxo_default_dequant_tables(float* table, float* inv_table) {
     pos += 3u * 64u * kKindShort[k] * kKindLong[k];
   }
   return pos == JXLHIP_DEQUANT_TABLE_FLOATS ? 0 : -1;
+}
+
+int jxo_default_dequant_tables(float* table, float* inv_table) {
+  return jxo_dequant_tables(NULL, table, inv_table);
 }

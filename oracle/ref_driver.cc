@@ -74,6 +74,7 @@
 #include "lib/jxl/enc_context_map.h"
 #include "lib/jxl/enc_entropy_coder.h"
 #include "lib/jxl/enc_params.h"
+#include "lib/jxl/enc_quant_weights.h"
 #include "lib/jxl/frame_header.h"
 
 #include "jxl_oracle.h"  // jxo_frame (POD mirror of the C ABI inputs)
@@ -88,6 +89,65 @@ struct Ref {
   JxlMemoryManager mm;
   Ref() { (void)MemoryManagerInit(&mm, nullptr); }
 };
+
+// jxlhip_quant_encoding[17] -> the reference's QuantEncoding objects
+bool ToQuantEncodings(const jxlhip_quant_encoding* enc, std::vector<QuantEncoding>* out) {
+  std::vector<QuantEncoding> v;
+  auto params = [](uint32_t nb, const float b[3][JXLHIP_MAX_DISTANCE_BANDS]) {
+    DctQuantWeightParams p;
+    p.num_distance_bands = nb;
+    for (int c = 0; c < 3; c++)
+      for (uint32_t i = 0; i < nb && i < DctQuantWeightParams::kMaxDistanceBands; i++) p.distance_bands[c][i] = b[c][i];
+    return p;
+  };
+  for (int k = 0; k < JXLHIP_NUM_QUANT_TABLES; k++) {
+    const jxlhip_quant_encoding& e = enc[k];
+    switch (e.mode) {
+      case JXLHIP_QUANT_LIBRARY: v.push_back(QuantEncoding::Library<0>()); break;
+      case JXLHIP_QUANT_ID: {
+        QuantEncoding::IdWeights w;
+        for (int c = 0; c < 3; c++)
+          for (int i = 0; i < 3; i++) w[c][i] = e.weights[c][i];
+        v.push_back(QuantEncoding::Identity(w));
+        break;
+      }
+      case JXLHIP_QUANT_DCT2: {
+        QuantEncoding::DCT2Weights w;
+        for (int c = 0; c < 3; c++)
+          for (int i = 0; i < 6; i++) w[c][i] = e.weights[c][i];
+        v.push_back(QuantEncoding::DCT2(w));
+        break;
+      }
+      case JXLHIP_QUANT_DCT4: {
+        QuantEncoding::DCT4Multipliers w;
+        for (int c = 0; c < 3; c++)
+          for (int i = 0; i < 2; i++) w[c][i] = e.weights[c][i];
+        v.push_back(QuantEncoding::DCT4(params(e.num_bands, e.bands), w));
+        break;
+      }
+      case JXLHIP_QUANT_DCT4X8: {
+        QuantEncoding::DCT4x8Multipliers w;
+        for (int c = 0; c < 3; c++) w[c] = e.weights[c][0];
+        v.push_back(QuantEncoding::DCT4X8(params(e.num_bands, e.bands), w));
+        break;
+      }
+      case JXLHIP_QUANT_AFV: {
+        QuantEncoding::AFVWeights w;
+        for (int c = 0; c < 3; c++)
+          for (int i = 0; i < 9; i++) w[c][i] = e.weights[c][i];
+        v.push_back(QuantEncoding::AFV(params(e.num_bands, e.bands), params(e.num_bands_afv_4x4, e.bands_afv_4x4), w));
+        break;
+      }
+      case JXLHIP_QUANT_DCT: v.push_back(QuantEncoding::DCT(params(e.num_bands, e.bands))); break;
+      default: return false;
+    }
+  }
+  *out = std::move(v);
+  return true;
+}
+
+// custom dequant-matrix encodings for the next DecodeFrame calls (empty = default library)
+std::vector<QuantEncoding> g_quant_encodings;
 
 Status FillState(const jxo_frame* f, CodecMetadata* metadata, FrameHeader* fh,
                  PassesDecoderState* dec_state, bool xyb_out) {
@@ -145,6 +205,7 @@ Status FillState(const jxo_frame* f, CodecMetadata* metadata, FrameHeader* fh,
   const FrameDimensions& fd = sh.frame_dim;
   const size_t xsb = fd.xsize_blocks, ysb = fd.ysize_blocks;
 
+  if (!g_quant_encodings.empty()) sh.matrices.SetEncodings(g_quant_encodings);
   JXL_RETURN_IF_ERROR(sh.matrices.EnsureComputed(sh.memory_manager, ~0u));
   sh.quantizer.~Quantizer();
   new (&sh.quantizer) Quantizer(sh.matrices, p.quant_dc, p.global_scale);
@@ -575,4 +636,47 @@ JXR_EXPORT int jxr_quant_dc_contexts(uint32_t xsb, uint32_t ysb, const int32_t* 
     return true;
   };
   return run() ? 0 : -1;
+}
+
+// ---- custom dequant-matrix encodings (a5) ------------------------------------------------
+// jxlhip_quant_encoding[17] -> the reference's QuantEncoding, written by the reference's
+// DequantMatricesEncode (enc_quant_weights.cc:116-142).  Returns the number of bytes or -1.
+JXR_EXPORT int64_t jxr_dequant_encode(const jxlhip_quant_encoding* enc, uint8_t* out, size_t cap) {
+  Ref ref;
+  std::vector<QuantEncoding> v;
+  if (!ToQuantEncodings(enc, &v)) return -1;
+  DequantMatrices m;
+  m.SetEncodings(v);
+  BitWriter writer{&ref.mm};
+  if (!DequantMatricesEncode(&ref.mm, m, &writer, LayerType::Quant, nullptr, nullptr)) return -1;
+  writer.ZeroPadToByte();
+  Span<const uint8_t> sp = writer.GetSpan();
+  if (sp.size() > cap) return -1;
+  memcpy(out, sp.data(), sp.size());
+  return static_cast<int64_t>(sp.size());
+}
+
+// DequantMatrices::Decode + EnsureComputed (quant_weights.cc:497-511,1211-1271) on raw bytes.
+// 0 ok (table filled, *bits = bits consumed), 1 Decode failed, 2 EnsureComputed failed.
+JXR_EXPORT int jxr_dequant_decode(const uint8_t* data, size_t size, float* table, size_t* bits) {
+  Ref ref;
+  DequantMatrices m;
+  BitReader br(Bytes(data, size));
+  Status ok = m.Decode(&ref.mm, &br, nullptr);
+  const size_t consumed = br.TotalBitsConsumed();
+  const bool in_bounds = br.AllReadsWithinBounds();
+  (void)br.Close();
+  if (!ok || !in_bounds) return 1;
+  if (!m.EnsureComputed(&ref.mm, ~0u)) return 2;
+  memcpy(table, m.Matrix(AcStrategyType::DCT, 0), sizeof(float) * JXLHIP_DEQUANT_TABLE_FLOATS);
+  *bits = consumed;
+  return 0;
+}
+
+// Frames decoded after this call use these dequant-matrix encodings (NULL = back to the default
+// library) instead of jxo_frame::dequant_table, which the reference cannot take as floats.
+JXR_EXPORT int jxr_set_quant_encodings(const jxlhip_quant_encoding* enc) {
+  g_quant_encodings.clear();
+  if (!enc) return 0;
+  return ToQuantEncodings(enc, &g_quant_encodings) ? 0 : -1;
 }
