@@ -128,6 +128,19 @@ JXLHIP_EXPORT int jxlhip_ac_group_decode_submit(jxlhip_ctx* ctx, const jxlhip_ac
                                                 const int32_t* raw_quant, const uint8_t* quant_dc,
                                                 const uint8_t* data, size_t size, size_t* bit_pos);
 
+/* The multi-pass form (progressive AC: FrameDecoder::ProcessACGroup hands DecodeGroup one
+ * reader per pass, dec_frame.cc:455-516, dec_group.cc:575-590): pass p of the group is read
+ * from data[p][0..sizes[p]) starting at bit bit_pos[p] (advanced) with passes[p] and added
+ * << shifts[p] (frame_header.passes.shift; NULL = all 0).  The caller passes the sections of
+ * every pass it has; a later call for the same group with more passes re-decodes from pass 0
+ * (the slot is zeroed), which is what a progressive re-render does. */
+JXLHIP_EXPORT int jxlhip_ac_group_decode_submit_passes(jxlhip_ctx* ctx, uint32_t num_passes,
+                                                       const jxlhip_ac_pass* const* passes,
+                                                       const uint32_t* shifts, uint32_t group_idx,
+                                                       const uint8_t* ac_strategy, const int32_t* raw_quant,
+                                                       const uint8_t* quant_dc, const uint8_t* const* data,
+                                                       const size_t* sizes, size_t* bit_pos);
+
 #ifdef __cplusplus
 }
 #endif

@@ -581,13 +581,19 @@ static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void*
   return JXLHIP_OK;
 }
 
-// f1: entropy-decode one single-pass AC group into a pinned staging slot and
+// f1: entropy-decode all passes of one AC group into a pinned staging slot and
 // queue its upload.  The slot is reused only after its copies completed.
-int jxlhip_ac_group_decode_submit(jxlhip_ctx* c, const jxlhip_ac_pass* pass, uint32_t group_idx,
-                                  const uint8_t* ac_strategy, const int32_t* raw_quant,
-                                  const uint8_t* quant_dc, const uint8_t* data, size_t size,
-                                  size_t* bit_pos) {
-  if (!c || !pass || !ac_strategy || !raw_quant || !data || !bit_pos) return JXLHIP_ERR_INVALID_ARGUMENT;
+int jxlhip_ac_group_decode_submit_passes(jxlhip_ctx* c, uint32_t num_passes,
+                                         const jxlhip_ac_pass* const* passes, const uint32_t* shifts,
+                                         uint32_t group_idx, const uint8_t* ac_strategy,
+                                         const int32_t* raw_quant, const uint8_t* quant_dc,
+                                         const uint8_t* const* data, const size_t* sizes,
+                                         size_t* bit_pos) {
+  if (!c || !passes || !ac_strategy || !raw_quant || !data || !sizes || !bit_pos || num_passes == 0 ||
+      num_passes > 11)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  for (uint32_t p = 0; p < num_passes; p++)
+    if (!passes[p] || !data[p] || (shifts && shifts[p] > 3)) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "ac_group_decode_submit before frame_begin");
   const DevFrame& f = c->f;
   if (group_idx >= f.xsg * f.ysg) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad group %u", group_idx);
@@ -644,9 +650,11 @@ int jxlhip_ac_group_decode_submit(jxlhip_ctx* c, const jxlhip_ac_pass* pass, uin
   void* const ch[3] = {base, base + (size_t)JXLHIP_GROUP_COEFFS * esz, base + 2 * (size_t)JXLHIP_GROUP_COEFFS * esz};
   memset(base, 0, slot_bytes);  // coefficients are accumulated (dec_group.cc:527-531)
   size_t ncoeffs = 0;
-  int rc = jxlhip_ac_group_decode(pass, f.xsb, f.ysb, group_idx % f.xsg, group_idx / f.xsg, ac_strategy,
-                                  raw_quant, quant_dc, data, size, bit_pos, /*shift=*/0, f.coeff_type, ch,
-                                  &ncoeffs);
+  int rc = JXLHIP_OK;
+  for (uint32_t p = 0; p < num_passes && rc == JXLHIP_OK; p++)
+    rc = jxlhip_ac_group_decode(passes[p], f.xsb, f.ysb, group_idx % f.xsg, group_idx / f.xsg, ac_strategy,
+                                raw_quant, quant_dc, data[p], sizes[p], &bit_pos[p], shifts ? shifts[p] : 0,
+                                f.coeff_type, ch, &ncoeffs);
   if (rc == JXLHIP_OK) {
     const void* const src[3] = {ch[0], ch[1], ch[2]};
     rc = jxlhip_submit_group_ev(c, group_idx, src, ncoeffs, c->stage_ev[slot]);
@@ -658,6 +666,14 @@ int jxlhip_ac_group_decode_submit(jxlhip_ctx* c, const jxlhip_ac_pass* pass, uin
   c->stage_cv.notify_all();
   if (rc == JXLHIP_ERR_BAD_STREAM) return Fail(c, rc, "AC group %u: invalid entropy-coded data", group_idx);
   return rc;
+}
+
+int jxlhip_ac_group_decode_submit(jxlhip_ctx* c, const jxlhip_ac_pass* pass, uint32_t group_idx,
+                                  const uint8_t* ac_strategy, const int32_t* raw_quant,
+                                  const uint8_t* quant_dc, const uint8_t* data, size_t size,
+                                  size_t* bit_pos) {
+  return jxlhip_ac_group_decode_submit_passes(c, 1, &pass, nullptr, group_idx, ac_strategy, raw_quant,
+                                              quant_dc, &data, &size, bit_pos);
 }
 
 // ---- decode -------------------------------------------------------------------

@@ -420,16 +420,16 @@ class RealStream:
                  block_ctx_bytes=(10, np.uint8), rgb=(11, np.float32), section_offset=(12, np.uint64),
                  section_size=(13, np.uint64), params=(14, np.uint8), dequant_table=(15, np.float32))
 
-    def __init__(self, xsize, ysize, seed=1, distance=1.0, speed_tier=3, epf=-1):
+    def __init__(self, xsize, ysize, seed=1, distance=1.0, speed_tier=3, epf=-1, progressive=0):
         L = ref_lib()
         L.jxr_real_case_create.restype = C.c_void_p
-        L.jxr_real_case_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int]
+        L.jxr_real_case_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int, C.c_int]
         L.jxr_real_case_destroy.argtypes = [C.c_void_p]
         L.jxr_real_case_data.restype = C.c_void_p
         L.jxr_real_case_data.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.jxr_real_case_info.restype = C.c_uint64
         L.jxr_real_case_info.argtypes = [C.c_void_p, C.c_int]
-        h = L.jxr_real_case_create(xsize, ysize, seed, distance, speed_tier, epf)
+        h = L.jxr_real_case_create(xsize, ysize, seed, distance, speed_tier, epf, progressive)
         if not h:
             raise ValueError("reference encode/decode failed")
         try:
@@ -440,6 +440,8 @@ class RealStream:
                 setattr(self, name, a)
             (self.num_groups, self.num_dc_groups, self.num_histograms, self.used_acs, self.frame_offset,
              self.sections_offset) = [int(L.jxr_real_case_info(h, i)) for i in range(6)]
+            self.num_passes = int(L.jxr_real_case_info(h, 6))
+            self.shift = [int(L.jxr_real_case_info(h, 16 + i)) for i in range(self.num_passes)]
         finally:
             L.jxr_real_case_destroy(h)
         self.xsize, self.ysize = xsize, ysize
@@ -458,8 +460,9 @@ class RealStream:
     def ac_global(self):
         return self.section(1 + self.num_dc_groups)
 
-    def ac_group(self, g):
-        return self.section(2 + self.num_dc_groups + g)
+    def ac_group(self, g, pass_idx=0):
+        # AcGroupIndex (frame_dimensions / toc.h): passes are the outer dimension
+        return self.section(2 + self.num_dc_groups + pass_idx * self.num_groups + g)
 
     def frame(self, coeffs):
         """An oracle Frame over this stream's side info and the given coefficient buffers."""

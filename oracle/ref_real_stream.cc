@@ -96,6 +96,7 @@ struct RealCase {
   size_t sections_offset = 0; // first byte of the first section
   std::vector<uint64_t> section_offset, section_size;  // indexed by logical section id
   uint32_t xsize = 0, ysize = 0, num_groups = 0, num_dc_groups = 0, num_histograms = 0, used_acs = 0;
+  uint32_t num_passes = 1, shift[kMaxNumPasses] = {};  // frame_header.passes
   jxlhip_frame_params params{};
   std::vector<uint8_t> acs, sharp, quant_dc, bctx_bytes;
   std::vector<int32_t> raw_quant;
@@ -146,7 +147,8 @@ void FillImage(Image3F* img, uint32_t seed) {
   }
 }
 
-Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_tier, int epf, RealCase* out) {
+Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_tier, int epf, int progressive,
+           RealCase* out) {
   JxlMemoryManager mm;
   JXL_RETURN_IF_ERROR(MemoryManagerInit(&mm, nullptr));
   // ---- 1. encode
@@ -168,6 +170,9 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   cparams.dots = Override::kOff;
   cparams.noise = Override::kOff;
   cparams.epf = epf;  // -1 = the encoder's choice
+  // progressive: 1 = AC passes by frequency band, 2 = by quantisation (shifted passes)
+  if (progressive == 1) cparams.progressive_mode = Override::kOn;
+  if (progressive == 2) cparams.qprogressive_mode = Override::kOn;
   cparams.color_transform = ColorTransform::kXYB;
   JXL_RETURN_IF_ERROR(ParamsPostInit(&cparams));
   BitWriter writer{&mm};
@@ -236,7 +241,7 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   JXL_RETURN_IF_ERROR(fd.FinalizeFrame());
 
   // ---- 3. the inputs of the product's boundary, from the decoder's state
-  if (fh.encoding != FrameEncoding::kVarDCT || fh.passes.num_passes != 1 || fh.upsampling != 1 ||
+  if (fh.encoding != FrameEncoding::kVarDCT || fh.upsampling != 1 ||
       !fh.chroma_subsampling.Is444() || (fh.flags & (FrameHeader::kNoise | FrameHeader::kPatches |
                                                     FrameHeader::kSplines | FrameHeader::kUseDcFrame))) {
     return JXL_FAILURE("frame uses features outside the back-end's scope");
@@ -246,6 +251,8 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   out->xsize = xs;
   out->ysize = ys;
   out->num_histograms = sh.num_histograms;
+  out->num_passes = fh.passes.num_passes;
+  for (uint32_t i = 0; i < fh.passes.num_passes; i++) out->shift[i] = fh.passes.shift[i];
   out->used_acs = dec_state->used_acs;
   out->acs.resize(xsb * ysb);
   out->sharp.resize(xsb * ysb);
@@ -328,9 +335,9 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
 }  // namespace
 
 JXR_EXPORT void* jxr_real_case_create(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_tier,
-                                      int epf) {
+                                      int epf, int progressive) {
   auto c = std::make_unique<RealCase>();
-  if (!Run(xs, ys, seed, distance, speed_tier, epf, c.get())) return nullptr;
+  if (!Run(xs, ys, seed, distance, speed_tier, epf, progressive, c.get())) return nullptr;
   return c.release();
 }
 JXR_EXPORT void jxr_real_case_destroy(void* h) { delete static_cast<RealCase*>(h); }
@@ -362,7 +369,8 @@ JXR_EXPORT const void* jxr_real_case_data(void* h, int what, size_t* bytes) {
     default: *bytes = 0; return static_cast<const void*>(nullptr);
   }
 }
-// 0 num_groups, 1 num_dc_groups, 2 num_histograms, 3 used_acs, 4 frame offset, 5 sections offset
+// 0 num_groups, 1 num_dc_groups, 2 num_histograms, 3 used_acs, 4 frame offset, 5 sections offset,
+// 6 num_passes, 16+i shift of pass i
 JXR_EXPORT uint64_t jxr_real_case_info(void* h, int what) {
   RealCase* c = static_cast<RealCase*>(h);
   switch (what) {
@@ -372,6 +380,9 @@ JXR_EXPORT uint64_t jxr_real_case_info(void* h, int what) {
     case 3: return c->used_acs;
     case 4: return c->frame_offset;
     case 5: return c->sections_offset;
+    case 6: return c->num_passes;
+    case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26:
+      return c->shift[what - 16];
     default: return 0;
   }
 }

@@ -25,61 +25,56 @@ def ref(oracle):
 
 @pytest.fixture(scope="module")
 def L():
-    lib = C.CDLL(abi.library_path())
-    lib.jxlhip_block_ctx_map_decode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]
-    lib.jxlhip_ac_pass_decode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_uint32, C.c_uint32,
-                                          C.c_void_p, C.POINTER(C.c_void_p)]
-    lib.jxlhip_ac_pass_destroy.argtypes = [C.c_void_p]
-    lib.jxlhip_ac_pass_destroy.restype = None
-    lib.jxlhip_ac_pass_max_num_bits.argtypes = [C.c_void_p]
-    lib.jxlhip_ac_pass_max_num_bits.restype = C.c_uint32
-    lib.jxlhip_ac_group_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
-                                           C.c_uint32, C.c_uint32, C.c_void_p * 3, C.POINTER(C.c_size_t)]
-    return lib
+    return abi.load_library()
 
 
 def ceil_log2(n):
     return (n - 1).bit_length()
 
 
-def entropy_decode(L, rs):
-    """AC global + AC group sections of rs through the product's entropy decoder.
-    Returns (coeff_type, the three coefficient buffers)."""
+def open_ac_global(L, rs):
+    """ProcessACGlobal (dec_frame.cc:372-421) on the stream's AC-global section: the block
+    context map from DC global, then jxlhip_ac_global_decode.  Returns (pass handles,
+    coefficient type)."""
     bctx = abi.BlockCtxMap()
     pos = C.c_size_t(0)
     b = rs.block_ctx_bytes
     assert L.jxlhip_block_ctx_map_decode(b.ctypes.data, len(b), C.byref(pos), C.byref(bctx)) == 0
     glob = np.frombuffer(rs.ac_global(), np.uint8)
-    # ProcessACGlobal (dec_frame.cc:368-386): DequantMatrices::Decode -- one bit "all default" --
-    # then num_histograms - 1 in CeilLog2Nonzero(num_groups) bits
-    assert glob[0] & 1, "custom dequant matrices are not in scope"
-    nbits = ceil_log2(rs.num_groups)
-    num_histo = 1 + ((int(glob[0]) | int(glob[1]) << 8 | int(glob[2]) << 16) >> 1 & ((1 << nbits) - 1))
-    assert num_histo == rs.num_histograms
-    pos = C.c_size_t(1 + nbits)
-    h = C.c_void_p()
-    rc = L.jxlhip_ac_pass_decode(glob.ctypes.data, len(glob), C.byref(pos), rs.used_acs, num_histo,
-                                 C.byref(bctx), C.byref(h))
+    encs = abi.QuantEncodings()
+    nh, used, hs = C.c_uint32(0), C.c_size_t(0), (C.c_void_p * rs.num_passes)()
+    rc = L.jxlhip_ac_global_decode(glob.ctypes.data, len(glob), rs.num_groups, rs.num_passes, rs.used_acs,
+                                   C.byref(bctx), C.byref(encs), C.byref(nh), hs, C.byref(used))
     assert rc == 0, rc
-    assert (pos.value + 7) // 8 == len(glob), (pos.value, len(glob))
+    assert nh.value == rs.num_histograms
+    assert (used.value + 7) // 8 == len(glob), (used.value, len(glob))
+    assert all(e.mode == abi.QUANT_LIBRARY for e in encs)  # the encoder never writes custom matrices
+    # dec_frame.cc:414-421: 16-bit coefficient buffers only when no token, summed over the passes,
+    # can carry 16 bits (a flat histogram in the stream is enough to make the reference pick int32)
+    mx = max(L.jxlhip_ac_pass_max_num_bits(h) for h in hs) + ceil_log2(rs.num_passes)
+    return list(hs), 0 if mx < 16 else 1
+
+
+def entropy_decode(L, rs):
+    """AC global + every pass of every AC group section of rs through the product's
+    entropy decoder.  Returns (coeff_type, the three coefficient buffers)."""
+    hs, ct = open_ac_global(L, rs)
     try:
-        # dec_frame.cc:414-421: 16-bit coefficient buffers only when no token can carry 16 bits
-        # (a flat histogram in the stream is enough to make the reference pick int32)
-        ct = 0 if L.jxlhip_ac_pass_max_num_bits(h) < 16 else 1
         out = [np.zeros(rs.num_groups * 65536, np.int32 if ct else np.int16) for _ in range(3)]
         xsb, ysb, xsg = (rs.xsize + 7) // 8, (rs.ysize + 7) // 8, (rs.xsize + 255) // 256
         for g in range(rs.num_groups):
-            d = np.frombuffer(rs.ac_group(g), np.uint8)
-            gp, n = C.c_size_t(0), C.c_size_t(0)
             ptrs = (C.c_void_p * 3)(*[o[g * 65536:].ctypes.data for o in out])
-            rc = L.jxlhip_ac_group_decode(h, xsb, ysb, g % xsg, g // xsg, rs.ac_strategy.ctypes.data,
-                                          rs.raw_quant.ctypes.data, rs.quant_dc.ctypes.data, d.ctypes.data, len(d),
-                                          C.byref(gp), 0, ct, ptrs, C.byref(n))
-            assert rc == 0, (g, rc)
-            assert (gp.value + 7) // 8 == len(d), (g, gp.value, len(d))
+            for p in range(rs.num_passes):  # passes accumulate, each << its shift (dec_group.cc:520-526)
+                d = np.frombuffer(rs.ac_group(g, p), np.uint8)
+                gp, n = C.c_size_t(0), C.c_size_t(0)
+                rc = L.jxlhip_ac_group_decode(hs[p], xsb, ysb, g % xsg, g // xsg, rs.ac_strategy.ctypes.data,
+                                              rs.raw_quant.ctypes.data, rs.quant_dc.ctypes.data, d.ctypes.data,
+                                              len(d), C.byref(gp), rs.shift[p], ct, ptrs, C.byref(n))
+                assert rc == 0, (g, p, rc)
+                assert (gp.value + 7) // 8 == len(d), (g, p, gp.value, len(d))
     finally:
-        L.jxlhip_ac_pass_destroy(h)
+        for h in hs:
+            L.jxlhip_ac_pass_destroy(h)
     return ct, out
 
 
@@ -93,6 +88,20 @@ def entropy_decode(L, rs):
 ])
 def test_reference_encoded_stream_decodes_to_reference_pixels(L, ref, xs, ys, distance, tier, epf):
     rs = ref.RealStream(xs, ys, seed=xs + ys, distance=distance, speed_tier=tier, epf=epf)
+    check_cpu(L, rs)
+
+
+@pytest.mark.parametrize("progressive,passes", [(1, 3), (2, 2)])
+def test_progressive_passes_accumulate_to_reference_pixels(L, ref, progressive, passes):
+    """--progressive_ac (3 passes split by frequency band) and --qprogressive_ac (2 passes,
+    the first one shifted by 1): every pass has its own coefficient orders and histograms."""
+    rs = ref.RealStream(520, 392, seed=11, distance=1.5, speed_tier=3, progressive=progressive)
+    assert rs.num_passes == passes
+    assert (max(rs.shift) > 0) == (progressive == 2)
+    check_cpu(L, rs)
+
+
+def check_cpu(L, rs):
     ct, coeffs = entropy_decode(L, rs)
     assert any(np.any(c) for c in coeffs)
     fr = rs.frame(coeffs)
@@ -103,56 +112,54 @@ def test_reference_encoded_stream_decodes_to_reference_pixels(L, ref, xs, ys, di
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("xs,ys,distance,tier,epf", [
-    (512, 384, 1.0, 3, -1),
-    (520, 300, 3.0, 3, -1),
-    (384, 520, 2.0, 2, 1),
-    (300, 300, 1.0, 7, 0),
-    (2048, 1280, 1.0, 5, -1),   # 40 groups: the runner's threads race for the staging slots
+@pytest.mark.parametrize("xs,ys,distance,tier,epf,progressive", [
+    (512, 384, 1.0, 3, -1, 0),
+    (520, 300, 3.0, 3, -1, 0),
+    (384, 520, 2.0, 2, 1, 0),
+    (300, 300, 1.0, 7, 0, 0),
+    (2048, 1280, 1.0, 5, -1, 0),   # 40 groups: the runner's threads race for the staging slots; int32
+    (520, 392, 1.5, 3, -1, 1),     # 3 passes by frequency band
+    (520, 392, 1.5, 3, -1, 2),     # 2 passes, the first shifted by 1
 ])
-def test_reference_encoded_stream_through_hip_path(ref, xs, ys, distance, tier, epf):
+def test_reference_encoded_stream_through_hip_path(L, ref, xs, ys, distance, tier, epf, progressive):
     """The whole product on a genuine stream, as a libjxl maintainer would wire it:
     side info to the device, AC sections entropy-decoded by runner threads straight
-    into the pinned staging slots (jxlhip_ac_group_decode_submit), HIP decode."""
+    into the pinned staging slots (jxlhip_ac_group_decode_submit_passes), HIP decode."""
     import threading
 
-    import torch
-
     from libjxl_amd import VarDctDecoder
-    rs = ref.RealStream(xs, ys, seed=xs + ys, distance=distance, speed_tier=tier, epf=epf)
+    rs = ref.RealStream(xs, ys, seed=xs + ys, distance=distance, speed_tier=tier, epf=epf, progressive=progressive)
+    hs, ct = open_ac_global(L, rs)
     d = VarDctDecoder(0)
-    L = d.L
     params = abi.FrameParams.from_buffer_copy(rs.params.tobytes())
     params.output_kind = 1
-    bctx = abi.BlockCtxMap()
-    pos = C.c_size_t(0)
-    b = rs.block_ctx_bytes
-    assert L.jxlhip_block_ctx_map_decode(b.ctypes.data, len(b), C.byref(pos), C.byref(bctx)) == 0
-    glob = np.frombuffer(rs.ac_global(), np.uint8)
-    assert glob[0] & 1
-    nbits = ceil_log2(rs.num_groups)
-    num_histo = 1 + ((int(glob[0]) | int(glob[1]) << 8 | int(glob[2]) << 16) >> 1 & ((1 << nbits) - 1))
-    pos = C.c_size_t(1 + nbits)
-    h = C.c_void_p()
-    assert L.jxlhip_ac_pass_decode(glob.ctypes.data, len(glob), C.byref(pos), rs.used_acs, num_histo,
-                                   C.byref(bctx), C.byref(h)) == 0
-    params.coeff_type = 0 if L.jxlhip_ac_pass_max_num_bits(h) < 16 else 1  # dec_frame.cc:414-421
+    params.coeff_type = ct
     d.begin_frame(params)
+    dq = d.dequant_tables(None)   # the stream's encodings are all-library (checked in open_ac_global)
+    d.sync()
+    dqh = dq.cpu().numpy()
+    assert np.array_equal(dqh, rs.dequant_table)
     dc = [rs.dc_x, rs.dc_y, rs.dc_b]
     dc3 = (C.c_void_p * 3)(*[x.ctypes.data for x in dc])
     assert L.jxlhip_upload_side_info(d.ctx, rs.ac_strategy.ctypes.data, rs.raw_quant.ctypes.data,
                                      rs.epf_sharpness.ctypes.data, rs.ytox_map.ctypes.data,
-                                     rs.ytob_map.ctypes.data, dc3, rs.dequant_table.ctypes.data) == 0
+                                     rs.ytob_map.ctypes.data, dc3, dqh.ctypes.data) == 0
     errs = []
+    n = rs.num_passes
+    pass_arr = (C.c_void_p * n)(*hs)
+    shifts = (C.c_uint32 * n)(*rs.shift)
 
     def worker(tid, nthreads):
         for g in range(tid, rs.num_groups, nthreads):
-            sec = np.frombuffer(rs.ac_group(g), np.uint8)
-            gp = C.c_size_t(0)
-            rc = L.jxlhip_ac_group_decode_submit(d.ctx, h, g, rs.ac_strategy.ctypes.data, rs.raw_quant.ctypes.data,
-                                                 rs.quant_dc.ctypes.data, sec.ctypes.data, len(sec), C.byref(gp))
-            if rc != 0 or (gp.value + 7) // 8 != len(sec):
-                errs.append((g, rc, gp.value, len(sec)))
+            secs = [np.frombuffer(rs.ac_group(g, p), np.uint8) for p in range(n)]
+            datas = (C.c_void_p * n)(*[x.ctypes.data for x in secs])
+            sizes = (C.c_size_t * n)(*[len(x) for x in secs])
+            pos = (C.c_size_t * n)()
+            rc = L.jxlhip_ac_group_decode_submit_passes(d.ctx, n, pass_arr, shifts, g, rs.ac_strategy.ctypes.data,
+                                                        rs.raw_quant.ctypes.data, rs.quant_dc.ctypes.data, datas,
+                                                        sizes, pos)
+            if rc != 0 or any((pos[p] + 7) // 8 != len(secs[p]) for p in range(n)):
+                errs.append((g, rc, list(pos), [len(x) for x in secs]))
 
     threads = [threading.Thread(target=worker, args=(i, 12)) for i in range(12)]
     for th in threads:
@@ -162,7 +169,8 @@ def test_reference_encoded_stream_through_hip_path(ref, xs, ys, distance, tier, 
     assert not errs, errs
     got = d.decode_frame()
     d.sync()
-    L.jxlhip_ac_pass_destroy(h)
+    for h in hs:
+        L.jxlhip_ac_pass_destroy(h)
     got = got.cpu().numpy()
     d.close()
     scale = max(1.0, float(np.abs(rs.rgb).max()))
