@@ -87,7 +87,9 @@ typedef enum jxlhip_transfer {
   JXLHIP_TF_SRGB = 1,   /* OpRgb: TF_SRGB::EncodedFromDisplay (JXL_HIGH_PRECISION) */
   JXLHIP_TF_PQ = 2,     /* OpPq: TF_PQ(tf_param = intensity target in nits)::EncodedFromDisplay */
   JXLHIP_TF_709 = 3,    /* Op709: TF_709::EncodedFromDisplay */
-  JXLHIP_TF_GAMMA = 4   /* OpGamma: x <= 1e-5 ? 0 : FastPowf(x, tf_param = inverse gamma; DCI: 1/2.6) */
+  JXLHIP_TF_GAMMA = 4,  /* OpGamma: x <= 1e-5 ? 0 : FastPowf(x, tf_param = inverse gamma; DCI: 1/2.6) */
+  JXLHIP_TF_HLG = 5     /* OpHlg: HlgOOTF::ToSceneLight(tf_param = intensity target, luminances) on the
+                           pixel, then TF_HLG::EncodedFromDisplay per sample */
 } jxlhip_transfer;
 
 /* JxlDataType of the output buffer (include/jxl/types.h:40-60). */
@@ -106,7 +108,9 @@ typedef struct jxlhip_output_format {
   uint32_t num_channels;    /* 3 = RGB, 4 = RGBA (alpha = 1.0: the frame has no alpha channel) */
   uint32_t bits_per_sample; /* U8: 1..8, U16: 1..16; ignored for the float types */
   uint32_t swap_endianness; /* U16 / F16 / F32: byte-swap every sample (JXL_BIG_ENDIAN on this host) */
-  float tf_param;           /* PQ: OutputEncodingInfo::orig_intensity_target; GAMMA: inverse_gamma */
+  float tf_param;           /* PQ, HLG: OutputEncodingInfo::desired_intensity_target; GAMMA: inverse_gamma */
+  float luminances[3];      /* HLG: OutputEncodingInfo::luminances, the Y row of the output primaries'
+                               RGB->XYZ matrix (dec_xyb.cc:187-211; sRGB: 0.2126, 0.7152, 0.0722) */
 } jxlhip_output_format;
 
 /* Mirrors jxl::LoopFilter (lib/jxl/loop_filter.h:20-70); values as decoded. */

@@ -28,11 +28,12 @@ class OutputFormat(C.Structure):
     """jxlhip_output_format: FromLinearStage + WriteToOutputStage parameters."""
     _fields_ = [("transfer", C.c_uint32), ("sample_type", C.c_uint32),
                 ("num_channels", C.c_uint32), ("bits_per_sample", C.c_uint32),
-                ("swap_endianness", C.c_uint32), ("tf_param", C.c_float)]
+                ("swap_endianness", C.c_uint32), ("tf_param", C.c_float),
+                ("luminances", C.c_float * 3)]
 
 
 OUT_XYB_PLANAR, OUT_LINEAR_RGB_F32, OUT_PACKED = 0, 1, 2
-TF_LINEAR, TF_SRGB, TF_PQ, TF_709, TF_GAMMA = 0, 1, 2, 3, 4
+TF_LINEAR, TF_SRGB, TF_PQ, TF_709, TF_GAMMA, TF_HLG = 0, 1, 2, 3, 4, 5
 SAMPLE_F32, SAMPLE_U8, SAMPLE_U16, SAMPLE_F16 = 0, 1, 2, 3
 
 
@@ -111,6 +112,7 @@ def make_params(d):
         p.out_format.bits_per_sample = of.get("bits_per_sample", 0)
         p.out_format.swap_endianness = of.get("swap_endianness", 0)
         p.out_format.tf_param = of.get("tf_param", 0.0)
+        p.out_format.luminances[:] = of.get("luminances", (0.2126, 0.7152, 0.0722))
     return p
 
 

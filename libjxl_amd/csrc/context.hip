@@ -309,8 +309,9 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   if (p->output_kind == JXLHIP_OUT_PACKED) {
     const jxlhip_output_format& o = p->out_format;
     const uint32_t max_bits = o.sample_type == JXLHIP_SAMPLE_U8 ? 8 : 16;
-    if (o.transfer > JXLHIP_TF_GAMMA || o.sample_type > JXLHIP_SAMPLE_F16 ||
-        ((o.transfer == JXLHIP_TF_PQ || o.transfer == JXLHIP_TF_GAMMA) && !(o.tf_param > 0.0f)) ||
+    if (o.transfer > JXLHIP_TF_HLG || o.sample_type > JXLHIP_SAMPLE_F16 ||
+        ((o.transfer == JXLHIP_TF_PQ || o.transfer == JXLHIP_TF_GAMMA || o.transfer == JXLHIP_TF_HLG) &&
+         !(o.tf_param > 0.0f)) ||
         (o.num_channels != 3 && o.num_channels != 4) || o.swap_endianness > 1 ||
         ((o.sample_type == JXLHIP_SAMPLE_U8 || o.sample_type == JXLHIP_SAMPLE_U16) &&
          (o.bits_per_sample == 0 || o.bits_per_sample > max_bits)))
@@ -411,6 +412,13 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
     fp.dither = c->tables + 576;
     // TF_PQ's display_scaling_factor_to_10000_nits_ (transfer_functions-inl.h:146-148)
     fp.tf_scale = fp.fmt.transfer == JXLHIP_TF_PQ ? fp.fmt.tf_param * (1.0f / 10000.0f) : fp.fmt.tf_param;
+    fp.hlg_exponent = 0.0f;
+    if (fp.fmt.transfer == JXLHIP_TF_HLG) {
+      // HlgOOTF::ToSceneLight + HlgOOTF_Base (cms/tone_mapping-inl.h:113-119, tone_mapping.h:120-126)
+      const float gamma = (1 / 1.2f) * powf(1.111f, -log2f(fp.fmt.tf_param / 1000.f));
+      const float e = gamma - 1;
+      if (e < -0.01f || 0.01f < e) fp.hlg_exponent = e;
+    }
   }
   memcpy(c->lut.v, p->lf.epf_sharp_lut, sizeof(c->lut.v));
   c->fp = fp;

@@ -89,8 +89,32 @@ __device__ __forceinline__ float GammaFromLinear(float x, float inverse_gamma) {
   return x <= 1e-5f ? 0.0f : FastPowf(x, inverse_gamma);
 }
 
+// TF_HLG::EncodedFromDisplay (transfer_functions-inl.h:53-69): sqrt(3x) up to 1/12,
+// kA ln(12x - kB) + kC above (through FastLog2f), odd symmetry
+__device__ __forceinline__ float HlgFromLinear(float v) {
+  constexpr double kA = 0.17883277, kB = 1 - 4 * kA, kC = 0.5599107295, kInvLog2e = 0.6931471805599453;
+  const float x = __builtin_fabsf(v);
+  const float lo = __builtin_sqrtf(3.0f * x);
+  const float hi = __builtin_fmaf((float)(kA * kInvLog2e), FastLog2f(__builtin_fmaf(12.0f, x, (float)-kB)), (float)kC);
+  const float mag = x <= (float)(1.0 / 12.0) ? lo : hi;
+  return __builtin_copysignf(__builtin_fabsf(mag), v);
+}
+
+// HlgOOTF::Apply (cms/tone_mapping-inl.h:121-133): the whole pixel is scaled by
+// luminance^exponent (exponent == 0: the reference skips the OOTF)
+__device__ __forceinline__ void HlgOotf(const FilterParams& P, float* rgb) {
+  if (P.hlg_exponent == 0.0f) return;
+  const float lum = __builtin_fmaf(P.fmt.luminances[0], rgb[0],
+                                   __builtin_fmaf(P.fmt.luminances[1], rgb[1], P.fmt.luminances[2] * rgb[2]));
+  const float ratio = __builtin_fminf(FastPowf(lum, P.hlg_exponent), 1e9f);
+  rgb[0] *= ratio;
+  rgb[1] *= ratio;
+  rgb[2] *= ratio;
+}
+
 __device__ __forceinline__ float ApplyTransfer(uint32_t tf, float v, float tf_scale) {
   switch (tf) {
+    case JXLHIP_TF_HLG: return HlgFromLinear(v);
     case JXLHIP_TF_SRGB: return SrgbFromLinear(v);
     case JXLHIP_TF_PQ: return PqFromLinear(v, tf_scale);
     case JXLHIP_TF_709: return Bt709FromLinear(v);
@@ -148,10 +172,10 @@ __device__ __forceinline__ void PackSamples(const FilterParams& P, DitherPtr dit
   const jxlhip_output_format& F = P.fmt;
   const uint32_t st = Sel::sample_type(F);
   const uint32_t tf = Sel::transfer(F);
-  float v[4];
+  float v[4] = {rgb[0], rgb[1], rgb[2], 1.0f};
+  if (tf == JXLHIP_TF_HLG) HlgOotf(P, v);
 #pragma unroll
-  for (int c = 0; c < 3; c++) v[c] = ApplyTransfer(tf, rgb[c], P.tf_scale);
-  v[3] = 1.0f;
+  for (int c = 0; c < 3; c++) v[c] = ApplyTransfer(tf, v[c], P.tf_scale);
   if (st == JXLHIP_SAMPLE_U8) {
 #pragma unroll
     for (int c = 0; c < 4; c++) q[c] = ToUnsigned(P, dither, v[c], x, y, c, true);

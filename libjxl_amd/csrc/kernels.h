@@ -31,6 +31,7 @@ struct FilterParams {
   jxlhip_output_format fmt;
   float sample_mul;         // 2^bits_per_sample - 1
   float tf_scale;           // PQ: intensity_target / 10000; GAMMA: inverse gamma
+  float hlg_exponent;       // HLG: HlgOOTF exponent (gamma - 1), 0 = OOTF not applied
   const float* dither;      // 32x32 pattern (device)
 };
 

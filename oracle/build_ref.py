@@ -52,6 +52,9 @@ def available():
 def _compile(job):
     src, obj = job
     deps = [src] + ([os.path.join(SHIM, "hwy", h) for h in os.listdir(os.path.join(SHIM, "hwy"))])
+    if src.startswith(HERE):  # the drivers also see the C ABI and the oracle's POD mirror
+        inc = os.path.join(HERE, "..", "include")
+        deps += [os.path.join(inc, h) for h in os.listdir(inc)] + [os.path.join(HERE, "jxl_oracle.h")]
     if os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):
         return obj, ""
     extra = ["-I" + HERE] if src.startswith(HERE) else []

@@ -142,6 +142,7 @@ float jxo_srgb_from_linear(float v);
 float jxo_pq_from_linear(float v, float intensity_target);
 float jxo_709_from_linear(float x);
 float jxo_gamma_from_linear(float x, float inverse_gamma);
+float jxo_hlg_from_linear(float x);
 void jxo_pack_output(const jxo_frame* f, const float* rgb, size_t rgb_stride, void* out,
                      size_t out_stride_bytes, uint32_t row_begin, uint32_t row_end);
 int jxo_decode_frame(const jxo_frame* f, float* out, size_t out_stride_floats,

@@ -62,8 +62,49 @@ float jxo_gamma_from_linear(float x, float inverse_gamma) {
   return x <= 1e-5f ? 0.0f : jxo_fast_powf(x, inverse_gamma);
 }
 
+/* FastLog2f (fast_math-inl.h:46-68); same statement as in quant_tables.c */
+static float fast_log2f(float x) {
+  const float p0 = -1.8503833400518310E-06f, p1 = 1.4287160470083755E+00f, p2 = 7.4245873327820566E-01f;
+  const float q0 = 9.9032814277590719E-01f, q1 = 1.0096718572241148E+00f, q2 = 1.7409343003366853E-01f;
+  int32_t x_bits;
+  memcpy(&x_bits, &x, 4);
+  const int32_t exp_bits = (int32_t)((uint32_t)x_bits - 0x3f2aaaabu);
+  const int32_t exp_shifted = exp_bits >> 23;
+  const int32_t mant_bits = (int32_t)((uint32_t)x_bits - ((uint32_t)exp_shifted << 23));
+  float mantissa;
+  memcpy(&mantissa, &mant_bits, 4);
+  const float m = mantissa - 1.0f;
+  const float yp = fmaf(fmaf(p2, m, p1), m, p0);
+  const float yq = fmaf(fmaf(q2, m, q1), m, q0);
+  return yp / yq + (float)exp_shifted;
+}
+
+/* TF_HLG::EncodedFromDisplay (transfer_functions-inl.h:53-69) */
+float jxo_hlg_from_linear(float v) {
+  const double kA = 0.17883277, kB = 1 - 4 * kA, kC = 0.5599107295, kInvLog2e = 0.6931471805599453;
+  const float x = fabsf(v);
+  const float lo = sqrtf(3.0f * x);
+  const float hi = fmaf((float)(kA * kInvLog2e), fast_log2f(fmaf(12.0f, x, (float)-kB)), (float)kC);
+  const float mag = x <= (float)(1.0 / 12.0) ? lo : hi;
+  return copysignf(fabsf(mag), v);
+}
+
+/* HlgOOTF::ToSceneLight + Apply (cms/tone_mapping-inl.h:113-133, tone_mapping.h:120-126) */
+static void hlg_ootf(const jxlhip_output_format* F, float* v) {
+  const float gamma = (1 / 1.2f) * powf(1.111f, -log2f(F->tf_param / 1000.f));
+  const float e = gamma - 1;
+  if (!(e < -0.01f || 0.01f < e)) return;
+  const float lum = fmaf(F->luminances[0], v[0], fmaf(F->luminances[1], v[1], F->luminances[2] * v[2]));
+  const float pw = jxo_fast_powf(lum, e);
+  const float ratio = pw < 1e9f ? pw : 1e9f; /* Min(a, b) = a < b ? a : b */
+  v[0] *= ratio;
+  v[1] *= ratio;
+  v[2] *= ratio;
+}
+
 static float apply_tf(const jxlhip_output_format* F, float v) {
   switch (F->transfer) {
+    case JXLHIP_TF_HLG: return jxo_hlg_from_linear(v);
     case JXLHIP_TF_SRGB: return jxo_srgb_from_linear(v);
     case JXLHIP_TF_PQ: return jxo_pq_from_linear(v, F->tf_param);
     case JXLHIP_TF_709: return jxo_709_from_linear(v);
@@ -114,10 +155,9 @@ void jxo_pack_output(const jxo_frame* f, const float* rgb, size_t rgb_stride, vo
     uint8_t* row = (uint8_t*)out + (size_t)y * out_stride_bytes;
     for (uint32_t x = 0; x < p->xsize; x++) {
       float v[4];
-      for (int c = 0; c < 3; c++) {
-        const float lin = rgb[(size_t)y * rgb_stride + 3 * (size_t)x + c];
-        v[c] = apply_tf(F, lin);
-      }
+      for (int c = 0; c < 3; c++) v[c] = rgb[(size_t)y * rgb_stride + 3 * (size_t)x + c];
+      if (F->transfer == JXLHIP_TF_HLG) hlg_ootf(F, v);
+      for (int c = 0; c < 3; c++) v[c] = apply_tf(F, v[c]);
       v[3] = 1.0f;
       for (int c = 0; c < nc; c++) {
         const size_t i = (size_t)x * nc + c;

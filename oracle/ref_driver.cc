@@ -163,6 +163,9 @@ Status FillState(const jxo_frame* f, CodecMetadata* metadata, FrameHeader* fh,
   if (tf == JXLHIP_TF_PQ) {
     metadata->m.color_encoding.Tf().SetTransferFunction(TransferFunction::kPQ);
     metadata->m.SetIntensityTarget(p.out_format.tf_param);  // OutputEncodingInfo::orig_intensity_target
+  } else if (tf == JXLHIP_TF_HLG) {
+    metadata->m.color_encoding.Tf().SetTransferFunction(TransferFunction::kHLG);
+    metadata->m.SetIntensityTarget(p.out_format.tf_param);
   } else if (tf == JXLHIP_TF_709) {
     metadata->m.color_encoding.Tf().SetTransferFunction(TransferFunction::k709);
   } else if (tf == JXLHIP_TF_GAMMA) {

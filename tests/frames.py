@@ -37,3 +37,4 @@ def make_case(xsize, ysize, dequant=None, **kw):
                       npy["ac_strategy"], npy["raw_quant"], npy["epf_sharpness"],
                       npy["ytox_map"], npy["ytob_map"], npy["dc"], dequant)
     return params, t, fr
+

@@ -114,6 +114,20 @@ def run_packed(dec, ref, xs, ys, fmt, **kw):
                    dq.cpu().numpy())
     want = fr.decode_ref(threads=THREADS)
     assert got.shape == want.shape
+    if os.environ.get("JXLHIP_TEST_ARBITRATE"):  # debugging aid: who is off, the kernels or the reference run?
+        d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        if d.max() > 1:
+            mine = fr.decode(threads=8)
+            want1 = fr.decode_ref(threads=1)
+            out2 = dec.decode_frame()
+            dec.sync()
+            got2 = out2.cpu().numpy()
+            ys, xs = np.nonzero(d.max(axis=2) > 1)
+            y, x = int(ys[0]), int(xs[0])
+            print("ARBITRATE at", y, x, "got", got[y, x - 2:x + 3].tolist(), "want", want[y, x - 2:x + 3].tolist(),
+                  "oracle", mine[y, x - 2:x + 3].tolist(), "ref1", want1[y, x - 2:x + 3].tolist(),
+                  "gpu again", got2[y, x - 2:x + 3].tolist(), "| ref==ref1", np.array_equal(want, want1),
+                  "oracle==ref1", np.array_equal(mine, want1), "gpu==gpu2", np.array_equal(got, got2))
     return got, want
 
 
@@ -126,6 +140,10 @@ def test_packed_srgb_u8(dec, ref, gab, epf, nc):
     got, want = run_packed(dec, ref, 533, 401, dict(transfer=1, sample_type=1, num_channels=nc, bits_per_sample=8),
                            mix=synth.MIX_ALL, gab=gab, epf_iters=epf, intensity_target=80.0)
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    if d.max() > 1:  # say which side is off before failing
+        ys, xs, cs = np.nonzero(d > 1)
+        print("samples off by > 1:", len(ys), "rows", ys.min(), "-", ys.max(), "cols", xs.min(), "-", xs.max(),
+              "channels", sorted(set(cs.tolist())), "got", got[ys[0], xs[0]], "want", want[ys[0], xs[0]])
     assert d.max() <= 1
     assert (d != 0).mean() < 1e-3
     if nc == 4:
@@ -164,7 +182,8 @@ def test_packed_float_srgb(dec, ref, st, sw):
     assert (g[..., 3] == 1.0).all()
 
 
-@pytest.mark.parametrize("tf,par,it", [(2, 1000.0, 1000.0), (3, 0.0, 255.0), (4, 1 / 2.6, 255.0)])
+@pytest.mark.parametrize("tf,par,it", [(2, 1000.0, 1000.0), (3, 0.0, 255.0), (4, 1 / 2.6, 255.0), (5, 1000.0, 1000.0),
+                                       (5, 334.0, 334.0)])
 @pytest.mark.parametrize("st,bits", [(1, 8), (2, 16), (0, 0)])
 def test_packed_pq_709_gamma(dec, ref, tf, par, it, st, bits):
     """HDR / video transfer functions (PQ at 1000 nits, BT.709, DCI gamma) through the

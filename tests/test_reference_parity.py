@@ -123,7 +123,10 @@ PACKED_FORMATS = [
 
 
 @pytest.mark.parametrize("tf,par,it", [(2, 1000.0, 1000.0), (2, 255.0, 255.0), (3, 0.0, 255.0), (4, 1 / 2.6, 255.0),
-                                       (4, 0.45455, 80.0)])
+                                       (4, 0.45455, 80.0),
+                                       (5, 1000.0, 1000.0),   # HLG at 1000 nits: OOTF gamma 1/1.2
+                                       (5, 255.0, 255.0),     # ... at the SDR default
+                                       (5, 334.0, 334.0)])    # ... where the system gamma is ~1: OOTF skipped
 @pytest.mark.parametrize("st,bits_", [(1, 8), (2, 16), (0, 0)])
 def test_packed_output_pq_709_gamma(ref, tf, par, it, st, bits_):
     """FromLinearStage's OpPq (two rational polynomials in x^(1/4)), Op709 and OpGamma
