@@ -963,8 +963,12 @@ int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_
   const ZeroDensityLut& zd = ZdLut();
   const uint32_t nb = pass->num_block_ctxs;
   const uint32_t nqf = (uint32_t)pass->qf_thresholds.size();
-  // number of non-zeros per block, for the context of the next ones (GroupDecCache::num_nzeroes)
+  // number of non-zeros per block, for the context of the next ones (GroupDecCache::num_nzeroes).
+  // Zeroed: a damaged strategy map can leave cells that no varblock covers, and their
+  // (never written) counts feed the neighbours' contexts.  The map itself is validated on the
+  // device by k_prepare; here it only has to be harmless.
   int32_t nz[3][32][32];
+  memset(nz, 0, sizeof(nz));
   size_t offset = 0;
   for (uint32_t by = 0; by < gh; by++) {
     for (uint32_t bx = 0; bx < gw; bx++) {
