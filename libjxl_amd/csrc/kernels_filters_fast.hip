@@ -496,7 +496,7 @@ void LaunchPackedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
 
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st) {
-  if (epf_iters > 1 || (gab == 0 && epf_iters == 0)) return false;
+  if (epf_iters > 1) return false;
   if (f.xsize < 16) return false;  // multiply mirrored columns: generic kernel
 #define JXLHIP_FAST(G, E)                                  \
   if (gab == G && epf_iters == E) {                        \
@@ -505,6 +505,7 @@ bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int ep
     else LaunchPackedT<G, E>(f, p, st);                    \
     return true;                                           \
   }
+  JXLHIP_FAST(0, 0)  // no loop filter: the same row march is a streaming block-major -> RGB conversion
   JXLHIP_FAST(1, 0)
   JXLHIP_FAST(0, 1)
   JXLHIP_FAST(1, 1)
