@@ -117,6 +117,8 @@ struct State {
   v2f g[3][4];    // EPF: rows entering EPF (Gaborish output or input)
   v2f du[3][4], dl[3][4];
   v2f pv[4], ph[4];
+  v2f e[3][4];    // EPF == 2: EPF1 output rows entering EPF2
+  v2f dv[4];      // EPF == 2: channel-weighted |row - row above| of the e rows
 };
 
 // per-lane constants
@@ -127,6 +129,11 @@ struct Lane {
   int gx;             // first column of the pair (may lie outside the image)
   bool out0, out1;    // column is written by this wave
   v2f mul;            // EPF sigma multiplier of the two columns (border columns of an 8x8 block differ)
+  v2f mul2;           // ... of the third EPF stage
+  // EPF == 2, edge waves: the one out-of-image column EPF2 reads takes its mirror (= the
+  // edge column): pair (-2,-1): .y <- column 0; pair (W, W+1): .x <- column W-1 (W even);
+  // pair (W-1, W): .y <- .x (W odd)
+  bool fix_left, fix_right_even, fix_right_odd;
   int sx;             // block column of the pair for the sigma look-up (clamped)
   // packed 8-bit output: the dither pattern, staged in LDS (a global load per
   // sample would queue behind the row prefetch in the in-order vmcnt)
@@ -242,7 +249,7 @@ __device__ __forceinline__ void EmitPair(const v2f* v, const Lane& L, int gy, co
 template <int GAB, int EPF, int OUTK, int FMT, int PH>
 __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const FilterParams& P,
                                      const Lane& L, int prefetch_last_row, int y_begin, int y_end,
-                                     float& inv_sigma_blk) {
+                                     float& inv_sigma_blk, float& inv_sigma_blk2) {
   constexpr int S0 = PH & 3, S1 = (PH + 3) & 3, S2 = (PH + 2) & 3;  // r, r-1, r-2
   const int H = (int)f.ysize;
   v2f cur[3];
@@ -307,7 +314,8 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
     // 3c. EPF1 output row o = q-2
     o = q - 2;
     const float kMinSigma = -3.90524291751269967465540850526868f;
-    if ((o & 7) == 0 || o == y_begin) {
+    // first row whose result is used: y_begin, or the row above it when EPF2 reads it
+    if ((o & 7) == 0 || o == y_begin - (EPF == 2 ? 1 : 0)) {
       const int oc = o < 0 ? 0 : (o >= H ? H - 1 : o);
       const float is = f.inv_sigma[(size_t)(oc >> 3) * f.xsb + L.sx];
       // below the threshold the stage copies its input (stage_epf.cc:258-262):
@@ -336,6 +344,66 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
       a = Fma2(wS, s.g[c][Q1], a);
       outv[c] = a * inv_w;
     }
+    if constexpr (EPF == 2) {
+      // 3d. third EPF stage (EPF2Stage, stage_epf.cc:393-492) on the rows the second one
+      // produces: new row o enters, row o2 = o - 1 leaves.  Its SADs are single pixel
+      // differences, shared between the two pixels they separate (|a - b| is symmetric).
+      constexpr int E0 = Q2, E1 = Q3, E2 = Q0;  // rows o, o-1, o-2
+      if (L.edge) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const float from_right = FromRight(outv[c].x), from_left = FromLeft(outv[c].y);
+          outv[c].y = L.fix_left ? from_right : (L.fix_right_odd ? outv[c].x : outv[c].y);
+          outv[c].x = L.fix_right_even ? from_left : outv[c].x;
+        }
+      }
+      v2f dv = Abs2(outv[0] - s.e[0][E1]) * P.ch_scale[0];
+      dv = Fma2(Abs2(outv[1] - s.e[1][E1]), P.ch_scale[1], dv);
+      dv = Fma2(Abs2(outv[2] - s.e[2][E1]), P.ch_scale[2], dv);
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.e[c][E0] = outv[c];
+      s.dv[E0] = dv;
+      const int o2 = o - 1;
+      // |p(x) - p(x-1)| per column of row o2
+      v2f dh;
+      {
+        const v2f c0 = s.e[0][E1], c1 = s.e[1][E1], c2 = s.e[2][E1];
+        dh = Abs2(v2f{c0.x - FromLeft(c0.y), c0.y - c0.x}) * P.ch_scale[0];
+        dh = Fma2(Abs2(v2f{c1.x - FromLeft(c1.y), c1.y - c1.x}), P.ch_scale[1], dh);
+        dh = Fma2(Abs2(v2f{c2.x - FromLeft(c2.y), c2.y - c2.x}), P.ch_scale[2], dh);
+      }
+      if ((o2 & 7) == 0 || o2 == y_begin) {
+        const int oc = o2 < 0 ? 0 : (o2 >= H ? H - 1 : o2);
+        const float is = f.inv_sigma[(size_t)(oc >> 3) * f.xsb + L.sx];
+        inv_sigma_blk2 = is < kMinSigma ? -__builtin_inff() : is;
+      }
+      const int iy2 = o2 & 7;
+      const v2f mul2 = (iy2 == 0 || iy2 == 7) ? v2f{P.bsm[2], P.bsm[2]} : L.mul2;
+      const v2f inv_sigma2 = mul2 * inv_sigma_blk2;
+      // rows -1 and H are the mirrors of rows 0 and H-1: a zero difference, the centre as value
+      const bool top = o2 == 0, bottom = o2 == H - 1;
+      const v2f zero = {0.0f, 0.0f};
+      const v2f wN2 = EpfW(top ? zero : s.dv[E1], inv_sigma2);
+      const v2f wW2 = EpfW(dh, inv_sigma2);
+      const v2f wE2 = EpfW(v2f{dh.y, FromRight(dh.x)}, inv_sigma2);
+      const v2f wS2 = EpfW(bottom ? zero : dv, inv_sigma2);
+      v2f wsum2 = v2f{1.0f, 1.0f} + wN2;
+      wsum2 = wsum2 + wW2;
+      wsum2 = wsum2 + wE2;
+      wsum2 = wsum2 + wS2;
+      const v2f inv_w2 = {__builtin_amdgcn_rcpf(wsum2.x), __builtin_amdgcn_rcpf(wsum2.y)};
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const v2f ctr = s.e[c][E1];
+        v2f a = ctr;
+        a = Fma2(wN2, top ? ctr : s.e[c][E2], a);
+        a = FmaLeft(wW2, ctr, a);
+        a = FmaRight(wE2, ctr, a);
+        a = Fma2(wS2, bottom ? ctr : s.e[c][E0], a);
+        outv[c] = a * inv_w2;
+      }
+      o = o2;
+    }
   } else {
     o = q;
 #pragma unroll
@@ -349,7 +417,7 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
 
 template <int GAB, int EPF>
 struct FastGeom {
-  static constexpr int HX = GAB + 2 * EPF;        // halo rows / columns each side
+  static constexpr int HX = GAB + (EPF >= 1 ? 2 : 0) + (EPF == 2 ? 1 : 0);  // halo rows / columns each side
   static constexpr int HXP = (HX + 1) & ~1;       // in whole column pairs
   static constexpr int USE = 128 - 2 * HXP;       // output columns per wave
 };
@@ -397,6 +465,10 @@ __global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P
     // columns gx, gx+1 (gx even inside the image): only gx can be a block's
     // first column and only gx+1 its last
     L.mul = v2f{ix == 0 ? P.bsm[1] : P.sm[1], ix == 6 ? P.bsm[1] : P.sm[1]};
+    L.mul2 = v2f{ix == 0 ? P.bsm[2] : P.sm[2], ix == 6 ? P.bsm[2] : P.sm[2]};
+    L.fix_left = L.gx == -2;
+    L.fix_right_even = L.gx == W;       // only reached when W is even (gx is even)
+    L.fix_right_odd = L.gx == W - 1;    // W odd
   }
   // rows: input rows r = y_begin - HX .. y_end + HX - 1; the pipeline emits
   // row r - HX at step r.
@@ -422,16 +494,22 @@ __global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P
       s.g[c][k] = v2f{0.0f, 0.0f};
       s.du[c][k] = v2f{0.0f, 0.0f};
       s.dl[c][k] = v2f{0.0f, 0.0f};
+      s.e[c][k] = v2f{0.0f, 0.0f};
     }
     s.pv[k] = v2f{0.0f, 0.0f};
     s.ph[k] = v2f{0.0f, 0.0f};
+    s.dv[k] = v2f{0.0f, 0.0f};
   }
-  float inv_sigma_blk = -1.0f;
+  float inv_sigma_blk = -1.0f, inv_sigma_blk2 = -1.0f;
   for (int r = r_first; r <= r_last; r += 4) {
-    Step<GAB, EPF, OUTK, FMT, 0>(s, r, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
-    Step<GAB, EPF, OUTK, FMT, 1>(s, r + 1, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
-    Step<GAB, EPF, OUTK, FMT, 2>(s, r + 2, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
-    Step<GAB, EPF, OUTK, FMT, 3>(s, r + 3, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk);
+    Step<GAB, EPF, OUTK, FMT, 0>(s, r, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk,
+                                  inv_sigma_blk2);
+    Step<GAB, EPF, OUTK, FMT, 1>(s, r + 1, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk,
+                                  inv_sigma_blk2);
+    Step<GAB, EPF, OUTK, FMT, 2>(s, r + 2, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk,
+                                  inv_sigma_blk2);
+    Step<GAB, EPF, OUTK, FMT, 3>(s, r + 3, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk,
+                                  inv_sigma_blk2);
   }
 }
 
@@ -496,7 +574,7 @@ void LaunchPackedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
 
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st) {
-  if (epf_iters > 1) return false;
+  if (epf_iters > 2) return false;  // three iterations add EPF0 (7x7 reach): generic LDS kernel
   if (f.xsize < 16) return false;  // multiply mirrored columns: generic kernel
 #define JXLHIP_FAST(G, E)                                  \
   if (gab == G && epf_iters == E) {                        \
@@ -509,6 +587,8 @@ bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int ep
   JXLHIP_FAST(1, 0)
   JXLHIP_FAST(0, 1)
   JXLHIP_FAST(1, 1)
+  JXLHIP_FAST(0, 2)
+  JXLHIP_FAST(1, 2)
 #undef JXLHIP_FAST
   return false;
 }

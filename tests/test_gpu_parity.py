@@ -147,11 +147,12 @@ def test_full_pipeline_rgb(dec, dq, oracle, gab, epf, size):
     assert e <= TIGHT, e
 
 
-@pytest.mark.parametrize("gab,epf", [(1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("gab,epf", [(1, 0), (0, 1), (1, 1), (1, 2), (0, 2)])
 @pytest.mark.parametrize("size", [(533, 401), (61, 70), (1000, 130)])
 def test_generic_lds_filter_kernel_also_matches(dq, oracle, monkeypatch, gab, epf, size):
-    """Stage lists with <= 1 EPF pass normally take the register/DPP kernel; the
-    generic LDS kernel (used for epf_iters >= 2) must agree on them too."""
+    """Stage lists with <= 2 EPF passes normally take the register/DPP kernel; the
+    generic LDS kernel (used for epf_iters == 3 and frames narrower than 16) must agree on
+    them too."""
     monkeypatch.setenv("JXLHIP_FILTERS", "generic")
     d = VarDctDecoder(0)
     monkeypatch.delenv("JXLHIP_FILTERS")
@@ -189,11 +190,12 @@ def test_c1_1024_full_pipeline(dec, dq, oracle):
     assert rel_err(out.cpu().numpy(), ref) <= TIGHT
 
 
-def test_stripes_with_halo_exchange_equal_whole_frame(dec, dq, oracle):
+@pytest.mark.parametrize("epf", [3, 2, 1])
+def test_stripes_with_halo_exchange_equal_whole_frame(dec, dq, oracle, epf):
     """Multi-GPU decomposition on one device: two contexts decode the two
     group-row stripes, swap halo rows, and must reproduce the whole-frame
-    result bit for bit."""
-    params, t, fr = frames.make_case(600, 700, mix=synth.MIX_ALL, gab=True, epf_iters=3, seed=9)
+    result bit for bit (generic LDS kernel for 3 EPF passes, row-march kernel below)."""
+    params, t, fr = frames.make_case(600, 700, mix=synth.MIX_ALL, gab=True, epf_iters=epf, seed=9)
     devt = to_dev(t)
     dec.begin_frame(params)
     dec.set_inputs(devt, dq)

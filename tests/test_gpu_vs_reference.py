@@ -131,7 +131,7 @@ def run_packed(dec, ref, xs, ys, fmt, **kw):
     return got, want
 
 
-@pytest.mark.parametrize("gab,epf", [(True, 1), (False, 0), (True, 3)])
+@pytest.mark.parametrize("gab,epf", [(True, 1), (False, 0), (True, 3), (True, 2), (False, 2)])
 @pytest.mark.parametrize("nc", [3, 4])
 def test_packed_srgb_u8(dec, ref, gab, epf, nc):
     """What djxl writes by default (8-bit sRGB): the float pipeline differs from the
