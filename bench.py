@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--gab", type=int, default=1)
     ap.add_argument("--epf", type=int, default=1)
-    ap.add_argument("--mix", default="d1", choices=["d1", "dct8", "dct32", "all"])
+    ap.add_argument("--mix", default="d1",
+                    help="d1 | dct8 | dct32 | all, or an explicit area mix 'strategy:share,...' (e.g. 18:1 = all 64x64)")
     ap.add_argument("--coeff32", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also gather stripes on rank 0 each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,7 +101,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     mix = {"d1": synth.MIX_D1, "dct8": synth.MIX_DCT8, "dct32": synth.MIX_DCT32,
-           "all": synth.MIX_ALL}[args.mix]
+           "all": synth.MIX_ALL}.get(args.mix) or {int(k): float(v) for k, v in
+                                                    (kv.split(":") for kv in args.mix.split(","))}
     xs, ys = args.width, args.height * world
     params, t = synth.synth_frame(xs, ys, mix=mix, gab=bool(args.gab), epf_iters=args.epf,
                                   device=f"cuda:{local}", coeff_type=int(args.coeff32))

@@ -37,8 +37,8 @@ struct FilterParams {
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
                    const SharpLut& lut, hipStream_t st);
-// Three persistent launches (class families A, B and the large kinds) spread
-// over `streams`; `cells` = block cells of the band (bounds the unit count).
+// Five launches (k_dct8, the row-per-lane families R16 / R32, family A, the large kinds) on
+// streams[0] / streams[1 % nstreams]; `cells` = block cells of the band (bounds the unit count).
 void LaunchBlocks(const DevFrame& f, const WorkLists& wl, uint32_t cells, const float* wc,
                   const float* resample, hipStream_t* streams, int nstreams);
 // Returns 0, or -1 when the (gab, epf_iters, output_kind) combination is invalid.

@@ -132,6 +132,16 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
 }
 
 // ------------------------------------------------------------ block header
+// threadIdx.x through an opaque (volatile, empty) asm: the unit functions below run inside the
+// persistent loop of UnitDispatch, and without this every class's lane-dependent address
+// arithmetic is loop-invariant and gets hoisted out of the loop -- into registers that stay
+// live across ALL classes of the family (measured: 308 VGPRs).
+__device__ __forceinline__ int Tid() {
+  int t = (int)threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 struct BlockHdr {
   uint32_t abx, aby;
   size_t coef;  // element offset into coeffs[c]
@@ -503,7 +513,8 @@ __device__ __forceinline__ void Single64Unit(const DevFrame& f, int strategy,
                                              const WorkItem* __restrict__ list, uint32_t first,
                                              uint32_t n, unsigned char* smem) {
   uint4* lds = reinterpret_cast<uint4*>(smem);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = Tid();
+  const int lane = tid & 63, wave = tid >> 6;
   // the list has 64 entries of slack: lanes past the end read garbage that is
   // replaced by a duplicate of the last valid block
   WorkItem it = list[first + lane];
@@ -519,6 +530,357 @@ __device__ __forceinline__ void Single64Unit(const DevFrame& f, int strategy,
   }
   const int c = wave == 0 ? 1 : (wave == 1 ? 0 : 2);
   DecodeBlock64<CT>(f, strategy, it, lane, nvalid, lds + wave * Stage64<CT>::kLdsChunks, c);
+}
+
+// ------------------------------------------------------------------ k_dct8
+// DCT8 alone is ~45 % of a d1.0 frame and gets a kernel of its own with no LDS and few
+// registers.  EIGHT LANES share a block:
+//   lane = block-of-the-step (bits 0-2) | matrix row j (bits 3-5)
+// Lane (b, j) loads row j of the stored 8x8 coefficient matrix of all three channels (one
+// 16-byte load each: the block's 8 lanes fetch its whole 128-byte line), dequantises it with
+// chroma-from-luma, runs the 8-point IDCT along the row, the wave transposes the 8x8 matrix
+// across the 8 lanes in registers (v_permlane32_swap for lane bit 5, v_permlane16_swap for
+// bit 4, DPP row_ror:8 + selects for bit 3), a second IDCT, and the lane holds pixel row j:
+// two 16-byte stores, the block's 8 lanes writing its 256-byte tile.
+// The two 1-D passes run in the opposite order of IDCT2D (dct-inl.h:254-291), which needs the
+// transpose once instead of three times; the 1-D transform itself keeps the reference's
+// operation order, the result differs from the other order by rounding only.
+__device__ __forceinline__ void SwapHalves32(float& a, float& b) {  // a[32..63] <-> b[0..31]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void SwapRows16(float& a, float& b) {  // odd rows of a <-> even rows of b
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+// element (row j, register a) -> (row a, register j) for the lane mapping above
+__device__ __forceinline__ void Transpose8Lanes(float* w, bool bit3) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) SwapHalves32(w[k], w[k + 4]);
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (!(k & 2)) SwapRows16(w[k], w[k + 2]);
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    const float send = bit3 ? w[k] : w[k + 1];
+    const float recv =
+        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xf, 0xf, false));
+    w[k] = bit3 ? recv : w[k];
+    w[k + 1] = bit3 ? w[k + 1] : recv;
+  }
+}
+
+template <typename CT>
+struct Dct8Row {  // one matrix row of one channel as loaded
+  static constexpr int kVec = sizeof(CT) == 2 ? 1 : 2;
+  uint4 v[kVec];
+  __device__ __forceinline__ void Load(const void* base, size_t elem) {
+    const uint4* p = (const uint4*)((const CT*)base + elem);
+#pragma unroll
+    for (int i = 0; i < kVec; i++) v[i] = p[i];
+  }
+  __device__ __forceinline__ void Unpack(int32_t* q) const {
+    if constexpr (sizeof(CT) == 2) {
+      const uint32_t w[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        q[2 * i] = (int32_t)(int16_t)(w[i] & 0xffffu);
+        q[2 * i + 1] = (int32_t)w[i] >> 16;
+      }
+    } else {
+      const uint32_t w[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+#pragma unroll
+      for (int i = 0; i < 8; i++) q[i] = (int32_t)w[i];
+    }
+  }
+};
+
+template <typename CT>
+__global__ __launch_bounds__(256) void k_dct8(DevFrame f, const WorkItem* __restrict__ list,
+                                               const uint32_t* __restrict__ count) {
+  constexpr int kSteps = sizeof(CT) == 2 ? 4 : 2;  // steps of 8 blocks per wave
+  const uint32_t n = *count;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t first = (blockIdx.x * 4 + wave) * (kSteps * 8);
+  if (first >= n) return;
+  const int j = lane >> 3;  // matrix row (input), pixel row (output)
+  const bool bit3 = (lane & 8) != 0;
+  // this lane's 8 entries of the three dequant matrices (DequantLane, dec_group.cc:115-153)
+  float tab[3][8];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float4 t0 = *(const float4*)(f.dequant + c * 64 + j * 8);
+    const float4 t1 = *(const float4*)(f.dequant + c * 64 + j * 8 + 4);
+    tab[c][0] = t0.x, tab[c][1] = t0.y, tab[c][2] = t0.z, tab[c][3] = t0.w;
+    tab[c][4] = t1.x, tab[c][5] = t1.y, tab[c][6] = t1.z, tab[c][7] = t1.w;
+  }
+  WorkItem it[kSteps];
+  Dct8Row<CT> rows[kSteps][3];
+  float dcv[kSteps][3];
+  bool valid[kSteps];
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    const uint32_t b = first + s * 8 + (lane & 7);
+    valid[s] = b < n;
+    it[s] = list[valid[s] ? b : n - 1];
+  }
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    const size_t elem = (size_t)it[s].off * 64u + (size_t)j * 8u;
+    const size_t cell = (size_t)(it[s].pos >> 16) * f.xsb + (it[s].pos & 0xffffu);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      rows[s][c].Load(f.coeffs[c], elem);
+      dcv[s][c] = f.dc[c][cell];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < kSteps; s++) {
+    const BlockHdr h = MakeHdr(f, it[s]);
+    int32_t q[8];
+    float vy[8];
+    rows[s][1].Unpack(q);
+#pragma unroll
+    for (int k = 0; k < 8; k++) vy[k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tab[1][k] * h.sy);
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+      float v[8];
+      if (c == 1) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = vy[k];
+      } else {
+        const float sc = c == 0 ? h.sx : h.sb;
+        const float cc = c == 0 ? h.x_cc : h.b_cc;
+        rows[s][c].Unpack(q);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const float d = AdjustQuantBias(q[k], f.biases[c], f.biases[3]) * (tab[c][k] * sc);
+          v[k] = __builtin_fmaf(cc, vy[k], d);
+        }
+      }
+      if (j == 0) v[0] = dcv[s][c];
+      IdctReg<8>(v);
+      Transpose8Lanes(v, bit3);
+      IdctReg<8>(v);
+      if (valid[s]) {
+        float* dst = TilePtr(f, c, it[s].pos >> 16, it[s].pos & 0xffffu) + j * 8;
+        *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------- k_rowlane
+// The row-per-lane scheme of k_dct8 for the separable DCTs with sides 8..32 (16x8 .. 32x32,
+// ~43 % of a d1.0 frame).  The stored coefficient matrix is S x L (S = shorter side, rows of
+// L = longer side contiguous coefficients): S lanes share a varblock,
+//   lane = varblock-of-the-step (low bits) | matrix row j (high log2(S) bits)
+// and each lane loads, dequantises and transforms its row; the other dimension is reached by
+// transposing S x S register tiles across the S lanes (one exchange primitive per lane bit:
+// v_permlane32_swap, v_permlane16_swap, DPP row_ror:8, row_ror:4/12, quad_perm).  No LDS.
+//   R <  C (8x16): pass 1 along the row (as IDCT2D), transpose, pass 2, transpose back
+//   R >= C       : the long pass first (in the lane), one transpose, the short pass -- the
+//                  opposite order of IDCT2D (rounding-level difference, see k_dct8)
+// Either way a lane ends up with whole pixel rows: 16-byte stores into 8x8 tiles.
+template <int BIT>
+__device__ __forceinline__ void ExchangePair(float& a, float& b, int lane) {
+  if constexpr (BIT == 5) {
+    SwapHalves32(a, b);
+  } else if constexpr (BIT == 4) {
+    SwapRows16(a, b);
+  } else {
+    const bool set = (lane >> BIT) & 1;
+    const float send = set ? a : b;
+    float recv;
+    if constexpr (BIT == 3) {
+      recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xf, 0xf, false));
+    } else if constexpr (BIT == 2) {
+      // row_ror:4 delivers lane i-4, row_ror:12 lane i+4 (mod 16)
+      const float lo = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x124, 0xf, 0xf, false));
+      const float hi = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x12c, 0xf, 0xf, false));
+      recv = set ? lo : hi;
+    } else {
+      static_assert(BIT == 1, "lane bits 1..5");
+      // quad_perm [2,3,0,1]: lane i ^ 2
+      recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4e, 0xf, 0xf, false));
+    }
+    a = set ? recv : a;
+    b = set ? b : recv;
+  }
+}
+
+// element (row j, register a) -> (row a, register j) of an S x S tile held by S lanes
+template <int S>
+__device__ __forceinline__ void TransposeTile(float* w, int lane) {
+  constexpr int kLog = S == 8 ? 3 : (S == 16 ? 4 : 5);
+  constexpr int kLb0 = 6 - kLog;
+#pragma unroll
+  for (int t = kLog - 1; t >= 0; t--) {
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+      if (k & (1 << t)) continue;
+      if (kLb0 + t == 5) ExchangePair<5>(w[k], w[k | (1 << t)], lane);
+      else if (kLb0 + t == 4) ExchangePair<4>(w[k], w[k | (1 << t)], lane);
+      else if (kLb0 + t == 3) ExchangePair<3>(w[k], w[k | (1 << t)], lane);
+      else if (kLb0 + t == 2) ExchangePair<2>(w[k], w[k | (1 << t)], lane);
+      else ExchangePair<1>(w[k], w[k | (1 << t)], lane);
+    }
+  }
+}
+
+template <int R, int C, int STRATEGY, typename CT>
+__device__ __forceinline__ void RowLaneUnit(const DevFrame& f, const WorkItem* __restrict__ list,
+                                            uint32_t first, uint32_t n) {
+  constexpr int S = R < C ? R : C, L = R < C ? C : R;
+  constexpr int BPS = 64 / S;  // varblocks per wave
+  constexpr int CY = R / 8, CX = C / 8;
+  constexpr int kTiles = L / S;
+  constexpr int kVec = L * (int)sizeof(CT) / 16;  // 16-byte loads per row and channel
+  const int tid = Tid();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane / BPS;
+  const uint32_t vb = first + wave * BPS + (lane & (BPS - 1));
+  if (first + wave * BPS >= n) return;
+  const bool valid = vb < n;
+  const WorkItem it = list[valid ? vb : n - 1];
+  const BlockHdr h = MakeHdr(f, it);
+  uint4 raw[3][kVec];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const uint4* p = (const uint4*)((const CT*)f.coeffs[c] + h.coef + (size_t)j * L);
+#pragma unroll
+    for (int i = 0; i < kVec; i++) raw[c][i] = p[i];
+  }
+  // lowest frequencies from the DC patch (LowestFrequenciesFromDC, dec_transforms-inl.h:691-818):
+  // CY-point DCTs down the columns, CX-point DCTs along the rows, resampling scales; the lanes
+  // holding the LLF corner compute the whole (at most 2x2) patch and keep their entries
+  constexpr int kLlfLanes = CY < CX ? CY : CX;
+  constexpr int kLlfRegs = CY < CX ? CX : CY;
+  float llf[3][kLlfRegs];
+  if (j < kLlfLanes) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float* dc = f.dc[c] + (size_t)h.aby * f.xsb + h.abx;
+      float dp[CY][CX];
+#pragma unroll
+      for (int x = 0; x < CX; x++) {
+        float v[CY];
+#pragma unroll
+        for (int y = 0; y < CY; y++) v[y] = dc[(size_t)y * f.xsb + x];
+        DctReg<CY>(v);
+#pragma unroll
+        for (int y = 0; y < CY; y++) dp[y][x] = (1.0f / CY) * v[y];
+      }
+#pragma unroll
+      for (int y = 0; y < CY; y++) {
+        float v[CX];
+#pragma unroll
+        for (int x = 0; x < CX; x++) v[x] = dp[y][x];
+        DctReg<CX>(v);
+        const float ry = kResampleUpHost[CY + y];
+#pragma unroll
+        for (int x = 0; x < CX; x++) {
+          const float val = (1.0f / CX) * v[x];
+          if constexpr (CY < CX) {
+            if (j == y) llf[c][x] = val * ry * kResampleUpHost[CX + x];
+          } else {
+            if (j == x) llf[c][y] = val * kResampleUpHost[CX + x] * ry;
+          }
+        }
+      }
+    }
+  }
+  const float* __restrict__ tab = f.dequant + DequantOffset(STRATEGY) + j * L;
+  auto unpack = [&](const uint4* r, int32_t* q) {
+    if constexpr (sizeof(CT) == 2) {
+#pragma unroll
+      for (int i = 0; i < kVec; i++) {
+        const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          q[i * 8 + 2 * k] = (int32_t)(int16_t)(w[k] & 0xffffu);
+          q[i * 8 + 2 * k + 1] = (int32_t)w[k] >> 16;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kVec; i++) {
+        q[i * 4] = (int32_t)r[i].x;
+        q[i * 4 + 1] = (int32_t)r[i].y;
+        q[i * 4 + 2] = (int32_t)r[i].z;
+        q[i * 4 + 3] = (int32_t)r[i].w;
+      }
+    }
+  };
+  float vy[L];
+  {
+    int32_t q[L];
+    unpack(raw[1], q);
+#pragma unroll
+    for (int k = 0; k < L; k++)
+      vy[k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tab[R * C + k] * h.sy);
+  }
+#pragma unroll
+  for (int ci = 0; ci < 3; ci++) {
+    const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+    float v[L];
+    if (c == 1) {
+#pragma unroll
+      for (int k = 0; k < L; k++) v[k] = vy[k];
+    } else {
+      const float sc = c == 0 ? h.sx : h.sb;
+      const float cc = c == 0 ? h.x_cc : h.b_cc;
+      int32_t q[L];
+      unpack(raw[c], q);
+#pragma unroll
+      for (int k = 0; k < L; k++) {
+        const float d = AdjustQuantBias(q[k], f.biases[c], f.biases[3]) * (tab[c * R * C + k] * sc);
+        v[k] = __builtin_fmaf(cc, vy[k], d);
+      }
+    }
+    if (j < kLlfLanes) {
+#pragma unroll
+      for (int k = 0; k < kLlfRegs; k++) v[k] = llf[c][k];
+    }
+    IdctReg<L>(v);
+#pragma unroll
+    for (int t = 0; t < kTiles; t++) TransposeTile<S>(v + t * S, lane);
+#pragma unroll
+    for (int t = 0; t < kTiles; t++) IdctReg<S>(v + t * S);
+    if constexpr (R < C) {
+      // v[t*S + a] = pixel (a, t*S + j): back to rows
+#pragma unroll
+      for (int t = 0; t < kTiles; t++) TransposeTile<S>(v + t * S, lane);
+      // lane j = pixel row j (R = S <= 8 rows... or 16), all C columns
+      if (valid) {
+#pragma unroll
+        for (int g = 0; g < C / 8; g++) {
+          float* dst = TilePtr(f, c, h.aby + (j >> 3), h.abx + g) + (j & 7) * 8;
+          *(float4*)dst = make_float4(v[g * 8], v[g * 8 + 1], v[g * 8 + 2], v[g * 8 + 3]);
+          *(float4*)(dst + 4) = make_float4(v[g * 8 + 4], v[g * 8 + 5], v[g * 8 + 6], v[g * 8 + 7]);
+        }
+      }
+    } else {
+      // tile t: pixel row a = t*S + j, its C = S columns in v[t*S ..]
+      if (valid) {
+#pragma unroll
+        for (int t = 0; t < kTiles; t++) {
+          const int a = t * S + j;
+#pragma unroll
+          for (int g = 0; g < C / 8; g++) {
+            float* dst = TilePtr(f, c, h.aby + (a >> 3), h.abx + g) + (a & 7) * 8;
+            const float* src = v + t * S + g * 8;
+            *(float4*)dst = make_float4(src[0], src[1], src[2], src[3]);
+            *(float4*)(dst + 4) = make_float4(src[4], src[5], src[6], src[7]);
+          }
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------ k_medium
@@ -596,7 +958,7 @@ __device__ __forceinline__ void MediumFetch(const DevFrame& f, const BlockHdr* h
   using G = MediumGeom<R, C>;
   using LD = MediumLoads<R, C, CT>;
   using Raw = typename LD::Raw;
-  const int tid = threadIdx.x;
+  const int tid = Tid();
   const int c = tid >> 6, lane = tid & 63;
   const int b = lane / G::ML, i = lane % G::ML;
   if (b < nb && i < G::CX) {
@@ -635,7 +997,7 @@ __device__ __forceinline__ void MediumBatch(const DevFrame& f, const BlockHdr* h
   constexpr uint32_t kTab = DequantOffset(STRATEGY);
   float(*buf)[NB][BUF] = reinterpret_cast<float(*)[NB][BUF]>(smem);
   float(*dcp)[NB][CY * CX] = reinterpret_cast<float(*)[NB][CY * CX]>(smem + 12 * NB * BUF);
-  const int tid = threadIdx.x;
+  const int tid = Tid();
 
   const int c = tid >> 6, lane = tid & 63;
   const int b = lane / ML, i = lane % ML;
@@ -793,11 +1155,12 @@ __device__ __forceinline__ void MediumUnit(const DevFrame& f, const WorkItem* __
   using LD = MediumLoads<R, C, CT>;
   BlockHdr* hdr = reinterpret_cast<BlockHdr*>(smem + G::kHdrOffset);
   const int nvb = (int)min((uint32_t)G::kUnitVarblocks, n - first);
-  if ((int)threadIdx.x < nvb) hdr[threadIdx.x] = MakeHdr(f, list[first + threadIdx.x]);
+  const int tid0 = Tid();
+  if (tid0 < nvb) hdr[tid0] = MakeHdr(f, list[first + tid0]);
   if constexpr (LD::kPipelined) {
     const float4* __restrict__ tab = (const float4*)(f.dequant + DequantOffset(STRATEGY));
     float4* lt = reinterpret_cast<float4*>(smem + G::kTabOffset);
-    for (int k = threadIdx.x; k < 3 * LD::SIZE / 4; k += 192) lt[k] = tab[k];
+    for (int k = tid0; k < 3 * LD::SIZE / 4; k += 192) lt[k] = tab[k];
   }
   __syncthreads();
   LD cur;
@@ -982,15 +1345,18 @@ __global__ __launch_bounds__(256) void k_large(DevFrame f, const WorkItem* __res
 }
 
 // ------------------------------------------------------ class-family dispatch
-// Phase 1 is three launches, not one per class: a kernel owns a FAMILY of work
-// classes and workgroup u decodes UNIT u of the family -- 64 blocks of area of
-// one class, found from the class list lengths k_prepare left on the device.
-// The host never learns the list lengths, but the unit count is bounded
-// tightly by cells/64 + N, so there are no worst-case grids, no empty launches
-// and no tail of small kernels.  Family A: 64x64, 64x32, 32x64 and the ten
-// single-block classes (168 VGPRs, 50 KB LDS: three workgroups per CU); family
-// B: 16x8 .. 32x32 (~100 VGPRs, <= 26 KB); k_large (128x128 .. 256x256, never
-// emitted by libjxl) keeps its own launch because of its private scratch.
+// Phase 1 is five launches, not one per class:
+//   k_dct8          strategy 0 alone (~45 % of a d1.0 frame): row-per-lane, no LDS
+//   k_transform_r16 16x16, 16x8, 8x16: row-per-lane, no LDS, 4 waves per SIMD
+//   k_transform_r32 32x32, 32x16, 16x32, 32x8, 8x32: row-per-lane, 32 values per lane
+//   k_transform_a   64x64, 64x32, 32x64 (LDS-staged MediumUnit) and the nine special 8x8 kinds
+//                   (lane-per-block Single64Unit)
+//   k_large         128x128 .. 256x256 (never emitted by libjxl), private scratch
+// A family kernel owns several work classes; a workgroup decodes UNITS of the family -- 64 or
+// 128 blocks of area of ONE class, located from the class list lengths k_prepare left on the
+// device (a prefix over the family's counters in SGPRs).  The host never learns the list
+// lengths; it bounds the unit count by cells/64 + N and caps the grid at a few resident
+// generations, the workgroups loop (UnitDispatch).
 struct FamilyEntry {
   int cls;
   int unit_varblocks;
@@ -1023,52 +1389,49 @@ __device__ __forceinline__ UnitPick PickUnit(const FamilyEntry (&fam)[N], const 
 }
 
 static constexpr int kLdsFamilyA = MediumGeom<64, 64>::kLdsBytes > 3 * 16384 ? MediumGeom<64, 64>::kLdsBytes : 3 * 16384;
-static constexpr int kLdsFamilyB = MediumGeom<32, 32>::kLdsBytes;
 static_assert(sizeof(BlockHdr) <= 48, "header slots are 48 bytes");
 static_assert(MediumGeom<64, 32>::kLdsBytes <= kLdsFamilyA && MediumGeom<32, 64>::kLdsBytes <= kLdsFamilyA, "");
-static_assert(MediumGeom<16, 8>::kLdsBytes <= kLdsFamilyB && MediumGeom<8, 16>::kLdsBytes <= kLdsFamilyB &&
-              MediumGeom<16, 16>::kLdsBytes <= kLdsFamilyB && MediumGeom<32, 8>::kLdsBytes <= kLdsFamilyB &&
-              MediumGeom<8, 32>::kLdsBytes <= kLdsFamilyB && MediumGeom<32, 16>::kLdsBytes <= kLdsFamilyB &&
-              MediumGeom<16, 32>::kLdsBytes <= kLdsFamilyB, "");
 
 // A: 64x64, 64x32, 32x64 (long units first), then the ten single-block classes
-static constexpr FamilyEntry kFamilyA[13] = {
-    {kClsMedium0 + 8, 1},   {kClsMedium0 + 9, 2},   {kClsMedium0 + 10, 2},  {kClsDct8, 64},
+static constexpr FamilyEntry kFamilyA[12] = {
+    {kClsMedium0 + 8, 1},   {kClsMedium0 + 9, 2},   {kClsMedium0 + 10, 2},
     {kClsSpecial0 + 0, 64}, {kClsSpecial0 + 1, 64}, {kClsSpecial0 + 2, 64}, {kClsSpecial0 + 3, 64},
     {kClsSpecial0 + 4, 64}, {kClsSpecial0 + 5, 64}, {kClsSpecial0 + 6, 64}, {kClsSpecial0 + 7, 64},
     {kClsSpecial0 + 8, 64}};
 // B: 16x8 .. 32x32, long units first so that the drain ends on short ones
-static constexpr FamilyEntry kFamilyB[8] = {
-    {kClsMedium0 + 7, MediumGeom<32, 32>::kUnitVarblocks}, {kClsMedium0 + 5, MediumGeom<32, 16>::kUnitVarblocks},
-    {kClsMedium0 + 6, MediumGeom<16, 32>::kUnitVarblocks}, {kClsMedium0 + 2, MediumGeom<16, 16>::kUnitVarblocks},
-    {kClsMedium0 + 3, MediumGeom<32, 8>::kUnitVarblocks},  {kClsMedium0 + 4, MediumGeom<8, 32>::kUnitVarblocks},
-    {kClsMedium0 + 0, MediumGeom<16, 8>::kUnitVarblocks},  {kClsMedium0 + 1, MediumGeom<8, 16>::kUnitVarblocks}};
+// row-per-lane kernels, 4 waves x (64 / S) varblocks per unit.  R16: longer side 16 (4 waves per
+// SIMD), R32: longer side 32 (twice the registers per lane)
+static constexpr FamilyEntry kFamilyR16[3] = {{kClsMedium0 + 2, 16}, {kClsMedium0 + 0, 32}, {kClsMedium0 + 1, 32}};
+static constexpr FamilyEntry kFamilyR32[5] = {{kClsMedium0 + 7, 8},  {kClsMedium0 + 5, 16}, {kClsMedium0 + 6, 16},
+                                              {kClsMedium0 + 3, 32}, {kClsMedium0 + 4, 32}};
 static_assert(kMediumStrategy[8] == 18 && kMediumStrategy[9] == 19 && kMediumStrategy[10] == 20 &&
               kMediumStrategy[7] == 5 && kMediumStrategy[5] == 10 && kMediumStrategy[6] == 11 &&
               kMediumStrategy[2] == 4 && kMediumStrategy[3] == 8 && kMediumStrategy[4] == 9 &&
               kMediumStrategy[0] == 6 && kMediumStrategy[1] == 7, "class table mismatch");
 
-// One unit per workgroup: unit blockIdx.x of the family (the grid is the tight
-// upper bound cells/64 + N on the unit count, so at most a handful of
-// workgroups find nothing to do).  Deliberately NOT a persistent loop: with a
-// loop around the class switch the compiler hoists every class's invariants
-// into registers that stay live across all classes (measured: 308 VGPRs).
+// Workgroup w decodes units w, w + gridDim.x, ... of the family.  The host only knows the
+// bound cells/64 + N on the unit count; a grid of that size costs ~10 us per launch in
+// workgroups that find nothing to do when the family covers a small part of the frame, so
+// the grid is capped at a few resident generations and the workgroups loop.  (The unit
+// functions read their thread index through Tid(), which keeps the compiler from hoisting
+// every class's lane-dependent invariants out of this loop.)
 template <int N, typename Body>
 __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const WorkLists& wl,
                                              Body&& body) {
   uint32_t cnt[N];
 #pragma unroll
   for (int i = 0; i < N; i++) cnt[i] = wl.count[fam[i].cls * kCounterPad];
-  const UnitPick pick = PickUnit(fam, cnt, blockIdx.x);
-  if (pick.index < 0) return;
-  body(pick.index, wl.list[pick.cls], pick.first, pick.n);
+  for (uint32_t u = blockIdx.x;; u += gridDim.x) {
+    const UnitPick pick = PickUnit(fam, cnt, u);
+    if (pick.index < 0) return;
+    body(pick.index, wl.list[pick.cls], pick.first, pick.n);
+    __syncthreads();  // the next unit reuses the LDS
+  }
 }
 
 // Family A is compiled for three waves per SIMD (168 VGPRs, what its LDS use
 // allows anyway); the 64-point transforms of its three big classes would like
-// ~180 and spill a few values to scratch instead -- they are ~5 % of a d1.0
-// frame, and keeping them in this kernel hides their long single-workgroup
-// latency behind the DCT8 bulk (as a launch of their own: +33 us per 8K frame).
+// ~180 and spill a few values to scratch instead.  Together ~10 % of a d1.0 frame.
 template <typename CT>
 __global__ __launch_bounds__(192, sizeof(CT) == 2 ? 3 : 2) void k_transform_a(DevFrame f, WorkLists wl) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
@@ -1079,29 +1442,36 @@ __global__ __launch_bounds__(192, sizeof(CT) == 2 ? 3 : 2) void k_transform_a(De
                    case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
                    case 2: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
                    default:
-                     Single64Unit<CT>(f, index == 3 ? 0 : (int)kSpecialStrategy[index - 4], list,
-                                      first, n, smem);
+                     Single64Unit<CT>(f, (int)kSpecialStrategy[index - 3], list, first, n, smem);
                      break;
                  }
                });
 }
 
 template <typename CT>
-__global__ __launch_bounds__(192) void k_transform_b(DevFrame f, WorkLists wl) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyB];
-  UnitDispatch(kFamilyB, wl,
-           [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
-             switch (index) {
-               case 0: MediumUnit<32, 32, 5, CT>(f, list, first, n, smem); break;
-               case 1: MediumUnit<32, 16, 10, CT>(f, list, first, n, smem); break;
-               case 2: MediumUnit<16, 32, 11, CT>(f, list, first, n, smem); break;
-               case 3: MediumUnit<16, 16, 4, CT>(f, list, first, n, smem); break;
-               case 4: MediumUnit<32, 8, 8, CT>(f, list, first, n, smem); break;
-               case 5: MediumUnit<8, 32, 9, CT>(f, list, first, n, smem); break;
-               case 6: MediumUnit<16, 8, 6, CT>(f, list, first, n, smem); break;
-               default: MediumUnit<8, 16, 7, CT>(f, list, first, n, smem); break;
-             }
-           });
+__global__ __launch_bounds__(256) void k_transform_r16(DevFrame f, WorkLists wl) {
+  UnitDispatch(kFamilyR16, wl,
+               [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
+                 switch (index) {
+                   case 0: RowLaneUnit<16, 16, 4, CT>(f, list, first, n); break;
+                   case 1: RowLaneUnit<16, 8, 6, CT>(f, list, first, n); break;
+                   default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
+                 }
+               });
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256) void k_transform_r32(DevFrame f, WorkLists wl) {
+  UnitDispatch(kFamilyR32, wl,
+               [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
+                 switch (index) {
+                   case 0: RowLaneUnit<32, 32, 5, CT>(f, list, first, n); break;
+                   case 1: RowLaneUnit<32, 16, 10, CT>(f, list, first, n); break;
+                   case 2: RowLaneUnit<16, 32, 11, CT>(f, list, first, n); break;
+                   case 3: RowLaneUnit<32, 8, 8, CT>(f, list, first, n); break;
+                   default: RowLaneUnit<8, 32, 9, CT>(f, list, first, n); break;
+                 }
+               });
 }
 
 // --------------------------------------------------------------- launchers
@@ -1110,12 +1480,22 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
                           const float* resample, hipStream_t* streams, int nstreams) {
   const uint32_t units = cells / 64;
   const uint32_t grid_l = cells / 128 < 512u ? (cells / 128 ? cells / 128 : 1) : 512u;
-  hipLaunchKernelGGL((k_transform_a<CT>), dim3(units + 13), dim3(192), 0, streams[0], f, wl);
-  hipLaunchKernelGGL((k_transform_b<CT>), dim3(units + 8), dim3(192), 0, streams[1 % nstreams], f,
-                     wl);
+  constexpr uint32_t kDct8PerWg = sizeof(CT) == 2 ? 128 : 64;
+  // caps: residency of the kernel (workgroups per CU by LDS / registers) x 256 CUs x 2 generations
+  const uint32_t grid_a = units + 12 < 1536u ? units + 12 : 1536u;
+  const uint32_t grid_r16 = units + 3 < 4096u ? units + 3 : 4096u;
+  const uint32_t grid_r32 = units / 2 + 5 < 3072u ? units / 2 + 5 : 3072u;  // units of 128 blocks
+  // With two streams the latency-bound family A (a few hundred long 64x64 / 64x32 units and the
+  // special 8x8 kinds, LDS-heavy, low occupancy) runs beside the LDS-free bandwidth-bound k_dct8.
+  hipStream_t s0 = streams[0], s1 = streams[1 % nstreams];
+  hipLaunchKernelGGL((k_transform_a<CT>), dim3(grid_a), dim3(192), 0, s1, f, wl);
+  hipLaunchKernelGGL((k_dct8<CT>), dim3((cells + kDct8PerWg - 1) / kDct8PerWg), dim3(256), 0, s0, f,
+                     wl.list[kClsDct8], wl.count + kClsDct8 * kCounterPad);
+  hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
+  hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
   if (cells >= 256)
-    hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, streams[2 % nstreams], f,
-                       wl.list[kClsLarge], wl.count + kClsLarge * kCounterPad, wc, resample);
+    hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, s1, f, wl.list[kClsLarge],
+                       wl.count + kClsLarge * kCounterPad, wc, resample);
 }
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
