@@ -151,6 +151,11 @@ typedef struct jxlhip_frame_params {
   uint32_t stripe_group_rows;
   /* output_kind == JXLHIP_OUT_PACKED only */
   jxlhip_output_format out_format;
+  /* PassesDecoderState::used_acs (dec_cache.h:120): bit s set = raw strategy s
+     occurs in the frame; known once the DC groups are decoded.  A hint: transform
+     kernels of families without a set bit are not launched.  0 = unknown (everything
+     is launched; a strategy missing from a non-zero mask is NOT decoded). */
+  uint32_t used_acs;
 } jxlhip_frame_params;
 
 /* Device pointers of one frame's inputs.  Same content the reference keeps in

@@ -72,7 +72,8 @@ class FrameParams(C.Structure):
                 ("inverse_opsin_matrix", C.c_float * 9),
                 ("stripe_group_y0", C.c_uint32),
                 ("stripe_group_rows", C.c_uint32),
-                ("out_format", OutputFormat)]
+                ("out_format", OutputFormat),
+                ("used_acs", C.c_uint32)]
 
 
 class FrameInputs(C.Structure):
@@ -92,6 +93,7 @@ def make_params(d):
               "cfl_base_b", "cfl_color_factor", "stripe_group_y0",
               "stripe_group_rows"):
         setattr(p, k, d[k])
+    p.used_acs = d.get("used_acs", 0)
     p.quant_biases[:] = d["quant_biases"]
     p.opsin_biases[:] = d["opsin_biases"]
     p.inverse_opsin_matrix[:] = d["inverse_opsin_matrix"]

@@ -332,6 +332,7 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   f.xtiles = (f.xsb + 7) / 8;
   f.group_y0 = p->stripe_group_y0;
   f.group_rows = p->stripe_group_rows ? p->stripe_group_rows : f.ysg - f.group_y0;
+  f.used_acs = p->used_acs & 0x7FFFFFFu;
   if (f.group_y0 >= f.ysg || f.group_y0 + f.group_rows > f.ysg)
     return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "stripe [%u,+%u) outside %u group rows",
                 f.group_y0, f.group_rows, f.ysg);

@@ -105,6 +105,7 @@ struct DevFrame {
   uint32_t band_g0, band_g1;  // group rows whose work lists k_prepare builds
   uint32_t halo;              // LoopFilter::Padding()
   uint32_t coeff_type;
+  uint32_t used_acs;          // jxlhip_frame_params::used_acs (0 = unknown)
   float inv_global_scale, quant_scale;
   float x_dm, b_dm;
   float biases[4];

@@ -15,6 +15,8 @@
 
 #include <type_traits>
 
+#include <initializer_list>
+
 #include "dev_common.h"
 #include "kernels.h"
 
@@ -65,6 +67,8 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     bad = true;
     first = false;
   }
+  // a strategy the caller's used_acs mask rules out would never be decoded: report it
+  if (first && f.used_acs && !((f.used_acs >> s) & 1u)) bad = true;
   const uint32_t n64 = first ? cx * cy : 0;
   // exclusive scan of n64 over the 1024 threads
   uint32_t incl = n64;
@@ -1488,12 +1492,23 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
   // With two streams the latency-bound family A (a few hundred long 64x64 / 64x32 units and the
   // special 8x8 kinds, LDS-heavy, low occupancy) runs beside the LDS-free bandwidth-bound k_dct8.
   hipStream_t s0 = streams[0], s1 = streams[1 % nstreams];
-  hipLaunchKernelGGL((k_transform_a<CT>), dim3(grid_a), dim3(192), 0, s1, f, wl);
-  hipLaunchKernelGGL((k_dct8<CT>), dim3((cells + kDct8PerWg - 1) / kDct8PerWg), dim3(256), 0, s0, f,
-                     wl.list[kClsDct8], wl.count + kClsDct8 * kCounterPad);
-  hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
-  hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
-  if (cells >= 256)
+  // used_acs (when the caller knows it) says which families have work at all
+  auto any = [&](std::initializer_list<int> strategies) {
+    if (f.used_acs == 0) return true;
+    for (int st : strategies)
+      if (f.used_acs & (1u << st)) return true;
+    return false;
+  };
+  if (any({18, 19, 20, 1, 2, 3, 12, 13, 14, 15, 16, 17}))
+    hipLaunchKernelGGL((k_transform_a<CT>), dim3(grid_a), dim3(192), 0, s1, f, wl);
+  if (any({0}))
+    hipLaunchKernelGGL((k_dct8<CT>), dim3((cells + kDct8PerWg - 1) / kDct8PerWg), dim3(256), 0, s0, f,
+                       wl.list[kClsDct8], wl.count + kClsDct8 * kCounterPad);
+  if (any({4, 6, 7}))
+    hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
+  if (any({5, 8, 9, 10, 11}))
+    hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
+  if (cells >= 256 && any({21, 22, 23, 24, 25, 26}))
     hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, s1, f, wl.list[kClsLarge],
                        wl.count + kClsLarge * kCounterPad, wc, resample);
 }

@@ -194,7 +194,8 @@ def synth_frame(xsize, ysize, *, mix=None, gab=True, epf_iters=1, seed=0x4A584C,
         epf_border_sad_mul=bsm,
         opsin_biases=[-0.0037930732552754493] * 3,
         inverse_opsin_matrix=[float(f32(f32(v) * mul)) for v in inv],
-        stripe_group_y0=0, stripe_group_rows=0, out_format=out_format)
+        stripe_group_y0=0, stripe_group_rows=0, out_format=out_format,
+        used_acs=int(np.bitwise_or.reduce(1 << (np.unique(acs[(acs & 1) == 1]) >> 1).astype(np.int64))))
     tensors = dict(
         coeffs=coeffs,
         ac_strategy=torch.from_numpy(acs).to(dev),

@@ -56,7 +56,8 @@ class FrameParams(C.Structure):
                 ("inverse_opsin_matrix", C.c_float * 9),
                 ("stripe_group_y0", C.c_uint32),
                 ("stripe_group_rows", C.c_uint32),
-                ("out_format", OutputFormat)]
+                ("out_format", OutputFormat),
+                ("used_acs", C.c_uint32)]
 
 
 class OracleFrame(C.Structure):

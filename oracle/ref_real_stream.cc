@@ -302,6 +302,7 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   p.ysize = ys;
   p.coeff_type = JXLHIP_COEFF_I16;  // the test checks jxlhip_ac_pass_max_num_bits() < 16
   p.output_kind = JXLHIP_OUT_LINEAR_RGB_F32;
+  p.used_acs = dec_state->used_acs;
   const QuantizerParams qp = sh.quantizer.GetParams();
   p.global_scale = qp.global_scale;
   p.quant_dc = qp.quant_dc;

@@ -270,6 +270,26 @@ def test_bad_strategy_map_is_reported(dec, dq):
     dec.sync()  # flag is cleared, context usable again
 
 
+def test_used_acs_hint(dec, dq, oracle):
+    """jxlhip_frame_params::used_acs: families without a set bit are not launched (same pixels
+    as with the mask unknown); a mask that rules out a strategy the frame uses is an error."""
+    params, t, fr = frames.make_case(520, 300, mix={0: 3, 4: 1, 12: 0.5}, gab=True, epf_iters=1, seed=3)
+    assert params["used_acs"] == (1 << 0) | (1 << 4) | (1 << 12)
+    outs = []
+    for mask in (params["used_acs"], 0):
+        dec.begin_frame(dict(params, used_acs=mask))
+        dec.set_inputs(to_dev(t), dq)
+        outs.append(dec.decode_frame().clone())
+        dec.sync()
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0].cpu().numpy(), fr.decode(threads=4)) <= TIGHT
+    dec.begin_frame(dict(params, used_acs=(1 << 0) | (1 << 12)))   # 16x16 ruled out
+    dec.set_inputs(to_dev(t), dq)
+    dec.decode_frame()
+    with pytest.raises(abi.JxlHipError):
+        dec.sync()
+
+
 def test_dequant_dc_and_smoothing(dec, oracle):
     import oracle as O
     xs, ys = 333, 270
