@@ -356,186 +356,6 @@ __host__ __device__ constexpr TabOffsets MakeTabOffsets() {
 }
 static constexpr TabOffsets kSingleTabOffset = MakeTabOffsets();
 
-// ---- wave-cooperative staging for the single-block kernels ----------------
-// One lane decodes one 8x8 varblock in registers, but a lane-per-block global
-// access pattern touches 64 different cache lines per instruction.  So the
-// WAVE moves the data: 8 (int16) or 16 (int32) lanes fetch one block's
-// coefficients as whole 128-byte lines into LDS (XOR-swizzled so both sides
-// stay conflict-light), each lane then reads its own block from LDS; the 8x8
-// results go back through LDS so that every store instruction writes 64
-// 16-byte pieces that tile 32 half block-rows of the output.
-template <typename CT>
-struct Stage64 {
-  static constexpr int kChunks = sizeof(CT) * 64 / 16;  // 16-byte chunks per block: 8 / 16
-  static constexpr int kInChunks = 64 * kChunks;        // one channel of 64 blocks
-  // int16: both channels a wave needs are gathered at once (2 x 8 KB); the
-  // 16 KB result staging aliases them.  int32: one channel at a time (16 KB).
-  static constexpr bool kBothInFlight = sizeof(CT) == 2;
-  static constexpr int kLdsChunks = 1024;               // per wave: 16 KB
-};
-
-// issue the gather of channel c of the wave's 64 blocks into `buf`
-template <typename CT>
-__device__ __forceinline__ void WaveGather64(const DevFrame& f, int c, const uint32_t* blk_off,
-                                             uint4* buf, int lane) {
-  using S = Stage64<CT>;
-  constexpr int kBlocksPerInstr = 64 / S::kChunks;
-  const int sub = lane / S::kChunks, chunk = lane % S::kChunks;
-  const char* base = (const char*)f.coeffs[c];
-  // (no staging array: global loads and LDS stores do not alias, the scheduler
-  // issues all the loads before the first store)
-#pragma unroll
-  for (int i = 0; i < S::kChunks; i++) {
-    const size_t byte = (size_t)blk_off[i] * (64 * sizeof(CT)) + (size_t)chunk * 16;
-    const int blk = i * kBlocksPerInstr + sub;
-    buf[blk * S::kChunks + (chunk ^ (blk & (S::kChunks - 1)))] = *(const uint4*)(base + byte);
-  }
-}
-
-// this lane's block of the gathered channel -> q[64]
-template <typename CT>
-__device__ __forceinline__ void WaveFetch64(const uint4* buf, int lane, int32_t* q) {
-  using S = Stage64<CT>;
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int i = 0; i < S::kChunks; i++) {
-    const uint4 v = buf[lane * S::kChunks + (i ^ (lane & (S::kChunks - 1)))];
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    if constexpr (sizeof(CT) == 2) {
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        q[i * 8 + 2 * j] = (int32_t)(int16_t)(w[j] & 0xffffu);
-        q[i * 8 + 2 * j + 1] = (int32_t)w[j] >> 16;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; j++) q[i * 4 + j] = (int32_t)w[j];
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
-// px[64] of this lane's block -> LDS -> global.  The planes are block-major
-// (one 8x8 tile = 256 contiguous bytes), so store instruction i writes, for
-// lane l, 16-byte part (l & 15) of block i*4 + (l >> 4): four whole tiles =
-// 1 KB of consecutive bytes when the blocks are x-neighbours.  The LDS image
-// is XOR-swizzled per block so both the per-lane writes and the part-major
-// reads stay conflict-free.
-__device__ __forceinline__ void WaveStore64(const DevFrame& f, int c, uint32_t my_pos, int nvalid,
-                                            float4* lds, int lane, const float* px) {
-#pragma unroll
-  for (int j = 0; j < 16; j++)
-    lds[lane * 16 + (j ^ (lane & 15))] =
-        make_float4(px[j * 4], px[j * 4 + 1], px[j * 4 + 2], px[j * 4 + 3]);
-  __builtin_amdgcn_wave_barrier();
-  const int part = lane & 15, sub = lane >> 4;
-  const bool skip = (f.debug & 1) && px[0] != 12345.678f;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int b = i * 4 + sub;
-    const uint32_t pos = __shfl(my_pos, b, 64);
-    const float4 v = lds[b * 16 + (part ^ (b & 15))];
-    if (b < nvalid && !skip)
-      *(float4*)(TilePtr(f, c, pos >> 16, pos & 0xffffu) + part * 4) = v;
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
-// Dequantises one CHANNEL of one single-block varblock and runs its transform
-// (DequantLane, dec_group.cc:115-153).  Called by whole waves; the three
-// channels of a block are decoded by three different waves so that no wave
-// ever has to wait for its own stores before issuing its next loads (on gfx9
-// the in-order vmcnt covers stores too).  X and B recompute the luma
-// dequantisation they need for chroma-from-luma instead of sharing registers.
-// Lanes >= nvalid carry a duplicate of the last block.
-template <typename CT>
-__device__ __forceinline__ void DecodeBlock64(const DevFrame& f, int strategy, const WorkItem it,
-                                              int lane, int nvalid, uint4* lds, int c) {
-  using S = Stage64<CT>;
-  // the ten single-block kinds share this code; only the transform differs
-  // (their dequant tables are 3 x 64 floats at a strategy-dependent offset)
-  const float* __restrict__ tab = f.dequant + kSingleTabOffset.v[strategy];
-  const BlockHdr h = MakeHdr(f, it);
-  const float dcv = f.dc[c][(size_t)h.aby * f.xsb + h.abx];
-  // who owns the blocks this lane moves for the wave
-  uint32_t blk_off[S::kChunks];
-  {
-    constexpr int kBlocksPerInstr = 64 / S::kChunks;
-    const uint32_t my = (f.debug & 2) ? 0u : it.off;
-#pragma unroll
-    for (int i = 0; i < S::kChunks; i++)
-      blk_off[i] = __shfl(my, i * kBlocksPerInstr + lane / S::kChunks, 64);
-  }
-  uint4* bufY = lds;
-  uint4* bufC = S::kBothInFlight ? lds + S::kInChunks : lds;
-  WaveGather64<CT>(f, 1, blk_off, bufY, lane);
-  if (S::kBothInFlight && c != 1) WaveGather64<CT>(f, c, blk_off, bufC, lane);
-  float v[64], px[64];
-  {
-    int32_t q[64];
-    WaveFetch64<CT>(bufY, lane, q);
-#pragma unroll
-    for (int k = 0; k < 64; k++)
-      v[k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tab[64 + k] * h.sy);
-  }
-  if (c != 1) {  // wave-uniform
-    const float sc = c == 0 ? h.sx : h.sb;
-    const float cc = c == 0 ? h.x_cc : h.b_cc;
-    const float bias = c == 0 ? f.biases[0] : f.biases[2];
-    const float* __restrict__ tc = tab + c * 64;
-    int32_t q[64];
-    if (!S::kBothInFlight) WaveGather64<CT>(f, c, blk_off, bufC, lane);
-    WaveFetch64<CT>(bufC, lane, q);
-#pragma unroll
-    for (int k = 0; k < 64; k++) {
-      const float d = AdjustQuantBias(q[k], bias, f.biases[3]) * (tc[k] * sc);
-      v[k] = __builtin_fmaf(cc, v[k], d);
-    }
-  }
-  v[0] = dcv;
-  switch (strategy) {  // wave-uniform
-    case 0: Transform64<0>(v, px); break;
-    case 1: Transform64<1>(v, px); break;
-    case 2: Transform64<2>(v, px); break;
-    case 3: Transform64<3>(v, px); break;
-    case 12: Transform64<12>(v, px); break;
-    case 13: Transform64<13>(v, px); break;
-    case 14: Transform64<14>(v, px); break;
-    case 15: Transform64<15>(v, px); break;
-    case 16: Transform64<16>(v, px); break;
-    default: Transform64<17>(v, px); break;
-  }
-  WaveStore64(f, c, it.pos, nvalid, (float4*)lds, lane, px);
-}
-
-// One unit of a single-block class (0 = DCT8, the bulk; the 9 special kinds):
-// 64 varblocks starting at list[first].  Workgroup = 3 waves = the 3 channels of
-// the same 64 blocks; every wave is independent (own 16 KB LDS slice, no
-// workgroup barrier inside).
-template <typename CT>
-__device__ __forceinline__ void Single64Unit(const DevFrame& f, int strategy,
-                                             const WorkItem* __restrict__ list, uint32_t first,
-                                             uint32_t n, unsigned char* smem) {
-  uint4* lds = reinterpret_cast<uint4*>(smem);
-  const int tid = Tid();
-  const int lane = tid & 63, wave = tid >> 6;
-  // the list has 64 entries of slack: lanes past the end read garbage that is
-  // replaced by a duplicate of the last valid block
-  WorkItem it = list[first + lane];
-  const int nvalid = (int)min(64u, n - first);
-  {
-    const uint32_t lp = __shfl(it.pos, nvalid - 1, 64), lo = __shfl(it.off, nvalid - 1, 64),
-                   lq = __shfl(it.qc, nvalid - 1, 64);
-    if (lane >= nvalid) {
-      it.pos = lp;
-      it.off = lo;
-      it.qc = lq;
-    }
-  }
-  const int c = wave == 0 ? 1 : (wave == 1 ? 0 : 2);
-  DecodeBlock64<CT>(f, strategy, it, lane, nvalid, lds + wave * Stage64<CT>::kLdsChunks, c);
-}
-
 // ------------------------------------------------------------------ k_dct8
 // DCT8 alone is ~45 % of a d1.0 frame and gets a kernel of its own with no LDS and few
 // registers.  EIGHT LANES share a block:
@@ -602,12 +422,18 @@ struct Dct8Row {  // one matrix row of one channel as loaded
 };
 
 template <typename CT>
-__global__ __launch_bounds__(256) void k_dct8(DevFrame f, const WorkItem* __restrict__ list,
-                                               const uint32_t* __restrict__ count) {
-  constexpr int kSteps = sizeof(CT) == 2 ? 4 : 2;  // steps of 8 blocks per wave
-  const uint32_t n = *count;
+struct Dct8Geom {
+  static constexpr int kSteps = sizeof(CT) == 2 ? 4 : 2;  // steps of 8 blocks per wave
+  static constexpr uint32_t kPerWg = 4 * kSteps * 8;      // blocks per 256-thread workgroup
+};
+
+// workgroup `wg` of the DCT8 list (n entries)
+template <typename CT>
+__device__ __forceinline__ void Dct8Rows(const DevFrame& f, const WorkItem* __restrict__ list, uint32_t n,
+                                         uint32_t wg) {
+  constexpr int kSteps = Dct8Geom<CT>::kSteps;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t first = (blockIdx.x * 4 + wave) * (kSteps * 8);
+  const uint32_t first = (wg * 4 + wave) * (kSteps * 8);
   if (first >= n) return;
   const int j = lane >> 3;  // matrix row (input), pixel row (output)
   const bool bit3 = (lane & 8) != 0;
@@ -676,6 +502,127 @@ __global__ __launch_bounds__(256) void k_dct8(DevFrame f, const WorkItem* __rest
       }
     }
   }
+}
+
+// One special 8x8 kind (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3), one channel, 64
+// blocks: lane = block, everything in registers, the block's coefficient line and its tile moved
+// by the lane itself (16-byte pieces) -- no LDS, so these tasks can share a kernel (and its
+// occupancy) with the DCT8 rows.  A unit of 64 blocks of one of these kinds takes ~25 us from
+// first load to last store whatever the form; as tasks at the head of the DCT8 launch that
+// latency disappears behind the DCT8 bulk instead of being a launch of its own.
+template <typename CT>
+__device__ __forceinline__ void SpecialTask(const DevFrame& f, int strategy, const WorkItem* __restrict__ list,
+                                            uint32_t first, uint32_t n, int c) {
+  constexpr int kVec = 64 * (int)sizeof(CT) / 16;
+  const int lane = threadIdx.x & 63;
+  const uint32_t idx = first + lane;
+  const bool valid = idx < n;
+  const WorkItem it = list[valid ? idx : n - 1];
+  const BlockHdr h = MakeHdr(f, it);
+  const float* __restrict__ tab = f.dequant + kSingleTabOffset.v[strategy];
+  const float dcv = f.dc[c][(size_t)h.aby * f.xsb + h.abx];
+  auto unpack = [&](const uint4 r, int32_t* q) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    if constexpr (sizeof(CT) == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        q[2 * k] = (int32_t)(int16_t)(w[k] & 0xffffu);
+        q[2 * k + 1] = (int32_t)w[k] >> 16;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) q[k] = (int32_t)w[k];
+    }
+  };
+  constexpr int kPer = 16 / (int)sizeof(CT);  // coefficients per 16-byte piece
+  float v[64], px[64];
+  {
+    const uint4* p = (const uint4*)((const CT*)f.coeffs[1] + h.coef);
+    uint4 raw[kVec];
+#pragma unroll
+    for (int i = 0; i < kVec; i++) raw[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < kVec; i++) {
+      int32_t q[kPer];
+      unpack(raw[i], q);
+#pragma unroll
+      for (int k = 0; k < kPer; k++)
+        v[i * kPer + k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tab[64 + i * kPer + k] * h.sy);
+    }
+  }
+  if (c != 1) {  // wave-uniform
+    const float sc = c == 0 ? h.sx : h.sb;
+    const float cc = c == 0 ? h.x_cc : h.b_cc;
+    const float bias = c == 0 ? f.biases[0] : f.biases[2];
+    const float* __restrict__ tc = tab + c * 64;
+    const uint4* p = (const uint4*)((const CT*)f.coeffs[c] + h.coef);
+    uint4 raw[kVec];
+#pragma unroll
+    for (int i = 0; i < kVec; i++) raw[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < kVec; i++) {
+      int32_t q[kPer];
+      unpack(raw[i], q);
+#pragma unroll
+      for (int k = 0; k < kPer; k++) {
+        const float d = AdjustQuantBias(q[k], bias, f.biases[3]) * (tc[i * kPer + k] * sc);
+        v[i * kPer + k] = __builtin_fmaf(cc, v[i * kPer + k], d);
+      }
+    }
+  }
+  v[0] = dcv;
+  switch (strategy) {  // wave-uniform
+    case 1: Transform64<1>(v, px); break;
+    case 2: Transform64<2>(v, px); break;
+    case 3: Transform64<3>(v, px); break;
+    case 12: Transform64<12>(v, px); break;
+    case 13: Transform64<13>(v, px); break;
+    case 14: Transform64<14>(v, px); break;
+    case 15: Transform64<15>(v, px); break;
+    case 16: Transform64<16>(v, px); break;
+    default: Transform64<17>(v, px); break;
+  }
+  if (valid) {
+    float4* dst = (float4*)TilePtr(f, c, h.aby, h.abx);
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst[i] = make_float4(px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]);
+  }
+}
+
+// All single-block strategies in one launch: first the (unit, channel) tasks of the nine special
+// kinds, four per workgroup, then the DCT8 rows.
+template <typename CT>
+__global__ __launch_bounds__(256, 3) void k_transform_8(DevFrame f, WorkLists wl) {
+  uint32_t cnt[kNumSpecial];
+  uint32_t tasks = 0;
+#pragma unroll
+  for (int i = 0; i < kNumSpecial; i++) {
+    cnt[i] = wl.count[(kClsSpecial0 + i) * kCounterPad];
+    tasks += 3 * ((cnt[i] + 63) / 64);
+  }
+  const uint32_t special_wgs = (tasks + 3) / 4;
+  if (blockIdx.x >= special_wgs) {
+    Dct8Rows<CT>(f, wl.list[kClsDct8], wl.count[kClsDct8 * kCounterPad], blockIdx.x - special_wgs);
+    return;
+  }
+  const uint32_t task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= tasks) return;
+  uint32_t base = 0;
+  int cls = -1;
+  uint32_t first = 0, n = 0, chan = 0;
+#pragma unroll
+  for (int i = 0; i < kNumSpecial; i++) {
+    const uint32_t t = 3 * ((cnt[i] + 63) / 64);
+    if (cls < 0 && task < base + t) {
+      cls = i;
+      first = ((task - base) / 3) * 64;
+      chan = (task - base) % 3;
+      n = cnt[i];
+    }
+    base += t;
+  }
+  SpecialTask<CT>(f, (int)kSpecialStrategy[cls], wl.list[kClsSpecial0 + cls], first, n,
+                  chan == 0 ? 1 : (chan == 1 ? 0 : 2));
 }
 
 // --------------------------------------------------------------- k_rowlane
@@ -1071,18 +1018,30 @@ __device__ __forceinline__ void MediumBatch(const DevFrame& f, const BlockHdr* h
       }
     }
   } else {
+    // all loads of the batch first, then the arithmetic: inside one loop every step would wait
+    // for its own loads (~1.5 us each, six steps for a 64x64 varblock)
     using Raw = typename LD::Raw;
-    for (int k4 = tid * 4; k4 < nb * SIZE; k4 += 192 * 4) {
-      const int vb = k4 / SIZE, k = k4 % SIZE;
-      const size_t at = hdr[vb].coef + k;
-      const Raw rx = *(const Raw*)((const CT*)f.coeffs[0] + at);
-      const Raw ry = *(const Raw*)((const CT*)f.coeffs[1] + at);
-      const Raw rb = *(const Raw*)((const CT*)f.coeffs[2] + at);
-      TabStep t;
-      t.x = *(const float4*)(tab + k);
-      t.y = *(const float4*)(tab + SIZE + k);
-      t.b = *(const float4*)(tab + 2 * SIZE + k);
-      dequant_step(k4, rx, ry, rb, t);
+    constexpr int kIter = (NB * SIZE + 767) / 768;
+    Raw rx[kIter], ry[kIter], rb[kIter];
+    TabStep t[kIter];
+#pragma unroll
+    for (int it = 0; it < kIter; it++) {
+      const int k4 = tid * 4 + it * 768;
+      if (k4 < nb * SIZE) {
+        const int vb = k4 / SIZE, k = k4 % SIZE;
+        const size_t at = hdr[vb].coef + k;
+        rx[it] = *(const Raw*)((const CT*)f.coeffs[0] + at);
+        ry[it] = *(const Raw*)((const CT*)f.coeffs[1] + at);
+        rb[it] = *(const Raw*)((const CT*)f.coeffs[2] + at);
+        t[it].x = *(const float4*)(tab + k);
+        t[it].y = *(const float4*)(tab + SIZE + k);
+        t[it].b = *(const float4*)(tab + 2 * SIZE + k);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < kIter; it++) {
+      const int k4 = tid * 4 + it * 768;
+      if (k4 < nb * SIZE) dequant_step(k4, rx[it], ry[it], rb[it], t[it]);
     }
   }
   __syncthreads();
@@ -1350,11 +1309,12 @@ __global__ __launch_bounds__(256) void k_large(DevFrame f, const WorkItem* __res
 
 // ------------------------------------------------------ class-family dispatch
 // Phase 1 is five launches, not one per class:
-//   k_dct8          strategy 0 alone (~45 % of a d1.0 frame): row-per-lane, no LDS
+//   k_transform_8   every single-block strategy, no LDS: the nine special 8x8 kinds as
+//                   lane-per-block (unit, channel) tasks at the head of the grid, then DCT8
+//                   (~45 % of a d1.0 frame) row-per-lane
 //   k_transform_r16 16x16, 16x8, 8x16: row-per-lane, no LDS, 4 waves per SIMD
 //   k_transform_r32 32x32, 32x16, 16x32, 32x8, 8x32: row-per-lane, 32 values per lane
-//   k_transform_a   64x64, 64x32, 32x64 (LDS-staged MediumUnit) and the nine special 8x8 kinds
-//                   (lane-per-block Single64Unit)
+//   k_transform_a   64x64, 64x32, 32x64 (LDS-staged MediumUnit)
 //   k_large         128x128 .. 256x256 (never emitted by libjxl), private scratch
 // A family kernel owns several work classes; a workgroup decodes UNITS of the family -- 64 or
 // 128 blocks of area of ONE class, located from the class list lengths k_prepare left on the
@@ -1392,16 +1352,12 @@ __device__ __forceinline__ UnitPick PickUnit(const FamilyEntry (&fam)[N], const 
   return p;
 }
 
-static constexpr int kLdsFamilyA = MediumGeom<64, 64>::kLdsBytes > 3 * 16384 ? MediumGeom<64, 64>::kLdsBytes : 3 * 16384;
+static constexpr int kLdsFamilyA = MediumGeom<64, 64>::kLdsBytes;
 static_assert(sizeof(BlockHdr) <= 48, "header slots are 48 bytes");
 static_assert(MediumGeom<64, 32>::kLdsBytes <= kLdsFamilyA && MediumGeom<32, 64>::kLdsBytes <= kLdsFamilyA, "");
 
-// A: 64x64, 64x32, 32x64 (long units first), then the ten single-block classes
-static constexpr FamilyEntry kFamilyA[12] = {
-    {kClsMedium0 + 8, 1},   {kClsMedium0 + 9, 2},   {kClsMedium0 + 10, 2},
-    {kClsSpecial0 + 0, 64}, {kClsSpecial0 + 1, 64}, {kClsSpecial0 + 2, 64}, {kClsSpecial0 + 3, 64},
-    {kClsSpecial0 + 4, 64}, {kClsSpecial0 + 5, 64}, {kClsSpecial0 + 6, 64}, {kClsSpecial0 + 7, 64},
-    {kClsSpecial0 + 8, 64}};
+// A: 64x64, 64x32, 32x64 (long units first)
+static constexpr FamilyEntry kFamilyA[3] = {{kClsMedium0 + 8, 1}, {kClsMedium0 + 9, 2}, {kClsMedium0 + 10, 2}};
 // B: 16x8 .. 32x32, long units first so that the drain ends on short ones
 // row-per-lane kernels, 4 waves x (64 / S) varblocks per unit.  R16: longer side 16 (4 waves per
 // SIMD), R32: longer side 32 (twice the registers per lane)
@@ -1433,9 +1389,10 @@ __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const 
   }
 }
 
-// Family A is compiled for three waves per SIMD (168 VGPRs, what its LDS use
-// allows anyway); the 64-point transforms of its three big classes would like
-// ~180 and spill a few values to scratch instead.  Together ~10 % of a d1.0 frame.
+// Family A (64-point transforms, ~5 % of a d1.0 frame) is compiled for three waves per SIMD
+// (168 VGPRs, what its LDS use allows anyway); the 64-point transforms would like ~180 and
+// spill a few values to scratch instead.  In row-per-lane form (64 values per lane, > 256
+// registers, one wave per SIMD) these classes were 30 % slower.
 template <typename CT>
 __global__ __launch_bounds__(192, sizeof(CT) == 2 ? 3 : 2) void k_transform_a(DevFrame f, WorkLists wl) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
@@ -1444,10 +1401,7 @@ __global__ __launch_bounds__(192, sizeof(CT) == 2 ? 3 : 2) void k_transform_a(De
                  switch (index) {
                    case 0: MediumUnit<64, 64, 18, CT>(f, list, first, n, smem); break;
                    case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
-                   case 2: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
-                   default:
-                     Single64Unit<CT>(f, (int)kSpecialStrategy[index - 3], list, first, n, smem);
-                     break;
+                   default: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
                  }
                });
 }
@@ -1484,9 +1438,9 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
                           const float* resample, hipStream_t* streams, int nstreams) {
   const uint32_t units = cells / 64;
   const uint32_t grid_l = cells / 128 < 512u ? (cells / 128 ? cells / 128 : 1) : 512u;
-  constexpr uint32_t kDct8PerWg = sizeof(CT) == 2 ? 128 : 64;
+  constexpr uint32_t kDct8PerWg = Dct8Geom<CT>::kPerWg;
   // caps: residency of the kernel (workgroups per CU by LDS / registers) x 256 CUs x 2 generations
-  const uint32_t grid_a = units + 12 < 1536u ? units + 12 : 1536u;
+  const uint32_t grid_a = units + 3 < 1536u ? units + 3 : 1536u;
   const uint32_t grid_r16 = units + 3 < 4096u ? units + 3 : 4096u;
   const uint32_t grid_r32 = units / 2 + 5 < 3072u ? units / 2 + 5 : 3072u;  // units of 128 blocks
   // With two streams the latency-bound family A (a few hundred long 64x64 / 64x32 units and the
@@ -1499,11 +1453,16 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
       if (f.used_acs & (1u << st)) return true;
     return false;
   };
-  if (any({18, 19, 20, 1, 2, 3, 12, 13, 14, 15, 16, 17}))
+  if (any({18, 19, 20}))
     hipLaunchKernelGGL((k_transform_a<CT>), dim3(grid_a), dim3(192), 0, s1, f, wl);
-  if (any({0}))
-    hipLaunchKernelGGL((k_dct8<CT>), dim3((cells + kDct8PerWg - 1) / kDct8PerWg), dim3(256), 0, s0, f,
-                       wl.list[kClsDct8], wl.count + kClsDct8 * kCounterPad);
+  {
+    // worst cases: all cells special (3 tasks per 64 blocks, 4 tasks per workgroup) or all DCT8
+    const bool specials = any({1, 2, 3, 12, 13, 14, 15, 16, 17});
+    const uint32_t bound_s = specials ? (cells / 64 + kNumSpecial) * 3 / 4 + 1 : 0;
+    const uint32_t bound_8 = any({0}) ? (cells + kDct8PerWg - 1) / kDct8PerWg : 0;
+    const uint32_t grid_8 = (bound_s > bound_8 ? bound_s : bound_8) + (specials ? kNumSpecial : 0);
+    if (grid_8) hipLaunchKernelGGL((k_transform_8<CT>), dim3(grid_8), dim3(256), 0, s0, f, wl);
+  }
   if (any({4, 6, 7}))
     hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
   if (any({5, 8, 9, 10, 11}))
