@@ -57,7 +57,8 @@ typedef enum {
   JXLHIP_ERR_HIP = -4,         /* a HIP runtime call failed; see last_error */
   JXLHIP_ERR_BAD_STREAM = -5,  /* side info violates a format constraint */
   JXLHIP_ERR_STATE = -6,       /* call sequence error */
-  JXLHIP_ERR_UNSUPPORTED = -7  /* valid stream feature outside this back-end */
+  JXLHIP_ERR_UNSUPPORTED = -7, /* valid stream feature outside this back-end */
+  JXLHIP_ERR_RANGE = -8        /* a coefficient does not fit the 16-bit buffers: use JXLHIP_COEFF_I32 */
 } jxlhip_status;
 
 /* ACType, lib/jxl/dct_util.h:23; chosen per frame at lib/jxl/dec_frame.cc:421-431 */

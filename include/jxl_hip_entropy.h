@@ -109,7 +109,13 @@ JXLHIP_EXPORT int jxlhip_ac_global_decode(const uint8_t* data, size_t size, uint
  *   xsize_blocks/ysize_blocks: frame size in 8x8 blocks; group_x/y: AC group
  *   ac_strategy, raw_quant: whole-frame side info as in jxlhip_frame_inputs
  *   quant_dc: per-block DC context index (PassesSharedState::quant_dc), NULL = 0
- *   coeff_type: JXLHIP_COEFF_I16 / I32 element type of coeffs[]
+ *   coeff_type: JXLHIP_COEFF_I16 / I32 element type of coeffs[].  The reference picks 16-bit
+ *               buffers only when no token of the pass's code CAN carry 16 bits
+ *               (jxlhip_ac_pass_max_num_bits; one flat histogram in the stream is enough to
+ *               exceed that, and libjxl's encoder writes those routinely) although the values
+ *               rarely need them.  I16 may therefore be tried whatever max_num_bits says:
+ *               JXLHIP_ERR_RANGE reports a coefficient that left the 16-bit range (the frame
+ *               is then redone with I32), otherwise the result is exactly the reference's.
  *   ncoeffs (optional): slots used by the group (what jxlhip_submit_group takes)
  * 4:4:4 only (the VarDCT back-end does not implement chroma subsampling). */
 JXLHIP_EXPORT int jxlhip_ac_group_decode(const jxlhip_ac_pass* pass, uint32_t xsize_blocks,

@@ -23,7 +23,7 @@ namespace {
 constexpr int kPoolStreams = 4;
 constexpr int kMaxBlockStreams = 8;
 constexpr int kMaxBands = 64;
-constexpr int kStageSlots = 8;  // pinned staging buffers of jxlhip_ac_group_decode_submit
+constexpr int kStageSlots = 32;  // pinned staging buffers of jxlhip_ac_group_decode_submit (0.4 / 0.8 MB each)
 
 struct ProfSpan {
   hipEvent_t a, b;
@@ -189,6 +189,7 @@ const char* jxlhip_status_string(int status) {
     case JXLHIP_ERR_BAD_STREAM: return "side info violates a format constraint";
     case JXLHIP_ERR_STATE: return "call sequence error";
     case JXLHIP_ERR_UNSUPPORTED: return "stream feature outside this back-end";
+    case JXLHIP_ERR_RANGE: return "coefficient outside the 16-bit range: redo the frame with JXLHIP_COEFF_I32";
     default: return "unknown status";
   }
 }

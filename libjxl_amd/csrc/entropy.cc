@@ -969,6 +969,7 @@ int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_
   // device by k_prepare; here it only has to be harmless.
   int32_t nz[3][32][32];
   memset(nz, 0, sizeof(nz));
+  bool out_of_range = false;  // 16-bit buffers only
   size_t offset = 0;
   for (uint32_t by = 0; by < gh; by++) {
     for (uint32_t bx = 0; bx < gw; bx++) {
@@ -1019,7 +1020,13 @@ int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_
           const uint32_t u = reader.ReadHybridUint(hmap[ctx], br);
           const uint32_t magnitude = u >> 1, neg = (~u) & 1;  // UnpackSigned
           const int32_t coeff = (int32_t)((magnitude ^ (neg - 1)) << shift);
-          block[order[k]] = (T)(block[order[k]] + (T)coeff);
+          if constexpr (sizeof(T) == 2) {
+            const int32_t sum = (int32_t)block[order[k]] + coeff;
+            out_of_range |= sum != (int32_t)(int16_t)sum;
+            block[order[k]] = (T)sum;
+          } else {
+            block[order[k]] = (T)(block[order[k]] + (T)coeff);
+          }
           prev = u != 0;
           nzeros -= prev;
         }
@@ -1030,6 +1037,7 @@ int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_
   }
   if (reader.Corrupt() || !reader.FinalStateOk()) return kBad;
   if (!br->Healthy()) return kBad;
+  if (out_of_range) return JXLHIP_ERR_RANGE;
   if (ncoeffs) *ncoeffs = offset;
   return kOk;
 }

@@ -123,12 +123,37 @@ void FillImage(Image3F* img, uint32_t seed) {
   }
   const float cx = xs * (0.3f + 0.4f * rnd()), cy = ys * (0.3f + 0.4f * rnd());
   const float rad = 0.28f * std::min(xs, ys);
+  // broadband texture (amplitude ~ 1/f, 14 oriented components) whose strength varies slowly
+  // over the image: leaves smooth areas, mid-frequency areas and busy areas, like a photograph
+  constexpr int kWaves = 14;
+  float wfx[kWaves], wfy[kWaves], wph[kWaves], wamp[kWaves], wcol[kWaves][3];
+  for (int k = 0; k < kWaves; k++) {
+    const float freq = 0.015f * std::pow(1.45f, static_cast<float>(k));  // 0.015 .. 1.9 rad/px
+    const float ang = 6.2831853f * rnd();
+    wfx[k] = freq * std::cos(ang);
+    wfy[k] = freq * std::sin(ang);
+    wph[k] = 6.2831853f * rnd();
+    wamp[k] = 0.035f / std::sqrt(freq / 0.015f);
+    for (int c = 0; c < 3; c++) wcol[k][c] = 0.6f + 0.8f * rnd();
+  }
+  const float mfx = 6.2831853f / (0.37f * xs + 80.0f), mfy = 6.2831853f / (0.29f * ys + 60.0f);
   for (size_t y = 0; y < ys; y++) {
     float* rows[3] = {img->PlaneRow(0, y), img->PlaneRow(1, y), img->PlaneRow(2, y)};
     for (size_t x = 0; x < xs; x++) {
       const float t = static_cast<float>(y) / ys, u = static_cast<float>(x) / xs;
       float v[3];
       for (int c = 0; c < 3; c++) v[c] = c0[c] + (c1[c] - c0[c]) * (0.7f * t + 0.3f * u);
+      {
+        float strength = 0.5f + 0.5f * std::sin(mfx * x + 0.7f) * std::cos(mfy * y);
+        strength = strength * strength * 1.6f;
+        for (int k = 0; k < kWaves; k++) {
+          const float w = strength * wamp[k] * std::sin(wfx[k] * x + wfy[k] * y + wph[k]);
+          for (int c = 0; c < 3; c++) v[c] += w * wcol[k][c];
+        }
+        // sensor-like noise, stronger in the dark (shot noise), so that no area is perfectly smooth
+        const float grain = 0.012f + 0.02f * strength;
+        for (int c = 0; c < 3; c++) v[c] = std::max(v[c] + grain * (rnd() - 0.5f), 0.002f);
+      }
       const float dx = x - cx, dy = y - cy;
       if (dx * dx + dy * dy < rad * rad) {  // textured disc
         const float tex = 0.5f + 0.5f * std::sin(0.11f * x) * std::cos(0.07f * y + 0.013f * x);

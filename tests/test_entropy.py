@@ -125,6 +125,28 @@ def test_roundtrip_int32_large_values(L, ref):
         assert np.array_equal(out[c], npy["coeffs"][c]), c
 
 
+def test_16_bit_buffers_report_out_of_range_values(L, ref):
+    """JXLHIP_ERR_RANGE: a coefficient beyond +-32767 decoded into int16 buffers is reported (the
+    caller redoes the frame with int32), never wrapped; groups without such values decode."""
+    xs, ys = 520, 264
+    params, fr, npy = case(xs, ys, mix=synth.MIX_DCT32, gab=False, epf_iters=0, coeff_type=1, quant_mul=2.0, amp=40.0)
+    npy["coeffs"][1][5] = 40000          # group 0, first varblock, an AC position of the 32x32 matrix
+    npy["coeffs"][2][65536 + 37] = -33000  # group 1
+    glob, groups, used_acs, _ = fr.encode_ac_ref()
+    _, out = decode_all(L, npy, xs, ys, glob, groups, used_acs, 1, 1)
+    for c in range(3):
+        assert np.array_equal(out[c], npy["coeffs"][c]), c
+    rc, h, _ = open_pass(L, glob, used_acs, 1)
+    assert rc == 0
+    assert L.jxlhip_ac_pass_max_num_bits(h) >= 16
+    out16 = [np.zeros(len(groups) * 65536, np.int16) for _ in range(3)]
+    rcs = [decode_group(L, h, npy, xs, ys, gi, data, 0, out16)[0] for gi, data in enumerate(groups)]
+    L.jxlhip_ac_pass_destroy(h)
+    assert rcs[0] == -8 and rcs[1] == -8 and all(r == 0 for r in rcs[2:])
+    for c in range(3):  # the groups that fit are exact
+        assert np.array_equal(out16[c][2 * 65536:].astype(np.int32), npy["coeffs"][c][2 * 65536:])
+
+
 def test_ragged_sizes(L, ref):
     for xs, ys in ((8, 8), (1, 1), (257, 9), (300, 513)):
         params, fr, npy = case(xs, ys, mix=synth.MIX_D1, gab=False, epf_iters=0, seed=xs)

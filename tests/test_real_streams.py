@@ -55,10 +55,12 @@ def open_ac_global(L, rs):
     return list(hs), 0 if mx < 16 else 1
 
 
-def entropy_decode(L, rs):
+def entropy_decode(L, rs, force_ct=None):
     """AC global + every pass of every AC group section of rs through the product's
     entropy decoder.  Returns (coeff_type, the three coefficient buffers)."""
     hs, ct = open_ac_global(L, rs)
+    if force_ct is not None:
+        ct = force_ct
     try:
         out = [np.zeros(rs.num_groups * 65536, np.int32 if ct else np.int16) for _ in range(3)]
         xsb, ysb, xsg = (rs.xsize + 7) // 8, (rs.ysize + 7) // 8, (rs.xsize + 255) // 256
@@ -99,6 +101,18 @@ def test_progressive_passes_accumulate_to_reference_pixels(L, ref, progressive, 
     assert rs.num_passes == passes
     assert (max(rs.shift) > 0) == (progressive == 2)
     check_cpu(L, rs)
+
+
+def test_optimistic_16_bit_buffers_on_a_flat_histogram_stream(L, ref):
+    """The reference switches to int32 coefficient buffers as soon as a token COULD carry 16 bits
+    (a flat histogram does that); the values themselves fit 16 bits, and the decoder says so:
+    decoding into int16 succeeds (no JXLHIP_ERR_RANGE) and gives the same coefficients."""
+    rs = ref.RealStream(1024, 1280, seed=2304, distance=1.0, speed_tier=5)
+    ct, c32 = entropy_decode(L, rs)
+    assert ct == 1  # what dec_frame.cc:414-421 would pick
+    _, c16 = entropy_decode(L, rs, force_ct=0)
+    for a, b in zip(c16, c32):
+        assert a.dtype == np.int16 and np.array_equal(a.astype(np.int32), b)
 
 
 def check_cpu(L, rs):

@@ -1,0 +1,115 @@
+"""End to end on a GENUINE libjxl stream (tests/data/real_4k_d1.npz, written by
+tools/make_real_case.py from the reference encoder): AC-global decode, the AC groups entropy-decoded
+by N host threads straight into the pinned staging slots (jxlhip_ac_group_decode_submit), upload,
+HIP decode.  Prints wall times per stage and thread count.  GPU box: python tools/e2e_real.py"""
+import ctypes as C
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from libjxl_amd import VarDctDecoder, abi  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+path = args[0] if args else "tests/data/real_4k_d1.npz"
+d = np.load(path)
+xs, ys = int(d["xsize"]), int(d["ysize"])
+ng, ndc = int(d["num_groups"]), int(d["num_dc_groups"])
+cs = d["codestream"]
+off, size = d["section_offset"], d["section_size"]
+
+
+def section(i):
+    return cs[int(off[i]):int(off[i]) + int(size[i])]
+
+
+L = abi.load_library()
+dec = VarDctDecoder(0)
+bctx = abi.BlockCtxMap()
+pos = C.c_size_t(0)
+b = np.ascontiguousarray(d["block_ctx_bytes"])
+assert L.jxlhip_block_ctx_map_decode(b.ctypes.data, len(b), C.byref(pos), C.byref(bctx)) == 0
+glob = np.ascontiguousarray(section(1 + ndc))
+encs = abi.QuantEncodings()
+nh, used, hs = C.c_uint32(0), C.c_size_t(0), (C.c_void_p * 1)()
+t0 = time.perf_counter()
+assert L.jxlhip_ac_global_decode(glob.ctypes.data, len(glob), ng, 1, int(d["used_acs"]), C.byref(bctx), C.byref(encs),
+                                 C.byref(nh), hs, C.byref(used)) == 0
+t_global = time.perf_counter() - t0
+params = abi.FrameParams.from_buffer_copy(d["params"].tobytes())
+params.output_kind = 1
+# 16-bit buffers optimistically (jxl_hip_entropy.h): JXLHIP_ERR_RANGE would ask for a redo with --i32
+params.coeff_type = 1 if "--i32" in sys.argv else 0
+print("max_num_bits", L.jxlhip_ac_pass_max_num_bits(hs[0]), "(the reference would use",
+      "int16" if L.jxlhip_ac_pass_max_num_bits(hs[0]) < 16 else "int32", "buffers)")
+params.used_acs = int(d["used_acs"])
+acs = np.ascontiguousarray(d["ac_strategy"])
+rq = np.ascontiguousarray(d["raw_quant"])
+qdc = np.ascontiguousarray(d["quant_dc"])
+side = [np.ascontiguousarray(d[k]) for k in ("epf_sharpness", "ytox_map", "ytob_map", "dc_x", "dc_y", "dc_b")]
+groups = [np.ascontiguousarray(section(2 + ndc + g)) for g in range(ng)]
+ac_bytes = sum(len(g) for g in groups) + len(glob)
+print(f"{xs}x{ys}, {ng} groups, codestream {len(cs)} B (AC {ac_bytes} B = {8 * ac_bytes / (xs * ys):.2f} bpp), "
+      f"coeff_type {'i16' if params.coeff_type == 0 else 'i32'}, AC global decode {t_global * 1e3:.2f} ms")
+n = np.bincount(acs.ravel() >> 1, minlength=27)
+print("strategy share of blocks (%):", {i: round(100 * v / n.sum(), 1) for i, v in enumerate(n) if v})
+dec.begin_frame(params)
+dq = dec.dequant_tables(None)
+dec.sync()
+dqh = dq.cpu().numpy()
+dc3 = (C.c_void_p * 3)(*[x.ctypes.data for x in side[3:]])
+
+
+def run(nthreads):
+    t0 = time.perf_counter()
+    assert L.jxlhip_upload_side_info(dec.ctx, acs.ctypes.data, rq.ctypes.data, side[0].ctypes.data,
+                                     side[1].ctypes.data, side[2].ctypes.data, dc3, dqh.ctypes.data) == 0
+    errs = []
+
+    def worker(tid):
+        for g in range(tid, ng, nthreads):
+            gp = C.c_size_t(0)
+            rc = L.jxlhip_ac_group_decode_submit(dec.ctx, hs[0], g, acs.ctypes.data, rq.ctypes.data, qdc.ctypes.data,
+                                                 groups[g].ctypes.data, len(groups[g]), C.byref(gp))
+            if rc:
+                errs.append((g, rc))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    t1 = time.perf_counter()
+    out = dec.decode_frame()
+    dec.sync()
+    t2 = time.perf_counter()
+    return t1 - t0, t2 - t1, out
+
+
+run(8)
+for nt in (1, 4, 16, 32, 64, 128):
+    best = None
+    for _ in range(3):
+        r = run(nt)
+        if best is None or r[0] + r[1] < best[0] + best[1]:
+            best = r
+    te, tg, out = best
+    print(f"threads {nt:3d}: entropy decode + uploads {te * 1e3:7.2f} ms, kernels (after last upload) {tg * 1e3:6.2f} ms, "
+          f"end to end {xs * ys / (te + tg) / 1e6:8.1f} Mpx/s")
+# kernels alone, inputs resident
+dec.profile(True)
+for _ in range(20):
+    dec.decode_blocks()
+    dec.decode_filters(out)
+prof = dec.profile_read()
+dec.profile(False)
+print("kernels alone (ms):", {k: round(ms / max(c, 1), 4) for k, (ms, c) in prof.items()},
+      "->", round(xs * ys / sum(ms / max(c, 1) for ms, c in prof.values()) / 1e3, 1), "Mpx/s")
+sub = out.cpu().numpy()[::8, ::8]
+print("max |diff| vs reference pixels (8x subsample, f16):", float(np.abs(sub - d["rgb_sub8"].astype(np.float32)).max()))
+L.jxlhip_ac_pass_destroy(hs[0])
+dec.close()
