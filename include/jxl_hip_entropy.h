@@ -147,6 +147,24 @@ JXLHIP_EXPORT int jxlhip_ac_group_decode_submit_passes(jxlhip_ctx* ctx, uint32_t
                                                        const uint8_t* quant_dc, const uint8_t* const* data,
                                                        const size_t* sizes, size_t* bit_pos);
 
+/* All AC groups of a frame on a JxlParallelRunner (include/jxl/parallel_runner.h:127; e.g.
+ * JxlThreadParallelRunner of libjxl_threads_hip.so): what FrameDecoder::ProcessSections does
+ * with RunOnPool over ProcessACGroup (dec_frame.cc:700-760) once every AC section is present.
+ * runner == NULL runs the groups on the calling thread.  sections[p * num_groups + g] /
+ * sizes[...]: bytes of pass p of group g (each read from bit 0).  Groups outside the
+ * context's stripe are skipped.  Returns the first error of any group (JXLHIP_ERR_RANGE:
+ * redo the frame with JXLHIP_COEFF_I32), JXLHIP_ERR_STATE when the runner fails. */
+typedef int (*jxlhip_parallel_runner)(void* runner_opaque, void* jpegxl_opaque,
+                                      int (*init)(void* jpegxl_opaque, size_t num_threads),
+                                      void (*func)(void* jpegxl_opaque, uint32_t value, size_t thread_id),
+                                      uint32_t start_range, uint32_t end_range);
+JXLHIP_EXPORT int jxlhip_ac_groups_decode_submit(jxlhip_ctx* ctx, jxlhip_parallel_runner runner,
+                                                 void* runner_opaque, uint32_t num_passes,
+                                                 const jxlhip_ac_pass* const* passes, const uint32_t* shifts,
+                                                 const uint8_t* ac_strategy, const int32_t* raw_quant,
+                                                 const uint8_t* quant_dc, const uint8_t* const* sections,
+                                                 const size_t* sizes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <condition_variable>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -20,7 +21,7 @@ using namespace jxlhip;
 
 namespace {
 
-constexpr int kPoolStreams = 4;
+constexpr int kPoolStreams = 8;
 constexpr int kMaxBlockStreams = 8;
 constexpr int kMaxBands = 64;
 constexpr int kStageSlots = 32;  // pinned staging buffers of jxlhip_ac_group_decode_submit (0.4 / 0.8 MB each)
@@ -283,8 +284,8 @@ void jxlhip_destroy(jxlhip_ctx* c) {
     if (c->stage[i]) (void)hipHostFree(c->stage[i]);
   }
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
-                  c->error_flag, c->tables, c->up_coeffs[0], c->up_coeffs[1],
-                  c->up_coeffs[2], c->up_side, c->dc_tmp,       c->quant_enc};
+                  c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
+                  c->dc_tmp,     c->quant_enc};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -433,6 +434,7 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
 }
 
 static void ApplyInputs(jxlhip_ctx* c, const jxlhip_frame_inputs* in) {
+  c->f.coef_stride64 = in == &c->up_inputs ? 3072u : 1024u;
   for (int ch = 0; ch < 3; ch++) {
     c->f.coeffs[ch] = in->coeffs[ch];
     c->f.dc[ch] = in->dc[ch];
@@ -488,16 +490,20 @@ static size_t SideLayout(const DevFrame& f, size_t off[9]) {
 static int EnsureUploadBuffers(jxlhip_ctx* c) {
   const DevFrame& f = c->f;
   const size_t esz = f.coeff_type == JXLHIP_COEFF_I16 ? 2 : 4;
-  const size_t cbytes = (size_t)f.xsg * f.ysg * JXLHIP_GROUP_COEFFS * esz;
+  // one buffer, [group][channel][65536]: a group's three channels are contiguous, so the
+  // staging slot of jxlhip_ac_group_decode_submit goes up with ONE copy (three copies per group
+  // = ~400 hipMemcpyAsync calls per 4K frame were a 4.5 ms serial floor: the runtime serialises
+  // them whatever thread they come from)
+  const size_t cbytes = (size_t)f.xsg * f.ysg * 3 * JXLHIP_GROUP_COEFFS * esz;
   if (cbytes > c->up_coeff_bytes || !c->up_coeffs[0]) {
-    for (int ch = 0; ch < 3; ch++) {
-      if (c->up_coeffs[ch]) HIPCHK(c, hipFree(c->up_coeffs[ch]));
-      c->up_coeffs[ch] = nullptr;
-    }
+    if (c->up_coeffs[0]) HIPCHK(c, hipFree(c->up_coeffs[0]));
+    c->up_coeffs[0] = c->up_coeffs[1] = c->up_coeffs[2] = nullptr;
     c->up_coeff_bytes = 0;
-    for (int ch = 0; ch < 3; ch++) HIPCHK(c, hipMalloc(&c->up_coeffs[ch], cbytes));
+    HIPCHK(c, hipMalloc(&c->up_coeffs[0], cbytes));
     c->up_coeff_bytes = cbytes;
   }
+  c->up_coeffs[1] = (char*)c->up_coeffs[0] + (size_t)JXLHIP_GROUP_COEFFS * esz;
+  c->up_coeffs[2] = (char*)c->up_coeffs[0] + 2 * (size_t)JXLHIP_GROUP_COEFFS * esz;
   size_t off[9];
   const size_t sbytes = SideLayout(f, off);
   int rc;
@@ -570,6 +576,11 @@ static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void*
   const size_t esz = f.coeff_type == JXLHIP_COEFF_I16 ? 2 : 4;
   int slot;
   {
+    // only the bookkeeping is serialised: the copies themselves are issued concurrently by the
+    // runner's threads (with the lock around them, ~400 hipMemcpyAsync calls per 4K frame were
+    // a 4.5 ms serial floor of the whole upload path).  A thread issues its three copies and
+    // then its event on ONE stream in program order, so the event still follows its copies
+    // however other threads' calls interleave on that stream.
     std::lock_guard<std::mutex> lock(c->pool_mu);
     if (hipSetDevice(c->device) != hipSuccess) return JXLHIP_ERR_HIP;
     if (!c->up_coeffs[0]) {
@@ -578,16 +589,22 @@ static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void*
     }
     slot = (int)(c->pool_next++ % kPoolStreams);
     c->pool_dirty[slot] = true;
-    // copies of one slot are issued under the lock so the stream sees them in order
+  }
+  if (hipSetDevice(c->device) != hipSuccess) return JXLHIP_ERR_HIP;
+  const size_t chan = (size_t)JXLHIP_GROUP_COEFFS * esz;
+  char* dst0 = (char*)c->up_coeffs[0] + (size_t)group_idx * 3 * chan;
+  if ((const char*)coeffs[1] == (const char*)coeffs[0] + chan && (const char*)coeffs[2] == (const char*)coeffs[0] + 2 * chan) {
+    // the three channels sit in one staging slot: one copy up to the last used coefficient
+    hipError_t e = hipMemcpyAsync(dst0, coeffs[0], 2 * chan + ncoeffs * esz, hipMemcpyHostToDevice, c->pool[slot]);
+    if (e != hipSuccess) return Fail(c, JXLHIP_ERR_HIP, "submit_group: %s", hipGetErrorString(e));
+  } else {
     for (int ch = 0; ch < 3; ch++) {
-      char* dst = (char*)c->up_coeffs[ch] + (size_t)group_idx * JXLHIP_GROUP_COEFFS * esz;
-      hipError_t e = hipMemcpyAsync(dst, coeffs[ch], ncoeffs * esz, hipMemcpyHostToDevice,
-                                    c->pool[slot]);
+      hipError_t e = hipMemcpyAsync(dst0 + ch * chan, coeffs[ch], ncoeffs * esz, hipMemcpyHostToDevice, c->pool[slot]);
       if (e != hipSuccess) return Fail(c, JXLHIP_ERR_HIP, "submit_group: %s", hipGetErrorString(e));
     }
-    if (done && hipEventRecord(done, c->pool[slot]) != hipSuccess)
-      return Fail(c, JXLHIP_ERR_HIP, "submit_group: event record failed");
   }
+  if (done && hipEventRecord(done, c->pool[slot]) != hipSuccess)
+    return Fail(c, JXLHIP_ERR_HIP, "submit_group: event record failed");
   return JXLHIP_OK;
 }
 
@@ -676,6 +693,70 @@ int jxlhip_ac_group_decode_submit_passes(jxlhip_ctx* c, uint32_t num_passes,
   c->stage_cv.notify_all();
   if (rc == JXLHIP_ERR_BAD_STREAM) return Fail(c, rc, "AC group %u: invalid entropy-coded data", group_idx);
   return rc;
+}
+
+namespace {
+struct GroupsJob {
+  jxlhip_ctx* c;
+  uint32_t num_passes, num_groups;
+  const jxlhip_ac_pass* const* passes;
+  const uint32_t* shifts;
+  const uint8_t* acs;
+  const int32_t* raw_quant;
+  const uint8_t* quant_dc;
+  const uint8_t* const* sections;
+  const size_t* sizes;
+  std::atomic<int> status{JXLHIP_OK};
+};
+int GroupsInit(void*, size_t) { return 0; }
+void GroupsFunc(void* opaque, uint32_t g, size_t /*thread*/) {
+  GroupsJob* j = static_cast<GroupsJob*>(opaque);
+  if (j->status.load(std::memory_order_relaxed) != JXLHIP_OK) return;
+  const DevFrame& f = j->c->f;
+  const uint32_t gy = g / f.xsg;
+  if (gy < f.group_y0 || gy >= f.group_y0 + f.group_rows) return;  // another rank's stripe
+  const uint8_t* data[11];
+  size_t sizes[11], pos[11];
+  for (uint32_t p = 0; p < j->num_passes; p++) {
+    data[p] = j->sections[(size_t)p * j->num_groups + g];
+    sizes[p] = j->sizes[(size_t)p * j->num_groups + g];
+    pos[p] = 0;
+  }
+  const int rc = jxlhip_ac_group_decode_submit_passes(j->c, j->num_passes, j->passes, j->shifts, g, j->acs,
+                                                      j->raw_quant, j->quant_dc, data, sizes, pos);
+  if (rc != JXLHIP_OK) {
+    int expected = JXLHIP_OK;
+    j->status.compare_exchange_strong(expected, rc);
+  }
+}
+}  // namespace
+
+int jxlhip_ac_groups_decode_submit(jxlhip_ctx* c, jxlhip_parallel_runner runner, void* runner_opaque,
+                                   uint32_t num_passes, const jxlhip_ac_pass* const* passes,
+                                   const uint32_t* shifts, const uint8_t* ac_strategy,
+                                   const int32_t* raw_quant, const uint8_t* quant_dc,
+                                   const uint8_t* const* sections, const size_t* sizes) {
+  if (!c || !passes || !ac_strategy || !raw_quant || !sections || !sizes || num_passes == 0 || num_passes > 11)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "ac_groups_decode_submit before frame_begin");
+  GroupsJob job;
+  job.c = c;
+  job.num_passes = num_passes;
+  job.num_groups = c->f.xsg * c->f.ysg;
+  job.passes = passes;
+  job.shifts = shifts;
+  job.acs = ac_strategy;
+  job.raw_quant = raw_quant;
+  job.quant_dc = quant_dc;
+  job.sections = sections;
+  job.sizes = sizes;
+  if (runner) {
+    if (runner(runner_opaque, &job, GroupsInit, GroupsFunc, 0, job.num_groups) != 0)
+      return Fail(c, JXLHIP_ERR_STATE, "parallel runner failed");
+  } else {
+    for (uint32_t g = 0; g < job.num_groups; g++) GroupsFunc(&job, g, 0);
+  }
+  return job.status.load();
 }
 
 int jxlhip_ac_group_decode_submit(jxlhip_ctx* c, const jxlhip_ac_pass* pass, uint32_t group_idx,

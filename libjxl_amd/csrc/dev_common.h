@@ -106,6 +106,9 @@ struct DevFrame {
   uint32_t halo;              // LoopFilter::Padding()
   uint32_t coeff_type;
   uint32_t used_acs;          // jxlhip_frame_params::used_acs (0 = unknown)
+  uint32_t coef_stride64;     // coefficient slots / 64 between consecutive groups of coeffs[c]: 1024 (the
+                              // ACImage layout of caller-owned buffers) or 3072 (the context's upload buffer,
+                              // one group's three channels contiguous so that one copy moves a group)
   float inv_global_scale, quant_scale;
   float x_dm, b_dm;
   float biases[4];

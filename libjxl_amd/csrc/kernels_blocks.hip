@@ -122,7 +122,7 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     for (uint32_t w = 0; w < wave; w++) pos += wave_cls[w][cls];
     WorkItem it;
     it.pos = (aby << 16) | abx;
-    it.off = g * 1024u + off64;
+    it.off = g * f.coef_stride64 + off64;
     it.qc = ((uint32_t)cell_q & 0xffffu) | cell_cfl;
     it.pad = 0;
     wl.list[cls][pos] = it;

@@ -190,3 +190,47 @@ def test_reference_encoded_stream_through_hip_path(L, ref, xs, ys, distance, tie
     scale = max(1.0, float(np.abs(rs.rgb).max()))
     err = float(np.abs(got - rs.rgb).max()) / scale
     assert err <= 2e-5, err
+
+
+@pytest.mark.gpu
+def test_all_groups_on_the_parallel_runner(L, ref):
+    """jxlhip_ac_groups_decode_submit: every AC group of a genuine two-pass stream on the
+    JxlParallelRunner of libjxl_threads_hip.so (and on the calling thread), one C call."""
+    from libjxl_amd import VarDctDecoder
+    rs = ref.RealStream(776, 520, seed=21, distance=1.5, speed_tier=3, progressive=2)
+    hs, ct = open_ac_global(L, rs)
+    R = C.CDLL(abi.runner_library_path())
+    R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    pool = R.JxlThreadParallelRunnerCreate(None, 6)
+    n, ng = rs.num_passes, rs.num_groups
+    secs = [np.frombuffer(rs.ac_group(g, p), np.uint8) for p in range(n) for g in range(ng)]
+    ptrs = (C.c_void_p * len(secs))(*[x.ctypes.data for x in secs])
+    sizes = (C.c_size_t * len(secs))(*[len(x) for x in secs])
+    pass_arr = (C.c_void_p * n)(*hs)
+    shifts = (C.c_uint32 * n)(*rs.shift)
+    d = VarDctDecoder(0)
+    params = abi.FrameParams.from_buffer_copy(rs.params.tobytes())
+    params.output_kind = 1
+    params.coeff_type = 0  # optimistic 16-bit buffers whatever max_num_bits says
+    outs = []
+    for runner in (C.cast(R.JxlThreadParallelRunner, C.c_void_p), None):
+        d.begin_frame(params)
+        dc3 = (C.c_void_p * 3)(rs.dc_x.ctypes.data, rs.dc_y.ctypes.data, rs.dc_b.ctypes.data)
+        assert L.jxlhip_upload_side_info(d.ctx, rs.ac_strategy.ctypes.data, rs.raw_quant.ctypes.data,
+                                         rs.epf_sharpness.ctypes.data, rs.ytox_map.ctypes.data,
+                                         rs.ytob_map.ctypes.data, dc3, rs.dequant_table.ctypes.data) == 0
+        rc = L.jxlhip_ac_groups_decode_submit(d.ctx, runner, pool, n, pass_arr, shifts, rs.ac_strategy.ctypes.data,
+                                              rs.raw_quant.ctypes.data, rs.quant_dc.ctypes.data, ptrs, sizes)
+        assert rc == 0, rc
+        out = d.decode_frame()
+        d.sync()
+        outs.append(out.cpu().numpy())
+    R.JxlThreadParallelRunnerDestroy(pool)
+    for h in hs:
+        L.jxlhip_ac_pass_destroy(h)
+    d.close()
+    assert np.array_equal(outs[0], outs[1])
+    scale = max(1.0, float(np.abs(rs.rgb).max()))
+    assert float(np.abs(outs[0] - rs.rgb).max()) / scale <= 2e-5
