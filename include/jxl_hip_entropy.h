@@ -147,6 +147,18 @@ JXLHIP_EXPORT int jxlhip_ac_group_decode_submit_passes(jxlhip_ctx* ctx, uint32_t
                                                        const uint8_t* quant_dc, const uint8_t* const* data,
                                                        const size_t* sizes, size_t* bit_pos);
 
+/* ---- frame table of contents (row f4: the part of the front-end that locates the sections) ---- */
+/* NumTocEntries (toc.h:33-43): 1 when the frame is a single section, else DC global + DC groups
+ * + AC global + one per pass and AC group. */
+JXLHIP_EXPORT uint32_t jxlhip_num_toc_entries(uint32_t num_groups, uint32_t num_dc_groups, uint32_t num_passes);
+/* ReadGroupOffsets (toc.cc:28-115): the TOC that follows the frame header at bit *bit_pos of
+ * data -- optional permutation (Lehmer code, entropy coded), byte alignment, num_entries
+ * U32(kTocDist) sizes, byte alignment.  offsets[i] / sizes[i]: byte offset (relative to the first
+ * byte after the TOC) and size of LOGICAL section i (the permutation applied).  *bit_pos is
+ * advanced to that first byte; *total_size (optional) = sum of the sizes. */
+JXLHIP_EXPORT int jxlhip_toc_decode(const uint8_t* data, size_t size, size_t* bit_pos, uint32_t num_entries,
+                                    uint64_t* offsets, uint32_t* sizes, uint64_t* total_size);
+
 /* All AC groups of a frame on a JxlParallelRunner (include/jxl/parallel_runner.h:127; e.g.
  * JxlThreadParallelRunner of libjxl_threads_hip.so): what FrameDecoder::ProcessSections does
  * with RunOnPool over ProcessACGroup (dec_frame.cc:700-760) once every AC section is present.

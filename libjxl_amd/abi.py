@@ -145,7 +145,7 @@ EXPORTS = [
     "jxlhip_ac_pass_used_orders", "jxlhip_ac_pass_order", "jxlhip_ac_group_decode",
     "jxlhip_ac_group_decode_submit", "jxlhip_block_ctx_map_decode", "jxlhip_quant_dc_contexts",
     "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode", "jxlhip_ac_group_decode_submit_passes",
-    "jxlhip_ac_groups_decode_submit",
+    "jxlhip_ac_groups_decode_submit", "jxlhip_num_toc_entries", "jxlhip_toc_decode",
 ]
 
 
@@ -183,6 +183,9 @@ def load_library():
     L.jxlhip_ac_group_decode_submit.argtypes = [vp, vp, u32, vp, vp, vp, vp, sz, C.POINTER(sz)]
     L.jxlhip_ac_group_decode_submit_passes.argtypes = [vp, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp]
     L.jxlhip_ac_groups_decode_submit.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.jxlhip_num_toc_entries.argtypes = [u32, u32, u32]
+    L.jxlhip_num_toc_entries.restype = u32
+    L.jxlhip_toc_decode.argtypes = [vp, sz, C.POINTER(sz), u32, vp, vp, vp]
     L.jxlhip_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlhip_frame_set_inputs.argtypes = [vp, C.POINTER(FrameInputs)]
     L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]

@@ -1170,6 +1170,56 @@ int ReadQuantEncodings(BitReader* br, jxlhip_quant_encoding* enc) {  // DequantM
 }
 }  // namespace
 
+uint32_t jxlhip_num_toc_entries(uint32_t num_groups, uint32_t num_dc_groups, uint32_t num_passes) {
+  if (num_groups == 1 && num_passes == 1) return 1;
+  return 2 + num_dc_groups + num_groups * num_passes;
+}
+
+int jxlhip_toc_decode(const uint8_t* data, size_t size, size_t* bit_pos, uint32_t num_entries, uint64_t* offsets,
+                      uint32_t* sizes, uint64_t* total_size) {
+  if (!data || !bit_pos || !offsets || !sizes || num_entries == 0) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (num_entries > 65536) return kBad;  // toc.cc:32-37
+  if (*bit_pos >= size * 8) return kBad;
+  BitReader br(data, size, *bit_pos);
+  auto to_byte_boundary = [&]() {  // BitReader::JumpToByteBoundary: the padding must be zero
+    const uint32_t rem = (uint32_t)(br.BitsConsumed() % 8);
+    return rem == 0 || br.Read(8 - rem) == 0;
+  };
+  std::vector<uint32_t> perm;
+  if (br.Read(1)) {
+    // DecodePermutation (coeff_order.cc:66-80)
+    if ((size_t)num_entries * 12 > size * 8 - std::min(size * 8, br.BitsConsumed())) return kBad;
+    EntropyCode code;
+    int rc = DecodeEntropyCode(&br, kPermutationContexts, &code, false, 0);
+    if (rc) return rc;
+    SymbolReader reader(&code, &br);
+    if (!reader.Ok()) return JXLHIP_ERR_OUT_OF_MEMORY;
+    perm.resize(num_entries);
+    rc = ReadPermutation(0, num_entries, perm.data(), &br, &reader, code);
+    if (rc) return rc;
+    if (reader.Corrupt() || !reader.FinalStateOk()) return kBad;
+  }
+  if (!to_byte_boundary()) return kBad;
+  static const U32Dist kTocDist = {{10, 14, 22, 30}, {0, 1024, 17408, 4211712}};  // toc.h:25-26
+  std::vector<uint32_t> raw(num_entries);
+  for (uint32_t i = 0; i < num_entries; i++) raw[i] = ReadU32(&br, kTocDist);
+  if (!to_byte_boundary() || !br.Healthy()) return kBad;
+  std::vector<uint64_t> off(num_entries);
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < num_entries; i++) {
+    off[i] = total;
+    total += raw[i];
+  }
+  for (uint32_t i = 0; i < num_entries; i++) {
+    const uint32_t src = perm.empty() ? i : perm[i];
+    offsets[i] = off[src];
+    sizes[i] = raw[src];
+  }
+  if (total_size) *total_size = total;
+  *bit_pos = br.BitsConsumed();
+  return kOk;
+}
+
 int jxlhip_dequant_encodings_decode(const uint8_t* data, size_t size, size_t* bit_pos, jxlhip_quant_encoding* enc) {
   if (!data || !bit_pos || !enc) return JXLHIP_ERR_INVALID_ARGUMENT;
   BitReader br(data, size, *bit_pos);

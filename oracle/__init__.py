@@ -460,6 +460,7 @@ class RealStream:
             (self.num_groups, self.num_dc_groups, self.num_histograms, self.used_acs, self.frame_offset,
              self.sections_offset) = [int(L.jxr_real_case_info(h, i)) for i in range(6)]
             self.num_passes = int(L.jxr_real_case_info(h, 6))
+            self.toc_bit_offset = int(L.jxr_real_case_info(h, 7))
             self.shift = [int(L.jxr_real_case_info(h, 16 + i)) for i in range(self.num_passes)]
         finally:
             L.jxr_real_case_destroy(h)

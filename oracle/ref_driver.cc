@@ -75,6 +75,8 @@
 #include "lib/jxl/enc_entropy_coder.h"
 #include "lib/jxl/enc_params.h"
 #include "lib/jxl/enc_quant_weights.h"
+#include "lib/jxl/enc_toc.h"
+#include "lib/jxl/toc.h"
 #include "lib/jxl/frame_header.h"
 
 #include "jxl_oracle.h"  // jxo_frame (POD mirror of the C ABI inputs)
@@ -682,4 +684,38 @@ JXR_EXPORT int jxr_set_quant_encodings(const jxlhip_quant_encoding* enc) {
   g_quant_encodings.clear();
   if (!enc) return 0;
   return ToQuantEncodings(enc, &g_quant_encodings) ? 0 : -1;
+}
+
+// A frame TOC written by the reference (enc_toc.cc: WriteTocPermutation + WriteTocSizes); perm may
+// be NULL (no permutation).  Returns the number of bytes or -1.
+JXR_EXPORT int64_t jxr_toc_write(const uint32_t* sizes, uint32_t n, const uint32_t* perm, uint8_t* out, size_t cap) {
+  Ref ref;
+  BitWriter writer{&ref.mm};
+  std::vector<coeff_order_t> p;
+  if (perm) p.assign(perm, perm + n);
+  std::vector<size_t> sz(sizes, sizes + n);
+  if (!WriteTocPermutation(p, &writer, nullptr) || !WriteTocSizes(sz, &writer, nullptr)) return -1;
+  writer.ZeroPadToByte();
+  Span<const uint8_t> sp = writer.GetSpan();
+  if (sp.size() > cap) return -1;
+  memcpy(out, sp.data(), sp.size());
+  return static_cast<int64_t>(sp.size());
+}
+
+// ReadGroupOffsets (toc.cc:83-115) by the reference: 0 ok, 1 failure
+JXR_EXPORT int jxr_toc_read(const uint8_t* data, size_t size, uint32_t n, uint64_t* offsets, uint32_t* sizes,
+                            size_t* bits) {
+  Ref ref;
+  BitReader br(Bytes(data, size));
+  std::vector<uint64_t> off;
+  std::vector<uint32_t> sz;
+  uint64_t total = 0;
+  Status ok = ReadGroupOffsets(&ref.mm, n, &br, &off, &sz, &total);
+  *bits = br.TotalBitsConsumed();
+  const bool in_bounds = br.AllReadsWithinBounds();
+  (void)br.Close();
+  if (!ok || !in_bounds) return 1;
+  memcpy(offsets, off.data(), n * sizeof(uint64_t));
+  memcpy(sizes, sz.data(), n * sizeof(uint32_t));
+  return 0;
 }

@@ -94,6 +94,7 @@ struct RealCase {
   std::vector<uint8_t> codestream;
   size_t frame_offset = 0;    // first byte of the frame (header + TOC + sections)
   size_t sections_offset = 0; // first byte of the first section
+  size_t toc_bit_offset = 0;  // bits from the frame's first byte to the TOC (= size of the frame header)
   std::vector<uint64_t> section_offset, section_size;  // indexed by logical section id
   uint32_t xsize = 0, ysize = 0, num_groups = 0, num_dc_groups = 0, num_histograms = 0, used_acs = 0;
   uint32_t num_passes = 1, shift[kMaxNumPasses] = {};  // frame_header.passes
@@ -234,6 +235,13 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   const size_t header_bytes = reader.TotalBitsConsumed() / kBitsPerByte;
   JXL_RETURN_IF_ERROR(reader.Close());
   out->sections_offset = out->frame_offset + header_bytes;
+  {
+    BitReader br2(Bytes(in, avail));
+    FrameHeader fh2(&metadata);
+    JXL_RETURN_IF_ERROR(ReadFrameHeader(&br2, &fh2));
+    out->toc_bit_offset = br2.TotalBitsConsumed();
+    JXL_RETURN_IF_ERROR(br2.Close());
+  }
   const FrameHeader& fh = fd.GetFrameHeader();
   const FrameDimensions fdim = fh.ToFrameDimensions();
   out->num_groups = fdim.num_groups;
@@ -407,6 +415,7 @@ JXR_EXPORT uint64_t jxr_real_case_info(void* h, int what) {
     case 4: return c->frame_offset;
     case 5: return c->sections_offset;
     case 6: return c->num_passes;
+    case 7: return c->toc_bit_offset;
     case 16: case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24: case 25: case 26:
       return c->shift[what - 16];
     default: return 0;
