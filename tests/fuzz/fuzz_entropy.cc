@@ -123,6 +123,18 @@ int RunOnce(const Case& base, Rng* r, uint64_t* ok, uint64_t* rejected) {
   uint32_t used_acs = c.used_acs;
   if (what == 15) used_acs = r->Next() & 0x7FFFFFF;
 
+  {  // the stand-alone parsers on whatever bytes the damaged AC-global section now holds
+    Exact g(c.global);
+    const uint32_t n = 1 + r->Below(300);
+    std::vector<uint64_t> off(n);
+    std::vector<uint32_t> sz(n);
+    size_t tp = r->Below(16);
+    uint64_t total = 0;
+    (void)jxlhip_toc_decode(g.p, g.n, &tp, n, off.data(), sz.data(), &total);
+    jxlhip_quant_encoding enc[JXLHIP_NUM_QUANT_TABLES];
+    size_t dp = r->Below(64);
+    (void)jxlhip_dequant_encodings_decode(g.p, g.n, &dp, enc);
+  }
   jxlhip_block_ctx_map bcm;
   size_t pos = 0;
   Exact bc(c.bctx);
