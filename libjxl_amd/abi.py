@@ -59,6 +59,35 @@ class QuantEncoding(C.Structure):
 QuantEncodings = QuantEncoding * NUM_QUANT_TABLES
 
 
+class ImageInfo(C.Structure):
+    """jxlhip_image_info (include/jxl_hip_frame.h)."""
+    _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32), ("xyb_encoded", C.c_uint32),
+                ("num_extra_channels", C.c_uint32), ("ec_dim_shift", C.c_void_p), ("have_animation", C.c_uint32),
+                ("have_timecodes", C.c_uint32), ("is_preview", C.c_uint32)]
+
+
+class FrameHeader(C.Structure):
+    """jxlhip_frame_header (include/jxl_hip_frame.h)."""
+    _fields_ = [("all_default", C.c_uint32), ("frame_type", C.c_uint32), ("is_modular", C.c_uint32),
+                ("color_transform", C.c_uint32), ("flags", C.c_uint64), ("chroma_mode", C.c_uint32 * 3),
+                ("upsampling", C.c_uint32), ("group_size_shift", C.c_uint32), ("x_qm_scale", C.c_uint32),
+                ("b_qm_scale", C.c_uint32), ("num_passes", C.c_uint32), ("num_downsample", C.c_uint32),
+                ("shift", C.c_uint32 * 11), ("downsample", C.c_uint32 * 4), ("last_pass", C.c_uint32 * 4),
+                ("dc_level", C.c_uint32), ("custom_size_or_origin", C.c_uint32), ("x0", C.c_int32), ("y0", C.c_int32),
+                ("coded_xsize", C.c_uint32), ("coded_ysize", C.c_uint32), ("blend_mode", C.c_uint32),
+                ("blend_alpha_channel", C.c_uint32), ("blend_clamp", C.c_uint32), ("blend_source", C.c_uint32),
+                ("duration", C.c_uint32), ("timecode", C.c_uint32), ("is_last", C.c_uint32),
+                ("save_as_reference", C.c_uint32), ("save_before_color_transform", C.c_uint32),
+                ("name_length", C.c_uint32), ("extensions", C.c_uint64), ("lf_all_default", C.c_uint32),
+                ("gab_custom", C.c_uint32), ("epf_sharp_custom", C.c_uint32), ("epf_weight_custom", C.c_uint32),
+                ("epf_sigma_custom", C.c_uint32), ("lf", LoopFilter), ("epf_pass1_zeroflush", C.c_float),
+                ("epf_pass2_zeroflush", C.c_float), ("epf_sigma_for_modular", C.c_float), ("lf_extensions", C.c_uint64),
+                ("xsize", C.c_uint32), ("ysize", C.c_uint32), ("xsize_blocks", C.c_uint32), ("ysize_blocks", C.c_uint32),
+                ("group_dim", C.c_uint32), ("xsize_groups", C.c_uint32), ("ysize_groups", C.c_uint32),
+                ("num_groups", C.c_uint64), ("num_dc_groups", C.c_uint64), ("num_toc_entries", C.c_uint64),
+                ("x_dm_multiplier", C.c_float), ("b_dm_multiplier", C.c_float)]
+
+
 class FrameParams(C.Structure):
     _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32),
                 ("coeff_type", C.c_uint32), ("output_kind", C.c_uint32),
@@ -146,6 +175,8 @@ EXPORTS = [
     "jxlhip_ac_group_decode_submit", "jxlhip_block_ctx_map_decode", "jxlhip_quant_dc_contexts",
     "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode", "jxlhip_ac_group_decode_submit_passes",
     "jxlhip_ac_groups_decode_submit", "jxlhip_num_toc_entries", "jxlhip_toc_decode",
+    # include/jxl_hip_frame.h
+    "jxlhip_frame_header_decode",
 ]
 
 
@@ -186,6 +217,7 @@ def load_library():
     L.jxlhip_num_toc_entries.argtypes = [u32, u32, u32]
     L.jxlhip_num_toc_entries.restype = u32
     L.jxlhip_toc_decode.argtypes = [vp, sz, C.POINTER(sz), u32, vp, vp, vp]
+    L.jxlhip_frame_header_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(ImageInfo), C.POINTER(FrameHeader)]
     L.jxlhip_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlhip_frame_set_inputs.argtypes = [vp, C.POINTER(FrameInputs)]
     L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]

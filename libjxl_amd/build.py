@@ -20,6 +20,7 @@ def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "jxl_hip.h"))
     hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "jxl_hip_entropy.h"))
+    hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "jxl_hip_frame.h"))
     return hdrs
 
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/jxl_hip_entropy.h"
+#include "../../include/jxl_hip_frame.h"
 
 namespace {
 
@@ -1216,6 +1217,353 @@ int jxlhip_toc_decode(const uint8_t* data, size_t size, size_t* bit_pos, uint32_
     sizes[i] = raw[src];
   }
   if (total_size) *total_size = total;
+  *bit_pos = br.BitsConsumed();
+  return kOk;
+}
+
+// ---- frame header (frame_header.cc, loop_filter.cc, fields.cc) -------------------------------
+namespace {
+struct FieldReader {
+  explicit FieldReader(BitReader* b) : br(b) {}
+  BitReader* br;
+  bool ok = true;
+  bool Bool() { return br->Read(1) != 0; }
+  uint32_t Bits(uint32_t n) { return br->Read(n); }
+  // U32 with a four-way distribution: sel 0..3 -> offset[sel] + Bits(bits[sel])
+  uint32_t U32(const U32Dist& d) { return ReadU32(br, d); }
+  uint64_t U64() {  // U64Coder::Read, fields.cc:494-520
+    const uint32_t sel = br->Read(2);
+    if (sel == 0) return 0;
+    if (sel == 1) return 1 + br->Read(4);
+    if (sel == 2) return 17 + br->Read(8);
+    uint64_t result = br->Read(12);
+    uint32_t shift = 12;
+    while (br->Read(1)) {
+      if (shift == 60) {
+        result |= (uint64_t)br->Read(4) << shift;
+        break;
+      }
+      result |= (uint64_t)br->Read(8) << shift;
+      shift += 8;
+      if (!br->Healthy()) break;
+    }
+    return result;
+  }
+  float F16() {
+    float v = 0;
+    if (!ReadF16(br, &v)) ok = false;
+    return v;
+  }
+  // BeginExtensions + EndExtensions (fields.cc:201-255): the extension sizes, then skip their bits.
+  // The reference keeps the position / total of the LAST bundle that had extensions in the visitor
+  // and does not clear them for the next bundle, which is observable: a loop filter with extensions
+  // inside a frame header without any fails ("Read more extension bits than budgeted"), and with
+  // both, the frame header skips the loop filter's bit count again.  Reproduced as is.
+  uint64_t pos_after_ext_size = 0, total_extension_bits = 0;
+  bool Extensions(uint64_t* ext) {
+    *ext = U64();
+    if (*ext != 0) {
+      for (uint64_t rem = *ext; rem != 0; rem &= rem - 1) {
+        const uint64_t bits = U64();
+        if (total_extension_bits + bits < total_extension_bits) return false;
+        total_extension_bits += bits;
+      }
+      pos_after_ext_size = br->BitsConsumed();
+    }
+    if (pos_after_ext_size == 0) return true;
+    if (!br->Healthy()) return false;
+    const uint64_t end = pos_after_ext_size + total_extension_bits;
+    if (end < pos_after_ext_size) return false;
+    const uint64_t bits_read = br->BitsConsumed();
+    if (bits_read > end) return false;
+    uint64_t remaining = end - bits_read;
+    while (remaining > 0) {
+      const uint32_t n = remaining > 32 ? 32u : (uint32_t)remaining;
+      br->Read(n);
+      remaining -= n;
+      if (!br->Healthy()) return false;
+    }
+    return true;
+  }
+};
+
+int ReadLoopFilter(FieldReader* r, bool is_modular, jxlhip_frame_header* h) {  // loop_filter.cc:18-106
+  jxlhip_loop_filter& lf = h->lf;
+  // defaults
+  lf.gab = 1;
+  const float w1 = (float)(1.1 * 0.104699568f), w2 = (float)(1.1 * 0.055680538f);
+  for (int c = 0; c < 3; c++) {
+    lf.gab_weights[2 * c] = w1;
+    lf.gab_weights[2 * c + 1] = w2;
+  }
+  lf.epf_iters = 2;
+  for (int i = 0; i < 8; i++) lf.epf_sharp_lut[i] = (float)i / 7.0f;
+  lf.epf_channel_scale[0] = 40.0f;
+  lf.epf_channel_scale[1] = 5.0f;
+  lf.epf_channel_scale[2] = 3.5f;
+  h->epf_pass1_zeroflush = 0.45f;
+  h->epf_pass2_zeroflush = 0.6f;
+  lf.epf_quant_mul = 0.46f;
+  lf.epf_pass0_sigma_scale = 0.9f;
+  lf.epf_pass2_sigma_scale = 6.5f;
+  lf.epf_border_sad_mul = 0.6666666666666666f;
+  h->epf_sigma_for_modular = 1.0f;
+  h->gab_custom = h->epf_sharp_custom = h->epf_weight_custom = h->epf_sigma_custom = 0;
+  h->lf_extensions = 0;
+  h->lf_all_default = r->Bool();
+  if (h->lf_all_default) return kOk;
+  lf.gab = r->Bool();
+  if (lf.gab) {
+    h->gab_custom = r->Bool();
+    if (h->gab_custom) {
+      for (int c = 0; c < 3; c++) {
+        lf.gab_weights[2 * c] = r->F16();
+        lf.gab_weights[2 * c + 1] = r->F16();
+        if (fabsf(1.0f + (lf.gab_weights[2 * c] + lf.gab_weights[2 * c + 1]) * 4) < 1e-8) return kBad;
+      }
+    }
+  }
+  lf.epf_iters = r->Bits(2);
+  if (lf.epf_iters > 0) {
+    if (!is_modular) {
+      h->epf_sharp_custom = r->Bool();
+      if (h->epf_sharp_custom)
+        for (int i = 0; i < 8; i++) lf.epf_sharp_lut[i] = r->F16();
+    }
+    h->epf_weight_custom = r->Bool();
+    if (h->epf_weight_custom) {
+      for (int c = 0; c < 3; c++) lf.epf_channel_scale[c] = r->F16();
+      h->epf_pass1_zeroflush = r->F16();
+      h->epf_pass2_zeroflush = r->F16();
+    }
+    h->epf_sigma_custom = r->Bool();
+    if (h->epf_sigma_custom) {
+      if (!is_modular) lf.epf_quant_mul = r->F16();
+      lf.epf_pass0_sigma_scale = r->F16();
+      lf.epf_pass2_sigma_scale = r->F16();
+      lf.epf_border_sad_mul = r->F16();
+    }
+    if (is_modular) {
+      h->epf_sigma_for_modular = r->F16();
+      if (h->epf_sigma_for_modular < 1e-8) return kBad;
+    }
+  }
+  if (!r->ok) return kBad;
+  if (!r->Extensions(&h->lf_extensions)) return kBad;
+  return kOk;
+}
+
+struct Blending {
+  uint32_t mode = 0, alpha_channel = 0, clamp = 0, source = 0;
+};
+int ReadBlending(FieldReader* r, uint32_t num_ec, bool partial, Blending* b) {  // frame_header.cc:65-93
+  static const U32Dist kMode = {{0, 0, 0, 2}, {0, 1, 2, 3}};
+  b->mode = r->U32(kMode);
+  if (b->mode > 4) return kBad;
+  const bool blend = b->mode == 2 || b->mode == 3;  // kBlend, kAlphaWeightedAdd
+  if (num_ec > 0 && blend) {
+    static const U32Dist kAlpha = {{0, 0, 0, 3}, {0, 1, 2, 3}};
+    b->alpha_channel = r->U32(kAlpha);
+    if (b->alpha_channel >= num_ec) return kBad;
+  }
+  if ((num_ec > 0 && blend) || b->mode == 4) b->clamp = r->Bool();
+  if (b->mode != 0 || partial) {
+    static const U32Dist kSource = {{0, 0, 0, 0}, {0, 1, 2, 3}};
+    b->source = r->U32(kSource);
+  }
+  return kOk;
+}
+
+uint32_t DivCeilU(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+}  // namespace
+
+int jxlhip_frame_header_decode(const uint8_t* data, size_t size, size_t* bit_pos, const jxlhip_image_info* im,
+                               jxlhip_frame_header* h) {
+  if (!data || !bit_pos || !im || !h || im->num_extra_channels > 4096) return JXLHIP_ERR_INVALID_ARGUMENT;
+  memset(h, 0, sizeof(*h));
+  BitReader br(data, size, *bit_pos);
+  FieldReader r(&br);
+  // defaults of every field (Bundle::Init / SetDefault)
+  h->upsampling = 1;
+  h->group_size_shift = 1;
+  h->x_qm_scale = 3;
+  h->b_qm_scale = 2;
+  h->num_passes = 1;
+  h->is_last = 1;
+  h->color_transform = JXLHIP_CT_XYB;
+  const bool xyb = im->xyb_encoded != 0;
+  const uint32_t num_ec = im->num_extra_channels;
+  bool is_partial = false;
+  int rc = kOk;
+  h->all_default = r.Bool();
+  if (h->all_default) {
+    // SetDefault (fields.cc:88-118 visiting every field with its default): a regular, last VarDCT
+    // frame, one pass, default loop filter; the colour transform follows the image
+    h->color_transform = xyb ? JXLHIP_CT_XYB : JXLHIP_CT_NONE;
+    static const uint8_t kOne = 1;  // "all_default = 1" for the nested loop filter
+    BitReader lbr(&kOne, 1, 0);
+    FieldReader lr(&lbr);
+    ReadLoopFilter(&lr, false, h);
+    h->save_before_color_transform = 0;
+  } else {
+    static const U32Dist kType = {{0, 0, 0, 0}, {0, 1, 2, 3}};
+    h->frame_type = r.U32(kType);
+    if (im->is_preview && h->frame_type != JXLHIP_FRAME_REGULAR) return kBad;
+    h->is_modular = r.Bool();
+    h->flags = r.U64();
+    if (xyb) {
+      h->color_transform = JXLHIP_CT_XYB;
+    } else {
+      h->color_transform = r.Bool() ? JXLHIP_CT_YCBCR : JXLHIP_CT_NONE;
+    }
+    const bool use_dc_frame = (h->flags & JXLHIP_FLAG_USE_DC_FRAME) != 0;
+    if (h->color_transform == JXLHIP_CT_YCBCR && !use_dc_frame)
+      for (int c = 0; c < 3; c++) h->chroma_mode[c] = r.Bits(2);
+    static const U32Dist kPow2 = {{0, 0, 0, 0}, {1, 2, 4, 8}};
+    if (!use_dc_frame) {
+      h->upsampling = r.U32(kPow2);
+      for (uint32_t i = 0; i < num_ec; i++) {
+        const uint32_t ds = im->ec_dim_shift ? im->ec_dim_shift[i] : 0;
+        uint32_t ec = r.U32(kPow2);
+        ec <<= ds;
+        if (ec < h->upsampling || ec > 8) return kBad;
+        if (!br.Healthy()) return kBad;
+      }
+    }
+    if (h->is_modular) h->group_size_shift = r.Bits(2);
+    if (!h->is_modular && h->color_transform == JXLHIP_CT_XYB) {
+      h->x_qm_scale = r.Bits(3);
+      h->b_qm_scale = r.Bits(3);
+    } else {
+      h->x_qm_scale = h->b_qm_scale = 2;
+    }
+    if (h->frame_type != JXLHIP_FRAME_REFERENCE_ONLY) {  // Passes::VisitFields, frame_header.cc:137-176
+      static const U32Dist kNumPasses = {{0, 0, 0, 3}, {1, 2, 3, 4}};
+      h->num_passes = r.U32(kNumPasses);
+      if (h->num_passes != 1) {
+        static const U32Dist kNumDs = {{0, 0, 0, 1}, {0, 1, 2, 3}};
+        h->num_downsample = r.U32(kNumDs);
+        if (h->num_downsample > h->num_passes) return kBad;
+        for (uint32_t i = 0; i + 1 < h->num_passes; i++) h->shift[i] = r.Bits(2);
+        h->shift[h->num_passes - 1] = 0;
+        for (uint32_t i = 0; i < h->num_downsample; i++) {
+          h->downsample[i] = r.U32(kPow2);
+          if (i > 0 && h->downsample[i] >= h->downsample[i - 1]) return kBad;
+        }
+        static const U32Dist kLastPass = {{0, 0, 0, 3}, {0, 1, 2, 0}};
+        for (uint32_t i = 0; i < h->num_downsample; i++) {
+          h->last_pass[i] = r.U32(kLastPass);
+          if (i > 0 && h->last_pass[i] <= h->last_pass[i - 1]) return kBad;
+          if (h->last_pass[i] >= h->num_passes) return kBad;
+        }
+      }
+    }
+    if (h->frame_type == JXLHIP_FRAME_DC) {
+      static const U32Dist kLevel = {{0, 0, 0, 0}, {1, 2, 3, 4}};
+      h->dc_level = r.U32(kLevel);
+    }
+    if (h->frame_type != JXLHIP_FRAME_DC) {
+      h->custom_size_or_origin = r.Bool();
+      if (h->custom_size_or_origin) {
+        static const U32Dist kSize = {{8, 11, 14, 30}, {0, 256, 2304, 18688}};
+        const bool regular = h->frame_type == JXLHIP_FRAME_REGULAR || h->frame_type == JXLHIP_FRAME_SKIP_PROGRESSIVE;
+        if (regular) {
+          const uint32_t ux = r.U32(kSize), uy = r.U32(kSize);
+          h->x0 = (int32_t)((ux >> 1) ^ (~(ux & 1) + 1));  // UnpackSigned
+          h->y0 = (int32_t)((uy >> 1) ^ (~(uy & 1) + 1));
+        }
+        h->coded_xsize = r.U32(kSize);
+        h->coded_ysize = r.U32(kSize);
+        if (h->coded_xsize == 0 || h->coded_ysize == 0) return kBad;
+        if (regular) {
+          is_partial |= h->x0 > 0;
+          is_partial |= h->y0 > 0;
+          is_partial |= (int32_t)h->coded_xsize + h->x0 < (int32_t)im->xsize;
+          is_partial |= (int32_t)h->coded_ysize + h->y0 < (int32_t)im->ysize;
+        }
+      }
+    }
+    bool replace_all = true;
+    if (h->frame_type == JXLHIP_FRAME_REGULAR || h->frame_type == JXLHIP_FRAME_SKIP_PROGRESSIVE) {
+      Blending b;
+      if ((rc = ReadBlending(&r, num_ec, is_partial, &b))) return rc;
+      h->blend_mode = b.mode;
+      h->blend_alpha_channel = b.alpha_channel;
+      h->blend_clamp = b.clamp;
+      h->blend_source = b.source;
+      replace_all = b.mode == 0;
+      for (uint32_t i = 0; i < num_ec; i++) {
+        Blending e;
+        if ((rc = ReadBlending(&r, num_ec, is_partial, &e))) return rc;
+        replace_all &= e.mode == 0;
+        if (!br.Healthy()) return kBad;
+      }
+      if (im->is_preview && (!replace_all || h->custom_size_or_origin)) return kBad;
+      if (im->have_animation) {  // AnimationFrame, frame_header.cc:120-133
+        static const U32Dist kDuration = {{0, 0, 8, 32}, {0, 1, 0, 0}};
+        h->duration = r.U32(kDuration);
+        if (im->have_timecodes) h->timecode = r.Bits(32);
+      }
+      h->is_last = r.Bool();
+    } else {
+      h->is_last = 0;
+    }
+    if (h->frame_type != JXLHIP_FRAME_DC && !h->is_last) {
+      static const U32Dist kRef = {{0, 0, 0, 0}, {0, 1, 2, 3}};
+      h->save_as_reference = r.U32(kRef);
+    }
+    if (h->frame_type != JXLHIP_FRAME_DC) {
+      const bool can_be_referenced = !h->is_last && (h->duration == 0 || h->save_as_reference != 0);
+      const bool regular = h->frame_type == JXLHIP_FRAME_REGULAR || h->frame_type == JXLHIP_FRAME_SKIP_PROGRESSIVE;
+      if (can_be_referenced && h->blend_mode == 0 && !is_partial && regular) {
+        h->save_before_color_transform = r.Bool();
+      } else if (h->frame_type == JXLHIP_FRAME_REFERENCE_ONLY) {
+        h->save_before_color_transform = r.Bool();
+        const uint32_t fx = h->custom_size_or_origin ? h->coded_xsize : im->xsize;
+        const uint32_t fy = h->custom_size_or_origin ? h->coded_ysize : im->ysize;
+        if (!h->save_before_color_transform && (fx < im->xsize || fy < im->ysize || h->x0 != 0 || h->y0 != 0))
+          return kBad;
+      }
+    } else {
+      h->save_before_color_transform = 1;
+    }
+    {  // VisitNameString, frame_header.h:35-50
+      static const U32Dist kName = {{0, 4, 5, 10}, {0, 0, 16, 48}};
+      h->name_length = r.U32(kName);
+      for (uint32_t i = 0; i < h->name_length; i++) {
+        r.Bits(8);
+        if (!br.Healthy()) return kBad;
+      }
+    }
+    if ((rc = ReadLoopFilter(&r, h->is_modular != 0, h))) return rc;
+    if (!r.Extensions(&h->extensions)) return kBad;
+  }
+  if (!r.ok || !br.Healthy()) return kBad;
+  // FrameHeader::ToFrameDimensions
+  uint32_t xs = h->coded_xsize ? h->coded_xsize : im->xsize, ys = h->coded_ysize ? h->coded_ysize : im->ysize;
+  if (h->dc_level != 0) {
+    xs = DivCeilU(xs, 1u << (3 * h->dc_level));
+    ys = DivCeilU(ys, 1u << (3 * h->dc_level));
+  }
+  static const uint8_t kHShift[4] = {0, 1, 1, 0}, kVShift[4] = {0, 1, 0, 1};
+  uint32_t maxh = 0, maxv = 0;
+  for (int c = 0; c < 3; c++) {
+    maxh = std::max<uint32_t>(maxh, kHShift[h->chroma_mode[c]]);
+    maxv = std::max<uint32_t>(maxv, kVShift[h->chroma_mode[c]]);
+  }
+  h->group_dim = (256u >> 1) << h->group_size_shift;
+  h->xsize = DivCeilU(xs, h->upsampling);
+  h->ysize = DivCeilU(ys, h->upsampling);
+  h->xsize_blocks = DivCeilU(h->xsize, 8u << maxh) << maxh;
+  h->ysize_blocks = DivCeilU(h->ysize, 8u << maxv) << maxv;
+  h->xsize_groups = DivCeilU(h->xsize, h->group_dim);
+  h->ysize_groups = DivCeilU(h->ysize, h->group_dim);
+  h->num_groups = (uint64_t)h->xsize_groups * h->ysize_groups;
+  h->num_dc_groups = (uint64_t)DivCeilU(h->xsize_blocks, h->group_dim) * DivCeilU(h->ysize_blocks, h->group_dim);
+  h->num_toc_entries =
+      (h->num_groups == 1 && h->num_passes == 1) ? 1 : 2 + h->num_dc_groups + h->num_groups * h->num_passes;
+  h->x_dm_multiplier = powf(1 / (1.25f), (float)h->x_qm_scale - 2.0f);  // dec_cache.h:161-162
+  h->b_dm_multiplier = powf(1 / (1.25f), (float)h->b_qm_scale - 2.0f);
   *bit_pos = br.BitsConsumed();
   return kOk;
 }

@@ -719,3 +719,89 @@ JXR_EXPORT int jxr_toc_read(const uint8_t* data, size_t size, uint32_t n, uint64
   memcpy(sizes, sz.data(), n * sizeof(uint32_t));
   return 0;
 }
+
+
+// ReadFrameHeader (frame_header.cc) by the reference under a synthetic CodecMetadata.  Fills
+// out[] in the order tests/test_frame_header.py spells out.  0 ok, 1 failure.
+JXR_EXPORT int jxr_frame_header_read(const uint8_t* data, size_t size, uint32_t xsize, uint32_t ysize,
+                                     int xyb_encoded, uint32_t num_ec, const uint8_t* dim_shift, int have_animation,
+                                     int have_timecodes, int is_preview, uint64_t* out, size_t* bits) {
+  CodecMetadata metadata;
+  if (!metadata.size.Set(xsize, ysize)) return 1;
+  metadata.m.xyb_encoded = xyb_encoded != 0;
+  metadata.m.extra_channel_info.resize(num_ec);
+  for (uint32_t i = 0; i < num_ec; i++) metadata.m.extra_channel_info[i].dim_shift = dim_shift ? dim_shift[i] : 0;
+  metadata.m.have_animation = have_animation != 0;
+  metadata.m.animation.have_timecodes = have_timecodes != 0;
+  if (is_preview) {
+    metadata.m.have_preview = true;
+    if (!metadata.m.preview_size.Set(xsize, ysize)) return 1;
+  }
+  FrameHeader fh(&metadata);
+  fh.nonserialized_is_preview = is_preview != 0;
+  BitReader br(Bytes(data, size));
+  Status ok = ReadFrameHeader(&br, &fh);
+  *bits = br.TotalBitsConsumed();
+  const bool in_bounds = br.AllReadsWithinBounds();
+  (void)br.Close();
+  if (!ok || !in_bounds) return 1;
+  size_t n = 0;
+  auto put = [&](uint64_t v) { out[n++] = v; };
+  auto putf = [&](float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    out[n++] = u;
+  };
+  put(fh.all_default);
+  put(static_cast<uint32_t>(fh.frame_type));
+  put(fh.encoding == FrameEncoding::kModular);
+  put(fh.color_transform == ColorTransform::kXYB ? 0 : (fh.color_transform == ColorTransform::kNone ? 1 : 2));
+  put(fh.flags);
+  for (int c = 0; c < 3; c++) put(fh.chroma_subsampling.RawHShift(c) | (fh.chroma_subsampling.RawVShift(c) << 4));
+  put(fh.upsampling);
+  put(fh.group_size_shift);
+  put(fh.x_qm_scale);
+  put(fh.b_qm_scale);
+  put(fh.passes.num_passes);
+  put(fh.passes.num_downsample);
+  for (uint32_t i = 0; i < fh.passes.num_passes; i++) put(fh.passes.shift[i]);
+  for (uint32_t i = 0; i < fh.passes.num_downsample; i++) put(fh.passes.downsample[i]);
+  for (uint32_t i = 0; i < fh.passes.num_downsample; i++) put(fh.passes.last_pass[i]);
+  put(fh.dc_level);
+  put(fh.custom_size_or_origin);
+  put(static_cast<uint64_t>(static_cast<int64_t>(fh.frame_origin.x0)));
+  put(static_cast<uint64_t>(static_cast<int64_t>(fh.frame_origin.y0)));
+  put(fh.frame_size.xsize);
+  put(fh.frame_size.ysize);
+  put(static_cast<uint32_t>(fh.blending_info.mode));
+  put(fh.blending_info.alpha_channel);
+  put(fh.blending_info.clamp);
+  put(fh.blending_info.source);
+  put(fh.animation_frame.duration);
+  put(fh.animation_frame.timecode);
+  put(fh.is_last);
+  put(fh.save_as_reference);
+  put(fh.save_before_color_transform);
+  put(fh.name.size());
+  put(fh.extensions);
+  const LoopFilter& lf = fh.loop_filter;
+  put(lf.all_default);
+  put(lf.gab);
+  put(lf.gab_custom);
+  putf(lf.gab_x_weight1); putf(lf.gab_x_weight2); putf(lf.gab_y_weight1); putf(lf.gab_y_weight2);
+  putf(lf.gab_b_weight1); putf(lf.gab_b_weight2);
+  put(lf.epf_iters);
+  put(lf.epf_sharp_custom);
+  for (int i = 0; i < 8; i++) putf(lf.epf_sharp_lut[i]);
+  put(lf.epf_weight_custom);
+  for (int i = 0; i < 3; i++) putf(lf.epf_channel_scale[i]);
+  putf(lf.epf_pass1_zeroflush); putf(lf.epf_pass2_zeroflush);
+  put(lf.epf_sigma_custom);
+  putf(lf.epf_quant_mul); putf(lf.epf_pass0_sigma_scale); putf(lf.epf_pass2_sigma_scale);
+  putf(lf.epf_border_sad_mul); putf(lf.epf_sigma_for_modular);
+  put(lf.extensions);
+  const FrameDimensions fd = fh.ToFrameDimensions();
+  put(fd.xsize); put(fd.ysize); put(fd.xsize_blocks); put(fd.ysize_blocks); put(fd.group_dim);
+  put(fd.xsize_groups); put(fd.ysize_groups); put(fd.num_groups); put(fd.num_dc_groups);
+  return 0;
+}

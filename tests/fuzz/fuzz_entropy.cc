@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/jxl_hip_entropy.h"
+#include "../../include/jxl_hip_frame.h"
 
 namespace {
 struct Rng {
@@ -134,6 +135,13 @@ int RunOnce(const Case& base, Rng* r, uint64_t* ok, uint64_t* rejected) {
     jxlhip_quant_encoding enc[JXLHIP_NUM_QUANT_TABLES];
     size_t dp = r->Below(64);
     (void)jxlhip_dequant_encodings_decode(g.p, g.n, &dp, enc);
+    uint8_t shifts[8];
+    for (auto& sh : shifts) sh = (uint8_t)r->Below(4);
+    jxlhip_image_info im = {1 + r->Below(4000), 1 + r->Below(4000), r->Below(2), r->Below(9), shifts,
+                            r->Below(2), r->Below(2), r->Below(4) == 0};
+    jxlhip_frame_header fh;
+    size_t hp = r->Below(64);
+    (void)jxlhip_frame_header_decode(g.p, g.n, &hp, &im, &fh);
   }
   jxlhip_block_ctx_map bcm;
   size_t pos = 0;

@@ -24,6 +24,7 @@ def lib():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "jxl_hip.h")).read()
     text += open(os.path.join(ROOT, "include", "jxl_hip_entropy.h")).read()
+    text += open(os.path.join(ROOT, "include", "jxl_hip_frame.h")).read()
     return sorted(set(re.findall(r"JXLHIP_EXPORT[^;{]*?\b(jxlhip_\w+)\s*\(", text)))
 
 
