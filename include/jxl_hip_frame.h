@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "jxl_hip.h"
+#include "jxl_hip_entropy.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -77,6 +78,24 @@ typedef struct jxlhip_frame_header {
  * (and on truncation), JXLHIP_ERR_INVALID_ARGUMENT on bad arguments. */
 JXLHIP_EXPORT int jxlhip_frame_header_decode(const uint8_t* data, size_t size, size_t* bit_pos,
                                              const jxlhip_image_info* image, jxlhip_frame_header* out);
+
+/* The VarDCT part of the DC-global section in front of the modular global info
+ * (FrameDecoder::ProcessDCGlobal, dec_frame.cc:268-302): DequantMatrices::DecodeDC
+ * (quant_weights.cc:513-528), Quantizer::Decode (quantizer.cc:125-149), DecodeBlockCtxMap
+ * (entropy_coder.cc:25-61), ColorCorrelation::DecodeDC (chroma_from_luma.cc:24-44) -- the values
+ * jxlhip_frame_params, jxlhip_dequant_dc and the AC decoder take.  frame_flags: the frame header's
+ * flags; JXLHIP_ERR_UNSUPPORTED when patches, splines or noise precede these fields in the section. */
+typedef struct jxlhip_dc_global {
+  float dc_quant[3];          /* DequantMatrices::DCQuant(c); default 1/4096, 1/512, 1/256 */
+  int32_t global_scale;       /* Quantizer::global_scale_ */
+  int32_t quant_dc;           /* Quantizer::quant_dc_ */
+  uint32_t cfl_color_factor;  /* ColorCorrelation::color_factor_ (default 84) */
+  float cfl_base_x, cfl_base_b;
+  int32_t ytox_dc, ytob_dc;
+  jxlhip_block_ctx_map block_ctx_map;
+} jxlhip_dc_global;
+JXLHIP_EXPORT int jxlhip_dc_global_decode(const uint8_t* data, size_t size, size_t* bit_pos, uint64_t frame_flags,
+                                          jxlhip_dc_global* out);
 
 #ifdef __cplusplus
 }

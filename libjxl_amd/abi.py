@@ -59,6 +59,13 @@ class QuantEncoding(C.Structure):
 QuantEncodings = QuantEncoding * NUM_QUANT_TABLES
 
 
+class DcGlobal(C.Structure):
+    """jxlhip_dc_global (include/jxl_hip_frame.h)."""
+    _fields_ = [("dc_quant", C.c_float * 3), ("global_scale", C.c_int32), ("quant_dc", C.c_int32),
+                ("cfl_color_factor", C.c_uint32), ("cfl_base_x", C.c_float), ("cfl_base_b", C.c_float),
+                ("ytox_dc", C.c_int32), ("ytob_dc", C.c_int32), ("block_ctx_map", BlockCtxMap)]
+
+
 class ImageInfo(C.Structure):
     """jxlhip_image_info (include/jxl_hip_frame.h)."""
     _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32), ("xyb_encoded", C.c_uint32),
@@ -176,7 +183,7 @@ EXPORTS = [
     "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode", "jxlhip_ac_group_decode_submit_passes",
     "jxlhip_ac_groups_decode_submit", "jxlhip_num_toc_entries", "jxlhip_toc_decode",
     # include/jxl_hip_frame.h
-    "jxlhip_frame_header_decode",
+    "jxlhip_frame_header_decode", "jxlhip_dc_global_decode",
 ]
 
 
@@ -218,6 +225,7 @@ def load_library():
     L.jxlhip_num_toc_entries.restype = u32
     L.jxlhip_toc_decode.argtypes = [vp, sz, C.POINTER(sz), u32, vp, vp, vp]
     L.jxlhip_frame_header_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(ImageInfo), C.POINTER(FrameHeader)]
+    L.jxlhip_dc_global_decode.argtypes = [vp, sz, C.POINTER(sz), C.c_uint64, C.POINTER(DcGlobal)]
     L.jxlhip_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlhip_frame_set_inputs.argtypes = [vp, C.POINTER(FrameInputs)]
     L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]

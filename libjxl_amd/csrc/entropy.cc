@@ -1646,6 +1646,54 @@ int jxlhip_block_ctx_map_decode(const uint8_t* data, size_t size, size_t* bit_po
   return kOk;
 }
 
+int jxlhip_dc_global_decode(const uint8_t* data, size_t size, size_t* bit_pos, uint64_t frame_flags,
+                            jxlhip_dc_global* out) {
+  if (!data || !bit_pos || !out) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (frame_flags & (JXLHIP_FLAG_PATCHES | JXLHIP_FLAG_SPLINES | JXLHIP_FLAG_NOISE)) return JXLHIP_ERR_UNSUPPORTED;
+  memset(out, 0, sizeof(*out));
+  size_t pos;
+  {
+    BitReader br(data, size, *bit_pos);
+    // DequantMatrices::DecodeDC
+    out->dc_quant[0] = 1.0f / 4096.0f;
+    out->dc_quant[1] = 1.0f / 512.0f;
+    out->dc_quant[2] = 1.0f / 256.0f;
+    if (!br.Read(1)) {
+      for (int c = 0; c < 3; c++) {
+        float v;
+        if (!ReadF16(&br, &v)) return kBad;
+        v *= 1.0f / 128.0f;
+        if (v < 1e-8f) return kBad;
+        out->dc_quant[c] = v;
+      }
+    }
+    // QuantizerParams
+    static const U32Dist kGlobalScale = {{11, 11, 12, 16}, {1, 2049, 4097, 8193}};
+    static const U32Dist kQuantDc = {{0, 5, 8, 16}, {16, 1, 1, 1}};
+    out->global_scale = (int32_t)ReadU32(&br, kGlobalScale);
+    out->quant_dc = (int32_t)ReadU32(&br, kQuantDc);
+    if (!br.Healthy()) return kBad;
+    pos = br.BitsConsumed();
+  }
+  int rc = jxlhip_block_ctx_map_decode(data, size, &pos, &out->block_ctx_map);
+  if (rc) return rc;
+  BitReader br(data, size, pos);
+  out->cfl_color_factor = 84;
+  out->cfl_base_x = 0.0f;
+  out->cfl_base_b = 1.0f;  // jxl::cms::kYToBRatio
+  if (!br.Read(1)) {
+    static const U32Dist kColorFactor = {{0, 0, 8, 16}, {84, 256, 2, 258}};
+    out->cfl_color_factor = ReadU32(&br, kColorFactor);
+    if (!ReadF16(&br, &out->cfl_base_x) || fabsf(out->cfl_base_x) > 4.0f) return kBad;
+    if (!ReadF16(&br, &out->cfl_base_b) || fabsf(out->cfl_base_b) > 4.0f) return kBad;
+    out->ytox_dc = (int32_t)br.Read(8) - 128;
+    out->ytob_dc = (int32_t)br.Read(8) - 128;
+  }
+  if (!br.Healthy()) return kBad;
+  *bit_pos = br.BitsConsumed();
+  return kOk;
+}
+
 int jxlhip_quant_dc_contexts(const jxlhip_block_ctx_map* map, size_t n, const int32_t* const q[3], uint8_t* out) {
   if (!out || (map && map->num_dc_ctxs > 1 && (!q || !q[0] || !q[1] || !q[2]))) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!map || map->num_dc_ctxs <= 1) {

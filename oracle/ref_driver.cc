@@ -76,6 +76,7 @@
 #include "lib/jxl/enc_params.h"
 #include "lib/jxl/enc_quant_weights.h"
 #include "lib/jxl/enc_toc.h"
+#include "lib/jxl/entropy_coder.h"
 #include "lib/jxl/toc.h"
 #include "lib/jxl/frame_header.h"
 
@@ -803,5 +804,49 @@ JXR_EXPORT int jxr_frame_header_read(const uint8_t* data, size_t size, uint32_t 
   const FrameDimensions fd = fh.ToFrameDimensions();
   put(fd.xsize); put(fd.ysize); put(fd.xsize_blocks); put(fd.ysize_blocks); put(fd.group_dim);
   put(fd.xsize_groups); put(fd.ysize_groups); put(fd.num_groups); put(fd.num_dc_groups);
+  return 0;
+}
+
+// The VarDCT fields of the DC-global section by the reference (dec_frame.cc:297-302,63-79):
+// DequantMatrices::DecodeDC, Quantizer::Decode, DecodeBlockCtxMap, ColorCorrelation::DecodeDC.
+// out: 3 dc_quant (float bits), global_scale, quant_dc, color factor, base x / b (float bits),
+// ytox_dc, ytob_dc, num_dc_ctxs, num qf thresholds, ctx_map size, then the map.  0 ok, 1 failure.
+JXR_EXPORT int jxr_dc_global_read(const uint8_t* data, size_t size, uint64_t* out, size_t* bits) {
+  Ref ref;
+  BitReader br(Bytes(data, size));
+  DequantMatrices m;
+  Quantizer q(m);
+  BlockCtxMap bcm;
+  ColorCorrelation cc;
+  Status ok = [&]() -> Status {
+    JXL_RETURN_IF_ERROR(m.DecodeDC(&br));
+    JXL_RETURN_IF_ERROR(q.Decode(&br));
+    JXL_RETURN_IF_ERROR(DecodeBlockCtxMap(&ref.mm, &br, &bcm));
+    JXL_RETURN_IF_ERROR(cc.DecodeDC(&br));
+    return true;
+  }();
+  *bits = br.TotalBitsConsumed();
+  const bool in_bounds = br.AllReadsWithinBounds();
+  (void)br.Close();
+  if (!ok || !in_bounds) return 1;
+  size_t n = 0;
+  auto putf = [&](float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    out[n++] = u;
+  };
+  for (int c = 0; c < 3; c++) putf(m.DCQuant(c));
+  const QuantizerParams qp = q.GetParams();
+  out[n++] = qp.global_scale;
+  out[n++] = qp.quant_dc;
+  out[n++] = static_cast<uint32_t>(cc.GetColorFactor());
+  putf(cc.GetBaseCorrelationX());
+  putf(cc.GetBaseCorrelationB());
+  out[n++] = static_cast<uint64_t>(static_cast<int64_t>(cc.GetYToXDC()));
+  out[n++] = static_cast<uint64_t>(static_cast<int64_t>(cc.GetYToBDC()));
+  out[n++] = bcm.num_dc_ctxs;
+  out[n++] = bcm.qf_thresholds.size();
+  out[n++] = bcm.ctx_map.size();
+  for (uint8_t v : bcm.ctx_map) out[n++] = v;
   return 0;
 }

@@ -142,6 +142,9 @@ int RunOnce(const Case& base, Rng* r, uint64_t* ok, uint64_t* rejected) {
     jxlhip_frame_header fh;
     size_t hp = r->Below(64);
     (void)jxlhip_frame_header_decode(g.p, g.n, &hp, &im, &fh);
+    jxlhip_dc_global dg;
+    size_t gp = r->Below(64);
+    (void)jxlhip_dc_global_decode(g.p, g.n, &gp, 0, &dg);
   }
   jxlhip_block_ctx_map bcm;
   size_t pos = 0;

@@ -114,3 +114,57 @@ def test_random_bit_strings_against_the_reference(L, ref, cfg):
         else:
             agree_bad += 1
     assert agree_ok > 200 and agree_bad > 200, (agree_ok, agree_bad)
+
+
+def dc_both(L, R, data):
+    R.jxr_dc_global_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+    d = np.frombuffer(data, np.uint8)
+    g = abi.DcGlobal()
+    pos = C.c_size_t(0)
+    rc = L.jxlhip_dc_global_decode(d.ctypes.data, len(d), C.byref(pos), 0, C.byref(g))
+    out = np.zeros(16 + 3 * 13 * 64, np.uint64)
+    bits = C.c_size_t(0)
+    want_rc = R.jxr_dc_global_read(d.ctypes.data, len(d), out.ctypes.data, C.byref(bits))
+    m = g.block_ctx_map
+    got = [f32bits(v) for v in g.dc_quant] + [g.global_scale, g.quant_dc, g.cfl_color_factor, f32bits(g.cfl_base_x),
+                                              f32bits(g.cfl_base_b), g.ytox_dc & 0xFFFFFFFFFFFFFFFF,
+                                              g.ytob_dc & 0xFFFFFFFFFFFFFFFF, m.num_dc_ctxs, m.num_qf_thresholds,
+                                              m.ctx_map_size] + list(m.ctx_map[:m.ctx_map_size])
+    return rc, got, pos.value, want_rc, [int(v) for v in out[:len(got)]], bits.value, g
+
+
+def test_dc_global_of_genuine_codestreams(L, ref, oracle):
+    for kw in (dict(xsize=520, ysize=300, distance=1.0), dict(xsize=776, ysize=520, distance=3.0)):
+        rs = oracle.RealStream(seed=9, speed_tier=3, **kw)
+        rc, got, pos, want_rc, want, bits, g = dc_both(L, ref, rs.section(0))
+        assert rc == 0 and want_rc == 0 and pos == bits and got == want
+        p = rs.frame_params
+        assert (g.global_scale, g.quant_dc) == (p.global_scale, p.quant_dc)
+        assert (g.cfl_base_x, g.cfl_base_b, g.cfl_color_factor) == (p.cfl_base_x, p.cfl_base_b, p.cfl_color_factor)
+        # the block context map is the one the AC decoder of this stream was given
+        m = abi.BlockCtxMap()
+        q = C.c_size_t(0)
+        b = rs.block_ctx_bytes
+        assert L.jxlhip_block_ctx_map_decode(b.ctypes.data, len(b), C.byref(q), C.byref(m)) == 0
+        assert bytes(m) == bytes(g.block_ctx_map)
+    assert L.jxlhip_dc_global_decode(b.ctypes.data, len(b), C.byref(C.c_size_t(0)), 2, C.byref(abi.DcGlobal())) == -7
+
+
+def test_dc_global_random_bit_strings_against_the_reference(L, ref):
+    rng = np.random.default_rng(77)
+    ok = bad = 0
+    for trial in range(4000):
+        n = int(rng.integers(2, 64))
+        b = rng.integers(0, 256, n, dtype=np.uint8)
+        if trial % 2 == 0:
+            b[: n // 2] &= rng.integers(0, 256, dtype=np.uint8)
+        if trial % 4 == 1:
+            b[0] |= 1  # default DC quant
+        rc, got, pos, want_rc, want, bits, _ = dc_both(L, ref, b.tobytes())
+        assert (rc == 0) == (want_rc == 0), (trial, rc, want_rc, b.tobytes().hex())
+        if rc == 0:
+            ok += 1
+            assert pos == bits and got == want, (trial, b.tobytes().hex())
+        else:
+            bad += 1
+    assert ok > 100 and bad > 100, (ok, bad)
