@@ -616,6 +616,27 @@ class SymbolReader {  // ANSSymbolReader
   }
   bool Corrupt() const { return corrupt_; }
 
+  // The same for codes known to be plain ANS (no prefix codes, no LZ77) -- what libjxl's encoder
+  // writes for AC coefficients: no per-symbol mode tests, always inlined into the coefficient loop.
+  bool PlainAns() const { return !code_->use_prefix && !window_; }
+  __attribute__((always_inline)) inline uint32_t ReadHybridUintAns(uint32_t ctx, BitReader* br) {
+    br->Refill();
+    const uint32_t res = state_ & (kAnsTab - 1);
+    const AliasEntry* t = &code_->alias[(size_t)ctx << code_->log_alpha];
+    const uint32_t i = res >> log_entry_, pos = res & entry_mask_;
+    const AliasEntry& e = t[i];
+    const bool right = pos >= e.cutoff;
+    const uint32_t token = right ? e.right_value : i;
+    const uint32_t offset = (right ? e.offsets1 : 0u) + pos;
+    const uint32_t freq = right ? e.freq1 : e.freq0;
+    state_ = freq * (state_ >> kAnsLogTab) + offset;
+    if (state_ < (1u << 16)) {
+      state_ = (state_ << 16) | (uint32_t)br->Peek(16);
+      br->Consume(16);
+    }
+    return FinishHybridUint(code_->configs[ctx], token, br);
+  }
+
  private:
   inline uint32_t CopyOne() {
     const uint32_t v = window_[(copy_pos_++) & (kLz77Window - 1)];
@@ -945,10 +966,10 @@ const ZeroDensityLut& ZdLut() {
   return l;
 }
 
-template <typename T>
-int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
-                 const uint8_t* acs_map, const int32_t* raw_quant, const uint8_t* quant_dc, BitReader* br,
-                 uint32_t shift, T* const coeffs[3], size_t* ncoeffs) {
+template <typename T, bool kPlainAns>
+int DecodeGroupImpl(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
+                    const uint8_t* acs_map, const int32_t* raw_quant, const uint8_t* quant_dc, BitReader* br,
+                    uint32_t shift, T* const coeffs[3], size_t* ncoeffs) {
   const uint32_t bx0 = gx * 32, by0 = gy * 32;
   if (bx0 >= xsb || by0 >= ysb) return JXLHIP_ERR_INVALID_ARGUMENT;
   const uint32_t gw = std::min(32u, xsb - bx0), gh = std::min(32u, ysb - by0);
@@ -1004,7 +1025,8 @@ int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_
         // BlockCtxMap::NonZeroContext (ac_context.h:133-143)
         uint32_t nzp = predicted >= 64 ? 64u : (uint32_t)predicted;
         const uint32_t nzc = nzp < 8 ? nzp : 4 + nzp / 2;
-        uint32_t nzeros = reader.ReadHybridUint(cmap[ctx_offset + nzc * nb + block_ctx], br);
+        uint32_t nzeros = kPlainAns ? reader.ReadHybridUintAns(cmap[ctx_offset + nzc * nb + block_ctx], br)
+                                    : reader.ReadHybridUint(cmap[ctx_offset + nzc * nb + block_ctx], br);
         if (nzeros > size - covered) return kBad;
         const int32_t per_block = (int32_t)((nzeros + covered - 1) >> log2c);
         for (uint32_t y = 0; y < cy; y++)
@@ -1018,7 +1040,7 @@ int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_
           const uint32_t left = (nzeros + covered - 1) >> log2c;
           if (left >= 64) return kBad;  // more non-zeros than positions: invalid stream
           const uint32_t ctx = zd.v[left][k >> log2c] + prev;
-          const uint32_t u = reader.ReadHybridUint(hmap[ctx], br);
+          const uint32_t u = kPlainAns ? reader.ReadHybridUintAns(hmap[ctx], br) : reader.ReadHybridUint(hmap[ctx], br);
           const uint32_t magnitude = u >> 1, neg = (~u) & 1;  // UnpackSigned
           const int32_t coeff = (int32_t)((magnitude ^ (neg - 1)) << shift);
           if constexpr (sizeof(T) == 2) {
@@ -1041,6 +1063,15 @@ int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_
   if (out_of_range) return JXLHIP_ERR_RANGE;
   if (ncoeffs) *ncoeffs = offset;
   return kOk;
+}
+
+template <typename T>
+int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
+                 const uint8_t* acs_map, const int32_t* raw_quant, const uint8_t* quant_dc, BitReader* br,
+                 uint32_t shift, T* const coeffs[3], size_t* ncoeffs) {
+  if (!pass->code.use_prefix && !pass->code.lz77.enabled)
+    return DecodeGroupImpl<T, true>(pass, xsb, ysb, gx, gy, acs_map, raw_quant, quant_dc, br, shift, coeffs, ncoeffs);
+  return DecodeGroupImpl<T, false>(pass, xsb, ysb, gx, gy, acs_map, raw_quant, quant_dc, br, shift, coeffs, ncoeffs);
 }
 
 }  // namespace
