@@ -234,3 +234,44 @@ def test_all_groups_on_the_parallel_runner(L, ref):
     assert np.array_equal(outs[0], outs[1])
     scale = max(1.0, float(np.abs(rs.rgb).max()))
     assert float(np.abs(outs[0] - rs.rgb).max()) / scale <= 2e-5
+
+
+@pytest.mark.gpu
+def test_range_error_reaches_the_caller_of_the_runner_path(L, ref):
+    """A coefficient beyond 16 bits in an optimistically 16-bit frame: jxlhip_ac_groups_decode_submit
+    returns JXLHIP_ERR_RANGE, and the same frame redone with int32 buffers decodes."""
+    import frames
+    from libjxl_amd import VarDctDecoder, synth
+    xs, ys = 520, 264
+    params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_DCT32, gab=False, epf_iters=0, coeff_type=1, quant_mul=2.0,
+                                     amp=40.0)
+    coeffs = [c.numpy() for c in t["coeffs"]]
+    coeffs[1][5] = 40000
+    glob, groups, used_acs, _ = fr.encode_ac_ref()
+    g = np.frombuffer(glob, np.uint8)
+    pos, h = C.c_size_t(0), C.c_void_p()
+    assert L.jxlhip_ac_pass_decode(g.ctypes.data, len(g), C.byref(pos), used_acs, 1, None, C.byref(h)) == 0
+    secs = [np.frombuffer(x, np.uint8) if len(x) else np.zeros(1, np.uint8) for x in groups]
+    ptrs = (C.c_void_p * len(secs))(*[x.ctypes.data for x in secs])
+    sizes = (C.c_size_t * len(secs))(*[len(x) for x in groups])
+    pass_arr = (C.c_void_p * 1)(h)
+    npy = {k: (v.numpy() if not isinstance(v, list) else [x.numpy() for x in v]) for k, v in t.items()}
+    d = VarDctDecoder(0)
+    dq = d.default_dequant_tables().cpu().numpy()
+    results = []
+    for ct in (0, 1):
+        d.begin_frame(dict(params, coeff_type=ct, output_kind=1))
+        dc3 = (C.c_void_p * 3)(*[x.ctypes.data for x in npy["dc"]])
+        assert L.jxlhip_upload_side_info(d.ctx, npy["ac_strategy"].ctypes.data, npy["raw_quant"].ctypes.data,
+                                         npy["epf_sharpness"].ctypes.data, npy["ytox_map"].ctypes.data,
+                                         npy["ytob_map"].ctypes.data, dc3, dq.ctypes.data) == 0
+        results.append(L.jxlhip_ac_groups_decode_submit(d.ctx, None, None, 1, pass_arr, None, npy["ac_strategy"].ctypes.data,
+                                                        npy["raw_quant"].ctypes.data, None, ptrs, sizes))
+    assert results == [-8, 0]
+    out = d.decode_frame()
+    d.sync()
+    want = fr.decode_ref(threads=1)
+    L.jxlhip_ac_pass_destroy(h)
+    d.close()
+    scale = max(1.0, float(np.abs(want).max()))
+    assert float(np.abs(out.cpu().numpy() - want).max()) / scale <= 2e-5
