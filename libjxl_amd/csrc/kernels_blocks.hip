@@ -1312,8 +1312,10 @@ __global__ __launch_bounds__(256) void k_large(DevFrame f, const WorkItem* __res
 //   k_transform_8   every single-block strategy, no LDS: the nine special 8x8 kinds as
 //                   lane-per-block (unit, channel) tasks at the head of the grid, then DCT8
 //                   (~45 % of a d1.0 frame) row-per-lane
-//   k_transform_r16 16x16, 16x8, 8x16: row-per-lane, no LDS, 4 waves per SIMD
-//   k_transform_r32 32x32, 32x16, 16x32, 32x8, 8x32: row-per-lane, 32 values per lane
+//   k_transform_r   16x8 .. 32x32 row-per-lane, no LDS: the L = 32 classes (32x32, 32x16, 16x32,
+//                   32x8, 8x32; 32 values per lane) at the head of the grid, then 16x16, 16x8,
+//                   8x16.  (k_transform_r16 / r32: the two halves, launched alone when used_acs
+//                   says the other half has no work)
 //   k_transform_a   64x64, 64x32, 32x64 (LDS-staged MediumUnit)
 //   k_large         128x128 .. 256x256 (never emitted by libjxl), private scratch
 // A family kernel owns several work classes; a workgroup decodes UNITS of the family -- 64 or
@@ -1432,6 +1434,29 @@ __global__ __launch_bounds__(256) void k_transform_r32(DevFrame f, WorkLists wl)
                });
 }
 
+// Both row-per-lane families in one launch, the (few, long, register-heavy) L = 32 units first:
+// on a mixed frame their single-generation latency (~27 us as a launch of its own) disappears
+// behind the L = 16 bulk, at the price of the L = 16 units running at the L = 32 occupancy.
+static constexpr FamilyEntry kFamilyR[8] = {{kClsMedium0 + 7, 8},  {kClsMedium0 + 5, 16}, {kClsMedium0 + 6, 16},
+                                            {kClsMedium0 + 3, 32}, {kClsMedium0 + 4, 32}, {kClsMedium0 + 2, 16},
+                                            {kClsMedium0 + 0, 32}, {kClsMedium0 + 1, 32}};
+template <typename CT>
+__global__ __launch_bounds__(256) void k_transform_r(DevFrame f, WorkLists wl) {
+  UnitDispatch(kFamilyR, wl,
+               [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
+                 switch (index) {
+                   case 0: RowLaneUnit<32, 32, 5, CT>(f, list, first, n); break;
+                   case 1: RowLaneUnit<32, 16, 10, CT>(f, list, first, n); break;
+                   case 2: RowLaneUnit<16, 32, 11, CT>(f, list, first, n); break;
+                   case 3: RowLaneUnit<32, 8, 8, CT>(f, list, first, n); break;
+                   case 4: RowLaneUnit<8, 32, 9, CT>(f, list, first, n); break;
+                   case 5: RowLaneUnit<16, 16, 4, CT>(f, list, first, n); break;
+                   case 6: RowLaneUnit<16, 8, 6, CT>(f, list, first, n); break;
+                   default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
+                 }
+               });
+}
+
 // --------------------------------------------------------------- launchers
 template <typename CT>
 static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells, const float* wc,
@@ -1463,10 +1488,14 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     const uint32_t grid_8 = (bound_s > bound_8 ? bound_s : bound_8) + (specials ? kNumSpecial : 0);
     if (grid_8) hipLaunchKernelGGL((k_transform_8<CT>), dim3(grid_8), dim3(256), 0, s0, f, wl);
   }
-  if (any({4, 6, 7}))
-    hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
-  if (any({5, 8, 9, 10, 11}))
-    hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
+  if (any({4, 6, 7}) && any({5, 8, 9, 10, 11})) {  // -10 us per 8K d1.0 frame against two launches
+    hipLaunchKernelGGL((k_transform_r<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
+  } else {
+    if (any({4, 6, 7}))
+      hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
+    if (any({5, 8, 9, 10, 11}))
+      hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
+  }
   if (cells >= 256 && any({21, 22, 23, 24, 25, 26}))
     hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, s1, f, wl.list[kClsLarge],
                        wl.count + kClsLarge * kCounterPad, wc, resample);
