@@ -1379,11 +1379,12 @@ static_assert(kMediumStrategy[8] == 18 && kMediumStrategy[9] == 19 && kMediumStr
 // every class's lane-dependent invariants out of this loop.)
 template <int N, typename Body>
 __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const WorkLists& wl,
-                                             Body&& body) {
+                                             Body&& body, uint32_t first_wg = 0, uint32_t num_wgs = 0) {
   uint32_t cnt[N];
 #pragma unroll
   for (int i = 0; i < N; i++) cnt[i] = wl.count[fam[i].cls * kCounterPad];
-  for (uint32_t u = blockIdx.x;; u += gridDim.x) {
+  if (num_wgs == 0) num_wgs = gridDim.x - first_wg;  // workgroups [first_wg, first_wg + num_wgs) share the family
+  for (uint32_t u = blockIdx.x - first_wg;; u += num_wgs) {
     const UnitPick pick = PickUnit(fam, cnt, u);
     if (pick.index < 0) return;
     body(pick.index, wl.list[pick.cls], pick.first, pick.n);
@@ -1440,8 +1441,28 @@ __global__ __launch_bounds__(256) void k_transform_r32(DevFrame f, WorkLists wl)
 static constexpr FamilyEntry kFamilyR[8] = {{kClsMedium0 + 7, 8},  {kClsMedium0 + 5, 16}, {kClsMedium0 + 6, 16},
                                             {kClsMedium0 + 3, 32}, {kClsMedium0 + 4, 32}, {kClsMedium0 + 2, 16},
                                             {kClsMedium0 + 0, 32}, {kClsMedium0 + 1, 32}};
+// ... and, on its first `big_wgs` workgroups, the LDS-staged 64-point classes of family A: their
+// workgroups are three waves (the fourth ends at once; a finished wave no longer counts at the
+// workgroup barrier) looping over the big units, while the others loop over the row-per-lane units.
+// The 50 KB of LDS every workgroup of this launch then reserves cost the row-per-lane units
+// nothing: three workgroups per CU is what their registers allow anyway.  As a launch of its own
+// family A is ~22 us of pure latency per 8K d1.0 frame.
 template <typename CT>
-__global__ __launch_bounds__(256) void k_transform_r(DevFrame f, WorkLists wl) {
+__global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(DevFrame f, WorkLists wl, uint32_t big_wgs) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
+  if (blockIdx.x < big_wgs) {
+    if (threadIdx.x >= 192) return;
+    UnitDispatch(kFamilyA, wl,
+                 [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
+                   switch (index) {
+                     case 0: MediumUnit<64, 64, 18, CT>(f, list, first, n, smem); break;
+                     case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
+                     default: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
+                   }
+                 },
+                 0, big_wgs);
+    return;
+  }
   UnitDispatch(kFamilyR, wl,
                [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
                  switch (index) {
@@ -1454,7 +1475,8 @@ __global__ __launch_bounds__(256) void k_transform_r(DevFrame f, WorkLists wl) {
                    case 6: RowLaneUnit<16, 8, 6, CT>(f, list, first, n); break;
                    default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
                  }
-               });
+               },
+               big_wgs, 0);
 }
 
 // --------------------------------------------------------------- launchers
@@ -1478,7 +1500,9 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
       if (f.used_acs & (1u << st)) return true;
     return false;
   };
-  if (any({18, 19, 20}))
+  const bool merged_r = any({4, 6, 7}) && any({5, 8, 9, 10, 11});
+  const bool have_big = any({18, 19, 20});
+  if (have_big && !merged_r)
     hipLaunchKernelGGL((k_transform_a<CT>), dim3(grid_a), dim3(192), 0, s1, f, wl);
   {
     // worst cases: all cells special (3 tasks per 64 blocks, 4 tasks per workgroup) or all DCT8
@@ -1488,8 +1512,9 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     const uint32_t grid_8 = (bound_s > bound_8 ? bound_s : bound_8) + (specials ? kNumSpecial : 0);
     if (grid_8) hipLaunchKernelGGL((k_transform_8<CT>), dim3(grid_8), dim3(256), 0, s0, f, wl);
   }
-  if (any({4, 6, 7}) && any({5, 8, 9, 10, 11})) {  // -10 us per 8K d1.0 frame against two launches
-    hipLaunchKernelGGL((k_transform_r<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
+  if (merged_r) {  // -10 us per 8K d1.0 frame against two launches, -15 us more with family A inside
+    const uint32_t big_wgs = have_big ? (grid_a < 512u ? grid_a : 512u) : 0u;
+    hipLaunchKernelGGL((k_transform_r<CT>), dim3(big_wgs + grid_r16), dim3(256), 0, s0, f, wl, big_wgs);
   } else {
     if (any({4, 6, 7}))
       hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
