@@ -157,10 +157,10 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = px / (dt / args.steps) / 1e6
         # dominant SINGLE kernel of this rank's stripe: the "blocks" slot is a span
-        # over the four transform launches (k_transform_8 / r16 / r32 / a; the longest
-        # of them is ~0.4x the filter kernel in profiles/*_kernel_stats.csv), so the
-        # roofline is quoted on the fused Gaborish+EPF+XYB kernel, one launch per
-        # frame here.
+        # over the transform launches (k_prepare, k_transform_8, k_transform_r; the
+        # longest of them is ~0.4x the filter kernel in profiles/*_kernel_stats.csv),
+        # so the roofline is quoted on the fused Gaborish+EPF+XYB kernel, one launch
+        # per frame here.
         dom = "filters" if "filters" in kern else max(kern, key=kern.get)
         y0, y1 = sd.rows[rank]
         b_alg = algorithmic_bytes(xs, y1 - y0, 4 if args.coeff32 else 2)
