@@ -23,6 +23,97 @@
 extern "C" {
 #endif
 
+/* ---- The codestream's image header: signature, SizeHeader, ImageMetadata, CustomTransformData ----
+ * Replaces (libjxl tree, lib/jxl/):
+ *   the 0xFF 0x0A signature check and the read order            decode.cc:1049-1133
+ *   SizeHeader / PreviewHeader / AnimationHeader                 headers.cc:59-66,117-125,127-198
+ *   BitDepth, ExtraChannelInfo, ImageMetadata, ToneMapping,
+ *   OpsinInverseMatrix, CustomTransformData                      image_metadata.cc:25-61,72-197,199-245,
+ *                                                                270-392
+ *   ColorEncoding, Customxy, CustomTransferFunction, Enum()      color_encoding_internal.cc:106-216,
+ *                                                                fields.h:205-216, field_encodings.h:119-131
+ * What the back-end takes from it: the image size, xyb_encoded, the inverse opsin matrix / opsin biases /
+ * quant biases (jxlhip_frame_params), intensity_target (the 255/intensity_target scale of the matrix,
+ * dec_xyb.cc:175-186), the enumerated colour encoding and bit depth (jxlhip_output_format), and the inputs
+ * of jxlhip_frame_header_decode (jxlhip_image_info).
+ * Not here (colour management, out of scope): the ICC stream that follows when color_encoding.want_icc is
+ * set is left unread, and the reference's extra rejection of CUSTOM white points / primaries that its ICC
+ * synthesiser cannot express (ColorEncoding::CreateICC, cms/jxl_cms_internal.h:43-126) is not reproduced:
+ * such chromaticities are returned as coded. */
+typedef struct jxlhip_bit_depth {
+  uint32_t floating_point_sample, bits_per_sample, exponent_bits_per_sample;
+} jxlhip_bit_depth;
+
+enum { JXLHIP_EC_ALPHA = 0, JXLHIP_EC_DEPTH = 1, JXLHIP_EC_SPOT_COLOR = 2, JXLHIP_EC_SELECTION_MASK = 3,
+       JXLHIP_EC_BLACK = 4, JXLHIP_EC_CFA = 5, JXLHIP_EC_THERMAL = 6, JXLHIP_EC_UNKNOWN = 15, JXLHIP_EC_OPTIONAL = 16 };
+
+typedef struct jxlhip_extra_channel {
+  uint32_t all_default;
+  uint32_t type;               /* JXLHIP_EC_* */
+  jxlhip_bit_depth bit_depth;
+  uint32_t dim_shift;          /* 0..3 */
+  uint32_t name_length;
+  uint32_t alpha_associated;   /* type ALPHA */
+  float spot_color[4];         /* type SPOT_COLOR */
+  uint32_t cfa_channel;        /* type CFA */
+} jxlhip_extra_channel;
+
+enum { JXLHIP_CS_RGB = 0, JXLHIP_CS_GRAY = 1, JXLHIP_CS_XYB = 2, JXLHIP_CS_UNKNOWN = 3 };
+enum { JXLHIP_WP_D65 = 1, JXLHIP_WP_CUSTOM = 2, JXLHIP_WP_E = 10, JXLHIP_WP_DCI = 11 };
+enum { JXLHIP_PRIM_SRGB = 1, JXLHIP_PRIM_CUSTOM = 2, JXLHIP_PRIM_2100 = 9, JXLHIP_PRIM_P3 = 11 };
+/* transfer_function holds the CICP code as coded (1 = 709, 8 = linear, 13 = sRGB, 16 = PQ, 17 = DCI, 18 = HLG);
+ * jxlhip_output_format::transfer_function uses the back-end's own JXLHIP_TF_* numbering. */
+
+typedef struct jxlhip_color_encoding {
+  uint32_t all_default;        /* sRGB, D65, relative intent */
+  uint32_t want_icc;           /* an ICC stream follows the headers (not read here) */
+  uint32_t color_space;        /* JXLHIP_CS_* */
+  uint32_t white_point;        /* JXLHIP_WP_* */
+  uint32_t primaries;          /* JXLHIP_PRIM_*; meaningful for RGB / UNKNOWN colour spaces */
+  uint32_t have_gamma, gamma;  /* gamma in units of 1e-7 */
+  uint32_t transfer_function;
+  uint32_t rendering_intent;   /* 0 perceptual, 1 relative, 2 saturation, 3 absolute */
+  int32_t white_xy[2];         /* custom chromaticities in units of 1e-6 */
+  int32_t primaries_xy[6];     /* r.x r.y g.x g.y b.x b.y */
+} jxlhip_color_encoding;
+
+typedef struct jxlhip_image_header {
+  uint32_t xsize, ysize;                         /* SizeHeader */
+  uint32_t all_default;                          /* ImageMetadata::all_default */
+  uint32_t orientation;                          /* 1..8 */
+  uint32_t have_intrinsic_size, intrinsic_xsize, intrinsic_ysize;
+  uint32_t have_preview, preview_xsize, preview_ysize;
+  uint32_t have_animation, tps_numerator, tps_denominator, num_loops, have_timecodes;
+  jxlhip_bit_depth bit_depth;
+  uint32_t modular_16_bit_buffer_sufficient;
+  uint32_t num_extra_channels;
+  uint32_t xyb_encoded;
+  jxlhip_color_encoding color_encoding;
+  uint32_t tone_mapping_all_default;
+  float intensity_target, min_nits;
+  uint32_t relative_to_max_display;
+  float linear_below;
+  uint64_t extensions;
+  /* CustomTransformData */
+  uint32_t transform_all_default, opsin_all_default;
+  float inverse_opsin_matrix[9];                 /* UNSCALED (multiply by 255/intensity_target for frame_params) */
+  float opsin_biases[3];
+  float quant_biases[4];
+  uint32_t custom_weights_mask;                  /* bit 0/1/2: the 2x/4x/8x upsampling weights below are coded */
+  float upsampling2_weights[15], upsampling4_weights[55], upsampling8_weights[210]; /* zero when not coded
+                                                    (upsampling is outside the back-end; defaults not carried) */
+} jxlhip_image_header;
+
+/* Reads the image header of a bare codestream starting at byte 0 of data (0xFF 0x0A).  extra[] receives
+ * the first min(num_extra_channels, extra_capacity) channel descriptions (may be NULL with capacity 0).
+ * On success *bit_pos is the first bit after CustomTransformData when an ICC stream follows
+ * (color_encoding.want_icc), otherwise the byte-aligned position of the first frame header (the
+ * padding bits must be zero, BitReader::JumpToByteBoundary).  JXLHIP_ERR_BAD_STREAM on everything
+ * the reference rejects (see the note on custom chromaticities above) and on truncation. */
+JXLHIP_EXPORT int jxlhip_image_header_decode(const uint8_t* data, size_t size, size_t* bit_pos,
+                                             jxlhip_extra_channel* extra, size_t extra_capacity,
+                                             jxlhip_image_header* out);
+
 /* What the frame header's conditions read from the image header (CodecMetadata). */
 typedef struct jxlhip_image_info {
   uint32_t xsize, ysize;          /* image size, or the preview size when is_preview */

@@ -73,6 +73,45 @@ class ImageInfo(C.Structure):
                 ("have_timecodes", C.c_uint32), ("is_preview", C.c_uint32)]
 
 
+class BitDepth(C.Structure):
+    """jxlhip_bit_depth (include/jxl_hip_frame.h)."""
+    _fields_ = [("floating_point_sample", C.c_uint32), ("bits_per_sample", C.c_uint32),
+                ("exponent_bits_per_sample", C.c_uint32)]
+
+
+class ExtraChannel(C.Structure):
+    """jxlhip_extra_channel (include/jxl_hip_frame.h)."""
+    _fields_ = [("all_default", C.c_uint32), ("type", C.c_uint32), ("bit_depth", BitDepth), ("dim_shift", C.c_uint32),
+                ("name_length", C.c_uint32), ("alpha_associated", C.c_uint32), ("spot_color", C.c_float * 4),
+                ("cfa_channel", C.c_uint32)]
+
+
+class ColorEncoding(C.Structure):
+    """jxlhip_color_encoding (include/jxl_hip_frame.h)."""
+    _fields_ = [("all_default", C.c_uint32), ("want_icc", C.c_uint32), ("color_space", C.c_uint32),
+                ("white_point", C.c_uint32), ("primaries", C.c_uint32), ("have_gamma", C.c_uint32),
+                ("gamma", C.c_uint32), ("transfer_function", C.c_uint32), ("rendering_intent", C.c_uint32),
+                ("white_xy", C.c_int32 * 2), ("primaries_xy", C.c_int32 * 6)]
+
+
+class ImageHeader(C.Structure):
+    """jxlhip_image_header (include/jxl_hip_frame.h)."""
+    _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32), ("all_default", C.c_uint32), ("orientation", C.c_uint32),
+                ("have_intrinsic_size", C.c_uint32), ("intrinsic_xsize", C.c_uint32), ("intrinsic_ysize", C.c_uint32),
+                ("have_preview", C.c_uint32), ("preview_xsize", C.c_uint32), ("preview_ysize", C.c_uint32),
+                ("have_animation", C.c_uint32), ("tps_numerator", C.c_uint32), ("tps_denominator", C.c_uint32),
+                ("num_loops", C.c_uint32), ("have_timecodes", C.c_uint32), ("bit_depth", BitDepth),
+                ("modular_16_bit_buffer_sufficient", C.c_uint32), ("num_extra_channels", C.c_uint32),
+                ("xyb_encoded", C.c_uint32), ("color_encoding", ColorEncoding),
+                ("tone_mapping_all_default", C.c_uint32), ("intensity_target", C.c_float), ("min_nits", C.c_float),
+                ("relative_to_max_display", C.c_uint32), ("linear_below", C.c_float), ("extensions", C.c_uint64),
+                ("transform_all_default", C.c_uint32), ("opsin_all_default", C.c_uint32),
+                ("inverse_opsin_matrix", C.c_float * 9), ("opsin_biases", C.c_float * 3),
+                ("quant_biases", C.c_float * 4), ("custom_weights_mask", C.c_uint32),
+                ("upsampling2_weights", C.c_float * 15), ("upsampling4_weights", C.c_float * 55),
+                ("upsampling8_weights", C.c_float * 210)]
+
+
 class FrameHeader(C.Structure):
     """jxlhip_frame_header (include/jxl_hip_frame.h)."""
     _fields_ = [("all_default", C.c_uint32), ("frame_type", C.c_uint32), ("is_modular", C.c_uint32),
@@ -183,7 +222,7 @@ EXPORTS = [
     "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode", "jxlhip_ac_group_decode_submit_passes",
     "jxlhip_ac_groups_decode_submit", "jxlhip_num_toc_entries", "jxlhip_toc_decode",
     # include/jxl_hip_frame.h
-    "jxlhip_frame_header_decode", "jxlhip_dc_global_decode",
+    "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode",
 ]
 
 
@@ -226,6 +265,8 @@ def load_library():
     L.jxlhip_toc_decode.argtypes = [vp, sz, C.POINTER(sz), u32, vp, vp, vp]
     L.jxlhip_frame_header_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(ImageInfo), C.POINTER(FrameHeader)]
     L.jxlhip_dc_global_decode.argtypes = [vp, sz, C.POINTER(sz), C.c_uint64, C.POINTER(DcGlobal)]
+    L.jxlhip_image_header_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(ExtraChannel), sz,
+                                             C.POINTER(ImageHeader)]
     L.jxlhip_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlhip_frame_set_inputs.argtypes = [vp, C.POINTER(FrameInputs)]
     L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]

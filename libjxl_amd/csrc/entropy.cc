@@ -1599,6 +1599,267 @@ int jxlhip_frame_header_decode(const uint8_t* data, size_t size, size_t* bit_pos
   return kOk;
 }
 
+// ---- image header: SizeHeader, ImageMetadata, CustomTransformData (include/jxl_hip_frame.h) ----
+namespace {
+// Visitor::Enum (fields.h:205-216) + EnumValid (field_encodings.h:119-131)
+bool ReadEnum(FieldReader* r, uint64_t valid, uint32_t* v) {
+  static const U32Dist kEnum = {{0, 0, 4, 6}, {0, 1, 2, 18}};
+  *v = r->U32(kEnum);
+  return *v < 64 && ((valid >> *v) & 1) != 0;
+}
+
+uint32_t AspectRatioX(uint32_t ratio, uint32_t ysize) {  // headers.cc:36-47,61-63
+  static const uint32_t kNum[7] = {1, 12, 4, 3, 16, 5, 2}, kDen[7] = {1, 10, 3, 2, 9, 4, 1};
+  return (uint32_t)((uint64_t)ysize * kNum[ratio - 1] / kDen[ratio - 1]);
+}
+
+void ReadSizeHeader(FieldReader* r, uint32_t* xsize, uint32_t* ysize) {  // headers.cc:127-152
+  static const U32Dist kDim = {{9, 13, 18, 30}, {1, 1, 1, 1}};
+  const bool small = r->Bool();
+  *ysize = small ? (r->Bits(5) + 1) * 8 : r->U32(kDim);
+  const uint32_t ratio = r->Bits(3);
+  if (ratio != 0) {
+    *xsize = AspectRatioX(ratio, *ysize);
+  } else {
+    *xsize = small ? (r->Bits(5) + 1) * 8 : r->U32(kDim);
+  }
+}
+
+void ReadPreviewHeader(FieldReader* r, uint32_t* xsize, uint32_t* ysize) {  // headers.cc:154-180
+  static const U32Dist kDiv8 = {{0, 0, 5, 9}, {16, 32, 1, 33}}, kFull = {{6, 8, 10, 12}, {1, 65, 321, 1345}};
+  const bool div8 = r->Bool();
+  *ysize = div8 ? r->U32(kDiv8) * 8 : r->U32(kFull);
+  const uint32_t ratio = r->Bits(3);
+  if (ratio != 0) {
+    *xsize = AspectRatioX(ratio, *ysize);
+  } else {
+    *xsize = div8 ? r->U32(kDiv8) * 8 : r->U32(kFull);
+  }
+}
+
+bool ReadBitDepth(FieldReader* r, jxlhip_bit_depth* b) {  // image_metadata.cc:25-61
+  b->floating_point_sample = r->Bool();
+  if (!b->floating_point_sample) {
+    static const U32Dist kInt = {{0, 0, 0, 6}, {8, 10, 12, 1}};
+    b->bits_per_sample = r->U32(kInt);
+    b->exponent_bits_per_sample = 0;
+    return b->bits_per_sample <= 31;
+  }
+  static const U32Dist kFloat = {{0, 0, 0, 6}, {32, 16, 24, 1}};
+  b->bits_per_sample = r->U32(kFloat);
+  b->exponent_bits_per_sample = r->Bits(4) + 1;
+  if (b->exponent_bits_per_sample < 2 || b->exponent_bits_per_sample > 8) return false;
+  const int mantissa = (int)b->bits_per_sample - (int)b->exponent_bits_per_sample - 1;
+  return mantissa >= 2 && mantissa <= 23;
+}
+
+bool ReadExtraChannel(FieldReader* r, jxlhip_extra_channel* e) {  // image_metadata.cc:199-245
+  memset(e, 0, sizeof(*e));
+  e->bit_depth.bits_per_sample = 8;
+  e->cfa_channel = 1;
+  e->all_default = r->Bool();
+  if (e->all_default) return true;  // an 8-bit alpha channel, not associated
+  constexpr uint64_t kTypes = 0x7Full | (1ull << 15) | (1ull << 16);  // EnumBits(ExtraChannel), image_metadata.h:75-80
+  if (!ReadEnum(r, kTypes, &e->type)) return false;
+  if (!ReadBitDepth(r, &e->bit_depth)) return false;
+  static const U32Dist kShift = {{0, 0, 0, 3}, {0, 3, 4, 1}};
+  e->dim_shift = r->U32(kShift);
+  if ((1u << e->dim_shift) > 8) return false;
+  static const U32Dist kName = {{0, 4, 5, 10}, {0, 0, 16, 48}};  // VisitNameString, frame_header.h:35-50
+  e->name_length = r->U32(kName);
+  for (uint32_t i = 0; i < e->name_length; i++) {
+    r->Bits(8);
+    if (!r->br->Healthy()) return false;
+  }
+  if (e->type == JXLHIP_EC_ALPHA) e->alpha_associated = r->Bool();
+  if (e->type == JXLHIP_EC_SPOT_COLOR) {
+    for (float& c : e->spot_color) c = r->F16();
+  }
+  if (e->type == JXLHIP_EC_CFA) {
+    static const U32Dist kCfa = {{0, 2, 4, 8}, {1, 0, 3, 19}};
+    e->cfa_channel = r->U32(kCfa);
+  }
+  // kUnknown is a valid code that the reference nevertheless refuses (image_metadata.cc:236-243)
+  return r->ok && e->type != JXLHIP_EC_UNKNOWN;
+}
+
+int32_t ReadCustomXy(FieldReader* r) {  // color_encoding_internal.cc:106-120, pack_signed.h
+  static const U32Dist kXy = {{19, 19, 20, 21}, {0, 524288, 1048576, 2097152}};
+  const uint32_t u = r->U32(kXy);
+  return (int32_t)((u >> 1) ^ (0u - (u & 1)));
+}
+
+bool ReadColorEncoding(FieldReader* r, jxlhip_color_encoding* c) {  // color_encoding_internal.cc:148-216
+  memset(c, 0, sizeof(*c));
+  c->white_point = JXLHIP_WP_D65;
+  c->primaries = JXLHIP_PRIM_SRGB;
+  c->transfer_function = 13;
+  c->rendering_intent = 1;
+  c->gamma = 10000000;
+  c->all_default = r->Bool();
+  if (c->all_default) return true;
+  c->want_icc = r->Bool();
+  if (!ReadEnum(r, 0xF, &c->color_space)) return false;
+  if (c->want_icc) return true;  // the fields are not coded; the profile follows the headers
+  constexpr uint64_t kWhite = (1ull << 1) | (1ull << 2) | (1ull << 10) | (1ull << 11);
+  constexpr uint64_t kPrim = (1ull << 1) | (1ull << 2) | (1ull << 9) | (1ull << 11);
+  constexpr uint64_t kTf = (1ull << 1) | (1ull << 2) | (1ull << 8) | (1ull << 13) | (1ull << 16) | (1ull << 17) |
+                           (1ull << 18);
+  if (c->color_space != JXLHIP_CS_XYB) {  // XYB: implicitly D65
+    if (!ReadEnum(r, kWhite, &c->white_point)) return false;
+    if (c->white_point == JXLHIP_WP_CUSTOM) {
+      c->white_xy[0] = ReadCustomXy(r);
+      c->white_xy[1] = ReadCustomXy(r);
+    }
+  }
+  if (c->color_space != JXLHIP_CS_GRAY && c->color_space != JXLHIP_CS_XYB) {
+    if (!ReadEnum(r, kPrim, &c->primaries)) return false;
+    if (c->primaries == JXLHIP_PRIM_CUSTOM) {
+      for (int32_t& v : c->primaries_xy) v = ReadCustomXy(r);
+    }
+  }
+  if (c->color_space == JXLHIP_CS_XYB) {  // CustomTransferFunction::SetImplicit: gamma 1/3
+    c->have_gamma = 1;
+    c->gamma = 3333333;
+  } else {
+    c->have_gamma = r->Bool();
+    if (c->have_gamma) {
+      c->gamma = r->Bits(24);
+      if (c->gamma > 10000000u || (uint64_t)c->gamma * 8192 < 10000000u) return false;
+    } else if (!ReadEnum(r, kTf, &c->transfer_function)) {
+      return false;
+    }
+  }
+  if (!ReadEnum(r, 0xF, &c->rendering_intent)) return false;
+  if (c->color_space == JXLHIP_CS_UNKNOWN || (!c->have_gamma && c->transfer_function == 2)) return false;
+  // MaybeCreateProfileImpl (cms/jxl_cms_internal.h:989-995): an XYB profile exists for one intent only
+  if (c->color_space == JXLHIP_CS_XYB && c->rendering_intent != 0) return false;
+  return true;
+}
+}  // namespace
+
+int jxlhip_image_header_decode(const uint8_t* data, size_t size, size_t* bit_pos, jxlhip_extra_channel* extra,
+                               size_t extra_capacity, jxlhip_image_header* h) {
+  if (!data || !bit_pos || !h || (extra_capacity && !extra)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  memset(h, 0, sizeof(*h));
+  if (size < 2 || data[0] != 0xFF || data[1] != 0x0A) return kBad;  // decode.cc:1049
+  {
+    BitReader br(data, size, 16);
+    FieldReader r(&br);  // one visitor per Bundle::Read
+    ReadSizeHeader(&r, &h->xsize, &h->ysize);
+    if (!br.Healthy()) return kBad;
+    *bit_pos = br.BitsConsumed();
+  }
+  // ImageMetadata (image_metadata.cc:270-338); defaults first
+  h->orientation = 1;
+  h->bit_depth.bits_per_sample = 8;
+  h->modular_16_bit_buffer_sufficient = 1;
+  h->xyb_encoded = 1;
+  h->tps_numerator = 100;
+  h->tps_denominator = 1;
+  h->tone_mapping_all_default = 1;
+  h->intensity_target = 255.0f;
+  {
+    BitReader br(data, size, *bit_pos);
+    FieldReader r(&br);
+    h->all_default = r.Bool();
+    if (h->all_default) {
+      static const uint8_t kOne = 1;
+      BitReader cbr(&kOne, 1, 0);
+      FieldReader cr(&cbr);
+      ReadColorEncoding(&cr, &h->color_encoding);
+    } else {
+      const bool extra_fields = r.Bool();
+      if (extra_fields) {
+        h->orientation = r.Bits(3) + 1;
+        h->have_intrinsic_size = r.Bool();
+        if (h->have_intrinsic_size) ReadSizeHeader(&r, &h->intrinsic_xsize, &h->intrinsic_ysize);
+        h->have_preview = r.Bool();
+        if (h->have_preview) ReadPreviewHeader(&r, &h->preview_xsize, &h->preview_ysize);
+        h->have_animation = r.Bool();
+        if (h->have_animation) {  // AnimationHeader, headers.cc:183-196
+          static const U32Dist kNum = {{0, 0, 10, 30}, {100, 1000, 1, 1}}, kDen = {{0, 0, 8, 10}, {1, 1001, 1, 1}},
+                               kLoops = {{0, 3, 16, 32}, {0, 0, 0, 0}};
+          h->tps_numerator = r.U32(kNum);
+          h->tps_denominator = r.U32(kDen);
+          h->num_loops = r.U32(kLoops);
+          h->have_timecodes = r.Bool();
+        }
+      }
+      if (!ReadBitDepth(&r, &h->bit_depth)) return kBad;
+      h->modular_16_bit_buffer_sufficient = r.Bool();
+      static const U32Dist kNumEc = {{0, 0, 4, 12}, {0, 1, 2, 1}};
+      h->num_extra_channels = r.U32(kNumEc);
+      for (uint32_t i = 0; i < h->num_extra_channels; i++) {
+        jxlhip_extra_channel e;
+        if (!ReadExtraChannel(&r, &e) || !br.Healthy()) return kBad;
+        if (i < extra_capacity) extra[i] = e;
+      }
+      h->xyb_encoded = r.Bool();
+      if (!ReadColorEncoding(&r, &h->color_encoding)) return kBad;
+      if (extra_fields) {  // ToneMapping, image_metadata.cc:359-392
+        h->tone_mapping_all_default = r.Bool();
+        if (!h->tone_mapping_all_default) {
+          h->intensity_target = r.F16();
+          if (!r.ok || !(h->intensity_target > 0.f)) return kBad;
+          h->min_nits = r.F16();
+          if (!r.ok || h->min_nits < 0.f || h->min_nits > h->intensity_target) return kBad;
+          h->relative_to_max_display = r.Bool();
+          h->linear_below = r.F16();
+          if (!r.ok || h->linear_below < 0.f || (h->relative_to_max_display && h->linear_below > 1.0f)) return kBad;
+        }
+      }
+      if (!r.Extensions(&h->extensions)) return kBad;
+    }
+    if (!r.ok || !br.Healthy()) return kBad;
+    *bit_pos = br.BitsConsumed();
+  }
+  // CustomTransformData (image_metadata.cc:72-197) with its nested OpsinInverseMatrix (340-357)
+  static const float kInverseOpsin[9] = {11.031566901960783f, -9.866943921568629f, -0.16462299647058826f,
+                                         -3.254147380392157f, 4.418770392156863f,  -0.16462299647058826f,
+                                         -3.6588512862745097f, 2.7129230470588235f, 1.9459282392156863f};
+  memcpy(h->inverse_opsin_matrix, kInverseOpsin, sizeof(kInverseOpsin));
+  for (float& b : h->opsin_biases) b = -0.0037930732552754493f;
+  h->quant_biases[0] = 1.0f - 0.05465007330715401f;
+  h->quant_biases[1] = 1.0f - 0.07005449891748593f;
+  h->quant_biases[2] = 1.0f - 0.049935103337343655f;
+  h->quant_biases[3] = 0.145f;
+  h->opsin_all_default = 1;
+  {
+    BitReader br(data, size, *bit_pos);
+    FieldReader r(&br);
+    h->transform_all_default = r.Bool();
+    if (!h->transform_all_default) {
+      if (h->xyb_encoded) {
+        h->opsin_all_default = r.Bool();
+        if (!h->opsin_all_default) {
+          for (float& v : h->inverse_opsin_matrix) v = r.F16();
+          for (float& v : h->opsin_biases) v = r.F16();
+          for (float& v : h->quant_biases) v = r.F16();
+        }
+      }
+      h->custom_weights_mask = r.Bits(3);
+      if (h->custom_weights_mask & 1) {
+        for (float& v : h->upsampling2_weights) v = r.F16();
+      }
+      if (h->custom_weights_mask & 2) {
+        for (float& v : h->upsampling4_weights) v = r.F16();
+      }
+      if (h->custom_weights_mask & 4) {
+        for (float& v : h->upsampling8_weights) v = r.F16();
+      }
+    }
+    if (!r.ok || !br.Healthy()) return kBad;
+    if (!h->color_encoding.want_icc) {  // decode.cc:1133: the first frame starts on a byte
+      const uint32_t rem = (uint32_t)(br.BitsConsumed() % 8);
+      if (rem != 0 && br.Read(8 - rem) != 0) return kBad;
+      if (!br.Healthy()) return kBad;
+    }
+    *bit_pos = br.BitsConsumed();
+  }
+  return kOk;
+}
+
 int jxlhip_dequant_encodings_decode(const uint8_t* data, size_t size, size_t* bit_pos, jxlhip_quant_encoding* enc) {
   if (!data || !bit_pos || !enc) return JXLHIP_ERR_INVALID_ARGUMENT;
   BitReader br(data, size, *bit_pos);

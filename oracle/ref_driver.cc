@@ -850,3 +850,114 @@ JXR_EXPORT int jxr_dc_global_read(const uint8_t* data, size_t size, uint64_t* ou
   for (uint8_t v : bcm.ctx_map) out[n++] = v;
   return 0;
 }
+
+
+// The codestream's image header read by the reference: SizeHeader, ImageMetadata, CustomTransformData
+// (each its own Bundle::Read, decode.cc:1049-1133) and the jump to the byte boundary when no ICC
+// stream follows.  out[] in the order tests/test_image_header.py spells out; up to 8 extra channels.
+JXR_EXPORT int jxr_image_header_read(const uint8_t* data, size_t size, uint64_t* out, size_t* n_out, size_t* bits) {
+  if (size < 2 || data[0] != 0xFF || data[1] != kCodestreamMarker) return 1;
+  CodecMetadata metadata;
+  BitReader br(Bytes(data, size));
+  (void)br.ReadFixedBits<16>();
+  Status ok = Bundle::Read(&br, &metadata.size);
+  if (ok) ok = Bundle::Read(&br, &metadata.m);
+  if (ok) {
+    metadata.transform_data.nonserialized_xyb_encoded = metadata.m.xyb_encoded;
+    ok = Bundle::Read(&br, &metadata.transform_data);
+  }
+  if (ok && !metadata.m.color_encoding.WantICC()) ok = br.JumpToByteBoundary();
+  *bits = br.TotalBitsConsumed();
+  const bool in_bounds = br.AllReadsWithinBounds();
+  (void)br.Close();
+  if (!ok || !in_bounds) return 1;
+  size_t n = 0;
+  auto put = [&](uint64_t v) { out[n++] = v; };
+  auto putf = [&](float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    out[n++] = u;
+  };
+  auto put_depth = [&](const BitDepth& b) {
+    put(b.floating_point_sample);
+    put(b.bits_per_sample);
+    put(b.exponent_bits_per_sample);
+  };
+  const ImageMetadata& m = metadata.m;
+  put(metadata.size.xsize());
+  put(metadata.size.ysize());
+  put(m.all_default);
+  put(m.orientation);
+  put(m.have_intrinsic_size);
+  if (m.have_intrinsic_size) {
+    put(m.intrinsic_size.xsize());
+    put(m.intrinsic_size.ysize());
+  }
+  put(m.have_preview);
+  if (m.have_preview) {
+    put(m.preview_size.xsize());
+    put(m.preview_size.ysize());
+  }
+  put(m.have_animation);
+  if (m.have_animation) {
+    put(m.animation.tps_numerator);
+    put(m.animation.tps_denominator);
+    put(m.animation.num_loops);
+    put(m.animation.have_timecodes);
+  }
+  put_depth(m.bit_depth);
+  put(m.modular_16_bit_buffer_sufficient);
+  put(m.num_extra_channels);
+  put(m.xyb_encoded);
+  const auto& c = m.color_encoding.View();
+  put(m.color_encoding.all_default);
+  put(m.color_encoding.WantICC());
+  put(static_cast<uint32_t>(c.color_space));
+  if (!m.color_encoding.WantICC()) {
+    put(static_cast<uint32_t>(c.white_point));
+    if (c.white_point == WhitePoint::kCustom) {
+      put(static_cast<uint32_t>(c.white.x));
+      put(static_cast<uint32_t>(c.white.y));
+    }
+    if (c.HasPrimaries()) {
+      put(static_cast<uint32_t>(c.primaries));
+      if (c.primaries == Primaries::kCustom) {
+        for (const auto* p : {&c.red, &c.green, &c.blue}) {
+          put(static_cast<uint32_t>(p->x));
+          put(static_cast<uint32_t>(p->y));
+        }
+      }
+    }
+    put(c.tf.have_gamma);
+    put(c.tf.have_gamma ? c.tf.gamma : static_cast<uint32_t>(c.tf.transfer_function));
+    put(static_cast<uint32_t>(c.rendering_intent));
+  }
+  putf(m.tone_mapping.intensity_target);
+  putf(m.tone_mapping.min_nits);
+  put(m.tone_mapping.relative_to_max_display);
+  putf(m.tone_mapping.linear_below);
+  put(m.extensions);
+  const CustomTransformData& t = metadata.transform_data;
+  put(t.all_default);
+  for (int j = 0; j < 3; j++) {
+    for (int i = 0; i < 3; i++) putf(t.opsin_inverse_matrix.inverse_matrix[j][i]);
+  }
+  for (int i = 0; i < 3; i++) putf(t.opsin_inverse_matrix.opsin_biases[i]);
+  for (int i = 0; i < 4; i++) putf(t.opsin_inverse_matrix.quant_biases[i]);
+  put(t.custom_weights_mask);
+  if (t.custom_weights_mask & 1) for (float w : t.upsampling2_weights) putf(w);
+  if (t.custom_weights_mask & 2) for (float w : t.upsampling4_weights) putf(w);
+  if (t.custom_weights_mask & 4) for (float w : t.upsampling8_weights) putf(w);
+  for (size_t i = 0; i < m.extra_channel_info.size() && i < 8; i++) {
+    const ExtraChannelInfo& e = m.extra_channel_info[i];
+    put(static_cast<uint32_t>(e.type));
+    put_depth(e.bit_depth);
+    put(e.dim_shift);
+    put(e.name.size());
+    if (e.type == ExtraChannel::kAlpha) put(e.alpha_associated);
+    if (e.type == ExtraChannel::kSpotColor) for (float s : e.spot_color) putf(s);
+    if (e.type == ExtraChannel::kCFA) put(e.cfa_channel);
+  }
+  *n_out = n;
+  return 0;
+}

@@ -145,6 +145,16 @@ int RunOnce(const Case& base, Rng* r, uint64_t* ok, uint64_t* rejected) {
     jxlhip_dc_global dg;
     size_t gp = r->Below(64);
     (void)jxlhip_dc_global_decode(g.p, g.n, &gp, 0, &dg);
+    Bytes hb = c.global;  // the same bytes behind a codestream signature: the image header parser
+    if (hb.size() >= 2) {
+      hb[0] = 0xFF;
+      hb[1] = 0x0A;
+    }
+    Exact hx(hb);
+    std::vector<jxlhip_extra_channel> ec(r->Below(5));
+    jxlhip_image_header ih;
+    size_t ip = 0;
+    (void)jxlhip_image_header_decode(hx.p, hx.n, &ip, ec.empty() ? nullptr : ec.data(), ec.size(), &ih);
   }
   jxlhip_block_ctx_map bcm;
   size_t pos = 0;

@@ -1,0 +1,121 @@
+"""f4 + f1 chained: from the BYTES of a genuine codestream alone, the product's host parsers --
+jxlhip_image_header_decode -> jxlhip_frame_header_decode -> jxlhip_toc_decode ->
+jxlhip_dc_global_decode -> jxlhip_ac_global_decode -> jxlhip_ac_group_decode -- must arrive at
+the state the reference decoder holds for the same stream (oracle.RealStream = the reference's
+FrameDecoder run on it): the jxlhip_frame_params the back-end is started with, the section
+table, and the coefficients of the AC groups found through that table (checked through the pixels
+they decode to).  What is still taken from
+the reference here is what lives in the Modular-coded DC groups (strategy map, quant field, DC):
+SURVEY.md section 8 leaves Modular out of scope.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from libjxl_amd import abi
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not available")
+    oracle.ref_lib()
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def L():
+    return abi.load_library()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(xsize=520, ysize=300, distance=1.0),
+    dict(xsize=776, ysize=520, distance=3.0, progressive=1),
+    dict(xsize=640, ysize=264, distance=0.5, speed_tier=5),
+    dict(xsize=384, ysize=520, distance=2.0, epf=1),
+])
+def test_codestream_bytes_to_back_end_state(L, ref, kw):
+    kw = dict(dict(seed=11, speed_tier=3), **kw)
+    rs = ref.RealStream(**kw)
+    cs = np.ascontiguousarray(rs.codestream)
+    base, n = cs.ctypes.data, len(cs)
+
+    # image header
+    ih, pos = abi.ImageHeader(), C.c_size_t(0)
+    assert L.jxlhip_image_header_decode(base, n, C.byref(pos), None, 0, C.byref(ih)) == 0
+    assert not ih.color_encoding.want_icc and pos.value % 8 == 0
+    # frame header
+    info = abi.ImageInfo(ih.xsize, ih.ysize, ih.xyb_encoded, ih.num_extra_channels, None, ih.have_animation,
+                         ih.have_timecodes, 0)
+    fh = abi.FrameHeader()
+    assert L.jxlhip_frame_header_decode(base, n, C.byref(pos), C.byref(info), C.byref(fh)) == 0
+    assert not fh.is_modular and fh.color_transform == 0 and fh.flags & (1 | 2 | 16 | 32) == 0  # back-end eligible
+    # table of contents
+    nt = int(fh.num_toc_entries)
+    assert nt == L.jxlhip_num_toc_entries(int(fh.num_groups), int(fh.num_dc_groups), fh.num_passes) > 1
+    off, sz, total = np.zeros(nt, np.uint64), np.zeros(nt, np.uint32), C.c_uint64(0)
+    assert L.jxlhip_toc_decode(base, n, C.byref(pos), nt, off.ctypes.data, sz.ctypes.data, C.byref(total)) == 0
+    sections = pos.value // 8
+    assert sections + total.value == n
+    assert np.array_equal(off + np.uint64(sections), rs.section_offset)
+    assert np.array_equal(sz, rs.section_size.astype(np.uint32))
+
+    def section(i):
+        return cs[sections + int(off[i]): sections + int(off[i]) + int(sz[i])]
+
+    # DC global (section 0)
+    dcg, dpos = abi.DcGlobal(), C.c_size_t(0)
+    s0 = section(0)
+    assert L.jxlhip_dc_global_decode(s0.ctypes.data, len(s0), C.byref(dpos), fh.flags, C.byref(dcg)) == 0
+
+    # ---- the back-end's frame parameters, from the parsed headers alone ----
+    want = rs.frame_params
+    p = abi.FrameParams()
+    p.xsize, p.ysize = fh.xsize, fh.ysize
+    p.global_scale, p.quant_dc = dcg.global_scale, dcg.quant_dc
+    p.x_dm_multiplier, p.b_dm_multiplier = fh.x_dm_multiplier, fh.b_dm_multiplier
+    p.quant_biases[:] = ih.quant_biases[:]
+    p.cfl_base_x, p.cfl_base_b, p.cfl_color_factor = dcg.cfl_base_x, dcg.cfl_base_b, dcg.cfl_color_factor
+    p.lf = fh.lf
+    p.opsin_biases[:] = ih.opsin_biases[:]
+    scale = np.float32(255.0) / np.float32(ih.intensity_target)  # OpsinParams::Init, opsin_params.cc:35-45
+    p.inverse_opsin_matrix[:] = [float(np.float32(v) * scale) for v in ih.inverse_opsin_matrix]
+    for name in ("xsize", "ysize", "global_scale", "quant_dc", "x_dm_multiplier", "b_dm_multiplier", "cfl_base_x",
+                 "cfl_base_b", "cfl_color_factor"):
+        assert getattr(p, name) == getattr(want, name), name
+    assert bytes(p.lf) == bytes(want.lf)
+    for name in ("quant_biases", "opsin_biases", "inverse_opsin_matrix"):
+        assert list(getattr(p, name)) == list(getattr(want, name)), name
+    assert (fh.num_passes, list(fh.shift[:fh.num_passes])) == (rs.num_passes, rs.shift)
+
+    # ---- AC global (section 1 + num_dc_groups) with the block context map DC global produced ----
+    ng, ndc = int(fh.num_groups), int(fh.num_dc_groups)
+    glob = section(1 + ndc)
+    encs = abi.QuantEncodings()
+    nh, used, hs = C.c_uint32(0), C.c_size_t(0), (C.c_void_p * fh.num_passes)()
+    assert L.jxlhip_ac_global_decode(glob.ctypes.data, len(glob), ng, fh.num_passes, rs.used_acs,
+                                     C.byref(dcg.block_ctx_map), C.byref(encs), C.byref(nh), hs, C.byref(used)) == 0
+    try:
+        assert nh.value == rs.num_histograms and (used.value + 7) // 8 == len(glob)
+        # ---- every AC group, every pass, located through the table of contents ----
+        out = [np.zeros(ng * 65536, np.int32) for _ in range(3)]
+        xsg = int(fh.xsize_groups)
+        for g in range(ng):
+            ptrs = (C.c_void_p * 3)(*[o[g * 65536:].ctypes.data for o in out])
+            for ps in range(fh.num_passes):
+                d = section(2 + ndc + ps * ng + g)
+                gp, cnt = C.c_size_t(0), C.c_size_t(0)
+                assert L.jxlhip_ac_group_decode(hs[ps], fh.xsize_blocks, fh.ysize_blocks, g % xsg, g // xsg,
+                                                rs.ac_strategy.ctypes.data, rs.raw_quant.ctypes.data,
+                                                rs.quant_dc.ctypes.data, d.ctypes.data, len(d), C.byref(gp),
+                                                fh.shift[ps], 1, ptrs, C.byref(cnt)) == 0
+                assert (gp.value + 7) // 8 == len(d)
+    finally:
+        for h in hs:
+            L.jxlhip_ac_pass_destroy(h)
+    # the coefficients are right iff the pixels are: the C oracle's back-end on them vs the reference's output
+    fr = rs.frame(out)
+    fr.c.p.output_kind = 1
+    fr.c.p.coeff_type = 1
+    got = fr.decode(threads=4)
+    assert np.array_equal(got, rs.rgb), float(np.abs(got - rs.rgb).max())

@@ -1,0 +1,395 @@
+"""f4: the codestream's image header (SizeHeader, ImageMetadata with BitDepth / ExtraChannelInfo /
+ColorEncoding / ToneMapping, CustomTransformData with OpsinInverseMatrix: lib/jxl/headers.cc,
+image_metadata.cc, color_encoding_internal.cc) -- differential test against the reference's own
+Bundle::Read of the same bytes: headers of genuine codestreams, and thousands of random bit
+strings behind the 0xFF 0x0A signature, which walk every conditional branch, enum and rejection.
+Same verdict, same number of bits, same fields.  CPU only.
+
+One documented difference (include/jxl_hip_frame.h): the reference also refuses CUSTOM white
+points / primaries its ICC synthesiser cannot express; for strings that code custom chromaticities
+the test asks for agreement only when the reference accepts."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from libjxl_amd import abi
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not available")
+    R = oracle.ref_lib()
+    R.jxr_image_header_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_size_t)]
+    return R
+
+
+@pytest.fixture(scope="module")
+def L():
+    return abi.load_library()
+
+
+def f32bits(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def u32(v):
+    return int(v) & 0xFFFFFFFF
+
+
+def flatten(h, ec):
+    """jxlhip_image_header in the order oracle/ref_driver.cc jxr_image_header_read writes."""
+    o = [h.xsize, h.ysize, h.all_default, h.orientation, h.have_intrinsic_size]
+    if h.have_intrinsic_size:
+        o += [h.intrinsic_xsize, h.intrinsic_ysize]
+    o += [h.have_preview]
+    if h.have_preview:
+        o += [h.preview_xsize, h.preview_ysize]
+    o += [h.have_animation]
+    if h.have_animation:
+        o += [h.tps_numerator, h.tps_denominator, h.num_loops, h.have_timecodes]
+    b = h.bit_depth
+    o += [b.floating_point_sample, b.bits_per_sample, b.exponent_bits_per_sample]
+    o += [h.modular_16_bit_buffer_sufficient, h.num_extra_channels, h.xyb_encoded]
+    c = h.color_encoding
+    o += [c.all_default, c.want_icc, c.color_space]
+    if not c.want_icc:
+        o += [c.white_point]
+        if c.white_point == 2:
+            o += [u32(v) for v in c.white_xy]
+        if c.color_space in (0, 3):
+            o += [c.primaries]
+            if c.primaries == 2:
+                o += [u32(v) for v in c.primaries_xy]
+        o += [c.have_gamma, c.gamma if c.have_gamma else c.transfer_function, c.rendering_intent]
+    o += [f32bits(h.intensity_target), f32bits(h.min_nits), h.relative_to_max_display, f32bits(h.linear_below),
+          h.extensions, h.transform_all_default]
+    o += [f32bits(v) for v in h.inverse_opsin_matrix] + [f32bits(v) for v in h.opsin_biases]
+    o += [f32bits(v) for v in h.quant_biases] + [h.custom_weights_mask]
+    for bit, w in ((1, h.upsampling2_weights), (2, h.upsampling4_weights), (4, h.upsampling8_weights)):
+        if h.custom_weights_mask & bit:
+            o += [f32bits(v) for v in w]
+    for e in ec[:min(h.num_extra_channels, 8)]:
+        d = e.bit_depth
+        o += [e.type, d.floating_point_sample, d.bits_per_sample, d.exponent_bits_per_sample, e.dim_shift,
+              e.name_length]
+        if e.type == 0:
+            o += [e.alpha_associated]
+        if e.type == 2:
+            o += [f32bits(v) for v in e.spot_color]
+        if e.type == 5:
+            o += [e.cfa_channel]
+    return [int(v) for v in o]
+
+
+def both(L, R, data):
+    d = np.frombuffer(data, np.uint8)
+    h = abi.ImageHeader()
+    ec = (abi.ExtraChannel * 8)()
+    pos = C.c_size_t(0)
+    rc = L.jxlhip_image_header_decode(d.ctypes.data, len(d), C.byref(pos), ec, 8, C.byref(h))
+    out = np.zeros(800, np.uint64)
+    n, bits = C.c_size_t(0), C.c_size_t(0)
+    want_rc = R.jxr_image_header_read(d.ctypes.data, len(d), out.ctypes.data, C.byref(n), C.byref(bits))
+    return rc, h, ec, pos.value, want_rc, [int(v) for v in out[:n.value]], bits.value
+
+
+def test_headers_of_genuine_codestreams(L, ref, oracle):
+    for kw in (dict(xsize=520, ysize=300, distance=1.0), dict(xsize=776, ysize=520, distance=3.0, progressive=1),
+               dict(xsize=256, ysize=256), dict(xsize=200, ysize=136, epf=0)):
+        rs = oracle.RealStream(seed=9, speed_tier=3, **kw)
+        cs = rs.codestream.tobytes()
+        rc, h, ec, pos, want_rc, out, bits = both(L, ref, cs)
+        assert rc == 0 and want_rc == 0
+        assert pos == bits == rs.frame_offset * 8
+        assert flatten(h, ec) == out
+        assert (h.xsize, h.ysize, h.xyb_encoded, h.num_extra_channels) == (rs.xsize, rs.ysize, 1, 0)
+        # what the back-end takes from it is what the harness's decoder state holds
+        p = rs.frame_params
+        assert list(h.quant_biases) == list(p.quant_biases)
+        assert list(h.opsin_biases) == list(p.opsin_biases)
+        scale = np.float32(255.0) / np.float32(h.intensity_target)
+        assert [float(np.float32(v) * scale) for v in h.inverse_opsin_matrix] == list(p.inverse_opsin_matrix)
+        # ... and feeds the frame header parser
+        info = abi.ImageInfo(h.xsize, h.ysize, h.xyb_encoded, h.num_extra_channels, None, h.have_animation,
+                             h.have_timecodes, 0)
+        fh = abi.FrameHeader()
+        d = np.frombuffer(cs, np.uint8)
+        fpos = C.c_size_t(pos)
+        assert L.jxlhip_frame_header_decode(d.ctypes.data, len(d), C.byref(fpos), C.byref(info), C.byref(fh)) == 0
+        assert fpos.value == rs.frame_offset * 8 + rs.toc_bit_offset
+        assert fh.num_groups == rs.num_groups
+
+
+def has_custom_xy(h):
+    c = h.color_encoding
+    return (not c.want_icc) and (c.white_point == 2 or (c.color_space in (0, 3) and c.primaries == 2))
+
+
+class Bits:
+    """LSB-first bit writer with the field coders of lib/jxl/fields.cc (U32 selector + payload, Enum,
+    F16, U64) driven by a random generator: writes image headers that are valid most of the time,
+    with every branch taken, and now and then a value the format forbids."""
+
+    def __init__(self, rng, wild):
+        self.rng, self.wild, self.b = rng, wild, []
+
+    def put(self, v, n):
+        self.b += [(int(v) >> i) & 1 for i in range(n)]
+
+    def coin(self, p=0.5):
+        v = int(self.rng.random() < p)
+        self.put(v, 1)
+        return v
+
+    def rand(self, n):
+        v = int(self.rng.integers(0, 1 << n)) if n else 0
+        self.put(v, n)
+        return v
+
+    def u32(self, bits, weights=None):
+        sel = int(self.rng.choice(4, p=weights))
+        self.put(sel, 2)
+        self.rand(bits[sel])
+        return sel
+
+    def enum(self, valid):
+        v = int(self.rng.choice(valid)) if self.rng.random() > self.wild else int(self.rng.integers(0, 82))
+        if v < 2:
+            self.put(v, 2)
+        elif v < 18:
+            self.put(2, 2), self.put(v - 2, 4)
+        else:
+            self.put(3, 2), self.put(v - 18, 6)
+        return v
+
+    def f16(self, positive=False):
+        e = int(self.rng.integers(0, 31)) if self.rng.random() > self.wild / 4 else 31
+        v = int(self.rng.integers(0, 1024)) | (e << 10) | (0 if positive else int(self.rng.integers(0, 2)) << 15)
+        self.put(v, 16)
+
+    def u64(self, v):
+        if v == 0:
+            self.put(0, 2)
+        elif v <= 16:
+            self.put(1, 2), self.put(v - 1, 4)
+        elif v <= 272:
+            self.put(2, 2), self.put(v - 17, 8)
+        else:
+            self.put(3, 2), self.put(v & 0xFFF, 12)
+            v >>= 12
+            while v:
+                self.put(1, 1), self.put(v & 0xFF, 8)
+                v >>= 8
+            self.put(0, 1)
+
+    def size_header(self):
+        small = self.coin()
+        if small:
+            self.rand(5)
+        else:
+            self.u32((9, 13, 18, 30), (0.5, 0.3, 0.15, 0.05))
+        ratio = int(self.rng.integers(0, 8)) if self.rng.random() < 0.5 else 0
+        self.put(ratio, 3)
+        if ratio == 0:
+            if small:
+                self.rand(5)
+            else:
+                self.u32((9, 13, 18, 30), (0.5, 0.3, 0.15, 0.05))
+
+    def preview_header(self):
+        div8 = self.coin()
+        dist = (0, 0, 5, 9) if div8 else (6, 8, 10, 12)
+        self.u32(dist)
+        ratio = int(self.rng.integers(0, 8)) if self.rng.random() < 0.5 else 0
+        self.put(ratio, 3)
+        if ratio == 0:
+            self.u32(dist)
+
+    def bit_depth(self):
+        if not self.coin(0.3):
+            if self.u32((0, 0, 0, 0), (0.3, 0.3, 0.3, 0.1)) == 3:
+                self.put(int(self.rng.integers(0, 31 if self.rng.random() > self.wild else 64)), 6)
+            return
+        exp = int(self.rng.integers(2, 9))
+        if self.rng.random() < self.wild:
+            exp = int(self.rng.integers(1, 17))
+        sel = int(self.rng.integers(0, 4))
+        self.put(sel, 2)
+        if sel == 3:
+            bits = exp + 1 + int(self.rng.integers(2, 24))
+            self.put(min(max(bits - 1, 0), 63), 6)
+        self.put(exp - 1, 4)
+
+    def extra_channel(self):
+        if self.coin(0.2):
+            return
+        t = self.enum([0, 1, 2, 3, 4, 5, 6, 16, 16, 0, 2, 5] + ([15] if self.rng.random() < self.wild else []))
+        self.bit_depth()
+        self.u32((0, 0, 0, 3), (0.5, 0.3, 0.02, 0.18))
+        sel = self.u32((0, 4, 5, 0), (0.5, 0.3, 0.15, 0.05))  # name: selector 3 -> 48 + Bits(10), kept at 48..
+        n = 0
+        if sel == 1:
+            n = sum(self.b[-4 + i] << i for i in range(4))
+        elif sel == 2:
+            n = 16 + sum(self.b[-5 + i] << i for i in range(5))
+        elif sel == 3:
+            extra = int(self.rng.integers(0, 8))
+            self.put(extra, 10)
+            n = 48 + extra
+        for _ in range(n):
+            self.rand(8)
+        if t == 0:
+            self.coin()
+        if t == 2:
+            for _ in range(4):
+                self.f16()
+        if t == 5:
+            self.u32((0, 2, 4, 8))
+
+    def custom_xy(self):
+        for _ in range(2):
+            self.u32((19, 19, 20, 21), (0.7, 0.1, 0.1, 0.1))
+
+    def color_encoding(self):
+        if self.coin(0.25):
+            return
+        want_icc = self.coin(0.15)
+        cs = self.enum([0, 0, 0, 1, 2] + ([3] if self.rng.random() < self.wild else []))
+        if want_icc or cs >= 4:
+            return
+        if cs != 2:
+            if self.enum([1, 1, 2, 10, 11]) == 2:
+                self.custom_xy()
+        if cs in (0, 3):
+            if self.enum([1, 1, 2, 9, 11]) == 2:
+                for _ in range(3):
+                    self.custom_xy()
+        if cs != 2:
+            if self.coin(0.3):
+                g = int(self.rng.integers(1221, 10000001)) if self.rng.random() > self.wild else self.rng.integers(0, 1 << 24)
+                self.put(g, 24)
+            else:
+                self.enum([1, 8, 13, 16, 17, 18] + ([2] if self.rng.random() < self.wild else []))
+        self.enum([0, 1, 2, 3] if cs != 2 or self.rng.random() < self.wild else [0])
+
+    def image_header(self):
+        self.put(0xFF, 8), self.put(0x0A, 8)
+        self.size_header()
+        xyb = 1
+        if not self.coin(0.1):  # ImageMetadata not all_default
+            extra_fields = self.coin(0.6)
+            if extra_fields:
+                self.rand(3)
+                if self.coin(0.3):
+                    self.size_header()
+                if self.coin(0.3):
+                    self.preview_header()
+                if self.coin(0.3):
+                    self.u32((0, 0, 10, 30)), self.u32((0, 0, 8, 10)), self.u32((0, 3, 16, 32)), self.coin()
+            self.bit_depth()
+            self.coin(0.8)
+            sel = self.u32((0, 0, 4, 12), (0.4, 0.3, 0.25, 0.05))
+            num_ec = (0, 1, 2, 1)[sel]
+            if sel == 2:
+                k = int(self.rng.integers(0, 5))
+                self.b[-4:] = [(k >> i) & 1 for i in range(4)]
+                num_ec = 2 + k
+            elif sel == 3:
+                k = int(self.rng.integers(0, 9))
+                self.b[-12:] = [(k >> i) & 1 for i in range(12)]
+                num_ec = 1 + k
+            for _ in range(num_ec):
+                self.extra_channel()
+            xyb = self.coin(0.7)
+            self.color_encoding()
+            if extra_fields and not self.coin(0.3):  # ToneMapping
+                self.f16(positive=self.rng.random() > self.wild)
+                self.put(0, 16) if self.rng.random() < 0.6 else self.f16(positive=True)
+                self.coin()
+                self.put(0, 16) if self.rng.random() < 0.6 else self.f16(positive=True)
+            if self.rng.random() < 0.8:
+                self.u64(0)
+            else:  # extensions: a mask, one bit count per set bit, then the payload
+                mask = int(self.rng.integers(1, 1 << int(self.rng.integers(1, 20))))
+                self.u64(mask)
+                total = 0
+                for _ in range(bin(mask).count("1")):
+                    nb = int(self.rng.integers(0, 40))
+                    self.u64(nb)
+                    total += nb
+                if self.rng.random() < self.wild:
+                    total = max(0, total - 3)
+                for _ in range(total):
+                    self.rand(1)
+        if not self.coin(0.5):  # CustomTransformData not all_default
+            if xyb and not self.coin(0.4):
+                for _ in range(16):
+                    self.f16()
+            mask = int(self.rng.integers(0, 8)) if self.rng.random() < 0.4 else 0
+            self.put(mask, 3)
+            for bit, n in ((1, 15), (2, 55), (4, 210)):
+                if mask & bit:
+                    for _ in range(n):
+                        self.f16()
+        while len(self.b) % 8:
+            self.put(int(self.rng.random() < self.wild / 2), 1)
+        for _ in range(int(self.rng.integers(0, 4))):
+            self.rand(8)
+        return np.packbits(np.array(self.b, np.uint8), bitorder="little").tobytes()
+
+
+@pytest.mark.parametrize("flavour", range(8))
+def test_random_headers_against_the_reference(L, ref, flavour):
+    """flavours 0-4: headers WRITTEN field by field with random choices (valid most of the time:
+    deep paths -- extra channels, custom chromaticities, animation, tone mapping, extensions, custom
+    opsin matrix and upsampling weights); 5-7: raw random bit strings (mostly rejected)."""
+    rng = np.random.default_rng(4242 + flavour)
+    agree_ok = agree_bad = custom = 0
+    for trial in range(2500):
+        if flavour < 5:
+            data = Bits(rng, wild=(0.0, 0.03, 0.1, 0.03, 0.3)[flavour]).image_header()
+            if flavour == 3 and len(data) > 4:  # one flipped bit somewhere behind the signature
+                b = bytearray(data)
+                k = int(rng.integers(16, len(b) * 8))
+                b[k // 8] ^= 1 << (k % 8)
+                data = bytes(b)
+        else:
+            n = int(rng.integers(4, 40))
+            b = rng.integers(0, 256, n, dtype=np.uint8)
+            for _ in range(flavour - 5):
+                b[2:] &= rng.integers(0, 256, n - 2, dtype=np.uint8)  # sparser bits: short selectors, defaults
+            b[0], b[1] = 0xFF, 0x0A
+            data = b.tobytes()
+        rc, h, ec, pos, want_rc, out, bits = both(L, ref, data)
+        if rc == 0 and want_rc != 0 and has_custom_xy(h):
+            custom += 1  # the documented difference
+            continue
+        assert (rc == 0) == (want_rc == 0), (trial, rc, want_rc, data.hex())
+        if rc == 0:
+            agree_ok += 1
+            assert pos == bits, (trial, pos, bits, data.hex())
+            assert flatten(h, ec) == out, (trial, data.hex())
+        else:
+            agree_bad += 1
+    if flavour == 0:
+        assert agree_ok > 1200, (agree_ok, agree_bad, custom)
+    elif flavour < 5:
+        assert agree_ok > 300 and agree_bad > 100, (agree_ok, agree_bad, custom)
+    else:
+        assert agree_bad > 1000, (agree_ok, agree_bad, custom)
+
+
+def test_bad_arguments_and_signature(L):
+    h = abi.ImageHeader()
+    pos = C.c_size_t(0)
+    d = np.array([0xFF, 0x0B, 0, 0, 0, 0], np.uint8)
+    assert L.jxlhip_image_header_decode(d.ctypes.data, len(d), C.byref(pos), None, 0, C.byref(h)) == -5
+    assert L.jxlhip_image_header_decode(None, 0, C.byref(pos), None, 0, C.byref(h)) == -1
+    assert L.jxlhip_image_header_decode(d.ctypes.data, len(d), C.byref(pos), None, 4, C.byref(h)) == \
+        -1
+    d = np.array([0xFF, 0x0A], np.uint8)  # truncated right after the signature
+    assert L.jxlhip_image_header_decode(d.ctypes.data, len(d), C.byref(pos), None, 0, C.byref(h)) == -5
