@@ -36,10 +36,11 @@ extern "C" {
  * quant biases (jxlhip_frame_params), intensity_target (the 255/intensity_target scale of the matrix,
  * dec_xyb.cc:175-186), the enumerated colour encoding and bit depth (jxlhip_output_format), and the inputs
  * of jxlhip_frame_header_decode (jxlhip_image_info).
+ * The reference also refuses headers whose CUSTOM white point / primaries its ICC synthesiser cannot express
+ * (ColorEncoding::CreateICC at the end of VisitFields; cms/jxl_cms_internal.h:43-126,235-244,354-372,403-409):
+ * those conditions are restated (no profile is written), so the verdicts agree.
  * Not here (colour management, out of scope): the ICC stream that follows when color_encoding.want_icc is
- * set is left unread, and the reference's extra rejection of CUSTOM white points / primaries that its ICC
- * synthesiser cannot express (ColorEncoding::CreateICC, cms/jxl_cms_internal.h:43-126) is not reproduced:
- * such chromaticities are returned as coded. */
+ * set is left unread. */
 typedef struct jxlhip_bit_depth {
   uint32_t floating_point_sample, bits_per_sample, exponent_bits_per_sample;
 } jxlhip_bit_depth;
@@ -109,7 +110,7 @@ typedef struct jxlhip_image_header {
  * On success *bit_pos is the first bit after CustomTransformData when an ICC stream follows
  * (color_encoding.want_icc), otherwise the byte-aligned position of the first frame header (the
  * padding bits must be zero, BitReader::JumpToByteBoundary).  JXLHIP_ERR_BAD_STREAM on everything
- * the reference rejects (see the note on custom chromaticities above) and on truncation. */
+ * the reference rejects and on truncation. */
 JXLHIP_EXPORT int jxlhip_image_header_decode(const uint8_t* data, size_t size, size_t* bit_pos,
                                              jxlhip_extra_channel* extra, size_t extra_capacity,
                                              jxlhip_image_header* out);

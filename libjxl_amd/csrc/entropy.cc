@@ -1689,6 +1689,134 @@ int32_t ReadCustomXy(FieldReader* r) {  // color_encoding_internal.cc:106-120, p
   return (int32_t)((u >> 1) ^ (0u - (u & 1)));
 }
 
+// ---- can the reference synthesise an ICC profile for these custom chromaticities? ----
+// ColorEncoding::VisitFields ends in CreateICC() (color_encoding_internal.cc:207), so a header whose
+// CUSTOM white point / primaries make MaybeCreateProfileImpl fail is rejected by the reference.  Only
+// the conditions are restated here (no profile is written), in the reference's own mix of float and
+// double arithmetic: cms/jxl_cms_internal.h:43-126 (PrimariesToXYZ, AdaptToXYZD50), :235-244
+// (CIEXYZFromWhiteCIExy), :354-372, :403-409 (the s15Fixed16 range), base/matrix_ops.h.
+typedef float Mat3[3][3];
+bool S15Fixed16Ok(float v) { return -32767.995f <= v && v <= 32767.995f; }
+
+void MulMat(const Mat3 a, const Mat3 b, Mat3 c) {
+  for (int x = 0; x < 3; x++) {
+    const double t[3] = {b[0][x], b[1][x], b[2][x]};
+    for (int y = 0; y < 3; y++) c[y][x] = (float)(a[y][0] * t[0] + a[y][1] * t[1] + a[y][2] * t[2]);
+  }
+}
+
+void MulVec(const Mat3 a, const float b[3], float c[3]) {
+  for (int y = 0; y < 3; y++) {
+    double e = 0;
+    for (int x = 0; x < 3; x++) e += (double)a[y][x] * b[x];
+    c[y] = (float)e;
+  }
+}
+
+bool InvMat(Mat3 m) {
+  double t[3][3];
+  t[0][0] = (double)m[1][1] * m[2][2] - (double)m[1][2] * m[2][1];
+  t[0][1] = (double)m[0][2] * m[2][1] - (double)m[0][1] * m[2][2];
+  t[0][2] = (double)m[0][1] * m[1][2] - (double)m[0][2] * m[1][1];
+  t[1][0] = (double)m[1][2] * m[2][0] - (double)m[1][0] * m[2][2];
+  t[1][1] = (double)m[0][0] * m[2][2] - (double)m[0][2] * m[2][0];
+  t[1][2] = (double)m[0][2] * m[1][0] - (double)m[0][0] * m[1][2];
+  t[2][0] = (double)m[1][0] * m[2][1] - (double)m[1][1] * m[2][0];
+  t[2][1] = (double)m[0][1] * m[2][0] - (double)m[0][0] * m[2][1];
+  t[2][2] = (double)m[0][0] * m[1][1] - (double)m[0][1] * m[1][0];
+  const double det = m[0][0] * t[0][0] + m[0][1] * t[1][0] + m[0][2] * t[2][0];
+  if (std::abs(det) < 1e-10) return false;
+  const double idet = 1.0 / det;
+  for (int j = 0; j < 3; j++) {
+    for (int i = 0; i < 3; i++) m[j][i] = (float)(t[j][i] * idet);
+  }
+  return true;
+}
+
+bool WhiteInRange(float wx, float wy) { return (wx >= 0) && (wx <= 1) && (wy > 0) && (wy <= 1); }
+
+bool PrimariesToXyz(const float p[6], float wx, float wy, Mat3 out) {
+  if (!WhiteInRange(wx, wy)) return false;
+  const Mat3 prim = {{p[0], p[2], p[4]}, {p[1], p[3], p[5]}, {1.0f - p[0] - p[1], 1.0f - p[2] - p[3], 1.0f - p[4] - p[5]}};
+  Mat3 inv;
+  memcpy(inv, prim, sizeof(inv));
+  if (!InvMat(inv)) return false;
+  const float w[3] = {wx / wy, 1.0f, (1.0f - wx - wy) / wy};
+  if (!std::isfinite(w[0]) || !std::isfinite(w[2])) return false;
+  float xyz[3];
+  MulVec(inv, w, xyz);
+  const Mat3 a = {{xyz[0], 0, 0}, {0, xyz[1], 0}, {0, 0, xyz[2]}};
+  MulMat(prim, a, out);
+  return true;
+}
+
+bool AdaptToXyzD50(float wx, float wy, Mat3 out) {
+  static const Mat3 kBradford = {{0.8951f, 0.2664f, -0.1614f}, {-0.7502f, 1.7135f, 0.0367f}, {0.0389f, -0.0685f, 1.0296f}};
+  static const Mat3 kBradfordInv = {{0.9869929f, -0.1470543f, 0.1599627f},
+                                    {0.4323053f, 0.5183603f, 0.0492912f},
+                                    {-0.0085287f, 0.0400428f, 0.9684867f}};
+  if (!WhiteInRange(wx, wy)) return false;
+  const float w[3] = {wx / wy, 1.0f, (1.0f - wx - wy) / wy};
+  if (!std::isfinite(w[0]) || !std::isfinite(w[2])) return false;
+  const float w50[3] = {0.96422f, 1.0f, 0.82521f};
+  float lms[3], lms50[3];
+  MulVec(kBradford, w, lms);
+  MulVec(kBradford, w50, lms50);
+  if (lms[0] == 0 || lms[1] == 0 || lms[2] == 0) return false;
+  const Mat3 a = {{lms50[0] / lms[0], 0, 0}, {0, lms50[1] / lms[1], 0}, {0, 0, lms50[2] / lms[2]}};
+  if (!std::isfinite(a[0][0]) || !std::isfinite(a[1][1]) || !std::isfinite(a[2][2])) return false;
+  Mat3 b;
+  MulMat(a, kBradford, b);
+  MulMat(kBradfordInv, b, out);
+  return true;
+}
+
+bool IccExpressible(const jxlhip_color_encoding& c) {
+  const bool custom_white = c.white_point == JXLHIP_WP_CUSTOM;
+  const bool rgb = c.color_space == JXLHIP_CS_RGB;
+  if (c.color_space == JXLHIP_CS_XYB || !(custom_white || (rgb && c.primaries == JXLHIP_PRIM_CUSTOM))) return true;
+  double wx, wy;  // ColorEncoding::GetWhitePoint, cms/color_encoding_cms.h:435-465
+  switch (c.white_point) {
+    case JXLHIP_WP_CUSTOM: wx = c.white_xy[0] * (1.0 / 1000000), wy = c.white_xy[1] * (1.0 / 1000000); break;
+    case JXLHIP_WP_DCI: wx = 0.314, wy = 0.351; break;
+    case JXLHIP_WP_E: wx = wy = 1.0 / 3; break;
+    default: wx = 0.3127, wy = 0.3290; break;
+  }
+  if (c.color_space == JXLHIP_CS_GRAY) {  // the white point tag
+    if (std::abs(wy) < 1e-12) return false;
+    const float factor = (float)(1 / wy);
+    return S15Fixed16Ok((float)(wx * factor)) && S15Fixed16Ok((float)((1 - wx - wy) * factor));
+  }
+  if (wy == 0) return false;
+  Mat3 chad;  // the chromatic adaptation tag
+  if (!AdaptToXyzD50((float)wx, (float)wy, chad)) return false;
+  for (int j = 0; j < 3; j++) {
+    for (int i = 0; i < 3; i++) {
+      if (!S15Fixed16Ok(chad[j][i])) return false;
+    }
+  }
+  if (!rgb) return true;
+  static const double kSrgb[6] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204};
+  static const double k2100[6] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046};
+  static const double kP3[6] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060};
+  float p[6];  // GetPrimaries, cms/color_encoding_cms.h:354-395
+  for (int i = 0; i < 6; i++) {
+    p[i] = (float)(c.primaries == JXLHIP_PRIM_CUSTOM ? c.primaries_xy[i] * (1.0 / 1000000)
+                   : c.primaries == JXLHIP_PRIM_2100 ? k2100[i]
+                   : c.primaries == JXLHIP_PRIM_P3   ? kP3[i]
+                                                     : kSrgb[i]);
+  }
+  Mat3 to_xyz, d50, m;  // the rXYZ / gXYZ / bXYZ tags
+  if (!PrimariesToXyz(p, (float)wx, (float)wy, to_xyz) || !AdaptToXyzD50((float)wx, (float)wy, d50)) return false;
+  MulMat(d50, to_xyz, m);
+  for (int j = 0; j < 3; j++) {
+    for (int i = 0; i < 3; i++) {
+      if (!S15Fixed16Ok(m[j][i])) return false;
+    }
+  }
+  return true;
+}
+
 bool ReadColorEncoding(FieldReader* r, jxlhip_color_encoding* c) {  // color_encoding_internal.cc:148-216
   memset(c, 0, sizeof(*c));
   c->white_point = JXLHIP_WP_D65;
@@ -1734,7 +1862,7 @@ bool ReadColorEncoding(FieldReader* r, jxlhip_color_encoding* c) {  // color_enc
   if (c->color_space == JXLHIP_CS_UNKNOWN || (!c->have_gamma && c->transfer_function == 2)) return false;
   // MaybeCreateProfileImpl (cms/jxl_cms_internal.h:989-995): an XYB profile exists for one intent only
   if (c->color_space == JXLHIP_CS_XYB && c->rendering_intent != 0) return false;
-  return true;
+  return IccExpressible(*c);
 }
 }  // namespace
 
