@@ -189,6 +189,39 @@ typedef struct jxlhip_dc_global {
 JXLHIP_EXPORT int jxlhip_dc_global_decode(const uint8_t* data, size_t size, size_t* bit_pos, uint64_t frame_flags,
                                           jxlhip_dc_global* out);
 
+/* ---- The Modular-coded parts of a VarDCT frame: global MA tree and the DC groups ----
+ * Replaces (libjxl tree, lib/jxl/): ModularFrameDecoder::DecodeGlobalInfo (dec_modular.cc:207-316),
+ * FrameDecoder::ProcessDCGroup (dec_frame.cc:318-342) = DecodeVarDCTDC + DecodeAcMetadata
+ * (dec_modular.cc:427-562), over DecodeTree (modular/encoding/dec_ma.cc), ModularDecode
+ * (modular/encoding/encoding.cc:553-680) and the property / predictor definitions of
+ * modular/encoding/context_predict.h, the self-correcting predictor included.
+ * JXLHIP_ERR_UNSUPPORTED for what libjxl's encoder does not write into these streams: transforms
+ * (RCT, palette, squeeze), LZ77 with 2-D distances; also for chroma subsampling and DC frames. */
+typedef struct jxlhip_modular_tree jxlhip_modular_tree;
+
+/* The rest of the DC-global section behind jxlhip_dc_global_decode: *tree receives the global MA
+ * tree and its entropy code (NULL when the section carries none: every stream then has its own). */
+JXLHIP_EXPORT int jxlhip_modular_global_decode(const uint8_t* data, size_t size, size_t* bit_pos,
+                                               const jxlhip_frame_header* frame, jxlhip_modular_tree** tree);
+JXLHIP_EXPORT void jxlhip_modular_tree_destroy(jxlhip_modular_tree* tree);
+
+/* One DC group section (section 1 + dc_group of the TOC).  All outputs are FRAME-level arrays in the
+ * layouts jxlhip_upload_side_info / jxlhip_dequant_dc take, of which this call fills the group's
+ * rectangle (256x256 blocks at the default group size):
+ *   quant_dc[3]     X, Y, B: int32, xsize_blocks*ysize_blocks -- the input of jxlhip_dequant_dc, with
+ *                   *extra_precision (0..3): DequantDC multiplies by 1 / (1 << extra_precision)
+ *   ac_strategy     (type << 1) | first_block, one byte per block
+ *   raw_quant       int32 in [1, 256], written at the first block of each varblock
+ *   epf_sharpness   0..7 per block
+ *   ytox_map, ytob_map   int8 per 8x8 blocks, ceil(xsize_blocks/8) per row
+ *   *used_acs       |= bit per strategy type seen (jxlhip_frame_params::used_acs)
+ * Safe to call from several threads for different groups. */
+JXLHIP_EXPORT int jxlhip_dc_group_decode(const jxlhip_modular_tree* global_tree, const uint8_t* data, size_t size,
+                                         size_t* bit_pos, const jxlhip_frame_header* frame, uint32_t dc_group,
+                                         int32_t* const quant_dc[3], uint32_t* extra_precision,
+                                         uint8_t* ac_strategy, int32_t* raw_quant, uint8_t* epf_sharpness,
+                                         int8_t* ytox_map, int8_t* ytob_map, uint32_t* used_acs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,6 +223,7 @@ EXPORTS = [
     "jxlhip_ac_groups_decode_submit", "jxlhip_num_toc_entries", "jxlhip_toc_decode",
     # include/jxl_hip_frame.h
     "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode",
+    "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
 ]
 
 
@@ -265,6 +266,12 @@ def load_library():
     L.jxlhip_toc_decode.argtypes = [vp, sz, C.POINTER(sz), u32, vp, vp, vp]
     L.jxlhip_frame_header_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(ImageInfo), C.POINTER(FrameHeader)]
     L.jxlhip_dc_global_decode.argtypes = [vp, sz, C.POINTER(sz), C.c_uint64, C.POINTER(DcGlobal)]
+    L.jxlhip_modular_global_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(FrameHeader), C.POINTER(vp)]
+    L.jxlhip_modular_tree_destroy.argtypes = [vp]
+    L.jxlhip_modular_tree_destroy.restype = None
+    L.jxlhip_dc_group_decode.argtypes = [vp, vp, sz, C.POINTER(sz), C.POINTER(FrameHeader), C.c_uint32,
+                                         C.POINTER(vp), C.POINTER(C.c_uint32), vp, vp, vp, vp, vp,
+                                         C.POINTER(C.c_uint32)]
     L.jxlhip_image_header_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(ExtraChannel), sz,
                                              C.POINTER(ImageHeader)]
     L.jxlhip_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]

@@ -753,7 +753,7 @@ int DecodeEntropyCode(BitReader* br, size_t num_contexts, EntropyCode* code, boo
       while (!counts.empty() && counts.back() == 0) counts.pop_back();
       for (size_t s = 0; s < counts.size(); s++)
         if (counts[s]) code->UpdateMaxNumBits(h, (uint32_t)s);
-      if (!BuildAliasTable(counts, code->log_alpha, &code->alias[h << code->log_alpha])) return kBad;
+          if (!BuildAliasTable(counts, code->log_alpha, &code->alias[h << code->log_alpha])) return kBad;
       if (!br->Healthy()) return kBad;
     }
   }
@@ -1987,6 +1987,8 @@ int jxlhip_image_header_decode(const uint8_t* data, size_t size, size_t* bit_pos
   }
   return kOk;
 }
+
+#include "modular.inc"
 
 int jxlhip_dequant_encodings_decode(const uint8_t* data, size_t size, size_t* bit_pos, jxlhip_quant_encoding* enc) {
   if (!data || !bit_pos || !enc) return JXLHIP_ERR_INVALID_ARGUMENT;

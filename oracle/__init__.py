@@ -315,13 +315,16 @@ def ref_dequant_decode(data):
     return rc, t, bits.value
 
 
-def ref_dequant_dc(quant_dc, mul_dc, cfl_x_dc, cfl_b_dc, smooth):
-    """DequantDC (+AdaptiveDCSmoothing) by the reference; quant_dc: 3 int32 planes."""
+def ref_dequant_dc(quant_dc, mul_dc, cfl_x_dc, cfl_b_dc, smooth, mul=1.0):
+    """DequantDC (+AdaptiveDCSmoothing) by the reference; quant_dc: 3 int32 planes;
+    mul = 1 / (1 << extra_precision) of the DC group."""
     ysb, xsb = quant_dc[0].shape
     q = [np.ascontiguousarray(a, np.int32) for a in quant_dc]
     out = [np.zeros((ysb, xsb), np.float32) for _ in range(3)]
     m = np.ascontiguousarray(mul_dc, np.float32)
-    rc = ref_lib().jxr_dequant_dc(xsb, ysb, _p3(q), _p3(out), _p(m), cfl_x_dc, cfl_b_dc, int(smooth))
+    fn = ref_lib().jxr_dequant_dc_mul
+    fn.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]
+    rc = fn(xsb, ysb, _p3(q), _p3(out), _p(m), mul, cfl_x_dc, cfl_b_dc, int(smooth))
     assert rc == 0
     return out
 

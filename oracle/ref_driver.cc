@@ -58,6 +58,7 @@
 #include "lib/jxl/image_metadata.h"
 #include "lib/jxl/loop_filter.h"
 #include "lib/jxl/memory_manager_internal.h"
+#include "lib/jxl/modular/encoding/dec_ma.h"
 #include "lib/jxl/modular/modular_image.h"
 #include "lib/jxl/modular/transform/transform.h"
 #include "lib/jxl/ac_context.h"
@@ -552,8 +553,9 @@ JXR_EXPORT int jxr_default_dequant_tables(float* table) {
 }
 
 // DequantDC + AdaptiveDCSmoothing (lib/jxl/compressed_dc.cc:128-250), 4:4:4.
-JXR_EXPORT int jxr_dequant_dc(uint32_t xsb, uint32_t ysb, const int32_t* const quant_dc[3], float* const dc[3],
-                              const float mul_dc[3], float cfl_x_dc, float cfl_b_dc, int smooth) {
+// mul = 1 / (1 << extra_precision) of the DC group (dec_modular.cc:445-446)
+JXR_EXPORT int jxr_dequant_dc_mul(uint32_t xsb, uint32_t ysb, const int32_t* const quant_dc[3], float* const dc[3],
+                                  const float mul_dc[3], float mul, float cfl_x_dc, float cfl_b_dc, int smooth) {
   Ref ref;
   auto run = [&]() -> Status {
     JXL_ASSIGN_OR_RETURN(Image3F out, Image3F::Create(&ref.mm, xsb, ysb));
@@ -569,7 +571,7 @@ JXR_EXPORT int jxr_dequant_dc(uint32_t xsb, uint32_t ysb, const int32_t* const q
     const float cfl[4] = {cfl_x_dc, 0.0f, cfl_b_dc, 0.0f};
     BlockCtxMap bctx;
     JXL_ASSIGN_OR_RETURN(ImageB qdc, ImageB::Create(&ref.mm, xsb, ysb));
-    DequantDC(Rect(0, 0, xsb, ysb), &out, &qdc, im, dc_factors, 1.0f, cfl, YCbCrChromaSubsampling(), bctx);
+    DequantDC(Rect(0, 0, xsb, ysb), &out, &qdc, im, dc_factors, mul, cfl, YCbCrChromaSubsampling(), bctx);
     if (smooth) {
       JXL_RETURN_IF_ERROR(AdaptiveDCSmoothing(&ref.mm, dc_factors, &out, nullptr));
     }
@@ -581,6 +583,11 @@ JXR_EXPORT int jxr_dequant_dc(uint32_t xsb, uint32_t ysb, const int32_t* const q
     return true;
   };
   return run() ? 0 : -1;
+}
+
+JXR_EXPORT int jxr_dequant_dc(uint32_t xsb, uint32_t ysb, const int32_t* const quant_dc[3], float* const dc[3],
+                              const float mul_dc[3], float cfl_x_dc, float cfl_b_dc, int smooth) {
+  return jxr_dequant_dc_mul(xsb, ysb, quant_dc, dc, mul_dc, 1.0f, cfl_x_dc, cfl_b_dc, smooth);
 }
 
 JXR_EXPORT const char* jxr_describe(void) {
@@ -960,4 +967,27 @@ JXR_EXPORT int jxr_image_header_read(const uint8_t* data, size_t size, uint64_t*
   }
   *n_out = n;
   return 0;
+}
+
+
+// DecodeTree + DecodeHistograms (modular/encoding/dec_ma.cc, dec_ans.cc) by the reference at bit
+// position bit_pos of data: number of nodes, bits consumed after the tree and after the histograms.
+JXR_EXPORT int jxr_modular_tree_read(const uint8_t* data, size_t size, size_t bit_pos, size_t limit, uint64_t* out) {
+  Ref ref;
+  JxlMemoryManager* mm = &ref.mm;
+  BitReader br(Bytes(data, size));
+  br.SkipBits(bit_pos);
+  Tree tree;
+  Status ok = DecodeTree(mm, &br, &tree, limit);
+  out[0] = tree.size();
+  out[1] = br.TotalBitsConsumed();
+  ANSCode code;
+  std::vector<uint8_t> context_map;
+  if (ok) ok = DecodeHistograms(mm, &br, (tree.size() + 1) / 2, &code, &context_map);
+  out[2] = br.TotalBitsConsumed();
+  out[3] = code.lz77.enabled;
+  out[4] = code.use_prefix_code;
+  const bool in_bounds = br.AllReadsWithinBounds();
+  (void)br.Close();
+  return (ok && in_bounds) ? 0 : 1;
 }

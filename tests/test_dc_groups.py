@@ -1,0 +1,106 @@
+"""f4: the Modular-coded parts of a VarDCT frame -- the global MA tree in the DC-global section and
+the DC groups (quantized DC, strategy map, quant field, EPF sharpness, colour-correlation maps):
+jxlhip_modular_global_decode + jxlhip_dc_group_decode on the sections of genuine codestreams
+(written by the reference's encoder: learned MA trees, its choice of predictors incl. the
+self-correcting one, clustered histograms) must reproduce, bit for bit, what the reference's
+ModularFrameDecoder left in PassesSharedState for the same stream.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from libjxl_amd import abi
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not available")
+    oracle.ref_lib()
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def L():
+    return abi.load_library()
+
+
+def parse_to_sections(L, rs):
+    cs = np.ascontiguousarray(rs.codestream)
+    base, n = cs.ctypes.data, len(cs)
+    ih, pos = abi.ImageHeader(), C.c_size_t(0)
+    assert L.jxlhip_image_header_decode(base, n, C.byref(pos), None, 0, C.byref(ih)) == 0
+    info = abi.ImageInfo(ih.xsize, ih.ysize, ih.xyb_encoded, 0, None, 0, 0, 0)
+    fh = abi.FrameHeader()
+    assert L.jxlhip_frame_header_decode(base, n, C.byref(pos), C.byref(info), C.byref(fh)) == 0
+    nt = int(fh.num_toc_entries)
+    off, sz, total = np.zeros(nt, np.uint64), np.zeros(nt, np.uint32), C.c_uint64(0)
+    assert L.jxlhip_toc_decode(base, n, C.byref(pos), nt, off.ctypes.data, sz.ctypes.data, C.byref(total)) == 0
+    start = pos.value // 8
+    return cs, ih, fh, [cs[start + int(o): start + int(o) + int(s)] for o, s in zip(off, sz)]
+
+
+def decode_side_info(L, fh, sections):
+    """DC global (both halves) and every DC group; returns the frame-level arrays."""
+    s0 = sections[0]
+    dcg, dpos = abi.DcGlobal(), C.c_size_t(0)
+    assert L.jxlhip_dc_global_decode(s0.ctypes.data, len(s0), C.byref(dpos), fh.flags, C.byref(dcg)) == 0
+    tree = C.c_void_p()
+    assert L.jxlhip_modular_global_decode(s0.ctypes.data, len(s0), C.byref(dpos), C.byref(fh), C.byref(tree)) == 0
+    assert (dpos.value + 7) // 8 == len(s0)  # the DC-global section is consumed exactly
+    xsb, ysb = fh.xsize_blocks, fh.ysize_blocks
+    qdc = [np.zeros(xsb * ysb, np.int32) for _ in range(3)]
+    acs = np.zeros(xsb * ysb, np.uint8)
+    rq = np.zeros(xsb * ysb, np.int32)
+    sharp = np.zeros(xsb * ysb, np.uint8)
+    cw, chh = (xsb + 7) // 8, (ysb + 7) // 8
+    ytox, ytob = np.zeros(cw * chh, np.int8), np.zeros(cw * chh, np.int8)
+    used, prec = C.c_uint32(0), []
+    try:
+        for g in range(int(fh.num_dc_groups)):
+            d = sections[1 + g]
+            gp, ep = C.c_size_t(0), C.c_uint32(0)
+            ptrs = (C.c_void_p * 3)(*[q.ctypes.data for q in qdc])
+            rc = L.jxlhip_dc_group_decode(tree, d.ctypes.data, len(d), C.byref(gp), C.byref(fh), g, ptrs, C.byref(ep),
+                                          acs.ctypes.data, rq.ctypes.data, sharp.ctypes.data, ytox.ctypes.data,
+                                          ytob.ctypes.data, C.byref(used))
+            assert rc == 0, (g, rc)
+            assert (gp.value + 7) // 8 == len(d), (g, gp.value, len(d))
+            prec.append(ep.value)
+    finally:
+        L.jxlhip_modular_tree_destroy(tree)
+    return dcg, qdc, prec, acs, rq, sharp, ytox, ytob, used.value
+
+
+@pytest.mark.parametrize("kw", [
+    dict(xsize=520, ysize=300, distance=1.0, speed_tier=3),
+    dict(xsize=776, ysize=520, distance=3.0, speed_tier=3),
+    dict(xsize=640, ysize=264, distance=0.5, speed_tier=5),
+    dict(xsize=384, ysize=520, distance=2.0, speed_tier=2),
+    dict(xsize=300, ysize=300, distance=1.0, speed_tier=7),
+    dict(xsize=2200, ysize=264, distance=1.5, speed_tier=4),   # two DC groups side by side
+])
+def test_dc_groups_of_genuine_codestreams(L, ref, kw):
+    rs = ref.RealStream(seed=13, **kw)
+    cs, ih, fh, sections = parse_to_sections(L, rs)
+    dcg, qdc, prec, acs, rq, sharp, ytox, ytob, used = decode_side_info(L, fh, sections)
+    assert np.array_equal(acs, rs.ac_strategy.ravel())
+    first = (acs & 1) == 1
+    assert np.array_equal(rq[first], rs.raw_quant.ravel()[first])
+    assert np.array_equal(sharp, rs.epf_sharpness.ravel())
+    assert np.array_equal(ytox, rs.ytox_map.ravel()) and np.array_equal(ytob, rs.ytob_map.ravel())
+    assert used == rs.used_acs
+    # the quantized DC through the reference's own DequantDC + AdaptiveDCSmoothing = its DC image
+    assert len(set(prec)) == 1
+    xsb, ysb = fh.xsize_blocks, fh.ysize_blocks
+    smooth = not (fh.flags & 128)
+    f32 = np.float32
+    mul = f32(1.0) / f32(1 << prec[0])
+    inv_quant_dc = (f32(65536.0) / f32(dcg.global_scale)) / f32(dcg.quant_dc)   # quantizer.h:133-139
+    mul_dc = [f32(inv_quant_dc * f32(dcg.dc_quant[c])) for c in range(3)]
+    color_scale = f32(1.0) / f32(dcg.cfl_color_factor)                           # chroma_from_luma.h
+    cfl_x = float(f32(dcg.cfl_base_x) + f32(dcg.ytox_dc) * color_scale)
+    cfl_b = float(f32(dcg.cfl_base_b) + f32(dcg.ytob_dc) * color_scale)
+    got = ref.ref_dequant_dc([q.reshape(ysb, xsb) for q in qdc], mul_dc, cfl_x, cfl_b, smooth, mul=float(mul))
+    for c, want in enumerate((rs.dc_x, rs.dc_y, rs.dc_b)):
+        assert np.array_equal(got[c].ravel(), want.ravel()), c

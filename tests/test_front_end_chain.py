@@ -119,3 +119,72 @@ def test_codestream_bytes_to_back_end_state(L, ref, kw):
     fr.c.p.coeff_type = 1
     got = fr.decode(threads=4)
     assert np.array_equal(got, rs.rgb), float(np.abs(got - rs.rgb).max())
+
+
+@pytest.mark.parametrize("kw", [
+    dict(xsize=520, ysize=300, distance=1.0, speed_tier=3),
+    dict(xsize=776, ysize=520, distance=3.0, speed_tier=3, progressive=1),
+    dict(xsize=640, ysize=264, distance=0.5, speed_tier=5),
+    dict(xsize=2200, ysize=264, distance=1.5, speed_tier=4),  # two DC groups
+])
+def test_codestream_bytes_to_pixels_with_no_decoder_state_borrowed(L, ref, kw):
+    """The whole host front-end: NOTHING but the codestream bytes goes in.  Headers, TOC, DC
+    global, the Modular-coded DC groups (tests/test_dc_groups.py), AC global and the AC groups
+    are all parsed by the product; the resulting back-end inputs are rendered by the C oracle
+    and must equal the pixels the reference decoder produced for the same bytes.  (DequantDC +
+    smoothing run through the reference here; on the device they are jxlhip_dequant_dc, f2.)"""
+    import oracle as O
+    from test_dc_groups import decode_side_info, parse_to_sections
+    rs = ref.RealStream(seed=17, **kw)
+    cs, ih, fh, sections = parse_to_sections(L, rs)
+    dcg, qdc, prec, acs, rq, sharp, ytox, ytob, used = decode_side_info(L, fh, sections)
+    xsb, ysb, ng, ndc = fh.xsize_blocks, fh.ysize_blocks, int(fh.num_groups), int(fh.num_dc_groups)
+    # DC contexts for the AC entropy decoder, DC floats for the back-end
+    qctx = np.zeros(xsb * ysb, np.uint8)
+    qp = (C.c_void_p * 3)(*[q.ctypes.data for q in qdc])
+    assert L.jxlhip_quant_dc_contexts(C.byref(dcg.block_ctx_map), xsb * ysb, qp, qctx.ctypes.data) == 0
+    f32 = np.float32
+    inv_quant_dc = (f32(65536.0) / f32(dcg.global_scale)) / f32(dcg.quant_dc)
+    mul_dc = [f32(inv_quant_dc * f32(dcg.dc_quant[c])) for c in range(3)]
+    scale = f32(1.0) / f32(dcg.cfl_color_factor)
+    dc = ref.ref_dequant_dc([q.reshape(ysb, xsb) for q in qdc], mul_dc,
+                            float(f32(dcg.cfl_base_x) + f32(dcg.ytox_dc) * scale),
+                            float(f32(dcg.cfl_base_b) + f32(dcg.ytob_dc) * scale),
+                            not (fh.flags & 128), mul=float(f32(1.0) / f32(1 << prec[0])))
+    # AC global + groups
+    glob = sections[1 + ndc]
+    encs = abi.QuantEncodings()
+    nh, bits, hs = C.c_uint32(0), C.c_size_t(0), (C.c_void_p * fh.num_passes)()
+    assert L.jxlhip_ac_global_decode(glob.ctypes.data, len(glob), ng, fh.num_passes, used,
+                                     C.byref(dcg.block_ctx_map), C.byref(encs), C.byref(nh), hs, C.byref(bits)) == 0
+    coeffs = [np.zeros(ng * 65536, np.int32) for _ in range(3)]
+    try:
+        xsg = int(fh.xsize_groups)
+        for g in range(ng):
+            ptrs = (C.c_void_p * 3)(*[o[g * 65536:].ctypes.data for o in coeffs])
+            for ps in range(fh.num_passes):
+                d = sections[2 + ndc + ps * ng + g]
+                gp, cnt = C.c_size_t(0), C.c_size_t(0)
+                assert L.jxlhip_ac_group_decode(hs[ps], xsb, ysb, g % xsg, g // xsg, acs.ctypes.data, rq.ctypes.data,
+                                                qctx.ctypes.data, d.ctypes.data, len(d), C.byref(gp), fh.shift[ps], 1,
+                                                ptrs, C.byref(cnt)) == 0
+    finally:
+        for h in hs:
+            L.jxlhip_ac_pass_destroy(h)
+    # back-end parameters from the headers
+    p = O.FrameParams()
+    p.xsize, p.ysize, p.coeff_type, p.output_kind = fh.xsize, fh.ysize, 1, 1
+    p.global_scale, p.quant_dc = dcg.global_scale, dcg.quant_dc
+    p.x_dm_multiplier, p.b_dm_multiplier = fh.x_dm_multiplier, fh.b_dm_multiplier
+    p.quant_biases[:] = ih.quant_biases[:]
+    p.cfl_base_x, p.cfl_base_b, p.cfl_color_factor = dcg.cfl_base_x, dcg.cfl_base_b, dcg.cfl_color_factor
+    C.memmove(C.byref(p.lf), C.byref(fh.lf), C.sizeof(fh.lf))
+    p.opsin_biases[:] = ih.opsin_biases[:]
+    s = f32(255.0) / f32(ih.intensity_target)
+    p.inverse_opsin_matrix[:] = [float(f32(v) * s) for v in ih.inverse_opsin_matrix]
+    p.used_acs = used
+    table = O.dequant_tables(encs)
+    assert table is not None
+    fr = O.Frame(p, coeffs, acs, rq, sharp, ytox, ytob, [np.ascontiguousarray(d) for d in dc], table)
+    got = fr.decode(threads=4)
+    assert np.array_equal(got, rs.rgb), float(np.abs(got - rs.rgb).max())
