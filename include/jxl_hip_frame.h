@@ -1,6 +1,7 @@
 /* jxl_hip_frame.h -- host front-end pieces in front of the VarDCT back-end (SURVEY.md section
- * 8, row f4): the frame header, i.e. everything FrameDecoder::InitFrame reads before the table
- * of contents (jxlhip_toc_decode, jxl_hip_entropy.h).  Plain C ABI, host code only.
+ * 8, row f4): the image header, the frame header (everything FrameDecoder::InitFrame reads before
+ * the table of contents, jxlhip_toc_decode in jxl_hip_entropy.h), the DC-global section and the
+ * Modular-coded DC groups of a VarDCT frame.  Plain C ABI, host code only.
  *
  * Replaces, behaviour for behaviour (libjxl tree, lib/jxl/):
  *   FrameHeader::VisitFields, Passes, BlendingInfo, AnimationFrame   frame_header.cc:63-439

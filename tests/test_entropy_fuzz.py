@@ -70,3 +70,32 @@ def test_damaged_streams_under_asan_ubsan(fuzzer, cases):
     assert ok + rejected == iters
     assert rejected > iters // 4   # the damage is real ...
     assert ok > 0                  # ... and not everything is thrown away (side-info-only damage often decodes)
+
+
+def test_damaged_codestreams_through_the_front_end_chain_under_asan_ubsan(oracle, tmp_path):
+    """Headers, TOC, DC global, the Modular global tree and DC groups (csrc/modular.inc) on damaged
+    genuine codestreams: tests/fuzz/fuzz_codestream.cc."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not available")
+    oracle.ref_lib()
+    out = str(tmp_path / "fuzz_codestream")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-DJXLHIP_NO_DEVICE", os.path.join(ROOT, "tests", "fuzz", "fuzz_codestream.cc"),
+           ENTROPY, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    paths = []
+    for i, kw in enumerate([dict(xsize=264, ysize=200, seed=3, distance=1.0, speed_tier=3),
+                            dict(xsize=300, ysize=264, seed=4, distance=3.0, speed_tier=5),
+                            dict(xsize=520, ysize=136, seed=5, distance=0.5, speed_tier=2, progressive=1)]):
+        rs = oracle.RealStream(**kw)
+        p = str(tmp_path / ("cs%d.jxl" % i))
+        with open(p, "wb") as f:
+            f.write(rs.codestream.tobytes())
+        paths.append(p)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    iters = int(os.environ.get("JXLHIP_FUZZ_ITERS", "6000"))
+    r = subprocess.run([out, str(iters), "20260924"] + paths, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-4000:])
+    ok, rejected = map(int, r.stdout.split())
+    assert ok + rejected == iters and rejected > iters // 4 and ok > 0
