@@ -104,3 +104,43 @@ def test_dc_groups_of_genuine_codestreams(L, ref, kw):
     got = ref.ref_dequant_dc([q.reshape(ysb, xsb) for q in qdc], mul_dc, cfl_x, cfl_b, smooth, mul=float(mul))
     for c, want in enumerate((rs.dc_x, rs.dc_y, rs.dc_b)):
         assert np.array_equal(got[c].ravel(), want.ravel()), c
+
+
+def test_damaged_global_trees_fail_like_the_reference(L, ref):
+    """DecodeTree + ValidateTree + DecodeHistograms (modular/encoding/dec_ma.cc) on damaged DC-global
+    sections: same verdict and, when accepted, the same number of bits as the reference."""
+    R = ref.ref_lib()
+    R.jxr_modular_tree_read.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(77)
+    agree_ok = agree_bad = 0
+    for kw in (dict(xsize=520, ysize=300, distance=1.0, speed_tier=3), dict(xsize=640, ysize=264, distance=0.5, speed_tier=5),
+               dict(xsize=384, ysize=520, distance=2.0, speed_tier=2)):
+        rs = ref.RealStream(seed=13, **kw)
+        cs, ih, fh, sections = parse_to_sections(L, rs)
+        s0 = np.array(sections[0])
+        dcg, dpos = abi.DcGlobal(), C.c_size_t(0)
+        assert L.jxlhip_dc_global_decode(s0.ctypes.data, len(s0), C.byref(dpos), fh.flags, C.byref(dcg)) == 0
+        start = dpos.value
+        assert (s0[start // 8] >> (start % 8)) & 1  # has_tree
+        limit = min(1 << 22, 1024 + fh.xsize * fh.ysize * 3 // 16)
+        for trial in range(400):
+            b = s0.copy()
+            for _ in range(int(rng.integers(0, 4))):
+                k = int(rng.integers(start + 1, len(b) * 8))
+                b[k // 8] ^= np.uint8(1 << (k % 8))
+            if trial % 7 == 0:
+                b = b[: int(rng.integers(start // 8 + 2, len(b) + 1))].copy()
+            pos, tree = C.c_size_t(start), C.c_void_p()
+            rc = L.jxlhip_modular_global_decode(b.ctypes.data, len(b), C.byref(pos), C.byref(fh), C.byref(tree))
+            L.jxlhip_modular_tree_destroy(tree)
+            out = np.zeros(8, np.uint64)
+            want = R.jxr_modular_tree_read(b.ctypes.data, len(b), start + 1, limit, out.ctypes.data)
+            if rc == -7:
+                continue  # LZ77 in a damaged code: outside the slice (include/jxl_hip_frame.h)
+            assert (rc == 0) == (want == 0), (trial, rc, want, out[:5])
+            if rc == 0:
+                agree_ok += 1
+                assert pos.value == int(out[2]), (trial, pos.value, out[:3])
+            else:
+                agree_bad += 1
+    assert agree_ok > 100 and agree_bad > 100, (agree_ok, agree_bad)
