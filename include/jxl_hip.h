@@ -354,6 +354,20 @@ JXLHIP_EXPORT int jxlhip_dequant_dc(jxlhip_ctx* ctx,
                                     float* const dc_out[3],
                                     const float dc_quant[3], float cfl_x_dc,
                                     float cfl_b_dc, int smooth);
+/* The same with the per-DC-group multiplier 1 / (1 << extra_precision) that
+ * DecodeVarDCTDC reads in front of every DC group (dec_modular.cc:443-445) and
+ * DequantDC applies to the three factors of that group's rectangle
+ * (compressed_dc.cc:207-209) -- NOT to the AdaptiveDCSmoothing thresholds, which
+ * use the plain factors (FinalizeDC, dec_frame.cc:344-357).  extra_precision: HOST array,
+ * one byte (0..3, as jxlhip_dc_group_decode returns it) per DC group
+ * (2048x2048 px) in raster order, ceil(xsize_blocks/256) per row; NULL = all 0. */
+JXLHIP_EXPORT int jxlhip_dequant_dc_groups(jxlhip_ctx* ctx,
+                                           const int32_t* const quant_dc[3],
+                                           float* const dc_out[3],
+                                           const float dc_quant[3],
+                                           float cfl_x_dc, float cfl_b_dc,
+                                           int smooth,
+                                           const uint8_t* extra_precision);
 
 #ifdef __cplusplus
 }

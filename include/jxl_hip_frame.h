@@ -164,6 +164,10 @@ typedef struct jxlhip_frame_header {
   uint32_t xsize_groups, ysize_groups;
   uint64_t num_groups, num_dc_groups, num_toc_entries; /* 64-bit: a custom frame size may reach 2^30 squared */
   float x_dm_multiplier, b_dm_multiplier;
+  /* copied from jxlhip_image_info: the Modular parts of the frame carry the extra channels (alpha, depth, ...),
+     which this front-end does not decode -- jxlhip_modular_global_decode / jxlhip_dc_group_decode return
+     JXLHIP_ERR_UNSUPPORTED when it is non-zero (dec_modular.cc:230-262) */
+  uint32_t num_extra_channels;
 } jxlhip_frame_header;
 
 /* ReadFrameHeader (frame_header.cc:212-215): reads the header at bit *bit_pos of data (advanced to

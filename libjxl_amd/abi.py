@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "csrc", "libjxl_hip.so")
+# JXLHIP_SO: an experiment build of the library (tools/build_variant.py); default = the product
+_SO = os.environ.get("JXLHIP_SO") or os.path.join(_HERE, "csrc", "libjxl_hip.so")
 _RUNNER_SO = os.path.join(_HERE, "csrc", "libjxl_threads_hip.so")
 
 KERNEL_COUNT = 8
@@ -131,7 +132,8 @@ class FrameHeader(C.Structure):
                 ("xsize", C.c_uint32), ("ysize", C.c_uint32), ("xsize_blocks", C.c_uint32), ("ysize_blocks", C.c_uint32),
                 ("group_dim", C.c_uint32), ("xsize_groups", C.c_uint32), ("ysize_groups", C.c_uint32),
                 ("num_groups", C.c_uint64), ("num_dc_groups", C.c_uint64), ("num_toc_entries", C.c_uint64),
-                ("x_dm_multiplier", C.c_float), ("b_dm_multiplier", C.c_float)]
+                ("x_dm_multiplier", C.c_float), ("b_dm_multiplier", C.c_float),
+                ("num_extra_channels", C.c_uint32)]
 
 
 class FrameParams(C.Structure):
@@ -215,6 +217,7 @@ EXPORTS = [
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
     "jxlhip_profile_enable", "jxlhip_profile_read",
     "jxlhip_dequant_tables", "jxlhip_default_dequant_tables", "jxlhip_dequant_dc",
+    "jxlhip_dequant_dc_groups",
     # include/jxl_hip_entropy.h
     "jxlhip_ac_pass_decode", "jxlhip_ac_pass_destroy", "jxlhip_ac_pass_max_num_bits",
     "jxlhip_ac_pass_used_orders", "jxlhip_ac_pass_order", "jxlhip_ac_group_decode",
@@ -295,5 +298,6 @@ def load_library():
     L.jxlhip_ac_global_decode.argtypes = [vp, sz, u32, u32, u32, vp, vp, C.POINTER(u32), C.POINTER(vp),
                                           C.POINTER(sz)]
     L.jxlhip_dequant_dc.argtypes = [vp, vp * 3, vp * 3, vp, C.c_float, C.c_float, i32]
+    L.jxlhip_dequant_dc_groups.argtypes = [vp, vp * 3, vp * 3, vp, C.c_float, C.c_float, i32, vp]
     _lib = L
     return L

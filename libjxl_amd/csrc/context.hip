@@ -62,6 +62,8 @@ struct jxlhip_ctx {
   // upload path
   void* up_coeffs[3] = {nullptr, nullptr, nullptr};
   size_t up_coeff_bytes = 0;
+  uint32_t up_groups = 0;  // geometry the upload buffers were laid out for
+  size_t up_esz = 0;
   uint8_t* up_side = nullptr;  // one slab: acs, quant, sharp, ytox, ytob, dc*3, dequant
   size_t up_side_bytes = 0;
   jxlhip_frame_inputs up_inputs{};
@@ -81,6 +83,8 @@ struct jxlhip_ctx {
   // dc scratch
   float* dc_tmp = nullptr;
   size_t dc_tmp_floats = 0;
+  uint8_t* dc_prec = nullptr;  // per-DC-group extra_precision of jxlhip_dequant_dc_groups
+  size_t dc_prec_bytes = 0;
   // transform-kernel fan-out (JXLHIP_BLOCK_STREAMS: 3 = one stream per family; default 1 = back to back on the
   // main stream, measured 15 % faster than letting the families compete for the CUs)
   int nblock_streams = 1;
@@ -285,7 +289,7 @@ void jxlhip_destroy(jxlhip_ctx* c) {
   }
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
-                  c->dc_tmp,     c->quant_enc};
+                  c->dc_tmp,     c->quant_enc,  c->dc_prec};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -408,6 +412,12 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   fp.sm[2] = (float)(p->lf.epf_pass2_sigma_scale * 1.65);
   for (int i = 0; i < 3; i++) fp.bsm[i] = fp.sm[i] * p->lf.epf_border_sad_mul;
   memcpy(fp.minv, p->inverse_opsin_matrix, sizeof(fp.minv));
+  for (int j = 0; j < 3; j++)
+    for (int k = 0; k < 4; k++) fp.mcol[j][k] = fp.minv[3 * (k % 3) + j];
+  for (int ch = 0; ch < 3; ch++) {
+    fp.xyb_bias[ch] = -fp.cbrt_bias[ch];
+    fp.xyb_bias[3 + ch] = fp.opsin_bias[ch];
+  }
   if (p->output_kind == JXLHIP_OUT_PACKED) {
     fp.fmt = p->out_format;
     const bool is_int = fp.fmt.sample_type == JXLHIP_SAMPLE_U8 || fp.fmt.sample_type == JXLHIP_SAMPLE_U16;
@@ -502,6 +512,8 @@ static int EnsureUploadBuffers(jxlhip_ctx* c) {
     HIPCHK(c, hipMalloc(&c->up_coeffs[0], cbytes));
     c->up_coeff_bytes = cbytes;
   }
+  c->up_groups = f.xsg * f.ysg;
+  c->up_esz = esz;
   c->up_coeffs[1] = (char*)c->up_coeffs[0] + (size_t)JXLHIP_GROUP_COEFFS * esz;
   c->up_coeffs[2] = (char*)c->up_coeffs[0] + 2 * (size_t)JXLHIP_GROUP_COEFFS * esz;
   size_t off[9];
@@ -583,7 +595,9 @@ static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void*
     // however other threads' calls interleave on that stream.
     std::lock_guard<std::mutex> lock(c->pool_mu);
     if (hipSetDevice(c->device) != hipSuccess) return JXLHIP_ERR_HIP;
-    if (!c->up_coeffs[0]) {
+    // (re)sized for THIS frame's group count and coefficient type: a context reused for a larger
+    // frame or another coefficient type must not write past the previous frame's allocation
+    if (!c->up_coeffs[0] || c->up_groups != f.xsg * f.ysg || c->up_esz != esz) {
       int rc = EnsureUploadBuffers(c);
       if (rc) return rc;
     }
@@ -1084,6 +1098,12 @@ int jxlhip_default_dequant_tables(jxlhip_ctx* c, float* table_dev) {
 
 int jxlhip_dequant_dc(jxlhip_ctx* c, const int32_t* const quant_dc[3], float* const dc_out[3],
                       const float dc_quant[3], float cfl_x_dc, float cfl_b_dc, int smooth) {
+  return jxlhip_dequant_dc_groups(c, quant_dc, dc_out, dc_quant, cfl_x_dc, cfl_b_dc, smooth, nullptr);
+}
+
+int jxlhip_dequant_dc_groups(jxlhip_ctx* c, const int32_t* const quant_dc[3], float* const dc_out[3],
+                             const float dc_quant[3], float cfl_x_dc, float cfl_b_dc, int smooth,
+                             const uint8_t* extra_precision) {
   if (!c || !quant_dc || !dc_out) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "dequant_dc before frame_begin");
   for (int ch = 0; ch < 3; ch++)
@@ -1099,7 +1119,24 @@ int jxlhip_dequant_dc(jxlhip_ctx* c, const int32_t* const quant_dc[3], float* co
   int rc;
   if ((rc = Grow(c, &c->dc_tmp, &c->dc_tmp_floats, 3 * n))) return rc;
   float* tmp[3] = {c->dc_tmp, c->dc_tmp + n, c->dc_tmp + 2 * n};
-  LaunchDequantDC(f.xsb, f.ysb, quant_dc, dc_out, tmp, mul_dc, cfl_x_dc, cfl_b_dc, smooth,
+  const uint8_t* prec_dev = nullptr;
+  if (extra_precision) {
+    // at most a few dozen bytes (one per 2048x2048-pixel DC group): staged behind the DC scratch
+    const size_t ndc = (size_t)((f.xsb + 255) / 256) * ((f.ysb + 255) / 256);
+    bool any = false;
+    for (size_t i = 0; i < ndc; i++) {
+      if (extra_precision[i] > 3) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "extra_precision > 3");
+      any |= extra_precision[i] != 0;
+    }
+    if (any) {
+      if ((rc = Grow(c, &c->dc_prec, &c->dc_prec_bytes, ndc))) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->dc_prec, extra_precision, ndc, hipMemcpyHostToDevice, c->stream));
+      // the source may be a short-lived host array: the copy is pageable, hence already staged by
+      // the runtime when hipMemcpyAsync returns
+      prec_dev = c->dc_prec;
+    }
+  }
+  LaunchDequantDC(f.xsb, f.ysb, quant_dc, dc_out, tmp, mul_dc, cfl_x_dc, cfl_b_dc, smooth, prec_dev,
                   c->stream);
   HIPCHK(c, hipGetLastError());
   return JXLHIP_OK;

@@ -738,10 +738,10 @@ int DecodeEntropyCode(BitReader* br, size_t num_contexts, EntropyCode* code, boo
       } else {
         code->prefix[h].SetSingle(0);
       }
-      for (size_t k = 0; k < (1u << kRootBits) && k < code->prefix[h].table.size(); k++) {
-        const PrefixEntry& e = code->prefix[h].table[k];
+      // every entry that names a symbol, second-level ones included (dec_ans.cc:226-230); root
+      // slots that point to a sub-table carry bits > kRootBits
+      for (const PrefixEntry& e : code->prefix[h].table)
         if (e.bits <= kRootBits) code->UpdateMaxNumBits(h, e.value);
-      }
       if (!br->Healthy()) return kBad;
     }
   } else {
@@ -1595,6 +1595,7 @@ int jxlhip_frame_header_decode(const uint8_t* data, size_t size, size_t* bit_pos
       (h->num_groups == 1 && h->num_passes == 1) ? 1 : 2 + h->num_dc_groups + h->num_groups * h->num_passes;
   h->x_dm_multiplier = powf(1 / (1.25f), (float)h->x_qm_scale - 2.0f);  // dec_cache.h:161-162
   h->b_dm_multiplier = powf(1 / (1.25f), (float)h->b_qm_scale - 2.0f);
+  h->num_extra_channels = im->num_extra_channels;
   *bit_pos = br.BitsConsumed();
   return kOk;
 }

@@ -24,6 +24,8 @@ struct FilterParams {
   float opsin_bias[3];   // OpsinParams::opsin_biases
   float cbrt_bias[3];    // cbrt(opsin_biases)
   float minv[9];         // inverse opsin matrix * 255/intensity_target
+  float xyb_bias[6];     // -cbrt_bias[0..2], opsin_bias[0..2] (kernels_filters_fast.hip)
+  float mcol[3][4];      // its columns, wrapped: (m[j], m[3+j], m[6+j], m[j]) (kernels_filters_fast.hip)
   void* out;
   size_t out_stride;        // RGB / packed: bytes per row; XYB: floats per row
   size_t out_plane_stride;  // XYB only
@@ -60,7 +62,7 @@ void LaunchDequantTables(float* table, const jxlhip_quant_encoding* enc_dev, int
                          hipStream_t st);
 void LaunchDequantDC(uint32_t xsb, uint32_t ysb, const int32_t* const q[3], float* const dc[3],
                      float* const tmp[3], const float mul_dc[3], float cfl_x, float cfl_b,
-                     int smooth, hipStream_t st);
+                     int smooth, const uint8_t* extra_precision, hipStream_t st);
 
 }  // namespace jxlhip
 #endif

@@ -10,26 +10,33 @@
 //     from the neighbouring LANE through DPP wave_shr/wave_shl (no LDS, no
 //     barrier);
 //   * vertical neighbours come from a sliding window of rows kept in registers
-//     (4-slot rings, slot = row & 3, resolved at compile time by unrolling the
-//     row loop 4x);
-//   * input rows are prefetched 4 rows ahead (one 8-byte load per lane, row
-//     and channel; the row base is scalar), output rows leave as 24-byte
-//     non-temporal RGB stores.
+//     (rings of 8 / 4 slots, slot = row & 7 / & 3, resolved at compile time by
+//     unrolling the row loop 8x);
+//   * input rows are prefetched in bursts of four rows = whole 128-byte lines of
+//     the block-major planes (one 8-byte load per lane, row and channel; the row
+//     base is scalar), output rows leave as 24-byte non-temporal RGB stores.
 //
-// Measured on MI355X (8K d1.0, JXLHIP_DEBUG ablations): arithmetic alone 135 us,
-// + plane reads 140 us, + output stores 210 us = 4.0 TB/s of HBM traffic, where a
-// plain device copy reaches 5.0-5.4 TB/s (read + write).  Tried and measured
-// without gain: 8-row prefetch (-8 %), 3 waves per SIMD, and routing the RGB row
-// through LDS so that every store instruction writes whole 64-byte lines (same
-// time: the kernel is bound by mixed read/write HBM traffic, not by the number
-// of write requests).
+// The kernel is written against its VALU ISSUE count (SQ counters of round 1: 218 VALU instructions
+// per row step and wave, the SIMDs' VALU ports 57 % busy at 2 waves per SIMD -- issue-bound, not
+// latency-bound).  Round 2 brought the row step to ~118 VALU instructions (tools/isa_loops.py on the
+// -S listing): channel-summed difference images before the plus-shaped sums, weights through the
+// packed FMA's [0, 1] output clamp, XYB -> RGB on pixel pairs with per-half matrix rows picked by
+// op_sel, DPP operands folded into VOP2 instructions (v_add/v_sub/v_fmac ..._dpp), one 8-slot input
+// ring instead of prefetch + input rings (no register copies between rings), SGPR-based addressing
+// for every load and store, a running output-row pointer, part of the wave-uniform constants kept in
+// VGPRs (the loop wanted more than 102 SGPRs).  Measured on MI355X (8K d1.0, JXLHIP_DEBUG
+// ablations): arithmetic alone 135 -> 94 us; with the plane reads 127-137 us; whole kernel 215-235 us
+// (866 MB: 3.9 TB/s, where a device copy moves 4.8-5.0) -- what remains is the block-major read
+// path and the mixed read / write stream, not arithmetic.  Tried and measured
+// without gain: 3 workgroups per CU, deeper single-row prefetch (see kAhead), routing the RGB row
+// through LDS so that every store instruction writes whole 64-byte lines.
 //
 // EPF1 (lib/jxl/render_pipeline/stage_epf.cc:225-367) is evaluated through an
-// exact regrouping of the reference's sums: with Du(x,y) = |p(x,y-1) - p(x,y)|
-// and Dl(x,y) = |p(x-1,y) - p(x,y)|, the four SADs of pixel (x,y) are the
-// plus-shaped sums  PV(x,y), PH(x,y), PH(x+1,y), PV(x,y+1)  of Du / Dl -- same
-// terms, same order, same rounding as the reference (N, W, E, S), but each
-// plus-sum is computed once per pixel instead of four times.
+// regrouping of the reference's sums: with Du(x,y) = sum_c scale_c |p_c(x,y-1) - p_c(x,y)|
+// and Dl(x,y) = sum_c scale_c |p_c(x-1,y) - p_c(x,y)|, the four SADs of pixel (x,y) are the
+// plus-shaped sums  PV(x,y), PH(x,y), PH(x+1,y), PV(x,y+1)  of Du / Dl -- the reference's 15
+// non-negative terms per SAD in another association (per channel first there, per position first
+// here), each plus-sum computed once per pixel instead of four times.
 //
 // Border rule (simple_render_pipeline.cc:129-164): stages read their input
 // mirrored at the true image edge.  Gaborish of the mirrored input IS the
@@ -47,17 +54,22 @@ namespace jxlhip {
 
 namespace {
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ int MirrorF(int x, int n) {
   while (x < 0 || x >= n) x = x < 0 ? -x - 1 : 2 * n - 1 - x;
   return x;
 }
+// one reflection: rows of this kernel overshoot the image by less than 16 and LaunchFiltersFast only
+// takes frames of at least 16 rows
+__device__ __forceinline__ int Mirror1(int y, int n) {
+  y = y < 0 ? -y - 1 : y;
+  return y >= n ? 2 * n - 1 - y : y;
+}
 
-// row part of a block-major plane offset (the lane adds its tile column)
-__device__ __forceinline__ size_t RowOffset(const DevFrame& f, int y) {
+// byte offset of row y inside a block-major plane (the lane adds its tile column); 32-bit: the
+// launcher sends planes of 4 GB and more to the generic kernel
+__device__ __forceinline__ uint32_t RowOffset(const DevFrame& f, int y) {
   const uint32_t ry = (uint32_t)(y - f.plane_y0);
-  return (size_t)(ry >> 3) * f.tile_stride * 64u + ((ry & 7u) << 3);
+  return (ry >> 3) * (f.tile_stride * 256u) + ((ry & 7u) << 5);
 }
 
 // value held by the previous / next lane (0 at the wave's ends: those lanes
@@ -68,54 +80,107 @@ __device__ __forceinline__ float FromLeft(float v) {
 __device__ __forceinline__ float FromRight(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
-// For the column pair p = (x, x+1), the left neighbours are (x-1, x) and the
-// right neighbours (x+1, x+2): one of each comes from the adjacent lane.  The
-// helpers keep those operations scalar so that the DPP read folds into the
-// arithmetic instruction (v_add_f32_dpp, v_sub_f32_dpp, v_fmac_f32_dpp);
-// everything that stays inside the lane is written on pairs and becomes packed
-// fp32.
-__device__ __forceinline__ v2f AddLeft(v2f acc, v2f p) {
-  return v2f{acc.x + FromLeft(p.y), acc.y + p.x};
-}
-__device__ __forceinline__ v2f AddRight(v2f acc, v2f p) {
-  return v2f{acc.x + p.y, acc.y + FromRight(p.x)};
-}
-
-// |v| materialised by an instruction the optimiser cannot see through: as an
-// fabs it would be folded into its consumers as a source modifier, which forces
-// them into the VOP3 encoding -- no DPP operand, no packed form.
-__device__ __forceinline__ float AbsOpaque(float v) {
-  float r;
-  asm("v_and_b32 %0, 0x7fffffff, %1" : "=v"(r) : "v"(v));
-  return r;
-}
-__device__ __forceinline__ v2f Abs2(v2f v) { return v2f{AbsOpaque(v.x), AbsOpaque(v.y)}; }
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f Fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f Fma2(v2f a, float b, v2f c) {
   return __builtin_elementwise_fma(a, v2f{b, b}, c);
 }
 
-__device__ __forceinline__ v2f FmaLeft(v2f w, v2f p, v2f a) {
-  return v2f{__builtin_fmaf(w.x, FromLeft(p.y), a.x), __builtin_fmaf(w.y, p.x, a.y)};
-}
-__device__ __forceinline__ v2f FmaRight(v2f w, v2f p, v2f a) {
-  return v2f{__builtin_fmaf(w.x, p.y, a.x), __builtin_fmaf(w.y, FromRight(p.x), a.y)};
+// Keeps a scalar result scalar: without it the SLP vectoriser fuses the two halves of a pair
+// that are computed by DIFFERENT instructions (one with a DPP operand, one without) into one packed
+// operation fed by explicit v_mov_b32_dpp / v_mov -- three instructions instead of two.
+__device__ __forceinline__ float Scalar(float v) {
+  asm("" : "+v"(v));
+  return v;
 }
 
-// max(0, 1 + sad * inv_sigma) (stage_epf.cc:62-71).  maxNum semantics on
-// purpose: a block whose sigma is below the filter threshold carries
-// inv_sigma = -inf, which turns every weight into 0 (also 0 * -inf = NaN).
+// A per-lane 32-bit byte offset that the optimiser cannot hoist out of the row loop as a 64-bit
+// value: added to a wave-uniform base inside the same basic block it becomes the VGPR offset of an
+// SGPR-based access (global_load v, v_off, s[base:base+1]) -- no VALU address arithmetic per access
+// (hoisted, every load and store pays a v_lshl_add_u64).  The value is redefined IN PLACE: a copy
+// per use would cost what the address arithmetic did.
+__device__ __forceinline__ uint32_t LaneOffset(uint32_t& v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// Input rows are requested in bursts of kBurst rows, the first of them kAhead rows before its step.
+// Four rows of an 8x8 tile share a 128-byte line: asked for together the line crosses L2 -> L1 once
+// (per-row requests found it evicted again: L1 -> L2 read requests were 3.7x the plane bytes).
+// Measured on MI355X, 8K d1.0, kernel time: (kAhead, kBurst) = (2, 1) 0.237 ms, (1, 2) 0.238,
+// (2, 2) 0.229, (1, 4) 0.215; prefetching further ahead with single-row requests is slower
+// ((3, 1) 0.248, (4, 1) 0.251).
+#ifndef JXLHIP_FILTER_AHEAD
+#define JXLHIP_FILTER_AHEAD 1
+#endif
+static constexpr int kAhead = JXLHIP_FILTER_AHEAD;
+#ifndef JXLHIP_FILTER_BURST
+#define JXLHIP_FILTER_BURST 4
+#endif
+static constexpr int kBurst = JXLHIP_FILTER_BURST;  // 1, 2 or 4
+static_assert(kAhead >= 1 && kAhead + kBurst <= 5 && (kBurst == 1 || kBurst == 2 || kBurst == 4),
+              "input ring of 8: rows r-3 .. r+kAhead+kBurst-1 must fit");
+
+// max(0, 1 + sad * inv_sigma) (stage_epf.cc:46-50).  sad >= 0 and inv_sigma < 0, so the value
+// never exceeds 1 and the [0, 1] output clamp of the packed FMA IS ZeroIfNegative: one VALU issue
+// for the weights of two pixels (v_pk_fma + 2 v_max before).  A block whose sigma is below the
+// filter threshold carries inv_sigma = -inf: every weight becomes 0 (0 * -inf = NaN clamps to 0
+// as well: the kernel runs with DX10_CLAMP).
 __device__ __forceinline__ v2f EpfW(v2f sad, v2f inv_sigma) {
-  const v2f v = Fma2(sad, inv_sigma, v2f{1.0f, 1.0f});
-  return v2f{__builtin_fmaxf(v.x, 0.0f), __builtin_fmaxf(v.y, 0.0f)};
+  v2f w;
+  asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel_hi:[1,1,0] clamp" : "=v"(w) : "v"(sad), "v"(inv_sigma));
+  return w;
+}
+
+// sum over the channels of scale[c] * |d[c]| for the two columns of the lane: scalar FMAs with the
+// |.| source modifier (a packed FMA has none: the v_and pair it needs makes it three issues)
+__device__ __forceinline__ v2f AbsScaleSum(const v2f* d, const FilterParams& P) {
+  float x = __builtin_fabsf(d[0].x) * P.ch_scale[0];
+  float y = __builtin_fabsf(d[0].y) * P.ch_scale[0];
+  x = __builtin_fmaf(__builtin_fabsf(d[1].x), P.ch_scale[1], x);
+  y = __builtin_fmaf(__builtin_fabsf(d[1].y), P.ch_scale[1], y);
+  x = __builtin_fmaf(__builtin_fabsf(d[2].x), P.ch_scale[2], x);
+  y = __builtin_fmaf(__builtin_fabsf(d[2].y), P.ch_scale[2], y);
+  return v2f{Scalar(x), Scalar(y)};
+}
+
+// acc + (p(x-1), p(x)) and acc + (p(x+1), p(x+2)) for the column pair (x, x+1)
+__device__ __forceinline__ v2f AddLeftS(v2f acc, v2f p) {
+  return v2f{Scalar(FromLeft(p.y) + acc.x), Scalar(acc.y + p.x)};
+}
+__device__ __forceinline__ v2f AddRightS(v2f acc, v2f p) {
+  return v2f{Scalar(acc.x + p.y), Scalar(FromRight(p.x) + acc.y)};
+}
+// a + w * (p(x-1), p(x)) and a + w * (p(x+1), p(x+2)).  The neighbouring lane's value enters as the
+// DPP operand of a VOP2 v_fmac_f32 (the compiler leaves a v_mov_b32_dpp in front of a VOP3 v_fma_f32).
+// p must be an OLD value (written at least two VALU instructions earlier: the DPP read hazard, which
+// the compiler does not track through inline asm): callers pass ring rows of earlier steps only.
+__device__ __forceinline__ v2f FmaLeftS(v2f w, v2f p, v2f a) {
+  float ax = a.x;
+  asm("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(ax) : "v"(p.y), "v"(w.x));
+  return v2f{ax, Scalar(__builtin_fmaf(w.y, p.x, a.y))};
+}
+__device__ __forceinline__ v2f FmaRightS(v2f w, v2f p, v2f a) {
+  float ay = a.y;
+  asm("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(ay) : "v"(p.x), "v"(w.y));
+  return v2f{Scalar(__builtin_fmaf(w.x, p.y, a.x)), ay};
 }
 
 struct State {
-  v2f pre[3][4];  // prefetched input rows
-  v2f in[3][4];   // GAB: input rows
+  // Input rows, one ring of 8: row r sits in slot r & 7 from its prefetch (4 rows ahead) until the
+  // stages no longer read it -- as Gaborish input (rows r .. r-2) or, without Gaborish, as the
+  // rows entering EPF (r .. r-3).  (Separate prefetch / input rings cost a register copy per row and
+  // channel: a ring's slots are fixed registers across loop iterations.)  The row loop is unrolled
+  // 8x so that every slot index is a compile-time constant.
+  v2f x[3][8];
   v2f hs[3][4];   // GAB: left + right of the input rows
-  v2f g[3][4];    // EPF: rows entering EPF (Gaborish output or input)
-  v2f du[3][4], dl[3][4];
+  v2f g[3][4];    // GAB && EPF: Gaborish output rows entering EPF
+  // EPF1's SADs are sums over the three channels of scale[c] * |difference|; the sums over the
+  // channels are taken FIRST (du: against the row above, dl: against the column to the left), the
+  // plus-shaped sums run on those two images -- a third of the additions of per-channel
+  // plus-sums, the same 15 non-negative terms per SAD in another association (a few ulp of the
+  // SAD, far below what the weight's max(0, 1 + sad * inv_sigma) resolves)
+  v2f du[4], dl[4];
   v2f pv[4], ph[4];
   v2f e[3][4];    // EPF == 2: EPF1 output rows entering EPF2
   v2f dv[4];      // EPF == 2: channel-weighted |row - row above| of the e rows
@@ -125,7 +190,6 @@ struct State {
 struct Lane {
   uint32_t byte_off;  // byte offset of the lane's aligned column pair inside a plane row
   bool sel0, sel1;    // edge waves: which half of the loaded pair each column takes
-  bool edge;          // wave-uniform: the strip touches a mirrored image edge
   int gx;             // first column of the pair (may lie outside the image)
   bool out0, out1;    // column is written by this wave
   v2f mul;            // EPF sigma multiplier of the two columns (border columns of an 8x8 block differ)
@@ -134,20 +198,78 @@ struct Lane {
   // edge column): pair (-2,-1): .y <- column 0; pair (W, W+1): .x <- column W-1 (W even);
   // pair (W-1, W): .y <- .x (W odd)
   bool fix_left, fix_right_even, fix_right_odd;
-  int sx;             // block column of the pair for the sigma look-up (clamped)
+  uint32_t sx4;       // 4 * block column of the pair for the sigma look-up (clamped)
+  uint32_t out_off;   // byte offset of the pair's first sample inside an output row (float RGB / XYB planes)
   // packed 8-bit output: the dither pattern, staged in LDS (a global load per
   // sample would queue behind the row prefetch in the in-order vmcnt)
   const float __attribute__((address_space(3))) * dither;
 };
 
-__device__ __forceinline__ v2f LoadPair(const float* rowp, const Lane& L) {
-  const v2f v = *(const v2f*)((const char*)rowp + L.byte_off);
-  if (!L.edge) return v;
+// EDGE (wave-uniform, a template parameter of the march): the strip touches a mirrored image edge
+template <bool EDGE>
+__device__ __forceinline__ v2f LoadPair(const char* rowp, Lane& L) {
+  const v2f v = *(const v2f*)(rowp + L.byte_off);
+  if constexpr (!EDGE) return v;
   return v2f{L.sel0 ? v.y : v.x, L.sel1 ? v.y : v.x};
 }
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// XYB -> linear RGB (emit.h XybToRgb, dec_xyb-inl.h:38-86) for the lane's two pixels at once.  The
+// three results come out in the order the 24-byte store wants them -- (r0 g0) (b0 r1) (g1 b1) --
+// by letting each packed operation pick its matrix row per half (the operand pairs {m0,m3},
+// {m6,m0}, {m3,m6} ... live in SGPR pairs) and broadcast one of the two pixels through op_sel.
+// Wave-uniform constants of the XYB -> RGB tail that are kept in VGPRs on purpose: with everything
+// in SGPRs the row loop needs more than the 102 a wave has and pays ~14 v_readlane_b32 (spill
+// reloads) per row
+struct XybConsts {
+  v2f b01, b23, b45;        // xyb_bias pairs
+  v2f m0a, m1a, m2a;        // mcol[j][2..3]: rows 2 | 0 of column j
+};
+__device__ __forceinline__ v2f InVgpr(v2f v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ XybConsts MakeXybConsts(const FilterParams& P) {
+  XybConsts k;
+  k.b01 = InVgpr(v2f{P.xyb_bias[0], P.xyb_bias[1]});
+  k.b23 = InVgpr(v2f{P.xyb_bias[2], P.xyb_bias[3]});
+  k.b45 = InVgpr(v2f{P.xyb_bias[4], P.xyb_bias[5]});
+  k.m0a = InVgpr(v2f{P.mcol[0][2], P.mcol[0][3]});
+  k.m1a = InVgpr(v2f{P.mcol[1][2], P.mcol[1][3]});
+  k.m2a = InVgpr(v2f{P.mcol[2][2], P.mcol[2][3]});
+  return k;
+}
+
+struct RgbPairs {
+  v2f p0, p1, p2;  // (r0, g0), (b0, r1), (g1, b1)
+};
+__device__ __forceinline__ RgbPairs XybToRgbPair(const v2f* v, const FilterParams& P, const XybConsts& K) {
+  v2f gr = v[1] + v[0], gg = v[1] - v[0], gb = v[2];
+  // xyb_bias = (-cbrt_bias[0..2], opsin_bias[0..2]): x - b == x + (-b) exactly; as an addition the
+  // splat operand is one SGPR picked by op_sel instead of a duplicated pair
+  gr = gr + v2f{K.b01.x, K.b01.x};
+  gg = gg + v2f{K.b01.y, K.b01.y};
+  gb = gb + v2f{K.b23.x, K.b23.x};
+  const v2f mr = Fma2(gr * gr, gr, v2f{K.b23.y, K.b23.y});
+  const v2f mg = Fma2(gg * gg, gg, v2f{K.b45.x, K.b45.x});
+  const v2f mb = Fma2(gb * gb, gb, v2f{K.b45.y, K.b45.y});
+  // mcol[j] = (m[j], m[3+j], m[6+j], m[j]): column j of the matrix, wrapped -- its three aligned /
+  // overlapping pairs (rows 0|1, rows 2|0, rows 1|2) are the per-half constants of the three
+  // results, two SGPRs each picked by op_sel
+  const float(*mc)[4] = P.mcol;
+  RgbPairs o;
+  // (r0, g0): pixel 0 against rows 0 and 1
+  o.p0 = Fma2(v2f{mb.x, mb.x}, v2f{mc[2][0], mc[2][1]},
+              Fma2(v2f{mg.x, mg.x}, v2f{mc[1][0], mc[1][1]}, v2f{mr.x, mr.x} * v2f{mc[0][0], mc[0][1]}));
+  // (b0, r1): pixel 0 against row 2, pixel 1 against row 0
+  o.p1 = Fma2(mb, K.m2a, Fma2(mg, K.m1a, mr * K.m0a));
+  // (g1, b1): pixel 1 against rows 1 and 2
+  o.p2 = Fma2(v2f{mb.y, mb.y}, v2f{mc[2][1], mc[2][2]},
+              Fma2(v2f{mg.y, mg.y}, v2f{mc[1][1], mc[1][2]}, v2f{mr.y, mr.y} * v2f{mc[0][1], mc[0][2]}));
+  return o;
+}
 
 // The output is written once and never read by this pipeline: streaming
 // (non-temporal) stores keep it from displacing the XYB planes in L2 / MALL.
@@ -189,51 +311,52 @@ __device__ __forceinline__ void StoreRgb8Pair(const FilterParams& P, const Lane&
   }
 }
 
-template <int OUTK, int FMT>
-__device__ __forceinline__ void EmitPair(const v2f* v, const Lane& L, int gy, const DevFrame& f,
-                                         const FilterParams& P) {
-  const int gy_rel = gy - (int)f.y0;
+template <int OUTK, int FMT, bool EDGE>
+__device__ __forceinline__ void EmitPair(const v2f* v, Lane& L, int gy, char* out_row, const FilterParams& P,
+                                         const XybConsts& K) {
   if constexpr (OUTK == JXLHIP_OUT_PACKED) {
     // FromLinearStage + WriteToOutputStage (emit.h); the packed formats move
     // 3..16 bytes per pixel, a fraction of the float output
     using Sel = FmtSel<FMT>;
-    char* row = (char*)P.out + (size_t)gy_rel * P.out_stride;
-    float a[3], b[3];
-    XybToRgb(v[0].x, v[1].x, v[2].x, P, a);
-    XybToRgb(v[0].y, v[1].y, v[2].y, P, b);
+    char* row = out_row;
+    const RgbPairs o = XybToRgbPair(v, P, K);
+    const float a[3] = {o.p0.x, o.p0.y, o.p1.x}, b[3] = {o.p1.y, o.p2.x, o.p2.y};
     if (Sel::sample_type(P.fmt) == JXLHIP_SAMPLE_U8 && Sel::channels(P.fmt) == 3) {
       StoreRgb8Pair<Sel>(P, L, row, gy, a, b);  // all lanes: uses DPP
-    } else if (L.out0 && L.out1) {
+    } else if (EDGE ? (L.out0 && L.out1) : L.out0) {
       StorePackedPair<Sel>(P, L.dither, row, L.gx, gy, a, b);
+    } else if (!EDGE) {
     } else if (L.out0) {
       StorePackedPixel<Sel>(P, L.dither, row, L.gx, gy, a);
     } else if (L.out1) {
       StorePackedPixel<Sel>(P, L.dither, row, L.gx + 1, gy, b);
     }
   } else if constexpr (OUTK == JXLHIP_OUT_LINEAR_RGB_F32) {
-    float* dst = (float*)((char*)P.out + (size_t)gy_rel * P.out_stride) + 3 * (size_t)L.gx;
-    float a[3], b[3];
-    XybToRgb(v[0].x, v[1].x, v[2].x, P, a);
-    XybToRgb(v[0].y, v[1].y, v[2].y, P, b);
-    if (L.out0 && L.out1) {  // 24 contiguous bytes
-      __builtin_nontemporal_store(f4u{a[0], a[1], a[2], b[0]}, (f4u*)dst);
-      __builtin_nontemporal_store(f2u{b[1], b[2]}, (f2u*)(dst + 4));
+    float* dst = (float*)(out_row + LaneOffset(L.out_off));
+    const RgbPairs o = XybToRgbPair(v, P, K);
+    // inside the image the two columns of a pair are written or skipped together (only column W-1
+    // of an odd width separates them: an edge wave)
+    if (EDGE ? (L.out0 && L.out1) : L.out0) {  // 24 contiguous bytes
+      __builtin_nontemporal_store(f4u{o.p0.x, o.p0.y, o.p1.x, o.p1.y}, (f4u*)dst);
+      __builtin_nontemporal_store(f2u{o.p2.x, o.p2.y}, (f2u*)(dst + 4));
+    } else if (!EDGE) {
     } else if (L.out0) {
-      __builtin_nontemporal_store(a[0], dst);
-      __builtin_nontemporal_store(a[1], dst + 1);
-      __builtin_nontemporal_store(a[2], dst + 2);
+      __builtin_nontemporal_store(o.p0.x, dst);
+      __builtin_nontemporal_store(o.p0.y, dst + 1);
+      __builtin_nontemporal_store(o.p1.x, dst + 2);
     } else if (L.out1) {
-      __builtin_nontemporal_store(b[0], dst + 3);
-      __builtin_nontemporal_store(b[1], dst + 4);
-      __builtin_nontemporal_store(b[2], dst + 5);
+      __builtin_nontemporal_store(o.p1.y, dst + 3);
+      __builtin_nontemporal_store(o.p2.x, dst + 4);
+      __builtin_nontemporal_store(o.p2.y, dst + 5);
     }
   } else {
-    float* dst = (float*)P.out + (size_t)gy_rel * P.out_stride + L.gx;
+    LaneOffset(L.out_off);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      float* d = dst + c * P.out_plane_stride;
-      if (L.out0 && L.out1) {
+      float* d = (float*)(out_row + (size_t)c * P.out_plane_stride * 4 + L.out_off);
+      if (EDGE ? (L.out0 && L.out1) : L.out0) {
         __builtin_nontemporal_store(f2u{v[c].x, v[c].y}, (f2u*)d);
+      } else if (!EDGE) {
       } else if (L.out0) {
         __builtin_nontemporal_store(v[c].x, d);
       } else if (L.out1) {
@@ -246,23 +369,28 @@ __device__ __forceinline__ void EmitPair(const v2f* v, const Lane& L, int gy, co
 // One row step.  PH = (r - r_first) & 3 is the ring slot of input row r.
 // Row bookkeeping: q = row leaving Gaborish (r-1 with GAB, r without),
 // p = q-1 = row whose plus-sums are completed, o = q-2 = EPF output row.
-template <int GAB, int EPF, int OUTK, int FMT, int PH>
+// DBG: JXLHIP_DEBUG ablation bits of this kernel, compiled in only for the launch that asks for
+// them (4: no output stores, 8: input rows stay in L1).
+template <int GAB, int EPF, int OUTK, int FMT, int PH, bool EDGE, int DBG>
 __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const FilterParams& P,
-                                     const Lane& L, int prefetch_last_row, int y_begin, int y_end,
-                                     float& inv_sigma_blk, float& inv_sigma_blk2) {
-  constexpr int S0 = PH & 3, S1 = (PH + 3) & 3, S2 = (PH + 2) & 3;  // r, r-1, r-2
+                                     Lane& L, int prefetch_last_row, int y_begin, int y_end,
+                                     float& inv_sigma_blk, float& inv_sigma_blk2, char* out_row, const XybConsts& K) {
+  constexpr int S0 = PH & 3, S1 = (PH + 3) & 3, S2 = (PH + 2) & 3;  // r, r-1, r-2 in the 4-slot rings
+  constexpr int X0 = PH & 7, X1 = (PH + 7) & 7, X2 = (PH + 6) & 7, X3 = (PH + 5) & 7;  // ... in the input ring
   const int H = (int)f.ysize;
-  v2f cur[3];
-  // 1. take row r from the prefetch ring, refill the slot with row r+4
-  {
-    int pr = r + 4;
-    pr = pr > prefetch_last_row ? prefetch_last_row : pr;
-    if (f.debug & 8) pr = y_begin + (pr & 7);  // ablation: reads stay in L1
-    const size_t off = RowOffset(f, MirrorF(pr, H));
+  // 1. row r has arrived in slot X0; every kBurst-th step starts the loads of the next kBurst rows
+  // (r + kAhead ...) into slots whose rows are dead.  Four rows of a tile share a 128-byte line: asked
+  // for together, the line crosses L2 -> L1 once instead of once per row.
+  if constexpr (PH % kBurst == 0) {
+    LaneOffset(L.byte_off);
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      cur[c] = s.pre[c][S0];
-      s.pre[c][S0] = LoadPair(f.xyb[c] + off, L);
+    for (int b = 0; b < kBurst; b++) {
+      int pr = r + kAhead + b;
+      pr = pr > prefetch_last_row ? prefetch_last_row : pr;
+      if constexpr (DBG & 8) pr = y_begin + (pr & 7);  // ablation: reads stay in L1
+      const uint32_t off = RowOffset(f, Mirror1(pr, H));
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][(PH + kAhead + b) & 7] = LoadPair<EDGE>((const char*)f.xyb[c] + off, L);
     }
   }
   // 2. Gaborish (stage_gaborish.cc:33-99) for row q = r-1
@@ -270,54 +398,61 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
   if constexpr (GAB) {
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      s.in[c][S0] = cur[c];
-      s.hs[c][S0] = v2f{FromLeft(cur[c].y) + cur[c].y, cur[c].x + FromRight(cur[c].x)};
-      const v2f sum1 = s.hs[c][S1] + (s.in[c][S2] + s.in[c][S0]);
+      const v2f cur = s.x[c][X0];
+      s.hs[c][S0] = v2f{Scalar(FromLeft(cur.y) + cur.y), Scalar(FromRight(cur.x) + cur.x)};
+      const v2f sum1 = s.hs[c][S1] + (s.x[c][X2] + cur);
       const v2f sum2 = s.hs[c][S2] + s.hs[c][S0];
-      gq[c] = Fma2(sum2, P.gab_w[c][2], Fma2(sum1, P.gab_w[c][1], s.in[c][S1] * P.gab_w[c][0]));
+      gq[c] = Fma2(sum2, P.gab_w[c][2], Fma2(sum1, P.gab_w[c][1], s.x[c][X1] * P.gab_w[c][0]));
     }
   } else {
 #pragma unroll
-    for (int c = 0; c < 3; c++) gq[c] = cur[c];
+    for (int c = 0; c < 3; c++) gq[c] = s.x[c][X0];
   }
-  constexpr int Q0 = GAB ? S1 : S0;  // slot of row q
+  constexpr int Q0 = GAB ? S1 : S0;  // slot of row q in the 4-slot rings
   constexpr int Q1 = (Q0 + 3) & 3, Q2 = (Q0 + 2) & 3, Q3 = (Q0 + 1) & 3;  // q-1, q-2, q-3
   const int q = GAB ? r - 1 : r;
+  // rows q-1, q-2, q-3 of the image entering EPF: the Gaborish ring, or the input ring itself
+  v2f gq1[3], gq2[3], gq3[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    gq1[c] = GAB ? s.g[c][Q1] : s.x[c][X1];
+    gq2[c] = GAB ? s.g[c][Q2] : s.x[c][X2];
+    gq3[c] = GAB ? s.g[c][Q3] : s.x[c][X3];
+  }
   v2f outv[3];
   int o;
   if constexpr (EPF) {
-    // 3a. differences of the new row q
+    // 3a. channel-weighted differences of the new row q against the row above / the column to the left
+    {
+      v2f dvert[3], dhor[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      s.g[c][Q0] = gq[c];
-      s.du[c][Q0] = Abs2(s.g[c][Q1] - gq[c]);
-      s.dl[c][Q0] = Abs2(v2f{FromLeft(gq[c].y) - gq[c].x, gq[c].x - gq[c].y});
+      for (int c = 0; c < 3; c++) {
+        dvert[c] = gq1[c] - gq[c];
+        dhor[c] = v2f{Scalar(FromLeft(gq[c].y) - gq[c].x), Scalar(gq[c].x - gq[c].y)};
+        if constexpr (GAB) s.g[c][Q0] = gq[c];
+      }
+      s.du[Q0] = AbsScaleSum(dvert, P);
+      s.dl[Q0] = AbsScaleSum(dhor, P);
     }
-    // 3b. plus-sums of row p = q-1 (order: up, left, centre, right, down)
-    v2f pv = {0.0f, 0.0f}, ph = {0.0f, 0.0f};
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const v2f du_c = s.du[c][Q1], dl_c = s.dl[c][Q1];
-      v2f v = AddLeft(s.du[c][Q2], du_c);
+    // 3b. plus-sums of row p = q-1 (up, left, centre, right, down)
+    {
+      const v2f du_c = s.du[Q1], dl_c = s.dl[Q1];
+      v2f v = AddLeftS(s.du[Q2], du_c);
       v = v + du_c;
-      v = AddRight(v, du_c);
-      v = v + s.du[c][Q0];
-      v2f h = AddLeft(s.dl[c][Q2], dl_c);
+      v = AddRightS(v, du_c);
+      s.pv[Q1] = v + s.du[Q0];
+      v2f h = AddLeftS(s.dl[Q2], dl_c);
       h = h + dl_c;
-      h = AddRight(h, dl_c);  // |p(x,y) - p(x+1,y)| = Dl(x+1,y)
-      h = h + s.dl[c][Q0];
-      pv = Fma2(v, P.ch_scale[c], pv);
-      ph = Fma2(h, P.ch_scale[c], ph);
+      h = AddRightS(h, dl_c);  // |p(x,y) - p(x+1,y)| = Dl(x+1,y)
+      s.ph[Q1] = h + s.dl[Q0];
     }
-    s.pv[Q1] = pv;
-    s.ph[Q1] = ph;
-    // 3c. EPF1 output row o = q-2
+  // 3c. EPF1 output row o = q-2
     o = q - 2;
     const float kMinSigma = -3.90524291751269967465540850526868f;
     // first row whose result is used: y_begin, or the row above it when EPF2 reads it
     if ((o & 7) == 0 || o == y_begin - (EPF == 2 ? 1 : 0)) {
       const int oc = o < 0 ? 0 : (o >= H ? H - 1 : o);
-      const float is = f.inv_sigma[(size_t)(oc >> 3) * f.xsb + L.sx];
+      const float is = *(const float*)((const char*)(f.inv_sigma + (size_t)(oc >> 3) * f.xsb) + LaneOffset(L.sx4));
       // below the threshold the stage copies its input (stage_epf.cc:258-262):
       // -inf zeroes the four weights, and (c + 0) * rcp(1) == c exactly
       inv_sigma_blk = is < kMinSigma ? -__builtin_inff() : is;
@@ -336,12 +471,11 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
     const v2f inv_w = {__builtin_amdgcn_rcpf(wsum.x), __builtin_amdgcn_rcpf(wsum.y)};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      const v2f ctr = s.g[c][Q2];
-      v2f a = ctr;
-      a = Fma2(wN, s.g[c][Q3], a);
-      a = FmaLeft(wW, ctr, a);
-      a = FmaRight(wE, ctr, a);
-      a = Fma2(wS, s.g[c][Q1], a);
+      const v2f ctr = gq2[c];
+      v2f a = Fma2(wN, gq3[c], ctr);
+      a = FmaLeftS(wW, ctr, a);
+      a = FmaRightS(wE, ctr, a);
+      a = Fma2(wS, gq1[c], a);
       outv[c] = a * inv_w;
     }
     if constexpr (EPF == 2) {
@@ -349,7 +483,7 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
       // produces: new row o enters, row o2 = o - 1 leaves.  Its SADs are single pixel
       // differences, shared between the two pixels they separate (|a - b| is symmetric).
       constexpr int E0 = Q2, E1 = Q3, E2 = Q0;  // rows o, o-1, o-2
-      if (L.edge) {
+      if constexpr (EDGE) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
           const float from_right = FromRight(outv[c].x), from_left = FromLeft(outv[c].y);
@@ -357,24 +491,22 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
           outv[c].x = L.fix_right_even ? from_left : outv[c].x;
         }
       }
-      v2f dv = Abs2(outv[0] - s.e[0][E1]) * P.ch_scale[0];
-      dv = Fma2(Abs2(outv[1] - s.e[1][E1]), P.ch_scale[1], dv);
-      dv = Fma2(Abs2(outv[2] - s.e[2][E1]), P.ch_scale[2], dv);
+      v2f dvert[3], dhor[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        dvert[c] = outv[c] - s.e[c][E1];
+        const v2f e1 = s.e[c][E1];
+        dhor[c] = v2f{Scalar(FromLeft(e1.y) - e1.x), Scalar(e1.x - e1.y)};  // |p(x) - p(x-1)| per column of row o2
+      }
+      const v2f dv = AbsScaleSum(dvert, P);
+      const v2f dh = AbsScaleSum(dhor, P);
 #pragma unroll
       for (int c = 0; c < 3; c++) s.e[c][E0] = outv[c];
       s.dv[E0] = dv;
       const int o2 = o - 1;
-      // |p(x) - p(x-1)| per column of row o2
-      v2f dh;
-      {
-        const v2f c0 = s.e[0][E1], c1 = s.e[1][E1], c2 = s.e[2][E1];
-        dh = Abs2(v2f{c0.x - FromLeft(c0.y), c0.y - c0.x}) * P.ch_scale[0];
-        dh = Fma2(Abs2(v2f{c1.x - FromLeft(c1.y), c1.y - c1.x}), P.ch_scale[1], dh);
-        dh = Fma2(Abs2(v2f{c2.x - FromLeft(c2.y), c2.y - c2.x}), P.ch_scale[2], dh);
-      }
       if ((o2 & 7) == 0 || o2 == y_begin) {
         const int oc = o2 < 0 ? 0 : (o2 >= H ? H - 1 : o2);
-        const float is = f.inv_sigma[(size_t)(oc >> 3) * f.xsb + L.sx];
+        const float is = *(const float*)((const char*)(f.inv_sigma + (size_t)(oc >> 3) * f.xsb) + LaneOffset(L.sx4));
         inv_sigma_blk2 = is < kMinSigma ? -__builtin_inff() : is;
       }
       const int iy2 = o2 & 7;
@@ -395,10 +527,9 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const v2f ctr = s.e[c][E1];
-        v2f a = ctr;
-        a = Fma2(wN2, top ? ctr : s.e[c][E2], a);
-        a = FmaLeft(wW2, ctr, a);
-        a = FmaRight(wE2, ctr, a);
+        v2f a = Fma2(wN2, top ? ctr : s.e[c][E2], ctr);
+        a = FmaLeftS(wW2, ctr, a);
+        a = FmaRightS(wE2, ctr, a);
         a = Fma2(wS2, bottom ? ctr : s.e[c][E0], a);
         outv[c] = a * inv_w2;
       }
@@ -410,8 +541,8 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
     for (int c = 0; c < 3; c++) outv[c] = gq[c];
   }
   // 4. emit
-  if (o >= y_begin && o < y_end && !((f.debug & 4) && outv[0].x != 12345.678f)) {
-    EmitPair<OUTK, FMT>(outv, L, o, f, P);
+  if (o >= y_begin && o < y_end && !((DBG & 4) && outv[0].x != 12345.678f)) {
+    EmitPair<OUTK, FMT, EDGE>(outv, L, o, out_row, P, K);
   }
 }
 
@@ -422,10 +553,78 @@ struct FastGeom {
   static constexpr int USE = 128 - 2 * HXP;       // output columns per wave
 };
 
-template <int GAB, int EPF, int OUTK, int FMT>
-__global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P, int RH) {
+template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, int DBG>
+__device__ __forceinline__ void March(const DevFrame& f, const FilterParams& P, Lane& L, int y_begin,
+                                      int y_end) {
+  constexpr int HX = FastGeom<GAB, EPF>::HX;
+  const int H = (int)f.ysize;
+  // rows: input rows r = y_begin - HX .. y_end + HX - 1; the pipeline emits
+  // row r - HX at step r.
+  const int r_first = y_begin - HX;
+  const int r_last = y_end + HX - 1;
+  // the prefetcher runs kAhead rows ahead: clamp to the last row this
+  // context holds (plane rows cover [y0 - halo, y1_padded + halo))
+  const int plane_last = f.plane_y0 + (int)f.plane_tile_rows * 8 - 1;
+  int prefetch_last_row = r_last;
+  // mirrored rows always fall inside the plane; direct rows must too
+  if (prefetch_last_row > plane_last && prefetch_last_row < H) prefetch_last_row = plane_last;
+  State s;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    // rows r_first .. r_first + kAhead - 1 are in flight when the first step runs; the slots of the
+    // (not yet existing) rows above them start as zero like the other rings
+    const bool fetch = k < kAhead;
+    int pr = r_first + k;
+    pr = pr > prefetch_last_row ? prefetch_last_row : pr;
+    const uint32_t off = RowOffset(f, Mirror1(pr, H));
+    LaneOffset(L.byte_off);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      if (fetch) s.x[c][k] = LoadPair<EDGE>((const char*)f.xyb[c] + off, L);
+      else s.x[c][k] = v2f{0.0f, 0.0f};
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      s.hs[c][k] = v2f{0.0f, 0.0f};
+      s.g[c][k] = v2f{0.0f, 0.0f};
+      s.e[c][k] = v2f{0.0f, 0.0f};
+    }
+    s.du[k] = v2f{0.0f, 0.0f};
+    s.dl[k] = v2f{0.0f, 0.0f};
+    s.pv[k] = v2f{0.0f, 0.0f};
+    s.ph[k] = v2f{0.0f, 0.0f};
+    s.dv[k] = v2f{0.0f, 0.0f};
+  }
+  float inv_sigma_blk = -1.0f, inv_sigma_blk2 = -1.0f;
+  const XybConsts KC = MakeXybConsts(P);
+  // output row of step r is row r - HX: a running pointer instead of a 64-bit product per row
+  const size_t out_row_bytes = OUTK == JXLHIP_OUT_XYB_PLANAR ? P.out_stride * 4 : P.out_stride;
+  char* out_row = (char*)P.out + (ptrdiff_t)(r_first - HX - (int)f.y0) * (ptrdiff_t)out_row_bytes;
+#define JXLHIP_STEP(K)                                                                                         \
+  Step<GAB, EPF, OUTK, FMT, K, EDGE, DBG>(s, r + K, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk, \
+                                          inv_sigma_blk2, out_row, KC);                                        \
+  out_row += out_row_bytes
+  for (int r = r_first; r <= r_last; r += 8) {
+    JXLHIP_STEP(0);
+    JXLHIP_STEP(1);
+    JXLHIP_STEP(2);
+    JXLHIP_STEP(3);
+    if (r + 4 > r_last) break;
+    JXLHIP_STEP(4);
+    JXLHIP_STEP(5);
+    JXLHIP_STEP(6);
+    JXLHIP_STEP(7);
+  }
+#undef JXLHIP_STEP
+}
+
+template <int GAB, int EPF, int OUTK, int FMT, int DBG>
+__global__ __launch_bounds__(256, EPF == 2 ? 2 : 3) void k_filters_fast(DevFrame f, FilterParams P, int RH) {
   using G = FastGeom<GAB, EPF>;
-  constexpr int HX = G::HX, HXP = G::HXP, USE = G::USE;
+  constexpr int HXP = G::HXP, USE = G::USE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float __attribute__((address_space(3)))* dither_lds = nullptr;
   if constexpr (OUTK == JXLHIP_OUT_PACKED) {  // before any wave leaves: whole-workgroup barrier
@@ -437,7 +636,7 @@ __global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P
     dither_lds = (const float __attribute__((address_space(3)))*)s_dither;
   }
   const int strip = blockIdx.x * 4 + wave;
-  const int W = (int)f.xsize, H = (int)f.ysize;
+  const int W = (int)f.xsize;
   const int x_first = strip * USE;  // first output column of the wave (even)
   if (x_first >= W) return;
   const int y_begin = (int)f.fy0 + blockIdx.y * RH;
@@ -446,79 +645,39 @@ __global__ __launch_bounds__(256) void k_filters_fast(DevFrame f, FilterParams P
   Lane L;
   L.gx = x_first - HXP + 2 * lane;
   L.dither = dither_lds;
-  {
-    // the lane's two columns, mirrored into the image, always fall into one
-    // aligned pair of plane columns (the planes are allocated in whole 8x8
-    // tiles, so column W exists when W is odd)
-    const int m0 = MirrorF(L.gx, W), m1 = MirrorF(L.gx + 1, W);
-    const int base = m0 & ~1;
-    L.sel0 = m0 & 1;
-    L.sel1 = m1 & 1;
-    L.byte_off = ((uint32_t)(base >> 3) * 64u + (uint32_t)(base & 7)) * 4u;
-    L.edge = x_first - HXP < 0 || x_first - HXP + 128 > W;
-    const bool lane_in = lane >= HXP / 2 && lane < 64 - HXP / 2;
-    L.out0 = lane_in && L.gx < W;
-    L.out1 = lane_in && L.gx + 1 < W;
-    const int gxc = L.gx < 0 ? 0 : (L.gx >= W ? W - 1 : L.gx);
-    L.sx = gxc >> 3;
-    const int ix = gxc & 7;
-    // columns gx, gx+1 (gx even inside the image): only gx can be a block's
-    // first column and only gx+1 its last
-    L.mul = v2f{ix == 0 ? P.bsm[1] : P.sm[1], ix == 6 ? P.bsm[1] : P.sm[1]};
-    L.mul2 = v2f{ix == 0 ? P.bsm[2] : P.sm[2], ix == 6 ? P.bsm[2] : P.sm[2]};
-    L.fix_left = L.gx == -2;
-    L.fix_right_even = L.gx == W;       // only reached when W is even (gx is even)
-    L.fix_right_odd = L.gx == W - 1;    // W odd
-  }
-  // rows: input rows r = y_begin - HX .. y_end + HX - 1; the pipeline emits
-  // row r - HX at step r.
-  const int r_first = y_begin - HX;
-  const int r_last = y_end + HX - 1;
-  // the prefetcher may run up to 4 rows ahead: clamp to the last row this
-  // context holds (plane rows cover [y0 - halo, y1_padded + halo))
-  const int plane_last = f.plane_y0 + (int)f.plane_tile_rows * 8 - 1;
-  int prefetch_last_row = r_last;
-  // mirrored rows always fall inside the plane; direct rows must too
-  if (prefetch_last_row > plane_last && prefetch_last_row < H) prefetch_last_row = plane_last;
-  State s;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    int pr = r_first + k;
-    pr = pr > prefetch_last_row ? prefetch_last_row : pr;
-    const size_t off = RowOffset(f, MirrorF(pr, H));
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      s.pre[c][k] = LoadPair(f.xyb[c] + off, L);
-      s.in[c][k] = v2f{0.0f, 0.0f};
-      s.hs[c][k] = v2f{0.0f, 0.0f};
-      s.g[c][k] = v2f{0.0f, 0.0f};
-      s.du[c][k] = v2f{0.0f, 0.0f};
-      s.dl[c][k] = v2f{0.0f, 0.0f};
-      s.e[c][k] = v2f{0.0f, 0.0f};
-    }
-    s.pv[k] = v2f{0.0f, 0.0f};
-    s.ph[k] = v2f{0.0f, 0.0f};
-    s.dv[k] = v2f{0.0f, 0.0f};
-  }
-  float inv_sigma_blk = -1.0f, inv_sigma_blk2 = -1.0f;
-  for (int r = r_first; r <= r_last; r += 4) {
-    Step<GAB, EPF, OUTK, FMT, 0>(s, r, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk,
-                                  inv_sigma_blk2);
-    Step<GAB, EPF, OUTK, FMT, 1>(s, r + 1, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk,
-                                  inv_sigma_blk2);
-    Step<GAB, EPF, OUTK, FMT, 2>(s, r + 2, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk,
-                                  inv_sigma_blk2);
-    Step<GAB, EPF, OUTK, FMT, 3>(s, r + 3, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk,
-                                  inv_sigma_blk2);
-  }
+  // the lane's two columns, mirrored into the image, always fall into one
+  // aligned pair of plane columns (the planes are allocated in whole 8x8
+  // tiles, so column W exists when W is odd)
+  const int m0 = MirrorF(L.gx, W), m1 = MirrorF(L.gx + 1, W);
+  const int base = m0 & ~1;
+  L.sel0 = m0 & 1;
+  L.sel1 = m1 & 1;
+  L.byte_off = ((uint32_t)(base >> 3) * 64u + (uint32_t)(base & 7)) * 4u;
+  const bool edge = x_first - HXP < 0 || x_first - HXP + 128 > W;  // wave-uniform
+  const bool lane_in = lane >= HXP / 2 && lane < 64 - HXP / 2;
+  L.out0 = lane_in && L.gx < W;
+  L.out1 = lane_in && L.gx + 1 < W;
+  const int gxc = L.gx < 0 ? 0 : (L.gx >= W ? W - 1 : L.gx);
+  L.sx4 = (uint32_t)(gxc >> 3) * 4u;
+  L.out_off = (uint32_t)(L.gx < 0 ? 0 : L.gx) * (OUTK == JXLHIP_OUT_LINEAR_RGB_F32 ? 12u : 4u);
+  const int ix = gxc & 7;
+  // columns gx, gx+1 (gx even inside the image): only gx can be a block's
+  // first column and only gx+1 its last
+  L.mul = v2f{ix == 0 ? P.bsm[1] : P.sm[1], ix == 6 ? P.bsm[1] : P.sm[1]};
+  L.mul2 = v2f{ix == 0 ? P.bsm[2] : P.sm[2], ix == 6 ? P.bsm[2] : P.sm[2]};
+  L.fix_left = L.gx == -2;
+  L.fix_right_even = L.gx == W;       // only reached when W is even (gx is even)
+  L.fix_right_odd = L.gx == W - 1;    // W odd
+  if (edge) March<GAB, EPF, OUTK, FMT, true, DBG>(f, P, L, y_begin, y_end);
+  else March<GAB, EPF, OUTK, FMT, false, DBG>(f, P, L, y_begin, y_end);
 }
 
 // Rows per wave.  Every wave costs (RH + 2*HX) row steps and all waves of a
 // launch take the same time, so the launch runs in ceil(workgroups / resident
 // workgroups) generations: pick the RH that minimises generations * steps
 // instead of leaving a mostly empty last generation.  Resident capacity: 256
-// CUs x 2 workgroups (2 waves per SIMD at < 256 VGPRs).  JXLHIP_FILTER_RH
-// overrides.
+// CUs x 3 workgroups (3 waves per SIMD at <= 168 VGPRs).  JXLHIP_FILTER_RH /
+// JXLHIP_FILTER_RESIDENT override.
 int FilterRowsPerWave(unsigned wgx, unsigned rows, int hx) {
   static const int forced = [] {
     const char* e = getenv("JXLHIP_FILTER_RH");
@@ -550,7 +709,23 @@ void LaunchFastT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
   const unsigned wgx = (strips + 3) / 4;
   const int RH = FilterRowsPerWave(wgx, f.fy1 - f.fy0, G::HX);
   const dim3 grid(wgx, (f.fy1 - f.fy0 + RH - 1) / RH);
-  hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT>), grid, dim3(256), 0, st, f, p, RH);
+  // JXLHIP_DEBUG ablations (bits 4 / 8) exist for the BASELINE stage list with float output only
+  if constexpr (GAB == 1 && EPF == 1 && OUTK == 1) {
+    const int dbg = (int)(f.debug & 12u);
+    if (dbg == 4) {
+      hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 4>), grid, dim3(256), 0, st, f, p, RH);
+      return;
+    }
+    if (dbg == 8) {
+      hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 8>), grid, dim3(256), 0, st, f, p, RH);
+      return;
+    }
+    if (dbg == 12) {
+      hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 12>), grid, dim3(256), 0, st, f, p, RH);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 0>), grid, dim3(256), 0, st, f, p, RH);
 }
 
 // The formats djxl writes most (8-bit sRGB for PNG / PPM / JPEG-like consumers,
@@ -575,7 +750,9 @@ void LaunchPackedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st) {
   if (epf_iters > 2) return false;  // three iterations add EPF0 (7x7 reach): generic LDS kernel
-  if (f.xsize < 16) return false;  // multiply mirrored columns: generic kernel
+  if (f.xsize < 16 || f.ysize < 16) return false;  // multiply mirrored columns / rows: generic kernel
+  // row offsets inside a plane are 32-bit
+  if ((uint64_t)f.plane_tile_rows * f.tile_stride * 256u >= (1ull << 32)) return false;
 #define JXLHIP_FAST(G, E)                                  \
   if (gab == G && epf_iters == E) {                        \
     if (output_kind == 0) LaunchFastT<G, E, 0>(f, p, st);  \

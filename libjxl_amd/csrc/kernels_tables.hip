@@ -132,17 +132,26 @@ __global__ __launch_bounds__(256) void k_dequant_tables(float* __restrict__ tabl
   table[i] = 1.0f / w;
 }
 
-__global__ __launch_bounds__(256) void k_dequant_dc(size_t n, const int32_t* __restrict__ qx,
+// extra_precision (optional): one byte per DC group (2048x2048 px = 256x256 blocks): the group's
+// factors are multiplied by 1 / (1 << extra_precision) (DecodeVarDCTDC, dec_modular.cc:443-445)
+__global__ __launch_bounds__(256) void k_dequant_dc(uint32_t xs, uint32_t ys, const int32_t* __restrict__ qx,
                                                     const int32_t* __restrict__ qy,
                                                     const int32_t* __restrict__ qb,
                                                     float* __restrict__ ox, float* __restrict__ oy,
                                                     float* __restrict__ ob, float mx, float my,
-                                                    float mb, float cfl_x, float cfl_b) {
+                                                    float mb, float cfl_x, float cfl_b,
+                                                    const uint8_t* __restrict__ extra_precision) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float in_x = (float)qx[i] * mx;
-  const float in_y = (float)qy[i] * my;
-  const float in_b = (float)qb[i] * mb;
+  if (i >= (size_t)xs * ys) return;
+  float mul = 1.0f;
+  if (extra_precision) {
+    const uint32_t y = (uint32_t)(i / xs), x = (uint32_t)(i % xs);
+    const uint32_t p = extra_precision[(size_t)(y >> 8) * ((xs + 255) >> 8) + (x >> 8)] & 3u;
+    mul = 1.0f / (float)(1u << p);
+  }
+  const float in_x = (float)qx[i] * (mx * mul);
+  const float in_y = (float)qy[i] * (my * mul);
+  const float in_b = (float)qb[i] * (mb * mul);
   oy[i] = in_y;
   ox[i] = __builtin_fmaf(in_y, cfl_x, in_x);
   ob[i] = __builtin_fmaf(in_y, cfl_b, in_b);
@@ -214,13 +223,13 @@ void LaunchDequantTables(float* table, const jxlhip_quant_encoding* enc_dev, int
 
 void LaunchDequantDC(uint32_t xsb, uint32_t ysb, const int32_t* const q[3], float* const dc[3],
                      float* const tmp[3], const float mul_dc[3], float cfl_x, float cfl_b,
-                     int smooth, hipStream_t st) {
+                     int smooth, const uint8_t* extra_precision, hipStream_t st) {
   const size_t n = (size_t)xsb * ysb;
   const bool do_smooth = smooth && xsb > 2 && ysb > 2;
   float* const* first = do_smooth ? tmp : dc;
-  hipLaunchKernelGGL(k_dequant_dc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, q[0],
+  hipLaunchKernelGGL(k_dequant_dc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xsb, ysb, q[0],
                      q[1], q[2], first[0], first[1], first[2], mul_dc[0], mul_dc[1], mul_dc[2],
-                     cfl_x, cfl_b);
+                     cfl_x, cfl_b, extra_precision);
   if (do_smooth) {
     DcPlanes p;
     for (int c = 0; c < 3; c++) {
