@@ -2,15 +2,20 @@
 """bench.py -- Mpixels/s of the VarDCT decode back-end on MI355X.
 
 One "step" = one pass of the hot path (dequant -> inverse transforms ->
-Gaborish -> EPF1 -> XYB->linear RGB) over one synthetic frame whose quantized
+[Gaborish] -> [EPF] -> XYB->linear RGB) over one synthetic frame whose quantized
 coefficients and side info are already resident in HBM; output stays in HBM.
 
-  N = 1 : BASELINE.json configs[2]: 7680x4320 RGB, d1.0-like (Gaborish + EPF1),
-          int16 coefficients, d1.0/e7-like strategy mix.
-  N > 1 : weak scaling: a 7680 x (4320*N) frame split into N group-row stripes
-          (one rank per GPU), halo rows exchanged with the two neighbours over
-          RCCL between the two phases; each rank's output stripe stays in its HBM
-          (pass --gather to also time the collection on rank 0).
+Workloads = BASELINE.json's configs, `--config`:
+  c1  1024x1024    d1.0 mix, Gaborish+EPF1, int16          (configs[0]; cpu_baseline: 1 thread)
+  c2  3840x2160    d1.0 mix, filters off, int16             (configs[1])
+  c3  7680x4320    d1.0 mix, Gaborish+EPF1, int16           (configs[2]; DEFAULT at --gpus 1)
+  c4  15360x8640   as c3, group-row stripes over the ranks, gather on rank 0 INSIDE the step
+                                                            (configs[3]; DEFAULT at --gpus N>1)
+  c5  7680x4320    all DCT32x32, int32 coefficients, HDR intensity target 1000, d0.5-like quant,
+                   filters off                               (configs[4])
+N>1 is strong scaling of c4: the 16K frame is fixed, every rank decodes its stripe (halo rows exchanged with the
+two neighbours between the phases) and rank 0 collects the stripes.  `--config c4 --gpus 1` is the same frame on
+one GPU (the base of the scaling curve).
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -25,6 +30,17 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
+CONFIGS = {
+    "c1": dict(width=1024, height=1024, gab=1, epf=1, mix="d1", coeff32=False, intensity=255.0, quant_mul=1.0),
+    "c2": dict(width=3840, height=2160, gab=0, epf=0, mix="d1", coeff32=False, intensity=255.0, quant_mul=1.0),
+    "c3": dict(width=7680, height=4320, gab=1, epf=1, mix="d1", coeff32=False, intensity=255.0, quant_mul=1.0),
+    "c4": dict(width=15360, height=8640, gab=1, epf=1, mix="d1", coeff32=False, intensity=255.0, quant_mul=1.0),
+    "c5": dict(width=7680, height=4320, gab=0, epf=0, mix="dct32", coeff32=True, intensity=1000.0, quant_mul=2.0),
+}
+METRIC = {"c1": "Mpixels/s decode (VarDCT d1.0, 1024x1024 RGB)", "c2": "Mpixels/s decode (VarDCT d1.0, 4K RGB, filters off)",
+          "c3": "Mpixels/s decode (VarDCT d1.0, 8K RGB)", "c4": "Mpixels/s decode (VarDCT d1.0, 16K RGB)",
+          "c5": "Mpixels/s decode (VarDCT d0.5, 8K HDR, DCT32x32)"}
+
 
 def algorithmic_bytes(xsize, ysize, coeff_bytes):
     """B = Wp*Hp*3*sizeof(coef) + Nblk*18 + W*H*12."""
@@ -32,7 +48,22 @@ def algorithmic_bytes(xsize, ysize, coeff_bytes):
     return wp * hp * 3 * coeff_bytes + (wp * hp // 64) * 18 + xsize * ysize * 12
 
 
-def cpu_baseline(args):
+def resolve_mix(name):
+    from libjxl_amd import synth
+    named = {"d1": synth.MIX_D1, "dct8": synth.MIX_DCT8, "dct32": synth.MIX_DCT32, "all": synth.MIX_ALL}
+    if name in named:
+        return named[name]
+    if name == "real4k":
+        # area shares of the strategies in a genuine libjxl d1.0 stream (tests/data/real_4k_d1.npz, written by
+        # the reference encoder: 42 % 64x64, 32 % 32x32, 7 % DCT8 ...)
+        import numpy as np
+        acs = np.load(os.path.join(ROOT, "tests", "data", "real_4k_d1.npz"))["ac_strategy"]
+        n = np.bincount(acs.ravel() >> 1, minlength=27)
+        return {int(s): float(v) for s, v in enumerate(n) if v}
+    return {int(k): float(v) for k, v in (kv.split(":") for kv in name.split(","))}
+
+
+def cpu_baseline(cfg, sample, threads):
     """libjxl's own CPU path timed on the host cores on a bounded sample of the
     same workload: oracle/_ref = the reference decoder sources compiled in place
     (DecodeGroupForRoundtrip + LowMemoryRenderPipeline, the executor djxl uses),
@@ -43,10 +74,11 @@ def cpu_baseline(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import frames
     import oracle
-    from libjxl_amd import synth
-    w, h = args.cpu_sample
-    cores = os.cpu_count() or 1
-    _, _, fr = frames.make_case(w, h, mix=synth.MIX_D1, gab=True, epf_iters=1)
+    w, h = sample
+    cores = threads or (os.cpu_count() or 1)
+    _, _, fr = frames.make_case(w, h, mix=resolve_mix(cfg["mix"]), gab=bool(cfg["gab"]), epf_iters=cfg["epf"],
+                                coeff_type=int(cfg["coeff32"]), intensity_target=cfg["intensity"],
+                                quant_mul=cfg["quant_mul"])
     use_ref = oracle.ref_available()
     run = (lambda: fr.decode_ref(threads=cores)) if use_ref else (lambda: fr.decode(threads=cores))
     run()  # warm
@@ -61,7 +93,7 @@ def cpu_baseline(args):
         "oracle/ C restatement (libjxl reference library not available)"
     return {"value": round(w * h * reps / t / 1e6, 2), "unit": "Mpixels/s", "cores": cores,
             "kind": "reference" if use_ref else "port",
-            "sample": f"{w}x{h} d1.0-like frame (Gaborish+EPF1), {reps} reps, {cores} threads over groups; {what}"}
+            "sample": f"{w}x{h} frame of this workload, {reps} reps, {cores} thread(s) over groups; {what}"}
 
 
 def main():
@@ -69,18 +101,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--width", type=int, default=7680)
-    ap.add_argument("--height", type=int, default=4320)
-    ap.add_argument("--gab", type=int, default=1)
-    ap.add_argument("--epf", type=int, default=1)
-    ap.add_argument("--mix", default="d1",
-                    help="d1 | dct8 | dct32 | all, or an explicit area mix 'strategy:share,...' (e.g. 18:1 = all 64x64)")
-    ap.add_argument("--coeff32", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="also gather stripes on rank 0 each step")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="BASELINE workload; default c3 at --gpus 1, c4 at --gpus N>1")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--gab", type=int, default=None)
+    ap.add_argument("--epf", type=int, default=None)
+    ap.add_argument("--mix", default=None,
+                    help="d1 | dct8 | dct32 | all | real4k (the strategy shares of a genuine libjxl d1.0 stream), or an "
+                         "explicit area mix 'strategy:share,...' (e.g. 18:1 = all 64x64)")
+    ap.add_argument("--coeff32", action="store_true", default=None)
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave the output stripes sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (N=1)")
     ap.add_argument("--calib-copy", action="store_true",
                     help="run one known-size (1 GiB) device copy so PMC passes can be calibrated")
-    ap.add_argument("--cpu-sample", type=int, nargs=2, default=[4096, 2160])
+    ap.add_argument("--cpu-sample", type=int, nargs=2, default=None)
     args = ap.parse_args()
 
     import torch
@@ -100,23 +136,31 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    mix = {"d1": synth.MIX_D1, "dct8": synth.MIX_DCT8, "dct32": synth.MIX_DCT32,
-           "all": synth.MIX_ALL}.get(args.mix) or {int(k): float(v) for k, v in
-                                                    (kv.split(":") for kv in args.mix.split(","))}
-    xs, ys = args.width, args.height * world
-    params, t = synth.synth_frame(xs, ys, mix=mix, gab=bool(args.gab), epf_iters=args.epf,
-                                  device=f"cuda:{local}", coeff_type=int(args.coeff32))
+    name = args.config or ("c3" if world == 1 else "c4")
+    cfg = dict(CONFIGS[name])
+    for k in ("width", "height", "gab", "epf", "mix"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    if args.coeff32:
+        cfg["coeff32"] = True
+    custom = any(getattr(args, k) is not None for k in ("width", "height", "gab", "epf", "mix")) or bool(args.coeff32)
+    xs, ys = cfg["width"], cfg["height"]
+    mix = resolve_mix(cfg["mix"])
+    params, t = synth.synth_frame(xs, ys, mix=mix, gab=bool(cfg["gab"]), epf_iters=cfg["epf"],
+                                  device=f"cuda:{local}", coeff_type=int(cfg["coeff32"]),
+                                  intensity_target=cfg["intensity"], quant_mul=cfg["quant_mul"])
     dec = VarDctDecoder(local)
     sd = stripes.StripeDecoder(dec, params, rank, world)
     dq = dec.default_dequant_tables()
     dec.set_inputs(t, dq)
     out = dec.alloc_output()
-    rows = [b - a for a, b in sd.rows]
+    gather = world > 1 and not args.no_gather
+    full = sd.alloc_gather(out) if gather else None
 
     def step():
         sd.decode(out)
-        if args.gather and world > 1:
-            stripes.gather_stripes(out, rows, rank, world)
+        if gather:
+            sd.gather(out, full)
 
     def fence():
         if world > 1:
@@ -152,44 +196,88 @@ def main():
     dec.profile(False)
     kern = {k: round(ms / max(n, 1), 4) for k, (ms, n) in prof.items()}
 
+    # the same step when the boundary hands over HOST buffers: pinned H2D of the
+    # coefficient stream, kernels, pinned D2H of the pixels.  Never `value`.
+    pcie = None
+    if world == 1 and not args.no_pcie:
+        host_c = [torch.empty(c.shape, dtype=c.dtype, pin_memory=True).copy_(c) for c in t["coeffs"]]
+        host_o = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+        n_pcie = max(3, min(args.steps, 10))
+
+        def pstep():
+            for d, h in zip(t["coeffs"], host_c):
+                d.copy_(h, non_blocking=True)
+            dec.decode_frame(out)
+            host_o.copy_(out, non_blocking=True)
+
+        pstep()
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        for _ in range(n_pcie):
+            pstep()
+        torch.cuda.synchronize()
+        pdt = (time.perf_counter() - p0) / n_pcie
+        pcie = {"value": round(xs * ys / pdt / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(pdt * 1e3, 3),
+                "h2d_bytes": int(sum(c.numel() * c.element_size() for c in host_c)),
+                "d2h_bytes": int(host_o.numel() * host_o.element_size()),
+                "what": "pinned H2D of the coefficient stream + kernels + pinned D2H of the f32 pixels, serial on one stream"}
+        del host_c, host_o
+
     if rank == 0:
         px = xs * ys
         ms_step = dt / args.steps * 1e3
         value = px / (dt / args.steps) / 1e6
-        # dominant SINGLE kernel of this rank's stripe: the "blocks" slot is a span
-        # over the transform launches (k_prepare, k_transform_8, k_transform_r; the
-        # longest of them is ~0.4x the filter kernel in profiles/*_kernel_stats.csv),
-        # so the roofline is quoted on the fused Gaborish+EPF+XYB kernel, one launch
-        # per frame here.
+        cb = 4 if cfg["coeff32"] else 2
+        # dominant SINGLE kernel of this rank's stripe: the fused Gaborish+EPF+XYB (or plane -> RGB) kernel, one
+        # launch per frame.  Three fractions of the 8 TB/s HBM peak:
+        #   frac        SURVEY 8(d)'s figure: the FRAME's algorithmic bytes over that kernel's time (the contract's
+        #               definition; a hybrid: the kernel never touches the coefficient stream)
+        #   frac_kernel the kernel's OWN algorithmic bytes (12 B/px planes in + output bytes out) over its time
+        #   frac_step   the frame's algorithmic bytes over the whole step (all launches) -- the honest end-to-end one
         dom = "filters" if "filters" in kern else max(kern, key=kern.get)
         y0, y1 = sd.rows[rank]
-        b_alg = algorithmic_bytes(xs, y1 - y0, 4 if args.coeff32 else 2)
+        b_alg = algorithmic_bytes(xs, y1 - y0, cb)
+        b_alg_frame = algorithmic_bytes(xs, ys, cb)
+        b_own = xs * (y1 - y0) * 24
         achieved = b_alg / (kern[dom] * 1e-3) / 1e9
-        traffic = None
+        traffic, tsrc = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf) and world == 1 and (xs, ys) == (7680, 4320):
+        if os.path.exists(tf) and world == 1 and name == "c3" and not custom:
             try:
                 traffic = json.load(open(tf)).get(dom)
+                tsrc = "profiles/pmc_traffic.json (replayed: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.sh)"
             except Exception:
                 traffic = None
         line = {
-            "metric": "Mpixels/s decode (VarDCT d1.0, 8K RGB)", "value": round(value, 1),
+            "metric": METRIC[name] if not custom else "Mpixels/s decode (VarDCT, custom workload)", "value": round(value, 1),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{xs}x{ys} RGB VarDCT d1.0-like frame, gab={args.gab} "
-                                   f"epf_iters={args.epf}, {'int32' if args.coeff32 else 'int16'} "
-                                   f"coefficients, strategy mix {args.mix}, linear RGB f32 out",
+            "config": {"workload": f"{name}{'*' if custom else ''}: {xs}x{ys} RGB VarDCT frame, gab={cfg['gab']} "
+                                   f"epf_iters={cfg['epf']}, {'int32' if cfg['coeff32'] else 'int16'} "
+                                   f"coefficients, strategy mix {cfg['mix']}, intensity_target {cfg['intensity']:g}, "
+                                   f"linear RGB f32 out",
                        "stripes": world, "halo_rows": dec.halo_rows(),
-                       "gather_in_step": bool(args.gather),
+                       "gather_in_step": bool(gather),
                        "kernel_ms": kern},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel": "k_filters_fast" if dom == "filters" else dom,
-                         "algorithmic_bytes_per_launch": b_alg},
+                         "frac_step": round(b_alg_frame / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_kernel": round(b_own / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": tsrc,
+                         "kernel": "k_filters_fast" if dom == "filters" else dom,
+                         "algorithmic_bytes_per_launch": b_alg,
+                         "algorithmic_bytes_frame": b_alg_frame,
+                         "kernel_own_bytes_per_launch": b_own},
         }
+        if pcie:
+            line["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
+            if name == "c1":
+                line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample or (1024, 1024), 1)
+            else:
+                line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample or (4096, 2160), 0)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

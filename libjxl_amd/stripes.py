@@ -89,6 +89,31 @@ class StripeDecoder:
         self.rows = [stripe_pixel_rows(params["ysize"], a, b) for a, b in self.parts]
         decoder.begin_frame(self.params)
 
+    # -- gather: the final collective of the 16K configuration ------------------
+    def alloc_gather(self, stripe):
+        """Rank 0: the whole-frame output buffer the stripes are received into (each stripe is a
+        contiguous row range of it: no staging, no concatenation); None elsewhere."""
+        if self.rank != 0:
+            return None
+        rows = sum(b - a for a, b in self.rows)
+        return torch.empty((rows,) + tuple(stripe.shape[1:]), dtype=stripe.dtype, device=stripe.device)
+
+    def gather(self, stripe, full):
+        """One point-to-point transfer per stripe straight into rank 0's frame (xGMI is
+        point-to-point: every stripe travels over its own link, no ring)."""
+        if self.world == 1:
+            return stripe
+        if self.rank == 0:
+            a, b = self.rows[0]
+            full[a:b].copy_(stripe)
+            ops = [dist.P2POp(dist.irecv, full[self.rows[r][0]:self.rows[r][1]], r, self.group)
+                   for r in range(1, self.world)]
+        else:
+            ops = [dist.P2POp(dist.isend, stripe, 0, self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return full
+
     def decode(self, out):
         d = self.dec
         if self.world == 1:
