@@ -264,7 +264,13 @@ JXLHIP_EXPORT int jxlhip_decode_filters(jxlhip_ctx* ctx, void* out,
                                         size_t out_stride,
                                         size_t out_plane_stride);
 
-/* Both phases (single GPU). */
+/* Both phases (single GPU).  When the context holds the whole frame (no stripe)
+ * and the stage list has at most two EPF passes this runs FUSED
+ * (kernels_fused.hip): the filter kernel decodes the DCT8 varblocks of its own
+ * window straight from the coefficient stream, those pixels never exist in
+ * HBM, and the XYB planes afterwards hold the other strategies' pixels only --
+ * jxlhip_export_xyb / jxlhip_halo_export need jxlhip_decode_blocks.
+ * JXLHIP_FUSE=0 in the environment forces the two-phase path. */
 JXLHIP_EXPORT int jxlhip_decode_frame(jxlhip_ctx* ctx, void* out,
                                       size_t out_stride,
                                       size_t out_plane_stride);

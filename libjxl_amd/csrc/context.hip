@@ -94,6 +94,9 @@ struct jxlhip_ctx {
   int band_rows = 0;  // JXLHIP_BAND_ROWS: group rows per band of decode_frame (0 = whole stripe, the default:
                       // measured on MI355X, bands of 1-9 group rows under-fill the chip and lose 10-70 %)
   bool generic_filters = false;  // JXLHIP_FILTERS=generic: LDS kernel for every stage list
+  bool fuse = true;              // JXLHIP_FUSE=0: jxlhip_decode_frame runs the two phases unfused
+  uint2* cell_info = nullptr;    // fused mode: per-cell coefficient offset + quant / CfL word (k_prepare)
+  size_t cell_info_items = 0;
   // profiling
   bool profiling = false;
   std::vector<ProfSpan> spans;
@@ -214,6 +217,8 @@ int jxlhip_create(int device, jxlhip_ctx** out) {
     c->generic_filters = e && !strcmp(e, "generic");
     const char* b = getenv("JXLHIP_BLOCK_STREAMS");
     if (b) c->nblock_streams = atoi(b);
+    const char* fu = getenv("JXLHIP_FUSE");
+    if (fu) c->fuse = atoi(fu) != 0;
     const char* br = getenv("JXLHIP_BAND_ROWS");
     if (br) c->band_rows = atoi(br);
     if (c->band_rows < 0) c->band_rows = 0;
@@ -289,7 +294,7 @@ void jxlhip_destroy(jxlhip_ctx* c) {
   }
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
-                  c->dc_tmp,     c->quant_enc,  c->dc_prec};
+                  c->dc_tmp,     c->quant_enc,  c->dc_prec,      c->cell_info};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -786,11 +791,15 @@ namespace {
 
 // k_prepare + the transform kernels for group rows [g0, g1) of the stripe,
 // using counter slot `band`.
-int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band) {
+int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, bool fused = false) {
   hipStream_t st = c->stream;
   DevFrame f = c->f;
   f.band_g0 = g0;
   f.band_g1 = g1;
+  f.fused = fused ? 1u : 0u;
+  f.cell_info = c->cell_info;
+  if (fused)  // every cell "from the planes" until k_prepare says otherwise
+    HIPCHK(c, hipMemsetAsync(c->cell_info, 0xFF, sizeof(uint2) * (size_t)f.xsb * f.ysb, st));
   WorkLists wl = c->wl;
   wl.count = c->counts + (size_t)band * kCountStride;
   const uint32_t cells = f.xsg * (g1 - g0) * 1024u;
@@ -818,11 +827,21 @@ int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band) {
 }
 
 // phase 2 for pixel rows [fy0, fy1) of the stripe
-int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint32_t fy1) {
+int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint32_t fy1, bool fused = false) {
   DevFrame f = c->f;
   f.fy0 = fy0;
   f.fy1 = fy1;
+  f.fused = fused ? 1u : 0u;
+  f.cell_info = c->cell_info;
   ProfBegin(c);
+  if (fused) {
+    if (!LaunchFused(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind, c->stream))
+      return Fail(c, JXLHIP_ERR_STATE, "fused kernel refused a frame FusedSupported accepted");
+    ProfMark(c, JXLHIP_KERNEL_FILTERS);
+    ProfEnd(c);
+    HIPCHK(c, hipGetLastError());
+    return JXLHIP_OK;
+  }
   const bool fast = !c->generic_filters && fy1 > fy0 &&
                     LaunchFiltersFast(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters,
                                       (int)c->p.output_kind, c->stream);
@@ -951,6 +970,17 @@ int jxlhip_decode_frame(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_
   fp.out = out;
   fp.out_stride = out_stride;
   fp.out_plane_stride = out_plane_stride;
+  // Whole frame on this context, one band: the fused kernel decodes the DCT8 blocks inside the filter
+  // march (kernels_fused.hip).  The split calls (jxlhip_decode_blocks / _filters) stay two-phase: a
+  // stripe's halo rows must exist in the planes for its neighbours.
+  if (c->fuse && !c->generic_filters && c->band_rows == 0 && f.group_y0 == 0 && f.group_rows == f.ysg &&
+      FusedSupported(f, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind)) {
+    if ((rc = Grow(c, &c->cell_info, &c->cell_info_items, (size_t)f.xsb * f.ysb))) return rc;
+    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, 0, true);
+    if (rc) return rc;
+    c->blocks_done = false;  // the planes do not hold the whole frame
+    return LaunchFiltersRows(c, fp, f.y0, f.y1, true);
+  }
   const uint32_t g_end = f.group_y0 + f.group_rows;
   uint32_t prev_y0 = f.y0;
   int band = 0;
@@ -989,6 +1019,9 @@ int jxlhip_sync(jxlhip_ctx* c) {
 int jxlhip_export_xyb(jxlhip_ctx* c, float* const dst[3], size_t dst_stride) {
   if (!c || !dst || !dst[0] || !dst[1] || !dst[2]) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "no frame");
+  if (!c->blocks_done)
+    return Fail(c, JXLHIP_ERR_STATE, "export_xyb needs jxlhip_decode_blocks (jxlhip_decode_frame may run fused: "
+                                     "DCT8 blocks then never reach the planes)");
   const DevFrame& f = c->f;
   const int rows = (int)(f.plane_tile_rows - 2) * 8;
   if (dst_stride < (size_t)f.xsb * 8) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "stride too small");

@@ -51,6 +51,7 @@ enum WorkClass : int {
 // counter block of one band: the list length of class c lives at
 // count[c * kCounterPad] -- one 128-byte line per counter, so that the ~20
 // atomics every k_prepare workgroup issues do not all serialise on one line
+static constexpr uint32_t kCellFromPlanes = 0xFFFFFFFFu;
 static constexpr int kCounterPad = 32;
 static constexpr int kCountStride = 32 * kCounterPad;
 static_assert(kNumClasses <= 32, "counter block layout");
@@ -134,8 +135,14 @@ struct DevFrame {
   uint32_t plane_tile_rows;
   float* inv_sigma;       // xsb*ysb, whole frame indexing
   int32_t* error_flag;
-  uint32_t debug;  // JXLHIP_DEBUG ablation bits (1: no block stores, 2: all blocks read stream offset 0,
-                   // 4: no filter output stores, 8: filter input rows stay in L1)
+  uint32_t debug;  // JXLHIP_DEBUG ablation bits of the phase-2 kernel (4: no output stores, 8: input rows
+                   // stay in L1), compiled in only for the launch that asks for them
+  // Fused mode (kernels_fused.hip): varblocks of the classes the fused kernel decodes itself (DCT8)
+  // are not put on a work list and never reach the XYB planes; k_prepare leaves their coefficient
+  // offset and quant / CfL word in cell_info[cell] (xsb*ysb entries, whole frame indexing; every
+  // other cell holds kCellFromPlanes in .x: its pixels come from the planes)
+  uint2* cell_info;
+  uint32_t fused;
 };
 
 // address of pixel (y, x) of channel c in the block-major planes

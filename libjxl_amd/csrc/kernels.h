@@ -52,6 +52,13 @@ int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_ite
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st);
 
+// Fused kernel (kernels_fused.hip): the row march fed from the coefficient stream (DCT8 decoded by the
+// filter wave itself, other classes copied from the planes).  FusedSupported: frames it takes --
+// decided before k_prepare, which routes the DCT8 blocks (DevFrame::fused).
+bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind);
+bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,
+                 hipStream_t st);
+
 // block-major plane rows <-> dense row-major staging
 void LaunchRowsCopy(const DevFrame& f, float* dense, int y_first, int nrows, int ncols,
                     size_t dense_stride, size_t dense_plane, int nch, bool to_dense,

@@ -1,13 +1,13 @@
 // kernels_blocks.hip -- phase 1 of the VarDCT back-end on gfx950:
-//   k_prepare   : per-group coefficient-offset scan + per-class work lists
-//                 (the block walk of DecodeGroupImpl, lib/jxl/dec_group.cc:275-359,
-//                 turned into a data-parallel scan) and ComputeSigma
-//                 (lib/jxl/epf.cc:39-133)
-//   k_block64   : single-block strategies (DCT8 and IDENTITY / DCT2X2 / DCT4X4 /
-//                 DCT4X8 / DCT8X4 / AFV0-3): dequant + CfL + inverse transform, one
-//                 lane per block in registers, wave-cooperative LDS-staged I/O
-//   k_medium    : 16x8 .. 64x64, LDS-staged, one lane per 1-D transform
-//   k_large     : 128x64 .. 256x256, output plane used as scratch
+//   k_prepare      : per-group coefficient-offset scan + per-class work lists (the block walk of
+//                    DecodeGroupImpl, lib/jxl/dec_group.cc:275-359, turned into a data-parallel
+//                    scan) and ComputeSigma (lib/jxl/epf.cc:39-133)
+//   k_transform_8  : every single-block strategy, no LDS: DCT8 row-per-lane (8 lanes per block,
+//                    register transposes), the nine special 8x8 kinds lane-per-block
+//   k_transform_r  : 16x8 .. 32x32 row-per-lane (k_transform_r16 / r32 when only one half has work),
+//                    with the LDS-staged 64-point classes (64x64, 64x32, 32x64; k_transform_a when
+//                    alone) on its first workgroups
+//   k_large        : 128x64 .. 256x256, output plane used as scratch
 // replacing DequantBlock + LowestFrequenciesFromDC + TransformToPixels
 // (lib/jxl/dec_group.cc:115-181,431-450, lib/jxl/dec_transforms-inl.h:456-818).
 #include <stdlib.h>
@@ -17,8 +17,7 @@
 
 #include <initializer_list>
 
-#include "dev_common.h"
-#include "kernels.h"
+#include "blocks_common.h"
 
 namespace jxlhip {
 
@@ -107,6 +106,7 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     uint32_t n = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) n += wave_cls[w][tid];
+    if (f.fused && tid == kClsDct8) n = 0;  // decoded by the fused kernel: no list
     wg_base[tid] = (n && in_stripe && group_ok) ? atomicAdd(&wl.count[tid * kCounterPad], n) : 0;
   }
   // sigma_quant of each varblock, scattered to the cells it covers
@@ -125,7 +125,8 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     it.off = g * f.coef_stride64 + off64;
     it.qc = ((uint32_t)cell_q & 0xffffu) | cell_cfl;
     it.pad = 0;
-    wl.list[cls][pos] = it;
+    if (f.fused && cls == kClsDct8) f.cell_info[cell] = make_uint2(it.off, it.qc);
+    else wl.list[cls][pos] = it;
   }
   // ComputeSigma (epf.cc:69-79), one cell per thread
   if (with_sigma && valid) {
@@ -133,38 +134,6 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     sigma = sigma < -1e-4f ? sigma : -1e-4f;
     f.inv_sigma[cell] = 1.0f / sigma;
   }
-}
-
-// ------------------------------------------------------------ block header
-// threadIdx.x through an opaque (volatile, empty) asm: the unit functions below run inside the
-// persistent loop of UnitDispatch, and without this every class's lane-dependent address
-// arithmetic is loop-invariant and gets hoisted out of the loop -- into registers that stay
-// live across ALL classes of the family (measured: 308 VGPRs).
-__device__ __forceinline__ int Tid() {
-  int t = (int)threadIdx.x;
-  asm volatile("" : "+v"(t));
-  return t;
-}
-
-struct BlockHdr {
-  uint32_t abx, aby;
-  size_t coef;  // element offset into coeffs[c]
-  float sx, sy, sb, x_cc, b_cc;
-};
-
-__device__ __forceinline__ BlockHdr MakeHdr(const DevFrame& f, const WorkItem it) {
-  BlockHdr h;
-  h.abx = it.pos & 0xffffu;
-  h.aby = it.pos >> 16;
-  h.coef = (f.debug & 2) ? 0 : (size_t)it.off * 64u;
-  const int quant = (int)(it.qc & 0xffffu);
-  const float s = f.inv_global_scale / (float)quant;  // dec_group.cc:164
-  h.sx = s * f.x_dm;
-  h.sy = s;
-  h.sb = s * f.b_dm;
-  h.x_cc = f.cfl_base_x + (float)(int8_t)((it.qc >> 16) & 0xffu) * f.color_scale;
-  h.b_cc = f.cfl_base_b + (float)(int8_t)(it.qc >> 24) * f.color_scale;
-  return h;
 }
 
 // ------------------------------------------------- single-block transforms
@@ -356,71 +325,6 @@ __host__ __device__ constexpr TabOffsets MakeTabOffsets() {
 }
 static constexpr TabOffsets kSingleTabOffset = MakeTabOffsets();
 
-// ------------------------------------------------------------------ k_dct8
-// DCT8 alone is ~45 % of a d1.0 frame and gets a kernel of its own with no LDS and few
-// registers.  EIGHT LANES share a block:
-//   lane = block-of-the-step (bits 0-2) | matrix row j (bits 3-5)
-// Lane (b, j) loads row j of the stored 8x8 coefficient matrix of all three channels (one
-// 16-byte load each: the block's 8 lanes fetch its whole 128-byte line), dequantises it with
-// chroma-from-luma, runs the 8-point IDCT along the row, the wave transposes the 8x8 matrix
-// across the 8 lanes in registers (v_permlane32_swap for lane bit 5, v_permlane16_swap for
-// bit 4, DPP row_ror:8 + selects for bit 3), a second IDCT, and the lane holds pixel row j:
-// two 16-byte stores, the block's 8 lanes writing its 256-byte tile.
-// The two 1-D passes run in the opposite order of IDCT2D (dct-inl.h:254-291), which needs the
-// transpose once instead of three times; the 1-D transform itself keeps the reference's
-// operation order, the result differs from the other order by rounding only.
-__device__ __forceinline__ void SwapHalves32(float& a, float& b) {  // a[32..63] <-> b[0..31]
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r[0]);
-  b = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void SwapRows16(float& a, float& b) {  // odd rows of a <-> even rows of b
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r[0]);
-  b = __uint_as_float(r[1]);
-}
-// element (row j, register a) -> (row a, register j) for the lane mapping above
-__device__ __forceinline__ void Transpose8Lanes(float* w, bool bit3) {
-#pragma unroll
-  for (int k = 0; k < 4; k++) SwapHalves32(w[k], w[k + 4]);
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-    if (!(k & 2)) SwapRows16(w[k], w[k + 2]);
-#pragma unroll
-  for (int k = 0; k < 8; k += 2) {
-    const float send = bit3 ? w[k] : w[k + 1];
-    const float recv =
-        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xf, 0xf, false));
-    w[k] = bit3 ? recv : w[k];
-    w[k + 1] = bit3 ? w[k + 1] : recv;
-  }
-}
-
-template <typename CT>
-struct Dct8Row {  // one matrix row of one channel as loaded
-  static constexpr int kVec = sizeof(CT) == 2 ? 1 : 2;
-  uint4 v[kVec];
-  __device__ __forceinline__ void Load(const void* base, size_t elem) {
-    const uint4* p = (const uint4*)((const CT*)base + elem);
-#pragma unroll
-    for (int i = 0; i < kVec; i++) v[i] = p[i];
-  }
-  __device__ __forceinline__ void Unpack(int32_t* q) const {
-    if constexpr (sizeof(CT) == 2) {
-      const uint32_t w[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        q[2 * i] = (int32_t)(int16_t)(w[i] & 0xffffu);
-        q[2 * i + 1] = (int32_t)w[i] >> 16;
-      }
-    } else {
-      const uint32_t w[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
-#pragma unroll
-      for (int i = 0; i < 8; i++) q[i] = (int32_t)w[i];
-    }
-  }
-};
-
 template <typename CT>
 struct Dct8Geom {
   static constexpr int kSteps = sizeof(CT) == 2 ? 4 : 2;  // steps of 8 blocks per wave
@@ -591,8 +495,10 @@ __device__ __forceinline__ void SpecialTask(const DevFrame& f, int strategy, con
 
 // All single-block strategies in one launch: first the (unit, channel) tasks of the nine special
 // kinds, four per workgroup, then the DCT8 rows.
+// The (unit, channel) tasks of the nine special kinds, four per workgroup: workgroup `wg` of them.
+// Returns the number of workgroups the tasks fill (wg >= that: nothing done).
 template <typename CT>
-__global__ __launch_bounds__(256, 3) void k_transform_8(DevFrame f, WorkLists wl) {
+__device__ __forceinline__ uint32_t SpecialWorkgroup(const DevFrame& f, const WorkLists& wl, uint32_t wg) {
   uint32_t cnt[kNumSpecial];
   uint32_t tasks = 0;
 #pragma unroll
@@ -601,12 +507,9 @@ __global__ __launch_bounds__(256, 3) void k_transform_8(DevFrame f, WorkLists wl
     tasks += 3 * ((cnt[i] + 63) / 64);
   }
   const uint32_t special_wgs = (tasks + 3) / 4;
-  if (blockIdx.x >= special_wgs) {
-    Dct8Rows<CT>(f, wl.list[kClsDct8], wl.count[kClsDct8 * kCounterPad], blockIdx.x - special_wgs);
-    return;
-  }
-  const uint32_t task = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (task >= tasks) return;
+  if (wg >= special_wgs) return special_wgs;
+  const uint32_t task = wg * 4 + (threadIdx.x >> 6);
+  if (task >= tasks) return special_wgs;
   uint32_t base = 0;
   int cls = -1;
   uint32_t first = 0, n = 0, chan = 0;
@@ -623,6 +526,14 @@ __global__ __launch_bounds__(256, 3) void k_transform_8(DevFrame f, WorkLists wl
   }
   SpecialTask<CT>(f, (int)kSpecialStrategy[cls], wl.list[kClsSpecial0 + cls], first, n,
                   chan == 0 ? 1 : (chan == 1 ? 0 : 2));
+  return special_wgs;
+}
+
+template <typename CT>
+__global__ __launch_bounds__(256, 3) void k_transform_8(DevFrame f, WorkLists wl) {
+  const uint32_t special_wgs = SpecialWorkgroup<CT>(f, wl, blockIdx.x);
+  if (blockIdx.x >= special_wgs)
+    Dct8Rows<CT>(f, wl.list[kClsDct8], wl.count[kClsDct8 * kCounterPad], blockIdx.x - special_wgs);
 }
 
 // --------------------------------------------------------------- k_rowlane
@@ -1448,9 +1359,16 @@ static constexpr FamilyEntry kFamilyR[8] = {{kClsMedium0 + 7, 8},  {kClsMedium0 
 // nothing: three workgroups per CU is what their registers allow anyway.  As a launch of its own
 // family A is ~22 us of pure latency per 8K d1.0 frame.
 template <typename CT>
-__global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(DevFrame f, WorkLists wl, uint32_t big_wgs) {
+__global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(DevFrame f, WorkLists wl, uint32_t big_wgs,
+                                                                               uint32_t special_wgs, uint32_t r_wgs) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
-  if (blockIdx.x < big_wgs) {
+  // fused mode: DCT8 is decoded by the fused kernel, and what k_transform_8 would be left with -- the
+  // special 8x8 kinds -- rides at the head of this launch instead of being a latency-bound launch of its own
+  if (blockIdx.x < special_wgs) {
+    SpecialWorkgroup<CT>(f, wl, blockIdx.x);
+    return;
+  }
+  if (blockIdx.x < special_wgs + big_wgs) {
     if (threadIdx.x >= 192) return;
     UnitDispatch(kFamilyA, wl,
                  [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
@@ -1460,7 +1378,7 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(De
                      default: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
                    }
                  },
-                 0, big_wgs);
+                 special_wgs, big_wgs);
     return;
   }
   UnitDispatch(kFamilyR, wl,
@@ -1476,7 +1394,7 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(De
                    default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
                  }
                },
-               big_wgs, 0);
+               special_wgs + big_wgs, r_wgs);
 }
 
 // --------------------------------------------------------------- launchers
@@ -1502,19 +1420,25 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
   };
   const bool merged_r = any({4, 6, 7}) && any({5, 8, 9, 10, 11});
   const bool have_big = any({18, 19, 20});
+  bool specials_in_r = false;
+  uint32_t grid_specials = 0;
   if (have_big && !merged_r)
     hipLaunchKernelGGL((k_transform_a<CT>), dim3(grid_a), dim3(192), 0, s1, f, wl);
   {
     // worst cases: all cells special (3 tasks per 64 blocks, 4 tasks per workgroup) or all DCT8
     const bool specials = any({1, 2, 3, 12, 13, 14, 15, 16, 17});
     const uint32_t bound_s = specials ? (cells / 64 + kNumSpecial) * 3 / 4 + 1 : 0;
-    const uint32_t bound_8 = any({0}) ? (cells + kDct8PerWg - 1) / kDct8PerWg : 0;
+    const uint32_t bound_8 = (any({0}) && !f.fused) ? (cells + kDct8PerWg - 1) / kDct8PerWg : 0;
     const uint32_t grid_8 = (bound_s > bound_8 ? bound_s : bound_8) + (specials ? kNumSpecial : 0);
-    if (grid_8) hipLaunchKernelGGL((k_transform_8<CT>), dim3(grid_8), dim3(256), 0, s0, f, wl);
+    specials_in_r = f.fused && merged_r && specials;
+    grid_specials = bound_s + kNumSpecial;
+    if (grid_8 && !specials_in_r) hipLaunchKernelGGL((k_transform_8<CT>), dim3(grid_8), dim3(256), 0, s0, f, wl);
   }
   if (merged_r) {  // -10 us per 8K d1.0 frame against two launches, -15 us more with family A inside
     const uint32_t big_wgs = have_big ? (grid_a < 512u ? grid_a : 512u) : 0u;
-    hipLaunchKernelGGL((k_transform_r<CT>), dim3(big_wgs + grid_r16), dim3(256), 0, s0, f, wl, big_wgs);
+    const uint32_t special_wgs = specials_in_r ? grid_specials : 0u;
+    hipLaunchKernelGGL((k_transform_r<CT>), dim3(special_wgs + big_wgs + grid_r16), dim3(256), 0, s0, f, wl, big_wgs,
+                       special_wgs, grid_r16);
   } else {
     if (any({4, 6, 7}))
       hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);

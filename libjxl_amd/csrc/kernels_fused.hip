@@ -1,0 +1,412 @@
+// kernels_fused.hip -- the loop-filter row march fed straight from the coefficient stream.
+//
+// Round 1's two phases move the frame's XYB planes through HBM twice (12 B/px written by the
+// transform kernels, 12 B/px read by the filter kernel: 0.8 of the 1.5 GB an 8K frame moved).  Here
+// the filter wave decodes the varblocks of its own 128-column window itself, one block row (8 pixel
+// rows) at a time, into a 12 KB per-wave LDS slab and marches over the slab -- those pixels never
+// exist in HBM.  What a wave can decode alone without holding more than 8 rows is the single-block
+// class that dominates a d1.0 frame, DCT8 (45 % of the area, row-per-lane: 8 lanes per block,
+// register transposes, as k_transform_8); every other varblock is still decoded by the class-sorted
+// kernels of phase 1 into the block-major planes, and the wave copies those cells' tiles into its
+// slab with LDS-DMA loads (global_load_lds_dword: HBM -> LDS without passing through registers).
+//
+//   wave window : 16 whole block columns [112 k - 8, 112 k + 120): 8 halo columns either side of the
+//                 112 output columns (the march needs <= 4), so that the window is made of whole
+//                 varblock cells; neighbouring windows share two block columns, decoded by both
+//   per group of 8 rows (r = 0 mod 8):
+//     Fill      : cell info of the 16 cells (k_prepare left coefficient offset + quant / CfL word of
+//                 every DCT8 block in DevFrame::cell_info; other cells say "from the planes");
+//                 LDS-DMA of the plane cells (24 instructions per 8 cells); DCT8 cells in steps of 8
+//                 blocks: dequant + CfL + IDCT x transpose x IDCT, two ds_write_b128 per channel
+//     8 x Step  : the row march of filters_march.h with SRC_LDS (ds_read_b64 per channel and row)
+//   mirroring   : columns through the lane's (mirrored) slab address; rows by the slab row index
+//                 (a group of 8 rows always lies in one block row: frames with 1..3 rows in their
+//                 last block row go to the two-phase path)
+//
+// The reference semantics are those of the two-phase path (simple_render_pipeline.cc:129-164,
+// loop_filter.h:26-29); the parity tests run both.
+#include <stdlib.h>
+
+#include "blocks_common.h"
+#include "filters_march.h"
+
+namespace jxlhip {
+
+namespace {
+
+typedef __attribute__((address_space(3))) float LdsF;
+typedef __attribute__((address_space(3))) uint32_t LdsU;
+
+static constexpr int kFusedHalo = 8;                      // window columns in front of the first output column
+static constexpr int kFusedUse = kSlabCols - 2 * kFusedHalo;  // 112 output columns per wave
+
+// The fill steps read their frame parameters (coefficient / DC / table / plane pointers, quantizer
+// scalars) from the KERNARG SEGMENT at the point of use instead of keeping them in SGPRs for the whole
+// march: the march alone wants the ~100 SGPRs a wave has, and what does not fit is spilled to VGPR
+// lanes and read back with v_readlane_b32 -- 14 VALU issues per row step in the first version of this
+// kernel.  (DevFrame is the kernel's first by-value argument: offset 0 of the segment.)  The pointer
+// is laundered through an empty asm so that the loads are not hoisted out of the row loop again.
+typedef const DevFrame __attribute__((address_space(4))) * FrameArgs;
+__device__ __forceinline__ FrameArgs Fresh(FrameArgs q) {
+  asm volatile("" : "+s"(q));
+  return q;
+}
+
+struct __attribute__((aligned(16))) WaveLds {
+  float slab[3 * kSlabPlaneFloats];  // [channel][row 0..7][column 0..127]
+  uint32_t list[16 * 4];             // DCT8 cells of the block row: (cell, coefficient offset, quant / CfL word)
+};
+
+// What a wave knows about the block row it fills next: the cell info of its 16 cells (lanes 0..15)
+// and, once that load has returned, which cells it decodes itself / copies from the planes.
+struct NextRow {
+  int nb;        // block row, -1 = none
+  uint2 ci;      // lanes 0..15: cell info
+  uint32_t m8;   // wave-uniform: DCT8 cells
+  uint32_t mp;   // wave-uniform: cells whose tiles come from the planes
+};
+
+__device__ __forceinline__ void NextRowRequest(FrameArgs fa, NextRow& n, int nb, int bc0) {
+  const FrameArgs f = Fresh(fa);
+  const int lane = threadIdx.x & 63;
+  const int c16 = bc0 + (lane & 15);
+  n.nb = nb;
+  n.ci = make_uint2(kCellFromPlanes, 0u);
+  if (nb >= 0 && lane < 16 && c16 >= 0 && c16 < (int)f->xsb) n.ci = f->cell_info[(size_t)nb * f->xsb + c16];
+}
+__device__ __forceinline__ void NextRowMasks(FrameArgs fa, NextRow& n, int bc0) {
+  const FrameArgs f = Fresh(fa);
+  const int lane = threadIdx.x & 63;
+  const int c16 = bc0 + (lane & 15);
+  const bool valid_cell = n.nb >= 0 && lane < 16 && c16 >= 0 && c16 < (int)f->xsb;
+  const bool is_dct8 = valid_cell && n.ci.x != kCellFromPlanes;
+  n.m8 = (uint32_t)__ballot(is_dct8) & 0xffffu;
+  n.mp = (uint32_t)__ballot(valid_cell && !is_dct8) & 0xffffu;
+}
+
+// Plane cells of block row n.nb, slab rows 2k and 2k+1, all three channels: three LDS-DMA
+// instructions of 1 KB (global_load_lds_dwordx4: lane l brings 16 bytes = columns 4 (l & 31) ..
+// of row 2k + (l >> 5); the LDS destination of a wave instruction is contiguous, which two
+// consecutive 128-float slab rows are).  Called when rows 2k, 2k+1 of the CURRENT block row have
+// been consumed: the copy overlaps the march over the remaining rows.
+__device__ __forceinline__ void DmaPlaneRows(FrameArgs fa, LdsF* slab, const NextRow& n, int bc0, int k) {
+  if (n.mp == 0) return;  // wave-uniform
+  const FrameArgs f = Fresh(fa);
+  const int lane = threadIdx.x & 63;
+  const int cell = (lane & 31) >> 1;
+  if ((n.mp >> cell) & 1u) {
+    const int row = 2 * k + (lane >> 5);
+    const size_t at = ((size_t)(n.nb - (f->plane_y0 >> 3)) * f->tile_stride + (size_t)(bc0 + cell)) * 64u + row * 8 + (lane & 1) * 4;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+      __builtin_amdgcn_global_load_lds(f->xyb[ch] + at, slab + ch * kSlabPlaneFloats + 2 * k * kSlabCols, 16, 0, 0);
+  }
+}
+
+// The rest of a block row's fill: the last two plane rows and the DCT8 cells -- the row-per-lane scheme
+// of k_transform_8 (kernels_blocks.hip), 8 blocks per step: dequant + CfL, IDCT, register transpose,
+// IDCT, two ds_write_b128 per channel.  nb: block row (inside the frame), bc0: block column of slab
+// column 0 (-1 at the left edge; cells outside the frame are skipped: no lane reads their columns).
+template <typename CT>
+__device__ __forceinline__ void FinishSlab(FrameArgs fa, WaveLds* w, const NextRow& n, int bc0, int first_plane_k) {
+  const FrameArgs f = Fresh(fa);
+  const int lane = threadIdx.x & 63;
+  LdsF* slab = (LdsF*)w->slab;
+  LdsU* list = (LdsU*)w->list;
+  const int nb = n.nb;
+  // every row of the previous block row has been read (this wave's own ds_write stay in order behind
+  // the reads; the DMA writes come through the vector memory path: wait for the reads explicitly)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int k = first_plane_k; k < 4; k++) DmaPlaneRows(fa, slab, n, bc0, k);
+  const uint32_t m8 = n.m8;
+  if (m8) {  // wave-uniform
+    const bool is_dct8 = lane < 16 && ((m8 >> lane) & 1u);
+    if (is_dct8) {
+      const uint32_t rank = __builtin_popcount(m8 & ((1u << lane) - 1u));
+      list[rank * 4 + 0] = (uint32_t)lane;
+      list[rank * 4 + 1] = n.ci.x;
+      list[rank * 4 + 2] = n.ci.y;
+    }
+    const int n8 = __builtin_popcount(m8);
+    const int j = lane >> 3;  // matrix row (input), pixel row (output)
+    const bool bit3 = (lane & 8) != 0;
+    for (int first = 0; first < n8; first += 8) {
+      const int b = first + (lane & 7);
+      const bool valid = b < n8;
+      const int bb = valid ? b : n8 - 1;
+      const int cell = (int)list[bb * 4 + 0];
+      WorkItem it;
+      it.pos = ((uint32_t)nb << 16) | (uint32_t)(bc0 + cell);
+      it.off = list[bb * 4 + 1];
+      it.qc = list[bb * 4 + 2];
+      it.pad = 0;
+      const size_t elem = (size_t)it.off * 64u + (size_t)j * 8u;
+      const size_t dc_at = (size_t)nb * f->xsb + (size_t)(bc0 + cell);
+      Dct8Row<CT> rows[3];
+      float dcv[3];
+      float tab[3][8];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        rows[c].Load(f->coeffs[c], elem);
+        dcv[c] = f->dc[c][dc_at];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float4 t0 = *(const float4*)(f->dequant + c * 64 + j * 8);
+        const float4 t1 = *(const float4*)(f->dequant + c * 64 + j * 8 + 4);
+        tab[c][0] = t0.x, tab[c][1] = t0.y, tab[c][2] = t0.z, tab[c][3] = t0.w;
+        tab[c][4] = t1.x, tab[c][5] = t1.y, tab[c][6] = t1.z, tab[c][7] = t1.w;
+      }
+      BlockHdr h;  // MakeHdr (blocks_common.h) on the kernarg copy of the frame
+      {
+        const int quant = (int)(it.qc & 0xffffu);
+        const float sq = f->inv_global_scale / (float)quant;  // dec_group.cc:164
+        h.sx = sq * f->x_dm;
+        h.sy = sq;
+        h.sb = sq * f->b_dm;
+        h.x_cc = f->cfl_base_x + (float)(int8_t)((it.qc >> 16) & 0xffu) * f->color_scale;
+        h.b_cc = f->cfl_base_b + (float)(int8_t)(it.qc >> 24) * f->color_scale;
+      }
+      const float bias0 = f->biases[0], bias1 = f->biases[1], bias2 = f->biases[2], bias3 = f->biases[3];
+      int32_t q[8];
+      float vy[8];
+      rows[1].Unpack(q);
+#pragma unroll
+      for (int k = 0; k < 8; k++) vy[k] = AdjustQuantBias(q[k], bias1, bias3) * (tab[1][k] * h.sy);
+#pragma unroll
+      for (int ci3 = 0; ci3 < 3; ci3++) {
+        const int c = ci3 == 0 ? 1 : (ci3 == 1 ? 0 : 2);
+        float v[8];
+        if (c == 1) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) v[k] = vy[k];
+        } else {
+          const float sc = c == 0 ? h.sx : h.sb;
+          const float cc = c == 0 ? h.x_cc : h.b_cc;
+          rows[c].Unpack(q);
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const float d = AdjustQuantBias(q[k], c == 0 ? bias0 : bias2, bias3) * (tab[c][k] * sc);
+            v[k] = __builtin_fmaf(cc, vy[k], d);
+          }
+        }
+        if (j == 0) v[0] = dcv[c];
+        IdctReg<8>(v);
+        Transpose8Lanes(v, bit3);
+        IdctReg<8>(v);
+        if (valid) {
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          typedef f4v __attribute__((address_space(3))) * P4;
+          LdsF* dst = slab + c * kSlabPlaneFloats + j * kSlabCols + cell * 8;
+          *(P4)dst = f4v{v[0], v[1], v[2], v[3]};
+          *(P4)(dst + 4) = f4v{v[4], v[5], v[6], v[7]};
+        }
+      }
+    }
+  }
+  // the LDS-DMA loads count in vmcnt; this wave's ds_write / ds_read stay in order by themselves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// block row the 8 rows of the group starting at row r come from (also when they are mirror rows: see the header)
+__device__ __forceinline__ int GroupBlockRow(int r, int nb_last) {
+  const int nb = r < 0 ? 0 : (r >> 3);
+  return nb > nb_last ? nb_last : nb;
+}
+
+template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, typename CT>
+__device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, const FilterParams& P, Lane& L, WaveLds* w, int bc0,
+                                           int y_begin, int y_end) {
+  constexpr int HX = MarchGeom<GAB, EPF>::HX;
+  const int H = (int)f.ysize;
+  const int r_first = y_begin - 8;  // y_begin is a multiple of 8: groups of 8 rows = block rows
+  const int r_last = y_end + HX - 1;
+  const int nb_last = (H - 1) >> 3;
+  LdsF* slab = (LdsF*)w->slab;
+  State s;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) s.x[c][k] = v2f{0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      s.hs[c][k] = v2f{0.0f, 0.0f};
+      s.g[c][k] = v2f{0.0f, 0.0f};
+      s.e[c][k] = v2f{0.0f, 0.0f};
+    }
+    s.du[k] = v2f{0.0f, 0.0f};
+    s.dl[k] = v2f{0.0f, 0.0f};
+    s.pv[k] = v2f{0.0f, 0.0f};
+    s.ph[k] = v2f{0.0f, 0.0f};
+    s.dv[k] = v2f{0.0f, 0.0f};
+  }
+  float inv_sigma_blk = -1.0f, inv_sigma_blk2 = -1.0f;
+  const XybConsts KC = MakeXybConsts(P);
+  const size_t out_row_bytes = OUTK == JXLHIP_OUT_XYB_PLANAR ? P.out_stride * 4 : P.out_stride;
+  char* out_row = (char*)P.out + (ptrdiff_t)(r_first - HX - (int)f.y0) * (ptrdiff_t)out_row_bytes;
+  // first block row: nothing to overlap with
+  NextRow nx;
+  NextRowRequest(fa, nx, GroupBlockRow(r_first, nb_last), bc0);
+  NextRowMasks(fa, nx, bc0);
+  FinishSlab<CT>(fa, w, nx, bc0, 0);
+#define JXLHIP_FSTEP(K)                                                                                     \
+  Step<GAB, EPF, OUTK, FMT, K, EDGE, 0, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk,      \
+                                                  inv_sigma_blk2, out_row, KC, slab_y0);                    \
+  out_row += out_row_bytes
+  for (int r = r_first; r <= r_last; r += 8) {
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    {
+      const int row0 = Mirror1(r, H) - slab_y0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
+    }
+    // The next block row is prepared while this one is marched over: its cell info is requested now, its
+    // plane tiles are DMA'd two slab rows at a time as soon as the march has consumed them (a group
+    // that reads mirror rows is followed by one from the SAME block row: the early copies then rewrite
+    // identical bytes), and what is left for the end -- the last two plane rows and the DCT8 cells --
+    // is FinishSlab.
+    const bool more = r + 8 <= r_last;
+    NextRowRequest(fa, nx, more ? GroupBlockRow(r + 8, nb_last) : -1, bc0);
+    JXLHIP_FSTEP(0);
+    JXLHIP_FSTEP(1);
+    NextRowMasks(fa, nx, bc0);
+    JXLHIP_FSTEP(2);
+    DmaPlaneRows(fa, slab, nx, bc0, 0);  // rows 0, 1: their reads completed in steps 0 / 1
+    JXLHIP_FSTEP(3);
+    JXLHIP_FSTEP(4);
+    DmaPlaneRows(fa, slab, nx, bc0, 1);
+    JXLHIP_FSTEP(5);
+    JXLHIP_FSTEP(6);
+    DmaPlaneRows(fa, slab, nx, bc0, 2);
+    JXLHIP_FSTEP(7);
+    if (more) FinishSlab<CT>(fa, w, nx, bc0, 3);
+  }
+#undef JXLHIP_FSTEP
+}
+
+template <int GAB, int EPF, int OUTK, int FMT, typename CT>
+__global__ __launch_bounds__(256, (EPF == 2 || OUTK == 2) ? 2 : 3) void k_fused(DevFrame f, FilterParams P, int RH) {
+  __shared__ WaveLds lds[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float __attribute__((address_space(3)))* dither_lds = nullptr;
+  if constexpr (OUTK == JXLHIP_OUT_PACKED) {  // before any wave leaves: whole-workgroup barrier
+    __shared__ float s_dither[1024];
+    if (P.fmt.sample_type == JXLHIP_SAMPLE_U8) {  // uniform
+      for (int i = threadIdx.x; i < 1024; i += 256) s_dither[i] = P.dither[i];
+      __syncthreads();
+    }
+    dither_lds = (const float __attribute__((address_space(3)))*)s_dither;
+  }
+  const int strip = blockIdx.x * 4 + wave;
+  const int W = (int)f.xsize;
+  const int x_first = strip * kFusedUse;  // first output column of the wave
+  if (x_first >= W) return;
+  const int y_begin = (int)f.fy0 + blockIdx.y * RH;
+  const int y_end = min(y_begin + RH, (int)f.fy1);
+  if (y_begin >= y_end) return;
+  const int x0 = x_first - kFusedHalo;  // first window column: a multiple of 8
+  Lane L;
+  L.gx = x0 + 2 * lane;
+  L.dither = dither_lds;
+  const int m0 = MirrorF(L.gx, W), m1 = MirrorF(L.gx + 1, W);
+  int base = (m0 & ~1) - x0;  // slab column of the aligned pair holding both mirrored columns
+  base = base < 0 ? 0 : (base > kSlabCols - 2 ? kSlabCols - 2 : base);  // lanes far outside the image: any address inside the slab
+  L.sel0 = m0 & 1;
+  L.sel1 = m1 & 1;
+  L.byte_off = 0;
+  L.slab = (const float __attribute__((address_space(3)))*)lds[wave].slab + base;
+  const bool edge = x0 < 0 || x0 + kSlabCols > W;  // wave-uniform
+  const bool lane_in = lane >= kFusedHalo / 2 && lane < 64 - kFusedHalo / 2;
+  L.out0 = lane_in && L.gx < W;
+  L.out1 = lane_in && L.gx + 1 < W;
+  const int gxc = L.gx < 0 ? 0 : (L.gx >= W ? W - 1 : L.gx);
+  L.sx4 = (uint32_t)(gxc >> 3) * 4u;
+  L.out_off = (uint32_t)(L.gx < 0 ? 0 : L.gx) * (OUTK == JXLHIP_OUT_LINEAR_RGB_F32 ? 12u : 4u);
+  const int ix = gxc & 7;
+  L.mul = v2f{ix == 0 ? P.bsm[1] : P.sm[1], ix == 6 ? P.bsm[1] : P.sm[1]};
+  L.mul2 = v2f{ix == 0 ? P.bsm[2] : P.sm[2], ix == 6 ? P.bsm[2] : P.sm[2]};
+  L.fix_left = L.gx == -2;
+  L.fix_right_even = L.gx == W;
+  L.fix_right_odd = L.gx == W - 1;
+  const int bc0 = x0 >> 3;  // arithmetic shift: -1 for the first window
+  const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  if (edge) MarchFused<GAB, EPF, OUTK, FMT, true, CT>(f, fa, P, L, &lds[wave], bc0, y_begin, y_end);
+  else MarchFused<GAB, EPF, OUTK, FMT, false, CT>(f, fa, P, L, &lds[wave], bc0, y_begin, y_end);
+}
+
+// rows per wave: a multiple of 8 (groups of 8 rows = block rows) that fills whole generations of
+// resident workgroups (2 per CU by registers)
+int FusedRowsPerWave(unsigned wgx, unsigned rows) {
+  static const int forced = [] {
+    const char* e = getenv("JXLHIP_FUSED_RH");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) return (forced + 7) & ~7;
+  static const unsigned resident = [] {
+    const char* e = getenv("JXLHIP_FUSED_RESIDENT");
+    return e ? (unsigned)atoi(e) : 256u * 3u;
+  }();
+  int best = 64;
+  double best_cost = 1e30;
+  for (int rh = 16; rh <= 512; rh += 8) {
+    const unsigned wgs = wgx * ((rows + rh - 1) / rh);
+    const unsigned gens = (wgs + resident - 1) / resident;
+    const double cost = (double)gens * (rh + 8 + 8);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = rh;
+    }
+  }
+  return best;
+}
+
+template <int GAB, int EPF, int OUTK, int FMT = -1>
+void LaunchFusedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
+  const unsigned strips = (f.xsize + kFusedUse - 1) / kFusedUse;
+  const unsigned wgx = (strips + 3) / 4;
+  const int RH = FusedRowsPerWave(wgx, f.fy1 - f.fy0);
+  const dim3 grid(wgx, (f.fy1 - f.fy0 + RH - 1) / RH);
+  if (f.coeff_type == JXLHIP_COEFF_I16)
+    hipLaunchKernelGGL((k_fused<GAB, EPF, OUTK, FMT, int16_t>), grid, dim3(256), 0, st, f, p, RH);
+  else
+    hipLaunchKernelGGL((k_fused<GAB, EPF, OUTK, FMT, int32_t>), grid, dim3(256), 0, st, f, p, RH);
+}
+
+}  // namespace
+
+// Frames the fused kernel takes (decided before k_prepare: it routes the DCT8 blocks).
+bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) {
+  (void)gab;
+  (void)output_kind;
+  if (epf_iters > 2) return false;                 // EPF0: generic kernel
+  if (f.xsize < 16 || f.ysize < 16) return false;  // multiply mirrored columns / rows
+  const uint32_t tail = f.ysize & 7u;
+  if (tail >= 1 && tail <= 3) return false;        // mirror rows below the frame leave the last block row
+  if ((f.fy0 & 7u) != 0) return false;
+  if ((uint64_t)f.plane_tile_rows * f.tile_stride * 256u >= (1ull << 32)) return false;
+  return true;
+}
+
+bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,
+                 hipStream_t st) {
+  if (!FusedSupported(f, gab, epf_iters, output_kind)) return false;
+#define JXLHIP_FUSED(G, E)                                      \
+  if (gab == G && epf_iters == E) {                             \
+    if (output_kind == 0) LaunchFusedT<G, E, 0>(f, p, st);      \
+    else if (output_kind == 1) LaunchFusedT<G, E, 1>(f, p, st); \
+    else LaunchFusedT<G, E, 2>(f, p, st);                       \
+    return true;                                                \
+  }
+  JXLHIP_FUSED(0, 0)
+  JXLHIP_FUSED(1, 0)
+  JXLHIP_FUSED(0, 1)
+  JXLHIP_FUSED(1, 1)
+  JXLHIP_FUSED(0, 2)
+  JXLHIP_FUSED(1, 2)
+#undef JXLHIP_FUSED
+  return false;
+}
+
+}  // namespace jxlhip
