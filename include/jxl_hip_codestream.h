@@ -1,0 +1,69 @@
+/* jxl_hip_codestream.h -- one call from the bytes of a .jxl file to pixels in HBM (SURVEY.md section 8, row f4:
+ * the host front-end in front of the VarDCT back-end, glued).
+ *
+ * What FrameDecoder does for a plain VarDCT still image, with the same order of operations (libjxl tree, lib/jxl/):
+ *   container boxes (jxlc / jxlp)                       decode.cc:1639-1672 (ParseBoxHeader), 1674-2020 (HandleBoxes)
+ *   signature, SizeHeader, ImageMetadata, transform data decode.cc:1049-1133  -> jxlhip_image_header_decode
+ *   FrameHeader, TOC                                    dec_frame.cc:96-189  -> jxlhip_frame_header_decode, jxlhip_toc_decode
+ *   ProcessDCGlobal                                     dec_frame.cc:268-302 -> jxlhip_dc_global_decode, jxlhip_modular_global_decode
+ *   ProcessDCGroup on the pool                          dec_frame.cc:318-342, 660-680 -> jxlhip_dc_group_decode on the runner
+ *   FinalizeDC (DequantDC + AdaptiveDCSmoothing)        dec_frame.cc:344-360, compressed_dc.cc:128-250 -> jxlhip_dequant_dc_groups (device)
+ *   ProcessACGlobal                                     dec_frame.cc:372-416 -> jxlhip_ac_global_decode, jxlhip_dequant_tables (device)
+ *   ProcessACGroup on the pool                          dec_frame.cc:455-560, 700-760 -> jxlhip_ac_groups_decode_submit
+ *   the render pipeline                                 dec_cache.cc:117-371 -> jxlhip_decode_frame (device)
+ * Everything this front-end does not decode is refused with JXLHIP_ERR_UNSUPPORTED so that the caller can hand the
+ * file to libjxl's CPU decoder: Modular-mode frames, extra channels (alpha ...), ICC profiles, animation / multiple
+ * frames, previews, patches / splines / noise, chroma subsampling and YCbCr (JPEG recompression), upsampling,
+ * cropped frames, DC frames, RAW dequant tables, Modular transforms inside the DC groups.
+ */
+#ifndef JXL_HIP_CODESTREAM_H_
+#define JXL_HIP_CODESTREAM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "jxl_hip.h"
+#include "jxl_hip_entropy.h"
+#include "jxl_hip_frame.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jxlhip_codestream_info {
+  uint32_t xsize, ysize;       /* image = frame size */
+  uint32_t container;          /* the bytes were an ISOBMFF container (jxlc / jxlp boxes) */
+  uint32_t orientation;        /* 1..8; the pixels are written in CODED orientation (djxl applies it afterwards) */
+  float intensity_target;      /* ImageMetadata::tone_mapping.intensity_target */
+  uint32_t bits_per_sample;    /* of the ORIGINAL image (metadata; the decode itself is float) */
+  uint32_t transfer_function;  /* enumerated colour encoding of the original: CICP code (13 = sRGB, 8 = linear, 16 = PQ, 18 = HLG ...) */
+  uint32_t primaries, white_point;
+  /* filled by jxlhip_decode_codestream only */
+  uint32_t num_passes, num_groups, num_dc_groups;
+  uint32_t epf_iters, gab;
+  uint32_t used_acs;
+  uint32_t coeff_type;         /* JXLHIP_COEFF_I16, or I32 after the JXLHIP_ERR_RANGE redo */
+  uint32_t fused;              /* reserved */
+} jxlhip_codestream_info;
+
+/* Headers only (no device needed): size and colour metadata of the first frame's image.  JXLHIP_ERR_BAD_STREAM /
+ * JXLHIP_ERR_UNSUPPORTED as the decode call would return them for the header part. */
+JXLHIP_EXPORT int jxlhip_codestream_basic_info(const uint8_t* data, size_t size, jxlhip_codestream_info* info);
+
+/* Decodes the (single, VarDCT) frame of a .jxl file or bare codestream into device memory.
+ *   runner / runner_opaque : a JxlParallelRunner (include/jxl/parallel_runner.h; e.g. JxlThreadParallelRunner of
+ *                            libjxl_threads_hip.so) for the DC groups and the AC groups; NULL = calling thread
+ *   output_kind, out_format: as jxlhip_frame_params (out_format only for JXLHIP_OUT_PACKED; NULL otherwise)
+ *   out, out_stride, out_plane_stride : as jxlhip_decode_frame (device pointer)
+ * The call returns after the frame is complete (jxlhip_sync included).  The context is left with the frame's
+ * inputs resident: jxlhip_decode_frame can re-render (another output format after a new jxlhip_frame_begin needs
+ * the inputs again: call this function again). */
+JXLHIP_EXPORT int jxlhip_decode_codestream(jxlhip_ctx* ctx, jxlhip_parallel_runner runner, void* runner_opaque,
+                                           const uint8_t* data, size_t size, uint32_t output_kind,
+                                           const jxlhip_output_format* out_format, void* out, size_t out_stride,
+                                           size_t out_plane_stride, jxlhip_codestream_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_HIP_CODESTREAM_H_ */

@@ -101,6 +101,15 @@ JXLHIP_EXPORT int jxlhip_ac_global_decode(const uint8_t* data, size_t size, uint
                                           jxlhip_quant_encoding* enc, uint32_t* num_histograms,
                                           jxlhip_ac_pass** passes, size_t* bits_consumed);
 
+/* The same from bit *bit_pos of data (advanced): frames that consist of ONE section carry DC global,
+ * the DC group, AC global and the AC group back to back without byte alignment
+ * (FrameDecoder::ProcessSections, dec_frame.cc:596-616). */
+JXLHIP_EXPORT int jxlhip_ac_global_decode_at(const uint8_t* data, size_t size, size_t* bit_pos,
+                                             uint32_t num_groups, uint32_t num_passes, uint32_t used_acs,
+                                             const jxlhip_block_ctx_map* block_ctx_map,
+                                             jxlhip_quant_encoding* enc, uint32_t* num_histograms,
+                                             jxlhip_ac_pass** passes);
+
 /* Decodes one pass of one AC group (DecodeGroup with GetBlockFromBitstream,
  * dec_group.cc:560-640,780-815): the histogram-set selector, then per varblock
  * in raster visit order and per channel (Y, X, B) the number of non-zeros and

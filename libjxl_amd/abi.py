@@ -136,6 +136,15 @@ class FrameHeader(C.Structure):
                 ("num_extra_channels", C.c_uint32)]
 
 
+class CodestreamInfo(C.Structure):
+    """jxlhip_codestream_info (include/jxl_hip_codestream.h)."""
+    _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32), ("container", C.c_uint32), ("orientation", C.c_uint32),
+                ("intensity_target", C.c_float), ("bits_per_sample", C.c_uint32), ("transfer_function", C.c_uint32),
+                ("primaries", C.c_uint32), ("white_point", C.c_uint32), ("num_passes", C.c_uint32),
+                ("num_groups", C.c_uint32), ("num_dc_groups", C.c_uint32), ("epf_iters", C.c_uint32),
+                ("gab", C.c_uint32), ("used_acs", C.c_uint32), ("coeff_type", C.c_uint32), ("fused", C.c_uint32)]
+
+
 class FrameParams(C.Structure):
     _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32),
                 ("coeff_type", C.c_uint32), ("output_kind", C.c_uint32),
@@ -223,10 +232,12 @@ EXPORTS = [
     "jxlhip_ac_pass_used_orders", "jxlhip_ac_pass_order", "jxlhip_ac_group_decode",
     "jxlhip_ac_group_decode_submit", "jxlhip_block_ctx_map_decode", "jxlhip_quant_dc_contexts",
     "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode", "jxlhip_ac_group_decode_submit_passes",
-    "jxlhip_ac_groups_decode_submit", "jxlhip_num_toc_entries", "jxlhip_toc_decode",
+    "jxlhip_ac_groups_decode_submit", "jxlhip_num_toc_entries", "jxlhip_toc_decode", "jxlhip_ac_global_decode_at",
     # include/jxl_hip_frame.h
     "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode",
     "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
+    # include/jxl_hip_codestream.h
+    "jxlhip_codestream_basic_info", "jxlhip_decode_codestream",
 ]
 
 
@@ -299,5 +310,8 @@ def load_library():
                                           C.POINTER(sz)]
     L.jxlhip_dequant_dc.argtypes = [vp, vp * 3, vp * 3, vp, C.c_float, C.c_float, i32]
     L.jxlhip_dequant_dc_groups.argtypes = [vp, vp * 3, vp * 3, vp, C.c_float, C.c_float, i32, vp]
+    L.jxlhip_codestream_basic_info.argtypes = [vp, sz, C.POINTER(CodestreamInfo)]
+    L.jxlhip_decode_codestream.argtypes = [vp, vp, vp, vp, sz, u32, vp, vp, sz, sz, C.POINTER(CodestreamInfo)]
+    L.jxlhip_ac_global_decode_at.argtypes = [vp, sz, C.POINTER(sz), u32, u32, u32, vp, vp, C.POINTER(u32), C.POINTER(vp)]
     _lib = L
     return L

@@ -21,6 +21,7 @@ def _deps():
     hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "jxl_hip.h"))
     hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "jxl_hip_entropy.h"))
     hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "jxl_hip_frame.h"))
+    hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "jxl_hip_codestream.h"))
     return hdrs
 
 

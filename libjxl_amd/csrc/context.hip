@@ -8,11 +8,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <atomic>
 #include <mutex>
 #include <vector>
 
+#include "../../include/jxl_hip_codestream.h"
 #include "../../include/jxl_hip_entropy.h"
 #include "kernels.h"
 #include "dither_pattern.inc"
@@ -85,6 +87,8 @@ struct jxlhip_ctx {
   size_t dc_tmp_floats = 0;
   uint8_t* dc_prec = nullptr;  // per-DC-group extra_precision of jxlhip_dequant_dc_groups
   size_t dc_prec_bytes = 0;
+  int32_t* qdc_dev = nullptr;  // jxlhip_decode_codestream: the quantized DC planes on their way to jxlhip_dequant_dc_groups
+  size_t qdc_dev_items = 0;
   // transform-kernel fan-out (JXLHIP_BLOCK_STREAMS: 3 = one stream per family; default 1 = back to back on the
   // main stream, measured 15 % faster than letting the families compete for the CUs)
   int nblock_streams = 1;
@@ -294,7 +298,8 @@ void jxlhip_destroy(jxlhip_ctx* c) {
   }
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
-                  c->dc_tmp,     c->quant_enc,  c->dc_prec,      c->cell_info};
+                  c->dc_tmp,     c->quant_enc,  c->dc_prec,      c->cell_info,
+                  c->qdc_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1174,5 +1179,7 @@ int jxlhip_dequant_dc_groups(jxlhip_ctx* c, const int32_t* const quant_dc[3], fl
   HIPCHK(c, hipGetLastError());
   return JXLHIP_OK;
 }
+
+#include "codestream.inc"
 
 }  // extern "C"

@@ -2003,12 +2003,22 @@ int jxlhip_dequant_encodings_decode(const uint8_t* data, size_t size, size_t* bi
 int jxlhip_ac_global_decode(const uint8_t* data, size_t size, uint32_t num_groups, uint32_t num_passes,
                             uint32_t used_acs, const jxlhip_block_ctx_map* block_ctx_map, jxlhip_quant_encoding* enc,
                             uint32_t* num_histograms, jxlhip_ac_pass** passes, size_t* bits_consumed) {
-  if (!data || !enc || !num_histograms || !passes || num_groups == 0 || num_passes == 0 || num_passes > 11)
+  size_t pos = 0;
+  const int rc = jxlhip_ac_global_decode_at(data, size, &pos, num_groups, num_passes, used_acs, block_ctx_map, enc,
+                                            num_histograms, passes);
+  if (rc == kOk && bits_consumed) *bits_consumed = pos;
+  return rc;
+}
+
+int jxlhip_ac_global_decode_at(const uint8_t* data, size_t size, size_t* bit_pos, uint32_t num_groups,
+                               uint32_t num_passes, uint32_t used_acs, const jxlhip_block_ctx_map* block_ctx_map,
+                               jxlhip_quant_encoding* enc, uint32_t* num_histograms, jxlhip_ac_pass** passes) {
+  if (!data || !bit_pos || !enc || !num_histograms || !passes || num_groups == 0 || num_passes == 0 || num_passes > 11)
     return JXLHIP_ERR_INVALID_ARGUMENT;
   for (uint32_t i = 0; i < num_passes; i++) passes[i] = nullptr;
-  size_t pos = 0;
+  size_t pos = *bit_pos;
   {
-    BitReader br(data, size, 0);
+    BitReader br(data, size, pos);
     const int rc = ReadQuantEncodings(&br, enc);
     if (rc) return rc;
     uint32_t bits = 0;  // CeilLog2Nonzero(num_groups)
@@ -2027,7 +2037,7 @@ int jxlhip_ac_global_decode(const uint8_t* data, size_t size, uint32_t num_group
       return rc;
     }
   }
-  if (bits_consumed) *bits_consumed = pos;
+  *bit_pos = pos;
   return kOk;
 }
 

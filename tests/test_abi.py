@@ -25,6 +25,7 @@ def declared_symbols():
     text = open(os.path.join(ROOT, "include", "jxl_hip.h")).read()
     text += open(os.path.join(ROOT, "include", "jxl_hip_entropy.h")).read()
     text += open(os.path.join(ROOT, "include", "jxl_hip_frame.h")).read()
+    text += open(os.path.join(ROOT, "include", "jxl_hip_codestream.h")).read()
     return sorted(set(re.findall(r"JXLHIP_EXPORT[^;{]*?\b(jxlhip_\w+)\s*\(", text)))
 
 

@@ -1,0 +1,154 @@
+"""jxlhip_decode_codestream / jxlhip_codestream_basic_info (include/jxl_hip_codestream.h): from the BYTES of a
+genuine libjxl stream (written by the reference's own encoder, oracle.RealStream) to pixels.
+
+  CPU suite : headers + container walk (jxlc, in- and out-of-order jxlp) against the stream's known geometry;
+              damaged containers refused.
+  GPU suite : the pixels of the HIP path -- host parsers, DC groups and AC groups on the JxlParallelRunner of
+              libjxl_threads_hip.so, DequantDC + smoothing, dequant tables and the whole back-end on the device --
+              against the pixels the REFERENCE decoder produced for the same bytes (the GPU twin of
+              tests/test_front_end_chain.py, which renders through the C oracle)."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from libjxl_amd import abi
+
+TIGHT = 2e-5
+
+CASES = [
+    dict(xsize=520, ysize=300, distance=1.0, speed_tier=3),
+    dict(xsize=776, ysize=520, distance=3.0, speed_tier=3, progressive=1),   # 3 AC passes
+    dict(xsize=640, ysize=264, distance=0.5, speed_tier=5),
+    dict(xsize=2200, ysize=264, distance=1.5, speed_tier=4),                 # two DC groups
+    dict(xsize=200, ysize=120, distance=1.0, speed_tier=3),                  # one section: no TOC permutation, bit-chained
+    dict(xsize=384, ysize=520, distance=2.0, speed_tier=3, epf=1),
+]
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not available")
+    oracle.ref_lib()
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def L():
+    return abi.load_library()
+
+
+def box(kind, payload):
+    return struct.pack(">I", 8 + len(payload)) + kind + payload
+
+
+SIG = b"\0\0\0\x0cJXL \r\n\x87\n"
+FTYP = box(b"ftyp", b"jxl \0\0\0\0jxl ")
+
+
+def containers(cs):
+    """The same codestream in the three container shapes the reference reads (decode.cc:1922-1990)."""
+    half = len(cs) // 2
+    yield "jxlc", SIG + FTYP + box(b"jxlc", cs)
+    yield "jxlp", SIG + FTYP + box(b"jxlp", struct.pack(">I", 0) + cs[:half]) + box(b"Exif", b"\0" * 12) + \
+        box(b"jxlp", struct.pack(">I", 0x80000001) + cs[half:])
+    yield "jxlp out of order", SIG + FTYP + box(b"jxlp", struct.pack(">I", 0x80000001) + cs[half:]) + \
+        box(b"jxlp", struct.pack(">I", 0) + cs[:half])
+
+
+def test_basic_info_and_container_walk(L, ref):
+    rs = ref.RealStream(seed=5, xsize=520, ysize=300, distance=1.0)
+    cs = rs.codestream.tobytes()
+    info = abi.CodestreamInfo()
+    assert L.jxlhip_codestream_basic_info(cs, len(cs), C.byref(info)) == 0
+    assert (info.xsize, info.ysize, info.container) == (520, 300, 0)
+    for name, blob in containers(cs):
+        info = abi.CodestreamInfo()
+        assert L.jxlhip_codestream_basic_info(blob, len(blob), C.byref(info)) == 0, name
+        assert (info.xsize, info.ysize, info.container) == (520, 300, 1), name
+    bad = [
+        b"\xff\x0b" + cs[2:],                                             # not the codestream signature
+        SIG[:11] + b"\x0b" + FTYP + box(b"jxlc", cs),                     # not the container signature
+        SIG + FTYP + box(b"jxlc", cs) + box(b"jxlc", cs),                 # "there can only be one jxlc box"
+        SIG + FTYP + box(b"jxlp", struct.pack(">I", 1) + cs),             # first jxlp index missing
+        SIG + FTYP + struct.pack(">I", 4000000) + b"jxlc" + cs[:64],      # box longer than the file
+        SIG + FTYP,                                                       # no codestream at all
+        cs[:5],                                                           # truncated headers
+    ]
+    for blob in bad:
+        assert L.jxlhip_codestream_basic_info(blob, len(blob), C.byref(info)) == -5, blob[:24]  # JXLHIP_ERR_BAD_STREAM
+
+
+def test_decode_without_device_fails_loudly(L, ref):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    ctx = C.c_void_p()
+    assert L.jxlhip_create(0, C.byref(ctx)) == -2  # JXLHIP_ERR_NO_DEVICE: no CPU fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [0, 6])
+@pytest.mark.parametrize("kw", CASES)
+def test_decode_codestream_matches_the_reference_decoder(L, ref, kw, workers):
+    import torch
+    from libjxl_amd import VarDctDecoder
+    rs = ref.RealStream(seed=23, **kw)
+    cs = rs.codestream.tobytes()
+    R = C.CDLL(abi.runner_library_path())
+    R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    pool = R.JxlThreadParallelRunnerCreate(None, workers) if workers else None
+    runner = C.cast(R.JxlThreadParallelRunner, C.c_void_p) if workers else None
+    dec = VarDctDecoder(0)
+    try:
+        blobs = [("bare", cs)] + (list(containers(cs))[1:] if workers else [])
+        for name, blob in blobs:
+            info = abi.CodestreamInfo()
+            assert L.jxlhip_codestream_basic_info(blob, len(blob), C.byref(info)) == 0
+            out = torch.empty((info.ysize, info.xsize, 3), dtype=torch.float32, device="cuda")
+            rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, blob, len(blob), 1, None, out.data_ptr(),
+                                            info.xsize * 12, 0, C.byref(info))
+            assert rc == 0, (name, rc, L.jxlhip_last_error(dec.ctx))
+            assert (info.num_passes, info.num_groups, info.num_dc_groups) == (rs.num_passes, rs.num_groups, rs.num_dc_groups)
+            assert info.used_acs == rs.used_acs
+            got = out.cpu().numpy()
+            scale = max(1.0, float(np.abs(rs.rgb).max()))
+            assert float(np.abs(got - rs.rgb).max()) / scale <= TIGHT, name
+        # packed 8-bit sRGB output of the same stream: decodes, and agrees with the float output to within a code
+        fmt = abi.OutputFormat(1, 1, 4, 8, 0, 0.0, (C.c_float * 3)(0.2126, 0.7152, 0.0722))
+        out8 = torch.empty((info.ysize, info.xsize, 4), dtype=torch.uint8, device="cuda")
+        rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, cs, len(cs), 2, C.byref(fmt), out8.data_ptr(),
+                                        info.xsize * 4, 0, None)
+        assert rc == 0, L.jxlhip_last_error(dec.ctx)
+        lin = np.clip(rs.rgb, 0, 1)
+        srgb = np.where(lin <= 0.0031308, lin * 12.92, 1.055 * np.power(lin, 1 / 2.4) - 0.055) * 255.0
+        d = np.abs(out8.cpu().numpy()[..., :3].astype(np.float32) - srgb)
+        assert d.max() <= 1.6 and (out8.cpu().numpy()[..., 3] == 255).all()
+    finally:
+        dec.close()
+        if pool:
+            R.JxlThreadParallelRunnerDestroy(pool)
+
+
+@pytest.mark.gpu
+def test_unsupported_streams_are_refused_not_misdecoded(L, ref):
+    """A damaged section must surface as an error, never as pixels."""
+    from libjxl_amd import VarDctDecoder
+    import torch
+    rs = ref.RealStream(seed=3, xsize=520, ysize=300, distance=1.0)
+    cs = bytearray(rs.codestream.tobytes())
+    o = int(rs.section_offset[2 + rs.num_dc_groups]) + 3   # inside the first AC group
+    for k in range(12):
+        cs[o + k] ^= 0x5A
+    dec = VarDctDecoder(0)
+    try:
+        out = torch.empty((300, 520, 3), dtype=torch.float32, device="cuda")
+        blob = bytes(cs)
+        rc = L.jxlhip_decode_codestream(dec.ctx, None, None, blob, len(blob), 1, None, out.data_ptr(), 520 * 12, 0, None)
+        assert rc != 0
+    finally:
+        dec.close()
