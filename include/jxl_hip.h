@@ -194,6 +194,32 @@ JXLHIP_EXPORT const char* jxlhip_status_string(int status);
 /* Replaces the per-decoder state setup of PassesDecoderState::Init
  * (dec_cache.h:153-229).  device = HIP device ordinal. */
 JXLHIP_EXPORT int jxlhip_create(int device, jxlhip_ctx** out);
+/* JxlMemoryManager (lib/include/jxl/memory_manager.h:45-63), restated so that this header stands alone; the
+ * layout is the reference's.  Both callbacks or none (lib/threads/thread_parallel_runner.cc:37-53): exactly
+ * one NULL is JXLHIP_ERR_INVALID_ARGUMENT. */
+typedef struct JxlMemoryManagerHip {
+  void* opaque;
+  void* (*alloc)(void* opaque, size_t size);
+  void (*free)(void* opaque, void* address);
+} JxlMemoryManagerHip;
+/* The same with the caller's memory manager: the context object and the pinned staging slots of
+ * the entropy decoder (pinned in place with hipHostRegister) come from it; device memory comes from hipMalloc,
+ * and the bookkeeping of the C++ containers inside the context from the C++ runtime. */
+JXLHIP_EXPORT int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlhip_ctx** out);
+/* One context over SEVERAL devices of this process ("groups shard across the GPUs of one
+ * node"): the frame is cut into contiguous stripes of AC-group rows (the first ysg % ndev stripes one row taller),
+ * stripe i lives on devices[i].  A device may be listed more than once (several stripes on one GPU).
+ * Supported on a multi context: jxlhip_frame_begin, jxlhip_upload_side_info, jxlhip_submit_group,
+ * jxlhip_ac_group(s)_decode_submit[_passes] (a group goes to the device of its stripe),
+ * jxlhip_decode_frame (out: device memory of devices[0]; the other stripes arrive by peer copies = the gather),
+ * jxlhip_decode_frame_host (every device copies its own stripe to the host rows: no gather), jxlhip_halo_rows,
+ * jxlhip_sync, jxlhip_last_error, jxlhip_destroy; everything else is JXLHIP_ERR_UNSUPPORTED.
+ * Between the two phases each stripe's LoopFilter::Padding() boundary rows go to its neighbours with
+ * hipMemcpyPeerAsync (xGMI when peer access is available), ordered by events only: the host never waits inside
+ * a frame.  Replaces GroupBorderAssigner / SaveBorders / LoadBorders across devices
+ * (lib/jxl/dec_group_border.cc:68-187) and the data-parallel contract of lib/jxl/base/data_parallel.h:50-78. */
+JXLHIP_EXPORT int jxlhip_create_multi(const int* devices, int num_devices,
+                                      const JxlMemoryManagerHip* memory_manager, jxlhip_ctx** out);
 JXLHIP_EXPORT void jxlhip_destroy(jxlhip_ctx* ctx);
 JXLHIP_EXPORT const char* jxlhip_last_error(const jxlhip_ctx* ctx);
 /* external != 0: all launches go to the caller's hipStream_t `hip_stream`
@@ -274,6 +300,15 @@ JXLHIP_EXPORT int jxlhip_decode_filters(jxlhip_ctx* ctx, void* out,
 JXLHIP_EXPORT int jxlhip_decode_frame(jxlhip_ctx* ctx, void* out,
                                       size_t out_stride,
                                       size_t out_plane_stride);
+
+/* The same into HOST memory (the buffer of JxlDecoderSetImageOutBuffer,
+ * lib/include/jxl/decode.h:1100-1140; ImageOutput::buffer / stride,
+ * lib/jxl/dec_cache.h:70-82): decodes into a context-owned device frame, copies
+ * it out with one strided device-to-host transfer and synchronises (returns
+ * what jxlhip_sync would).  Strides as for jxlhip_decode_frame, in host terms. */
+JXLHIP_EXPORT int jxlhip_decode_frame_host(jxlhip_ctx* ctx, void* host_out,
+                                           size_t out_stride,
+                                           size_t out_plane_stride);
 
 JXLHIP_EXPORT int jxlhip_sync(jxlhip_ctx* ctx);
 

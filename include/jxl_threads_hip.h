@@ -2,7 +2,9 @@
  * jxl_threads_hip.h -- the JxlParallelRunner of the MI355X back-end
  * ("jxl_threads -> HIP stream pool").
  *
- * libjxl_threads_hip.so exports the SAME four symbols as libjxl_threads
+ * libjxl_threads_hip.so exports the SAME nine symbols as libjxl_threads (the four of the
+ * thread-pool runner, the five of the resizable runner)
+ *
  * (lib/include/jxl/thread_parallel_runner.h:45-66, implemented in
  * lib/threads/thread_parallel_runner.cc:68-109), with the same contract
  * (lib/include/jxl/parallel_runner.h:105-129): init(opaque, num_threads) is
@@ -65,6 +67,18 @@ JXL_THREADS_HIP_EXPORT void* JxlThreadParallelRunnerCreate(
 JXL_THREADS_HIP_EXPORT void JxlThreadParallelRunnerDestroy(void* runner_opaque);
 /* :107-109 */
 JXL_THREADS_HIP_EXPORT size_t JxlThreadParallelRunnerDefaultNumWorkerThreads(void);
+
+/* lib/include/jxl/resizable_parallel_runner.h:46-69 (lib/threads/resizable_parallel_runner.cc:172-195): the
+ * runner whose thread count is set after the image size is known.  Same contract as the reference's: SetThreads(n)
+ * keeps n - 1 workers and the calling thread is thread 0 of every run; a single task runs inline with
+ * init(opaque, 1); SuggestThreads = min(hardware threads, xsize * ysize / 65536). */
+JXL_THREADS_HIP_EXPORT JxlParallelRetCode JxlResizableParallelRunner(
+    void* runner_opaque, void* jpegxl_opaque, JxlParallelRunInit init,
+    JxlParallelRunFunction func, uint32_t start_range, uint32_t end_range);
+JXL_THREADS_HIP_EXPORT void* JxlResizableParallelRunnerCreate(const JxlMemoryManager* memory_manager);
+JXL_THREADS_HIP_EXPORT void JxlResizableParallelRunnerSetThreads(void* runner_opaque, size_t num_threads);
+JXL_THREADS_HIP_EXPORT uint32_t JxlResizableParallelRunnerSuggestThreads(uint64_t xsize, uint64_t ysize);
+JXL_THREADS_HIP_EXPORT void JxlResizableParallelRunnerDestroy(void* runner_opaque);
 
 /* Extension: the hipStream_t owned by `thread_id` (0 = caller) of this runner,
  * or NULL when no device is present (the runner itself works without one). */

@@ -218,11 +218,12 @@ _lib = None
 EXPORTS = [
     "jxlhip_covered_blocks_x", "jxlhip_covered_blocks_y",
     "jxlhip_log2_covered_blocks", "jxlhip_quant_table_of_strategy",
-    "jxlhip_dequant_table_offset", "jxlhip_status_string", "jxlhip_create",
+    "jxlhip_dequant_table_offset", "jxlhip_status_string", "jxlhip_create", "jxlhip_create_ex", "jxlhip_create_multi",
     "jxlhip_destroy", "jxlhip_last_error", "jxlhip_set_stream",
     "jxlhip_frame_begin", "jxlhip_frame_set_inputs", "jxlhip_upload_side_info",
     "jxlhip_submit_group", "jxlhip_decode_blocks", "jxlhip_halo_rows",
     "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_frame",
+    "jxlhip_decode_frame_host",
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
     "jxlhip_profile_enable", "jxlhip_profile_read",
     "jxlhip_dequant_tables", "jxlhip_default_dequant_tables", "jxlhip_dequant_dc",
@@ -258,6 +259,8 @@ def load_library():
     L.jxlhip_last_error.restype = C.c_char_p
     L.jxlhip_last_error.argtypes = [vp]
     L.jxlhip_create.argtypes = [i32, C.POINTER(vp)]
+    L.jxlhip_create_ex.argtypes = [i32, vp, C.POINTER(vp)]
+    L.jxlhip_create_multi.argtypes = [vp, i32, vp, C.POINTER(vp)]
     L.jxlhip_destroy.argtypes = [vp]
     L.jxlhip_destroy.restype = None
     L.jxlhip_set_stream.argtypes = [vp, vp, i32]
@@ -298,6 +301,7 @@ def load_library():
     L.jxlhip_halo_import.argtypes = [vp, i32, vp]
     L.jxlhip_decode_filters.argtypes = [vp, vp, sz, sz]
     L.jxlhip_decode_frame.argtypes = [vp, vp, sz, sz]
+    L.jxlhip_decode_frame_host.argtypes = [vp, vp, sz, sz]
     L.jxlhip_sync.argtypes = [vp]
     L.jxlhip_export_xyb.argtypes = [vp, vp * 3, sz]
     L.jxlhip_get_sigma.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]

@@ -36,6 +36,17 @@ struct ProfSpan {
 }  // namespace
 
 struct jxlhip_ctx {
+  // jxlhip_create_multi: the context is a PARENT over one child context per device (a device may be
+  // listed more than once); frame-level calls fan out to the children, each of which decodes a stripe
+  // of group rows.  A parent owns no device memory of its own except the halo staging below.
+  std::vector<jxlhip_ctx*> children;
+  std::vector<std::pair<uint32_t, uint32_t>> stripes;  // (group_y0, group_rows) per child of the current frame
+  std::vector<float*> halo_send[2], halo_recv[2];      // per child: dense [3][halo][xsize] staging (0: up, 1: down)
+  std::vector<size_t> halo_floats;
+  std::vector<uint8_t*> stripe_out;                    // per child: its output stripe when the frame goes to another device / the host
+  std::vector<size_t> stripe_out_bytes;
+  std::vector<hipEvent_t> ev_blocks, ev_halo[2], ev_done;
+  JxlMemoryManagerHip mm{};                            // jxlhip_create_ex / _multi: who allocated this object
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;  // the one launches go to
@@ -87,6 +98,8 @@ struct jxlhip_ctx {
   size_t dc_tmp_floats = 0;
   uint8_t* dc_prec = nullptr;  // per-DC-group extra_precision of jxlhip_dequant_dc_groups
   size_t dc_prec_bytes = 0;
+  uint8_t* host_frame_dev = nullptr;  // jxlhip_decode_frame_host: the device frame in front of the D2H copy
+  size_t host_frame_bytes = 0;
   int32_t* qdc_dev = nullptr;  // jxlhip_decode_codestream: the quantized DC planes on their way to jxlhip_dequant_dc_groups
   size_t qdc_dev_items = 0;
   // transform-kernel fan-out (JXLHIP_BLOCK_STREAMS: 3 = one stream per family; default 1 = back to back on the
@@ -166,6 +179,42 @@ void ProfEnd(jxlhip_ctx* c) {
   c->prof_prev = nullptr;
 }
 
+// Pinned staging slots: memory from the caller's JxlMemoryManager when there is one (pinned in place
+// with hipHostRegister: "caller owns the host memory, the library pins it"), else hipHostMalloc.
+int StageAlloc(jxlhip_ctx* c, void** p, size_t bytes) {
+  if (c->mm.alloc) {
+    *p = c->mm.alloc(c->mm.opaque, bytes);
+    if (!*p) return JXLHIP_ERR_OUT_OF_MEMORY;
+    if (hipHostRegister(*p, bytes, hipHostRegisterDefault) != hipSuccess) {
+      c->mm.free(c->mm.opaque, *p);
+      *p = nullptr;
+      return JXLHIP_ERR_OUT_OF_MEMORY;
+    }
+    return JXLHIP_OK;
+  }
+  return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess ? JXLHIP_OK : JXLHIP_ERR_OUT_OF_MEMORY;
+}
+void StageFree(jxlhip_ctx* c, void* p) {
+  if (c->mm.alloc) {
+    (void)hipHostUnregister(p);
+    c->mm.free(c->mm.opaque, p);
+  } else {
+    (void)hipHostFree(p);
+  }
+}
+
+void MultiDestroy(jxlhip_ctx* c);
+int MultiFrameBegin(jxlhip_ctx* c, const jxlhip_frame_params* p);
+int MultiOwner(const jxlhip_ctx* c, uint32_t group_idx);
+int MultiDecodeFrame(jxlhip_ctx* c, void* out_dev, void* host_out, size_t out_stride, size_t out_plane_stride);
+int MultiSync(jxlhip_ctx* c);
+int MultiCheck(jxlhip_ctx* c, jxlhip_ctx* child, int rc);
+#define JXLHIP_NO_MULTI(c)                                                                                   \
+  do {                                                                                                       \
+    if ((c) && !(c)->children.empty())                                                                       \
+      return Fail((c), JXLHIP_ERR_UNSUPPORTED, "%s is not available on a multi-device context", __func__); \
+  } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -207,13 +256,34 @@ const char* jxlhip_status_string(int status) {
 }
 
 // ---- context ----------------------------------------------------------------
-int jxlhip_create(int device, jxlhip_ctx** out) {
+static jxlhip_ctx* NewCtx(const JxlMemoryManagerHip* mm) {
+  JxlMemoryManagerHip m{};
+  if (mm) m = *mm;
+  void* mem = m.alloc ? m.alloc(m.opaque, sizeof(jxlhip_ctx)) : malloc(sizeof(jxlhip_ctx));
+  if (!mem) return nullptr;
+  jxlhip_ctx* c = new (mem) jxlhip_ctx();
+  c->mm = m;
+  return c;
+}
+static void DeleteCtx(jxlhip_ctx* c) {
+  const JxlMemoryManagerHip m = c->mm;
+  c->~jxlhip_ctx();
+  if (m.free) m.free(m.opaque, c);
+  else free(c);
+}
+
+int jxlhip_create(int device, jxlhip_ctx** out) { return jxlhip_create_ex(device, nullptr, out); }
+
+int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlhip_ctx** out) {
   if (!out) return JXLHIP_ERR_INVALID_ARGUMENT;
   *out = nullptr;
+  // both callbacks or none (lib/threads/thread_parallel_runner.cc:37-53, lib/jxl/memory_manager_internal.h)
+  if (memory_manager && ((memory_manager->alloc == nullptr) != (memory_manager->free == nullptr)))
+    return JXLHIP_ERR_INVALID_ARGUMENT;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return JXLHIP_ERR_NO_DEVICE;
   if (device < 0 || device >= ndev) return JXLHIP_ERR_INVALID_ARGUMENT;
-  jxlhip_ctx* c = new (std::nothrow) jxlhip_ctx();
+  jxlhip_ctx* c = NewCtx(memory_manager);
   if (!c) return JXLHIP_ERR_OUT_OF_MEMORY;
   c->device = device;
   {
@@ -267,6 +337,7 @@ int jxlhip_create(int device, jxlhip_ctx** out) {
 
 void jxlhip_destroy(jxlhip_ctx* c) {
   if (!c) return;
+  if (!c->children.empty()) return MultiDestroy(c);
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (auto& s : c->spans) {
@@ -294,22 +365,23 @@ void jxlhip_destroy(jxlhip_ctx* c) {
       if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
       (void)hipEventDestroy(c->stage_ev[i]);
     }
-    if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+    if (c->stage[i]) StageFree(c, c->stage[i]);
   }
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
                   c->dc_tmp,     c->quant_enc,  c->dc_prec,      c->cell_info,
-                  c->qdc_dev};
+                  c->qdc_dev,    c->host_frame_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-  delete c;
+  DeleteCtx(c);
 }
 
 const char* jxlhip_last_error(const jxlhip_ctx* c) { return c ? c->err : ""; }
 
 int jxlhip_set_stream(jxlhip_ctx* c, void* hip_stream, int external) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->children.empty()) return jxlhip_set_stream(c->children[0], hip_stream, external);  // the frame's consumer is on devices[0]
   c->stream = external ? (hipStream_t)hip_stream : c->own_stream;
   return JXLHIP_OK;
 }
@@ -317,6 +389,7 @@ int jxlhip_set_stream(jxlhip_ctx* c, void* hip_stream, int external) {
 // ---- frame set-up -------------------------------------------------------------
 int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   if (!c || !p) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->children.empty()) return MultiFrameBegin(c, p);
   if (p->xsize == 0 || p->ysize == 0 || p->xsize > (1u << 19) || p->ysize > (1u << 19))
     return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "frame size %ux%u out of range", p->xsize,
                 p->ysize);
@@ -469,6 +542,7 @@ static void ApplyInputs(jxlhip_ctx* c, const jxlhip_frame_inputs* in) {
 
 int jxlhip_frame_set_inputs(jxlhip_ctx* c, const jxlhip_frame_inputs* in) {
   if (!c || !in) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);  // device pointers belong to one device: use the host-upload path
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "frame_set_inputs before frame_begin");
   for (int ch = 0; ch < 3; ch++)
     if (!in->coeffs[ch] || !in->dc[ch])
@@ -550,6 +624,13 @@ int jxlhip_upload_side_info(jxlhip_ctx* c, const uint8_t* ac_strategy, const int
                             const int8_t* ytob_map, const float* const dc[3],
                             const float* dequant_table) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->children.empty()) {
+    for (jxlhip_ctx* k : c->children) {
+      const int rc = jxlhip_upload_side_info(k, ac_strategy, raw_quant, epf_sharpness, ytox_map, ytob_map, dc, dequant_table);
+      if (rc) return MultiCheck(c, k, rc);
+    }
+    return JXLHIP_OK;
+  }
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "upload_side_info before frame_begin");
   if (!ac_strategy || !raw_quant || !ytox_map || !ytob_map || !dc || !dc[0] || !dc[1] ||
       !dc[2] || !dequant_table || (c->p.lf.epf_iters > 0 && !epf_sharpness))
@@ -590,6 +671,12 @@ int jxlhip_submit_group(jxlhip_ctx* c, uint32_t group_idx, const void* const coe
 static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void* const coeffs[3],
                                   size_t ncoeffs, hipEvent_t done) {
   if (!c || !coeffs) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->children.empty()) {
+    if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "submit_group before frame_begin");
+    const int o = MultiOwner(c, group_idx);
+    if (o < 0) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad group %u", group_idx);
+    return MultiCheck(c, c->children[o], jxlhip_submit_group_ev(c->children[o], group_idx, coeffs, ncoeffs, done));
+  }
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "submit_group before frame_begin");
   const DevFrame& f = c->f;
   if (group_idx >= f.xsg * f.ysg || ncoeffs > JXLHIP_GROUP_COEFFS || !coeffs[0] || !coeffs[1] ||
@@ -646,6 +733,12 @@ int jxlhip_ac_group_decode_submit_passes(jxlhip_ctx* c, uint32_t num_passes,
   for (uint32_t p = 0; p < num_passes; p++)
     if (!passes[p] || !data[p] || (shifts && shifts[p] > 3)) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "ac_group_decode_submit before frame_begin");
+  if (!c->children.empty()) {
+    const int o = MultiOwner(c, group_idx);
+    if (o < 0) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad group %u", group_idx);
+    return MultiCheck(c, c->children[o], jxlhip_ac_group_decode_submit_passes(c->children[o], num_passes, passes, shifts, group_idx, ac_strategy,
+                                                                              raw_quant, quant_dc, data, sizes, bit_pos));
+  }
   const DevFrame& f = c->f;
   if (group_idx >= f.xsg * f.ysg) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad group %u", group_idx);
   const size_t esz = f.coeff_type == JXLHIP_COEFF_I16 ? 2 : 4;
@@ -665,11 +758,11 @@ int jxlhip_ac_group_decode_submit_passes(jxlhip_ctx* c, uint32_t num_passes,
         for (int i = 0; i < kStageSlots; i++) {
           if (c->stage[i]) {
             if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
-            (void)hipHostFree(c->stage[i]);
+            StageFree(c, c->stage[i]);
             c->stage[i] = nullptr;
           }
           c->stage_state[i] = 0;
-          if (hipHostMalloc(&c->stage[i], slot_bytes, hipHostMallocDefault) != hipSuccess)
+          if (StageAlloc(c, &c->stage[i], slot_bytes) != JXLHIP_OK)
             return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
           if (!c->stage_ev[i] &&
               hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess)
@@ -763,6 +856,14 @@ int jxlhip_ac_groups_decode_submit(jxlhip_ctx* c, jxlhip_parallel_runner runner,
   if (!c || !passes || !ac_strategy || !raw_quant || !sections || !sizes || num_passes == 0 || num_passes > 11)
     return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "ac_groups_decode_submit before frame_begin");
+  if (!c->children.empty()) {  // every child takes the groups of its stripe (GroupsFunc skips the others)
+    for (jxlhip_ctx* k : c->children) {
+      const int rc = jxlhip_ac_groups_decode_submit(k, runner, runner_opaque, num_passes, passes, shifts, ac_strategy, raw_quant,
+                                                    quant_dc, sections, sizes);
+      if (rc) return MultiCheck(c, k, rc);
+    }
+    return JXLHIP_OK;
+  }
   GroupsJob job;
   job.c = c;
   job.num_passes = num_passes;
@@ -901,6 +1002,7 @@ int CheckOutArgs(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_s
 
 int jxlhip_decode_blocks(jxlhip_ctx* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);
   int rc = BeginDecode(c, 1);
   if (rc) return rc;
   rc = LaunchBlocksBand(c, c->f.group_y0, c->f.group_y0 + c->f.group_rows, 0);
@@ -916,6 +1018,7 @@ int jxlhip_halo_rows(const jxlhip_ctx* c) {
 
 static int HaloCopy(jxlhip_ctx* c, int which, float* dev, bool to_dense) {
   if (!c || !dev || which < 0 || which > 1) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "halo copy before frame_begin");
   const DevFrame& f = c->f;
   const uint32_t stripe_rows = f.y1 - f.y0;
@@ -946,6 +1049,7 @@ int jxlhip_halo_import(jxlhip_ctx* c, int which, const float* dev) {
 
 int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);
   if (!c->blocks_done) return Fail(c, JXLHIP_ERR_STATE, "decode_filters before decode_blocks");
   int rc = CheckOutArgs(c, out, out_stride, out_plane_stride);
   if (rc) return rc;
@@ -963,6 +1067,7 @@ int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t ou
 // time, so the default is one band = the whole stripe.
 int jxlhip_decode_frame(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->children.empty()) return out ? MultiDecodeFrame(c, out, nullptr, out_stride, out_plane_stride) : JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "decode needs frame_begin + inputs");
   const DevFrame& f = c->f;
   uint32_t br = c->band_rows ? (uint32_t)c->band_rows : f.group_rows;
@@ -1003,8 +1108,44 @@ int jxlhip_decode_frame(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_
   return LaunchFiltersRows(c, fp, prev_y0, f.y1);
 }
 
+// The boundary handing over a HOST buffer (what JxlDecoderSetImageOutBuffer gives libjxl): both phases
+// into a context-owned device frame, one strided device-to-host copy, synchronised.
+int jxlhip_decode_frame_host(jxlhip_ctx* c, void* host_out, size_t out_stride, size_t out_plane_stride) {
+  if (!c || !host_out) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->children.empty()) {
+    const int rc = MultiDecodeFrame(c, nullptr, host_out, out_stride, out_plane_stride);
+    return rc ? rc : MultiSync(c);
+  }
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "decode needs frame_begin + inputs");
+  const DevFrame& f = c->f;
+  const size_t rows = f.y1 - f.y0;
+  size_t row_bytes;
+  if (c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32) row_bytes = (size_t)f.xsize * 12;
+  else if (c->p.output_kind == JXLHIP_OUT_PACKED) {
+    const jxlhip_output_format& o = c->p.out_format;
+    row_bytes = (size_t)f.xsize * o.num_channels *
+                (o.sample_type == JXLHIP_SAMPLE_U8 ? 1 : (o.sample_type == JXLHIP_SAMPLE_F32 ? 4 : 2));
+  } else row_bytes = (size_t)f.xsize * 4;
+  const bool planar = c->p.output_kind == JXLHIP_OUT_XYB_PLANAR;
+  const size_t host_row = planar ? out_stride * 4 : out_stride;
+  if (host_row < row_bytes) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "host row stride %zu too small", out_stride);
+  const size_t dev_row = (row_bytes + 255) & ~(size_t)255;
+  const size_t planes = planar ? 3 : 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = Grow(c, &c->host_frame_dev, &c->host_frame_bytes, planes * rows * dev_row))) return rc;
+  rc = planar ? jxlhip_decode_frame(c, c->host_frame_dev, dev_row / 4, rows * dev_row / 4)
+              : jxlhip_decode_frame(c, c->host_frame_dev, dev_row, 0);
+  if (rc) return rc;
+  for (size_t pl = 0; pl < planes; pl++)
+    HIPCHK(c, hipMemcpy2DAsync((char*)host_out + pl * out_plane_stride * 4, host_row, c->host_frame_dev + pl * rows * dev_row,
+                               dev_row, row_bytes, rows, hipMemcpyDeviceToHost, c->stream));
+  return jxlhip_sync(c);
+}
+
 int jxlhip_sync(jxlhip_ctx* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->children.empty()) return MultiSync(c);
   HIPCHK(c, hipSetDevice(c->device));
   int32_t flag[2] = {0, 0};
   HIPCHK(c, hipMemcpyAsync(flag, c->error_flag, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
@@ -1023,6 +1164,7 @@ int jxlhip_sync(jxlhip_ctx* c) {
 // ---- taps ------------------------------------------------------------------------
 int jxlhip_export_xyb(jxlhip_ctx* c, float* const dst[3], size_t dst_stride) {
   if (!c || !dst || !dst[0] || !dst[1] || !dst[2]) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "no frame");
   if (!c->blocks_done)
     return Fail(c, JXLHIP_ERR_STATE, "export_xyb needs jxlhip_decode_blocks (jxlhip_decode_frame may run fused: "
@@ -1043,6 +1185,7 @@ int jxlhip_export_xyb(jxlhip_ctx* c, float* const dst[3], size_t dst_stride) {
 
 int jxlhip_get_sigma(jxlhip_ctx* c, float** inv_sigma, size_t* row_stride) {
   if (!c || !inv_sigma || !row_stride) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "no frame");
   *inv_sigma = c->f.inv_sigma;
   *row_stride = c->f.xsb;
@@ -1051,6 +1194,7 @@ int jxlhip_get_sigma(jxlhip_ctx* c, float** inv_sigma, size_t* row_stride) {
 
 int jxlhip_profile_enable(jxlhip_ctx* c, int enable) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);
   c->profiling = enable != 0;
   return JXLHIP_OK;
 }
@@ -1058,6 +1202,7 @@ int jxlhip_profile_enable(jxlhip_ctx* c, int enable) {
 int jxlhip_profile_read(jxlhip_ctx* c, float ms[JXLHIP_KERNEL_COUNT],
                         uint32_t launches[JXLHIP_KERNEL_COUNT]) {
   if (!c || !ms || !launches) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < JXLHIP_KERNEL_COUNT; i++) {
@@ -1104,6 +1249,7 @@ static void ResolveLibrary(int kind, jxlhip_quant_encoding* e) {
 
 int jxlhip_dequant_tables(jxlhip_ctx* c, const jxlhip_quant_encoding* enc, float* table_dev) {
   if (!c || !table_dev) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);
   static const uint32_t kSingleBlockKinds = 0x60F;  // kinds whose matrix is one 8x8 block
   for (int k = 0; k < JXLHIP_NUM_QUANT_TABLES; k++) {
     jxlhip_quant_encoding* e = &c->quant_enc_host[k];
@@ -1143,6 +1289,7 @@ int jxlhip_dequant_dc_groups(jxlhip_ctx* c, const int32_t* const quant_dc[3], fl
                              const float dc_quant[3], float cfl_x_dc, float cfl_b_dc, int smooth,
                              const uint8_t* extra_precision) {
   if (!c || !quant_dc || !dc_out) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JXLHIP_NO_MULTI(c);
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "dequant_dc before frame_begin");
   for (int ch = 0; ch < 3; ch++)
     if (!quant_dc[ch] || !dc_out[ch]) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "null plane");
@@ -1180,6 +1327,7 @@ int jxlhip_dequant_dc_groups(jxlhip_ctx* c, const int32_t* const quant_dc[3], fl
   return JXLHIP_OK;
 }
 
+#include "multi.inc"
 #include "codestream.inc"
 
 }  // extern "C"

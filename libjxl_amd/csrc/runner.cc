@@ -174,3 +174,134 @@ void* JxlHipParallelRunnerStream(void* runner_opaque, size_t thread_id) {
 }
 
 }  // extern "C"
+
+// ---- JxlResizableParallelRunner (lib/include/jxl/resizable_parallel_runner.h:46-69,
+// lib/threads/resizable_parallel_runner.cc:26-195): the runner djxl-like tools use when the number of
+// threads is only known once the image size is (JxlResizableParallelRunnerSuggestThreads).  Contract
+// of the reference: SetThreads(n) keeps n - 1 workers, the CALLING thread is thread 0 of every run;
+// init gets min(workers + 1, tasks) (1 for a single task, which runs inline).
+namespace {
+
+struct ResizableRunner {
+  JxlMemoryManager mm{};
+  std::mutex mu;
+  std::condition_variable cv_start, cv_done;
+  std::vector<std::thread> workers;
+  size_t desired = 0;     // workers that should exist
+  uint64_t epoch = 0;
+  size_t participants = 0;  // workers [0, participants) take part in the current run
+  size_t running = 0;
+  void* opaque = nullptr;
+  JxlParallelRunFunction func = nullptr;
+  uint32_t end = 0;
+  std::atomic<uint32_t> next{0};
+
+  void Drain(size_t thread_id) {
+    for (;;) {
+      const uint32_t t = next.fetch_add(1, std::memory_order_relaxed);
+      if (t >= end) return;
+      func(opaque, t, thread_id);
+    }
+  }
+  void WorkerMain(size_t id) {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        cv_start.wait(lock, [&] { return id >= desired || (epoch != seen && id < participants); });
+        if (id >= desired) return;
+        seen = epoch;
+      }
+      Drain(id + 1);
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        if (--running == 0) cv_done.notify_all();
+      }
+    }
+  }
+  void SetThreads(size_t num) {
+    if (num > 0) num -= 1;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      desired = num;
+    }
+    cv_start.notify_all();
+    for (size_t i = workers.size(); i < num; i++) workers.emplace_back([this, i] { WorkerMain(i); });
+    if (workers.size() > num) {
+      for (size_t i = num; i < workers.size(); i++) workers[i].join();
+      workers.resize(num);
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+JxlParallelRetCode JxlResizableParallelRunner(void* runner_opaque, void* jpegxl_opaque, JxlParallelRunInit init,
+                                              JxlParallelRunFunction func, uint32_t start_range,
+                                              uint32_t end_range) {
+  ResizableRunner* r = static_cast<ResizableRunner*>(runner_opaque);
+  if (!r || start_range > end_range) return JXL_PARALLEL_RET_RUNNER_ERROR;
+  if (start_range == end_range) return JXL_PARALLEL_RET_SUCCESS;
+  if (start_range + 1 == end_range) {
+    const JxlParallelRetCode rc = init(jpegxl_opaque, 1);
+    if (rc != 0) return rc;
+    func(jpegxl_opaque, start_range, 0);
+    return rc;
+  }
+  const size_t tasks = end_range - start_range;
+  const size_t n = r->workers.size() + 1 < tasks ? r->workers.size() + 1 : tasks;
+  const JxlParallelRetCode rc = init(jpegxl_opaque, n);
+  if (rc != 0) return rc;
+  {
+    std::lock_guard<std::mutex> lock(r->mu);
+    r->opaque = jpegxl_opaque;
+    r->func = func;
+    r->end = end_range;
+    r->next.store(start_range, std::memory_order_relaxed);
+    r->participants = n - 1;
+    r->running = n - 1;
+    r->epoch++;
+  }
+  r->cv_start.notify_all();
+  r->Drain(0);
+  std::unique_lock<std::mutex> lock(r->mu);
+  r->cv_done.wait(lock, [&] { return r->running == 0; });
+  return JXL_PARALLEL_RET_SUCCESS;
+}
+
+void* JxlResizableParallelRunnerCreate(const JxlMemoryManager* memory_manager) {
+  JxlMemoryManager mm{};
+  if (memory_manager) {
+    mm = *memory_manager;
+    if ((mm.alloc == nullptr) != (mm.free == nullptr)) return nullptr;
+  }
+  void* mem = MMAlloc(mm, sizeof(ResizableRunner));
+  if (!mem) return nullptr;
+  ResizableRunner* r = new (mem) ResizableRunner();
+  r->mm = mm;
+  return r;
+}
+
+void JxlResizableParallelRunnerSetThreads(void* runner_opaque, size_t num_threads) {
+  if (runner_opaque) static_cast<ResizableRunner*>(runner_opaque)->SetThreads(num_threads);
+}
+
+uint32_t JxlResizableParallelRunnerSuggestThreads(uint64_t xsize, uint64_t ysize) {
+  // ~one thread per group (resizable_parallel_runner.cc:189-194)
+  const uint64_t groups = xsize * ysize / (256 * 256);
+  const uint64_t hw = std::thread::hardware_concurrency();
+  return (uint32_t)(groups < hw ? groups : hw);
+}
+
+void JxlResizableParallelRunnerDestroy(void* runner_opaque) {
+  ResizableRunner* r = static_cast<ResizableRunner*>(runner_opaque);
+  if (!r) return;
+  r->SetThreads(0);
+  const JxlMemoryManager mm = r->mm;
+  r->~ResizableRunner();
+  MMFree(mm, r);
+}
+
+}  // extern "C"

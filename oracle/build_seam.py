@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY.  Compiles the drop-in boundary of INTEGRATION.md for real.
+
+Two shared libraries with the reference's PUBLIC decoder API (lib/include/jxl/decode.h: JxlDecoderCreate,
+JxlDecoderProcessInput, JxlDecoderSetImageOutBuffer ...; lib/jxl/decode.cc compiled in place) over the same
+reference translation units oracle/build_ref.py builds (objects reused from oracle/_ref/obj):
+
+  oracle/_ref/libjxl_dec_ref.so   the reference decoder, unmodified
+  oracle/_ref/libjxl_dec_hip.so   the same with FrameDecoder::ProcessSections handing the AC groups of eligible
+                                  frames to the HIP back-end: a patched COPY of lib/jxl/dec_frame.cc (written to
+                                  oracle/_build/seam/, git-ignored, never committed) + oracle/seam/hip_seam.cc,
+                                  linked against libjxl_amd/csrc/libjxl_hip.so
+
+The patch is three inserted statements, applied by anchor (PATCH below) -- the reference file is read where it
+lies under /root/reference; nothing of it is stored in this repository.  tests/test_seam.py drives both libraries
+through JxlDecoderProcessInput on genuine codestreams with the JxlParallelRunner of libjxl_threads_hip.so and
+holds their pixels to 2e-5 of each other.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import build_ref as B  # noqa: E402
+
+SEAM = os.path.join(HERE, "_build", "seam")
+ROOT = os.path.dirname(HERE)
+HIPLIB_DIR = os.path.join(ROOT, "libjxl_amd", "csrc")
+EXTRA_TUS = ["jxl/decode.cc", "jxl/icc_codec.cc", "jxl/decode_to_jpeg.cc"]  # what build_ref.py leaves out
+FLAGS = B.FLAGS + ["-DJPEGXL_ENABLE_BOXES=0", "-DJPEGXL_ENABLE_TRANSCODE_JPEG=0"]
+
+# (anchor line of lib/jxl/dec_frame.cc, text inserted BEFORE its FIRST occurrence); every anchor must exist
+DECL = ("namespace jxl {\n"
+        "class FrameDecoder;\n"
+        "Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sections, size_t num,\n"
+        "                         const std::vector<std::vector<size_t>>& ac_group_sec,\n"
+        "                         const std::vector<size_t>& desired_num_ac_passes, size_t ac_global_sec,\n"
+        "                         size_t ac_global_bit, FrameDecoder::SectionStatus* section_status, bool* done);\n"
+        "}  // namespace jxl\n")
+PATCH = [
+    # the declaration: after the file's own includes (FrameDecoder is complete there)
+    ("namespace jxl {", DECL),
+    ("  if (finalized_dc_ && ac_global_sec != num && !decoded_ac_global_) {",
+     "  // jxlhip seam: where AC global starts in its reader (a one-section frame shares the reader)\n"
+     "  const size_t jxlhip_ac_global_bit = ac_global_sec != num ? sections[ac_global_sec].br->TotalBitsConsumed() : 0;\n"),
+    ("    // Mark all the AC groups that we received as not complete yet.",
+     "    {  // jxlhip seam (oracle/seam/hip_seam.cc): the whole frame's AC groups on the HIP back-end when eligible\n"
+     "      bool jxlhip_done = false;\n"
+     "      JXL_RETURN_IF_ERROR(JxlHipTryAcGroups(this, sections, num, ac_group_sec, desired_num_ac_passes,\n"
+     "                                            ac_global_sec, jxlhip_ac_global_bit, section_status, &jxlhip_done));\n"
+     "      if (jxlhip_done) {\n"
+     "        MarkSections(sections, num, section_status);\n"
+     "        return true;\n"
+     "      }\n"
+     "    }\n"),
+]
+
+
+def patched_dec_frame():
+    src = open(os.path.join(B.REF, "lib", "jxl", "dec_frame.cc")).read()
+    out, hits = [], [0] * len(PATCH)
+    for line in src.split("\n"):
+        for i, (anchor, text) in enumerate(PATCH):
+            if line == anchor and hits[i] == 0:
+                out.append(text.rstrip("\n"))
+                hits[i] = 1
+        out.append(line)
+    if hits != [1] * len(PATCH):
+        raise RuntimeError("dec_frame.cc changed: patch anchors found: %s" % hits)
+    os.makedirs(SEAM, exist_ok=True)
+    path = os.path.join(SEAM, "dec_frame_hip.cc")
+    new = "\n".join(out)
+    if not os.path.exists(path) or open(path).read() != new:
+        open(path, "w").write(new)
+    return path
+
+
+def _cc(src, obj, extra=()):
+    if os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src) and \
+            os.path.getmtime(obj) > os.path.getmtime(os.path.abspath(__file__)):
+        return
+    r = subprocess.run([B.CXX] + FLAGS + list(extra) + ["-c", src, "-o", obj], capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("%s:\n%s" % (src, r.stderr[-6000:]))
+
+
+def available():
+    return B.available()
+
+
+def build(verbose=False):
+    ref_so = os.path.join(B.OUT, "libjxl_dec_ref.so")
+    hip_so = os.path.join(B.OUT, "libjxl_dec_hip.so")
+    if not B.available():
+        if os.path.exists(ref_so) and os.path.exists(hip_so):
+            return ref_so, hip_so  # prebuilt, travelled with the snapshot
+        raise RuntimeError("reference tree not present and no prebuilt seam libraries")
+    objs = B.build(only_compile=True)
+    os.makedirs(SEAM, exist_ok=True)
+    extra_objs = []
+    for f in EXTRA_TUS:
+        o = os.path.join(SEAM, f.replace("/", "__")[:-3] + ".o")
+        _cc(os.path.join(B.REF, "lib", f), o)
+        extra_objs.append(o)
+    inc = ["-I" + os.path.join(ROOT, "include")]
+    patched = patched_dec_frame()
+    o_patched = os.path.join(SEAM, "dec_frame_hip.o")
+    _cc(patched, o_patched, inc)
+    o_seam = os.path.join(SEAM, "hip_seam.o")
+    _cc(os.path.join(HERE, "seam", "hip_seam.cc"), o_seam, inc)
+    # the encoder's public API (JxlEncoder*) wants the JPEG-transcoding translation units: not part of a decoder library
+    objs = [o for o in objs if not o.endswith("jxl__encode.o")]
+    dec_frame_obj = [o for o in objs if o.endswith("jxl__dec_frame.o")]
+    assert len(dec_frame_obj) == 1
+    others = [o for o in objs if o != dec_frame_obj[0]]
+    link = ["-Wl,--gc-sections", "-Wl,-Bsymbolic", "-Wl,--no-undefined", "-lpthread", "-lm"]
+    for so, parts, libs in ((ref_so, objs + extra_objs, []),
+                            (hip_so, others + extra_objs + [o_patched, o_seam],
+                             ["-L" + HIPLIB_DIR, "-l:libjxl_hip.so", "-Wl,-rpath," + HIPLIB_DIR,
+                              "-Wl,-rpath,$ORIGIN/../../libjxl_amd/csrc"])):
+        r = subprocess.run([B.CXX, "-shared", "-fPIC", "-o", so] + parts + link + libs, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError("link %s failed:\n%s" % (so, r.stderr[-6000:]))
+    if verbose:
+        print("built", ref_so, hip_so)
+    return ref_so, hip_so
+
+
+if __name__ == "__main__":
+    build(verbose=True)

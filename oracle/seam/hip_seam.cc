@@ -1,0 +1,241 @@
+// TEST INFRASTRUCTURE (compiled into oracle/_ref/libjxl_dec_hip.so by oracle/build_seam.py; never part of the
+// product): the reference-side binding of INTEGRATION.md, compiled for real.
+//
+// oracle/build_seam.py makes a patched COPY of the reference's lib/jxl/dec_frame.cc (two inserted statements,
+// see there) in which FrameDecoder::ProcessSections, once DC global / DC groups / AC global are decoded by the
+// reference's own code and every AC section of the frame is present, calls JxlHipTryAcGroups() below instead of
+// running DecodeGroup + the CPU render pipeline per group (lib/jxl/dec_frame.cc:694-731).  This function is the
+// ~150 lines a libjxl maintainer would write: it lifts the per-frame state out of PassesSharedState /
+// PassesDecoderState (dec_cache.h:86-229, passes_state.h:48-95) into the C ABI of include/jxl_hip.h, hands the
+// AC sections' BYTES to the product's entropy decoder on the decoder's own JxlParallelRunner
+// (jxlhip_ac_groups_decode_submit), runs the HIP back-end and copies the pixels into the caller's
+// JxlDecoderSetImageOutBuffer buffer.  Frames it does not take (Modular, extra channels, blending, callbacks,
+// integer output, colour management ...) fall through to the untouched CPU path.
+//
+// FrameDecoder's members are private; a maintainer would add this as a member function.  Here the class
+// definition is taken as is and its access checks are lifted for this translation unit only.
+// (every standard header the reference headers pull in comes first, with its access specifiers intact)
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cinttypes>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <type_traits>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#define private public
+#define protected public
+#include "lib/jxl/dec_frame.h"
+#undef private
+#undef protected
+
+#include "jxl_hip.h"
+#include "jxl_hip_entropy.h"
+
+extern "C" {
+static std::atomic<int> g_frames{0};
+// how many frames went through the HIP back-end (the GPU test asserts the path was actually taken)
+__attribute__((visibility("default"))) int jxlhip_seam_frames_decoded() { return g_frames.load(); }
+}
+
+namespace jxl {
+
+namespace {
+jxlhip_ctx* Context() {
+  static jxlhip_ctx* ctx = [] {
+    jxlhip_ctx* c = nullptr;
+    const char* e = getenv("JXLHIP_SEAM_DEVICE");
+    if (jxlhip_create(e ? atoi(e) : 0, &c) != JXLHIP_OK) return static_cast<jxlhip_ctx*>(nullptr);
+    return c;
+  }();
+  return ctx;
+}
+
+struct HipPasses {
+  jxlhip_ac_pass* p[11] = {nullptr};
+  ~HipPasses() {
+    for (auto* q : p)
+      if (q) jxlhip_ac_pass_destroy(q);
+  }
+};
+}  // namespace
+
+Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sections, size_t num,
+                         const std::vector<std::vector<size_t>>& ac_group_sec,
+                         const std::vector<size_t>& desired_num_ac_passes, size_t ac_global_sec,
+                         size_t ac_global_bit, FrameDecoder::SectionStatus* section_status, bool* done) {
+  *done = false;
+  if (getenv("JXLHIP_SEAM_DISABLE")) return true;
+  const FrameHeader& fh = fd->frame_header_;
+  PassesDecoderState* ds = fd->dec_state_;
+  const PassesSharedState& sh = *ds->shared;
+  const FrameDimensions& dim = fd->frame_dim_;
+  const ImageMetadata& md = fh.nonserialized_metadata->m;
+  const OutputEncodingInfo& oe = ds->output_encoding_info;
+  const ImageOutput& mo = ds->main_output;
+  const size_t np = fh.passes.num_passes;
+  // ---- frames the back-end takes; everything else keeps the CPU path
+  if (!fd->decoded_ac_global_ || ac_global_sec == num) return true;  // AC global must arrive with the groups
+  if (fh.encoding != FrameEncoding::kVarDCT || fh.color_transform != ColorTransform::kXYB || !md.xyb_encoded) return true;
+  if (fh.flags & (FrameHeader::kNoise | FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kUseDcFrame)) return true;
+  if (!fh.chroma_subsampling.Is444() || fh.upsampling != 1 || fh.dc_level != 0) return true;
+  if (md.num_extra_channels != 0 || fh.custom_size_or_origin || fh.blending_info.mode != BlendMode::kReplace) return true;
+  if (!fh.is_last || fh.CanBeReferenced() || fh.frame_type != FrameType::kRegularFrame) return true;
+  if (fd->decoded_->IsJPEG() || ds->undo_orientation != Orientation::kIdentity) return true;
+  if (mo.callback.IsPresent() || !mo.buffer || mo.format.data_type != JXL_TYPE_FLOAT ||
+      (mo.format.num_channels != 3 && mo.format.num_channels != 4) || mo.format.endianness == JXL_BIG_ENDIAN)
+    return true;
+  if (!oe.color_encoding_is_original || oe.color_encoding.Channels() != 3) return true;
+  uint32_t transfer;
+  if (oe.color_encoding.Tf().IsSRGB()) transfer = JXLHIP_TF_SRGB;
+  else if (oe.color_encoding.Tf().IsLinear()) transfer = JXLHIP_TF_LINEAR;
+  else return true;
+  for (size_t g = 0; g < dim.num_groups; g++)  // the whole frame, nothing drawn yet
+    if (desired_num_ac_passes[g] != np || fd->decoded_passes_per_ac_group_[g] != 0) return true;
+  jxlhip_ctx* ctx = Context();
+  if (!ctx) return true;  // no device: CPU path
+
+  auto check = [&](int rc, const char* what) -> Status {
+    if (rc == JXLHIP_OK) return true;
+    return JXL_FAILURE("jxlhip %s: %s (%s)", what, jxlhip_status_string(rc), jxlhip_last_error(ctx));
+  };
+  // ---- per-frame parameters
+  jxlhip_frame_params p = {};
+  p.xsize = dim.xsize;
+  p.ysize = dim.ysize;
+  p.output_kind = JXLHIP_OUT_PACKED;
+  p.global_scale = sh.quantizer.global_scale_;
+  p.quant_dc = sh.quantizer.quant_dc_;
+  p.x_dm_multiplier = ds->x_dm_multiplier;
+  p.b_dm_multiplier = ds->b_dm_multiplier;
+  memcpy(p.quant_biases, oe.opsin_params.quant_biases, sizeof(p.quant_biases));
+  p.cfl_base_x = sh.cmap.base().GetBaseCorrelationX();
+  p.cfl_base_b = sh.cmap.base().GetBaseCorrelationB();
+  p.cfl_color_factor = static_cast<uint32_t>(sh.cmap.base().GetColorFactor());
+  const LoopFilter& lf = fh.loop_filter;
+  p.lf.gab = lf.gab ? 1 : 0;
+  const float gw[6] = {lf.gab_x_weight1, lf.gab_x_weight2, lf.gab_y_weight1, lf.gab_y_weight2, lf.gab_b_weight1, lf.gab_b_weight2};
+  memcpy(p.lf.gab_weights, gw, sizeof(gw));
+  p.lf.epf_iters = lf.epf_iters;
+  memcpy(p.lf.epf_sharp_lut, lf.epf_sharp_lut, sizeof(p.lf.epf_sharp_lut));
+  memcpy(p.lf.epf_channel_scale, lf.epf_channel_scale, sizeof(p.lf.epf_channel_scale));
+  p.lf.epf_quant_mul = lf.epf_quant_mul;
+  p.lf.epf_pass0_sigma_scale = lf.epf_pass0_sigma_scale;
+  p.lf.epf_pass2_sigma_scale = lf.epf_pass2_sigma_scale;
+  p.lf.epf_border_sad_mul = lf.epf_border_sad_mul;
+  for (int i = 0; i < 3; i++) p.opsin_biases[i] = oe.opsin_params.opsin_biases[i];
+  for (int i = 0; i < 9; i++) p.inverse_opsin_matrix[i] = oe.opsin_params.inverse_opsin_matrix[i * 4];
+  p.out_format.transfer = transfer;
+  p.out_format.sample_type = JXLHIP_SAMPLE_F32;
+  p.out_format.num_channels = mo.format.num_channels;
+  p.out_format.bits_per_sample = 32;
+  p.used_acs = ds->used_acs;
+
+  // ---- side info out of PassesSharedState, as dense arrays
+  const size_t xsb = dim.xsize_blocks, ysb = dim.ysize_blocks, nb = xsb * ysb;
+  const size_t xt = (xsb + 7) / 8, yt = (ysb + 7) / 8;
+  std::vector<uint8_t> acs(nb), sharp(nb), qctx(nb);
+  std::vector<int32_t> rq(nb);
+  std::vector<int8_t> ytox(xt * yt), ytob(xt * yt);
+  std::vector<float> dc(3 * nb);
+  for (size_t y = 0; y < ysb; y++) {
+    const AcStrategyRow row = sh.ac_strategy.ConstRow(y);
+    for (size_t x = 0; x < xsb; x++)
+      acs[y * xsb + x] = static_cast<uint8_t>((row[x].RawStrategy() << 1) | (row[x].IsFirstBlock() ? 1 : 0));
+    memcpy(&rq[y * xsb], sh.raw_quant_field.ConstRow(y), xsb * sizeof(int32_t));
+    memcpy(&sharp[y * xsb], sh.epf_sharpness.ConstRow(y), xsb);
+    memcpy(&qctx[y * xsb], sh.quant_dc.ConstRow(y), xsb);
+    for (int c = 0; c < 3; c++) memcpy(&dc[c * nb + y * xsb], sh.dc->ConstPlaneRow(c, y), xsb * sizeof(float));
+  }
+  for (size_t y = 0; y < yt; y++) {
+    memcpy(&ytox[y * xt], sh.cmap.ytox_map.ConstRow(y), xt);
+    memcpy(&ytob[y * xt], sh.cmap.ytob_map.ConstRow(y), xt);
+  }
+  const float* dc3[3] = {dc.data(), dc.data() + nb, dc.data() + 2 * nb};
+  const float* table = sh.matrices.Matrix(AcStrategyType::DCT, 0);  // = table_ (quant_weights.h:364-367), EnsureComputed by ProcessACGlobal
+
+  // ---- AC global once more, from its bytes, into the product's pass objects (histograms, coefficient orders)
+  jxlhip_block_ctx_map bcm = {};
+  for (int c = 0; c < 3; c++) {
+    bcm.num_dc_thresholds[c] = static_cast<uint32_t>(sh.block_ctx_map.dc_thresholds[c].size());
+    for (size_t i = 0; i < sh.block_ctx_map.dc_thresholds[c].size(); i++) bcm.dc_thresholds[c][i] = sh.block_ctx_map.dc_thresholds[c][i];
+  }
+  bcm.num_dc_ctxs = static_cast<uint32_t>(sh.block_ctx_map.num_dc_ctxs);
+  bcm.num_qf_thresholds = static_cast<uint32_t>(sh.block_ctx_map.qf_thresholds.size());
+  for (size_t i = 0; i < sh.block_ctx_map.qf_thresholds.size(); i++) bcm.qf_thresholds[i] = sh.block_ctx_map.qf_thresholds[i];
+  bcm.num_ctxs = static_cast<uint32_t>(sh.block_ctx_map.num_ctxs);
+  bcm.ctx_map_size = static_cast<uint32_t>(sh.block_ctx_map.ctx_map.size());
+  if (bcm.ctx_map_size > JXLHIP_BLOCK_CTX_MAP_MAX) return true;
+  memcpy(bcm.ctx_map, sh.block_ctx_map.ctx_map.data(), bcm.ctx_map_size);
+  const BitReader* gbr = sections[ac_global_sec].br;
+  jxlhip_quant_encoding enc[JXLHIP_NUM_QUANT_TABLES];
+  uint32_t num_hist = 0;
+  HipPasses passes;
+  size_t gpos = ac_global_bit;
+  JXL_RETURN_IF_ERROR(check(jxlhip_ac_global_decode_at(gbr->FirstByte(), gbr->TotalBytes(), &gpos, dim.num_groups, np,
+                                                       ds->used_acs, &bcm, enc, &num_hist, passes.p),
+                            "AC global"));
+
+  // ---- the groups' section bytes; a one-section frame carries its AC group behind AC global in the same reader
+  const bool single = dim.num_groups == 1 && np == 1;
+  std::vector<const uint8_t*> sec(np * dim.num_groups);
+  std::vector<size_t> sec_size(np * dim.num_groups);
+  std::vector<uint32_t> shifts(np);
+  for (size_t ps = 0; ps < np; ps++) shifts[ps] = fh.passes.shift[ps];
+  for (size_t ps = 0; ps < np && !single; ps++)
+    for (size_t g = 0; g < dim.num_groups; g++) {
+      const BitReader* br = sections[ac_group_sec[g][ps]].br;
+      sec[ps * dim.num_groups + g] = br->FirstByte();
+      sec_size[ps * dim.num_groups + g] = br->TotalBytes();
+    }
+
+  const jxlhip_ac_pass* pp[11];
+  for (size_t i = 0; i < np; i++) pp[i] = passes.p[i];
+  JxlParallelRunner runner = fd->pool_ ? fd->pool_->runner() : nullptr;
+  void* runner_opaque = fd->pool_ ? fd->pool_->runner_opaque() : nullptr;
+  for (uint32_t ct = JXLHIP_COEFF_I16; ct <= JXLHIP_COEFF_I32; ct++) {
+    p.coeff_type = ct;
+    JXL_RETURN_IF_ERROR(check(jxlhip_frame_begin(ctx, &p), "frame_begin"));
+    JXL_RETURN_IF_ERROR(check(jxlhip_upload_side_info(ctx, acs.data(), rq.data(), sharp.data(), ytox.data(), ytob.data(), dc3, table),
+                              "upload_side_info"));
+    int rc;
+    if (single) {
+      const uint8_t* d1[1] = {gbr->FirstByte()};
+      size_t s1[1] = {gbr->TotalBytes()}, b1[1] = {gpos};
+      rc = jxlhip_ac_group_decode_submit_passes(ctx, 1, pp, shifts.data(), 0, acs.data(), rq.data(), qctx.data(), d1, s1, b1);
+    } else {
+      rc = jxlhip_ac_groups_decode_submit(ctx, reinterpret_cast<jxlhip_parallel_runner>(runner), runner_opaque,
+                                          static_cast<uint32_t>(np), pp, shifts.data(), acs.data(), rq.data(), qctx.data(),
+                                          sec.data(), sec_size.data());
+    }
+    if (rc == JXLHIP_ERR_RANGE && ct == JXLHIP_COEFF_I16) continue;  // a coefficient needs 32 bits: redo
+    JXL_RETURN_IF_ERROR(check(rc, "AC groups"));
+    break;
+  }
+  JXL_RETURN_IF_ERROR(check(jxlhip_decode_frame_host(ctx, mo.buffer, mo.stride, 0), "decode_frame"));
+  for (size_t g = 0; g < dim.num_groups; g++) {
+    fd->decoded_passes_per_ac_group_[g] = static_cast<uint8_t>(np);
+    for (size_t ps = 0; ps < np && !single; ps++) section_status[ac_group_sec[g][ps]] = FrameDecoder::SectionStatus::kDone;
+  }
+  g_frames.fetch_add(1);
+  *done = true;
+  return true;
+}
+
+}  // namespace jxl

@@ -1,0 +1,90 @@
+"""jxlhip_create_multi (include/jxl_hip.h): one context over several devices, stripes of AC-group rows, halo rows
+and the final gather as stream-ordered peer copies below the C ABI.  A 1-GPU box lists device 0 several times
+(several stripes on one GPU: same code path, peer copies degenerate to same-device copies); with >= 2 devices
+visible the same test spreads the stripes over them."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import frames
+from libjxl_amd import VarDctDecoder, abi, synth
+
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-5
+
+
+def rel_err(got, ref):
+    return float(np.abs(got.astype(np.float64) - ref).max()) / max(1.0, float(np.abs(ref).max()))
+
+
+def run_multi(L, devices, params, t, table_host, host_out, monkeypatch=None):
+    ctx = C.c_void_p()
+    devs = (C.c_int * len(devices))(*devices)
+    assert L.jxlhip_create_multi(devs, len(devices), None, C.byref(ctx)) == 0
+    try:
+        p = abi.make_params(params)
+        assert L.jxlhip_frame_begin(ctx, C.byref(p)) == 0, L.jxlhip_last_error(ctx)
+        npy = {k: ([x.numpy() for x in v] if isinstance(v, list) else v.numpy()) for k, v in t.items()}
+        dc3 = (C.c_void_p * 3)(*[a.ctypes.data for a in npy["dc"]])
+        assert L.jxlhip_upload_side_info(ctx, npy["ac_strategy"].ctypes.data, npy["raw_quant"].ctypes.data,
+                                         npy["epf_sharpness"].ctypes.data, npy["ytox_map"].ctypes.data,
+                                         npy["ytob_map"].ctypes.data, dc3, table_host.ctypes.data) == 0
+        xs, ys = params["xsize"], params["ysize"]
+        ng = ((xs + 255) // 256) * ((ys + 255) // 256)
+        for g in range(ng):
+            ptrs = (C.c_void_p * 3)(*[c[g * 65536:].ctypes.data for c in npy["coeffs"]])
+            assert L.jxlhip_submit_group(ctx, g, ptrs, 65536) == 0, L.jxlhip_last_error(ctx)
+        if host_out:
+            out = np.zeros((ys, xs, 3), np.float32)
+            assert L.jxlhip_decode_frame_host(ctx, out.ctypes.data, xs * 12, 0) == 0, L.jxlhip_last_error(ctx)
+            return out
+        dev_out = torch.empty((ys, xs, 3), dtype=torch.float32, device=f"cuda:{devices[0]}")
+        assert L.jxlhip_decode_frame(ctx, dev_out.data_ptr(), xs * 12, 0) == 0, L.jxlhip_last_error(ctx)
+        assert L.jxlhip_sync(ctx) == 0, L.jxlhip_last_error(ctx)
+        return dev_out.cpu().numpy()
+    finally:
+        L.jxlhip_destroy(ctx)
+
+
+@pytest.mark.parametrize("nstripes,gather,host_out", [(2, False, False), (3, True, False), (2, False, True), (4, True, True)])
+@pytest.mark.parametrize("gab,epf", [(1, 1), (1, 2), (0, 0)])
+def test_multi_context_matches_single_context(oracle, monkeypatch, nstripes, gather, host_out, gab, epf):
+    L = abi.load_library()
+    xs, ys = 600, 1100  # 5 group rows
+    params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=bool(gab), epf_iters=epf, seed=91)
+    ref = fr.decode(threads=4)
+    # the dequant table and the single-context result (two-phase: what the stripes run)
+    monkeypatch.setenv("JXLHIP_FUSE", "0")
+    d = VarDctDecoder(0)
+    d.begin_frame(params)
+    dq = d.default_dequant_tables()
+    d.set_inputs({k: ([x.cuda() for x in v] if isinstance(v, list) else v.cuda()) for k, v in t.items()}, dq)
+    single = d.decode_frame().cpu().numpy()
+    d.sync()
+    table_host = dq.cpu().numpy()
+    d.close()
+    if gather:
+        monkeypatch.setenv("JXLHIP_MULTI_FORCE_GATHER", "1")
+    ndev = torch.cuda.device_count()
+    devices = [i % ndev for i in range(nstripes)]
+    got = run_multi(L, devices, params, t, table_host, host_out)
+    assert rel_err(got, ref) <= TIGHT
+    assert np.array_equal(got, single)  # stripes + halo exchange reproduce the whole-frame two-phase result bit for bit
+
+
+def test_multi_context_refuses_what_it_does_not_do():
+    L = abi.load_library()
+    ctx = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert L.jxlhip_create_multi(devs, 2, None, C.byref(ctx)) == 0
+    try:
+        assert L.jxlhip_decode_blocks(ctx) == -7  # JXLHIP_ERR_UNSUPPORTED
+        params, _ = synth.synth_frame(300, 200, mix=synth.MIX_DCT8)  # one group row: cannot be split in two
+        p = abi.make_params(params)
+        assert L.jxlhip_frame_begin(ctx, C.byref(p)) == -1
+    finally:
+        L.jxlhip_destroy(ctx)
+    bad = (C.c_int * 1)(99)
+    assert L.jxlhip_create_multi(bad, 1, None, C.byref(ctx)) == -1

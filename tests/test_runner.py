@@ -109,3 +109,39 @@ def test_memory_manager_rules(lib):
     bad = MemoryManager(None, ALLOC(alloc), FREE())
     assert not lib.JxlThreadParallelRunnerCreate(C.byref(bad), 1)
     assert lib.JxlThreadParallelRunnerDefaultNumWorkerThreads() >= 1
+
+
+def test_resizable_runner_contract(lib):
+    """JxlResizableParallelRunner* (lib/threads/resizable_parallel_runner.cc:26-195): the caller is thread 0,
+    SetThreads(n) keeps n - 1 workers, init sees min(workers + 1, tasks), a single task runs inline."""
+    lib.JxlResizableParallelRunnerCreate.restype = C.c_void_p
+    lib.JxlResizableParallelRunnerCreate.argtypes = [C.c_void_p]
+    lib.JxlResizableParallelRunnerSetThreads.argtypes = [C.c_void_p, C.c_size_t]
+    lib.JxlResizableParallelRunnerDestroy.argtypes = [C.c_void_p]
+    lib.JxlResizableParallelRunner.argtypes = [C.c_void_p, C.c_void_p, INIT, FUNC, C.c_uint32, C.c_uint32]
+    lib.JxlResizableParallelRunnerSuggestThreads.restype = C.c_uint32
+    lib.JxlResizableParallelRunnerSuggestThreads.argtypes = [C.c_uint64, C.c_uint64]
+    r = lib.JxlResizableParallelRunnerCreate(None)
+    assert r
+    lock = threading.Lock()
+    for threads in (0, 1, 4, 9, 2, 0):
+        lib.JxlResizableParallelRunnerSetThreads(r, threads)
+        workers = max(threads, 1) - 1
+        for (a, b) in [(0, 1), (7, 7), (3, 500), (0, 3)]:
+            seen, tids, nth = [], set(), []
+
+            def func(opaque, value, tid):
+                with lock:
+                    seen.append(value)
+                    tids.add(tid)
+
+            rc = lib.JxlResizableParallelRunner(r, None, INIT(lambda o, n: nth.append(n) or 0), FUNC(func), a, b)
+            assert rc == 0 and sorted(seen) == list(range(a, b))
+            if b > a:
+                want = 1 if b - a == 1 else min(workers + 1, b - a)
+                assert nth == [want] and all(t < want for t in tids)
+    assert lib.JxlResizableParallelRunner(r, None, INIT(lambda o, n: -3), FUNC(lambda o, v, t: None), 0, 9) == -3
+    lib.JxlResizableParallelRunnerDestroy(r)
+    import os
+    assert lib.JxlResizableParallelRunnerSuggestThreads(256, 256) == 1
+    assert lib.JxlResizableParallelRunnerSuggestThreads(1 << 20, 1 << 20) == os.cpu_count()

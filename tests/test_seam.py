@@ -1,0 +1,145 @@
+"""The drop-in boundary compiled for real (oracle/build_seam.py): the reference's PUBLIC decoder API
+(JxlDecoderCreate / JxlDecoderProcessInput / JxlDecoderSetImageOutBuffer, lib/include/jxl/decode.h) over
+
+  libjxl_dec_ref.so : the reference decoder, unmodified
+  libjxl_dec_hip.so : the same with FrameDecoder::ProcessSections patched so that the AC
+                      groups of eligible frames go through libjxl_hip.so (oracle/seam/hip_seam.cc)
+
+driven like djxl drives libjxl (tools/djxl_main.cc:377,525-533; lib/extras/dec/jxl.cc), with the
+JxlParallelRunner of libjxl_threads_hip.so.  CPU suite: both libraries build, export the API, and the patched one
+falls back to the CPU path without a device (same pixels).  GPU suite: "reference JxlDecoder + jxlhip back-end
+== unpatched reference JxlDecoder" within 2e-5, and the HIP path was actually taken."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from libjxl_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TIGHT = 2e-5
+
+JXL_DEC_SUCCESS, JXL_DEC_ERROR, JXL_DEC_NEED_MORE_INPUT, JXL_DEC_NEED_IMAGE_OUT_BUFFER = 0, 1, 2, 5
+JXL_DEC_BASIC_INFO, JXL_DEC_FULL_IMAGE = 0x40, 0x1000
+
+
+class PixelFormat(C.Structure):  # JxlPixelFormat, lib/include/jxl/types.h:80-105
+    _fields_ = [("num_channels", C.c_uint32), ("data_type", C.c_int), ("endianness", C.c_int), ("align", C.c_size_t)]
+
+
+@pytest.fixture(scope="module")
+def libs(oracle):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import build_seam
+    try:
+        ref_so, hip_so = build_seam.build()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    return ref_so, hip_so
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not available")
+    oracle.ref_lib()
+    return oracle
+
+
+def load(path):
+    L = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+    L.JxlDecoderCreate.restype = C.c_void_p
+    L.JxlDecoderCreate.argtypes = [C.c_void_p]
+    L.JxlDecoderDestroy.argtypes = [C.c_void_p]
+    L.JxlDecoderSetParallelRunner.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.JxlDecoderSubscribeEvents.argtypes = [C.c_void_p, C.c_int]
+    L.JxlDecoderSetInput.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.JxlDecoderCloseInput.argtypes = [C.c_void_p]
+    L.JxlDecoderProcessInput.argtypes = [C.c_void_p]
+    L.JxlDecoderGetBasicInfo.argtypes = [C.c_void_p, C.c_void_p]
+    L.JxlDecoderImageOutBufferSize.argtypes = [C.c_void_p, C.POINTER(PixelFormat), C.POINTER(C.c_size_t)]
+    L.JxlDecoderSetImageOutBuffer.argtypes = [C.c_void_p, C.POINTER(PixelFormat), C.c_void_p, C.c_size_t]
+    return L
+
+
+def jxl_decode(L, data, runner=None, runner_opaque=None, channels=3):
+    """JxlDecoder event loop of lib/extras/dec/jxl.cc, float output.  Returns [H, W, channels] float32."""
+    dec = L.JxlDecoderCreate(None)
+    assert dec
+    try:
+        if runner:
+            assert L.JxlDecoderSetParallelRunner(dec, runner, runner_opaque) == JXL_DEC_SUCCESS
+        assert L.JxlDecoderSubscribeEvents(dec, JXL_DEC_BASIC_INFO | JXL_DEC_FULL_IMAGE) == JXL_DEC_SUCCESS
+        assert L.JxlDecoderSetInput(dec, data, len(data)) == JXL_DEC_SUCCESS
+        L.JxlDecoderCloseInput(dec)
+        fmt = PixelFormat(channels, 0, 0, 0)  # JXL_TYPE_FLOAT, JXL_NATIVE_ENDIAN
+        out, w, h = None, 0, 0
+        while True:
+            st = L.JxlDecoderProcessInput(dec)
+            if st == JXL_DEC_BASIC_INFO:
+                info = (C.c_uint8 * 1024)()
+                assert L.JxlDecoderGetBasicInfo(dec, info) == JXL_DEC_SUCCESS
+                w, h = np.frombuffer(bytes(info[4:12]), np.uint32)  # JxlBasicInfo: have_container, xsize, ysize
+            elif st == JXL_DEC_NEED_IMAGE_OUT_BUFFER:
+                n = C.c_size_t(0)
+                assert L.JxlDecoderImageOutBufferSize(dec, C.byref(fmt), C.byref(n)) == JXL_DEC_SUCCESS
+                assert n.value == int(w) * int(h) * channels * 4
+                out = np.zeros((int(h), int(w), channels), np.float32)
+                assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), out.ctypes.data, n.value) == JXL_DEC_SUCCESS
+            elif st == JXL_DEC_FULL_IMAGE:
+                continue
+            elif st == JXL_DEC_SUCCESS:
+                break
+            else:
+                raise AssertionError(f"JxlDecoderProcessInput -> {st}")
+        return out
+    finally:
+        L.JxlDecoderDestroy(dec)
+
+
+def hip_runner():
+    R = C.CDLL(abi.runner_library_path())
+    R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    pool = R.JxlThreadParallelRunnerCreate(None, 6)
+    return R, C.cast(R.JxlThreadParallelRunner, C.c_void_p), pool
+
+
+def test_both_libraries_export_the_decoder_api_and_agree_on_the_cpu(libs, ref, monkeypatch):
+    """Without a device (or with the seam switched off) the patched decoder IS the reference decoder."""
+    monkeypatch.setenv("JXLHIP_SEAM_DISABLE", "1")
+    Lr, Lh = load(libs[0]), load(libs[1])
+    rs = ref.RealStream(seed=9, xsize=300, ysize=280, distance=1.0)
+    cs = rs.codestream.tobytes()
+    a = jxl_decode(Lr, cs)
+    b = jxl_decode(Lh, cs)
+    assert a.shape == (280, 300, 3) and np.array_equal(a, b)
+    assert Lh.jxlhip_seam_frames_decoded() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(xsize=520, ysize=300, distance=1.0, speed_tier=3),
+    dict(xsize=776, ysize=520, distance=3.0, speed_tier=3, progressive=1),
+    dict(xsize=2200, ysize=264, distance=1.5, speed_tier=4),
+    dict(xsize=200, ysize=120, distance=1.0, speed_tier=3),
+    dict(xsize=640, ysize=264, distance=0.5, speed_tier=5),
+])
+def test_reference_jxldecoder_with_hip_backend_matches_unpatched_reference(libs, ref, kw):
+    Lr, Lh = load(libs[0]), load(libs[1])
+    R, runner, pool = hip_runner()
+    try:
+        rs = ref.RealStream(seed=41, **kw)
+        cs = rs.codestream.tobytes()
+        for channels in (3, 4):
+            want = jxl_decode(Lr, cs, runner, pool, channels)
+            before = Lh.jxlhip_seam_frames_decoded()
+            got = jxl_decode(Lh, cs, runner, pool, channels)
+            assert Lh.jxlhip_seam_frames_decoded() == before + 1, "the frame did not go through the HIP back-end"
+            scale = max(1.0, float(np.abs(want).max()))
+            assert float(np.abs(got - want).max()) / scale <= TIGHT
+    finally:
+        R.JxlThreadParallelRunnerDestroy(pool)
