@@ -158,12 +158,13 @@ class VarDctDecoder:
     def halo_rows(self):
         return self.L.jxlhip_halo_rows(self.ctx)
 
-    def halo_export(self, which):
+    def halo_export(self, which, buf=None):
         """Dense [3, halo, xsize] tensor with this stripe's first (which=0) or
-        last (which=1) halo rows."""
+        last (which=1) halo rows (written into `buf` when given)."""
         p = self.params
-        buf = torch.empty((3, self.halo_rows(), p.xsize), dtype=torch.float32,
-                          device=f"cuda:{self.device}")
+        if buf is None:
+            buf = torch.empty((3, self.halo_rows(), p.xsize), dtype=torch.float32,
+                              device=f"cuda:{self.device}")
         _check(self.L, self.ctx, self.L.jxlhip_halo_export(self.ctx, which, C.c_void_p(buf.data_ptr())), "halo_export")
         return buf
 

@@ -88,6 +88,15 @@ class StripeDecoder:
         self.params = dict(params, stripe_group_y0=g0, stripe_group_rows=gr)
         self.rows = [stripe_pixel_rows(params["ysize"], a, b) for a, b in self.parts]
         decoder.begin_frame(self.params)
+        self._halo = None  # persistent send / receive buffers of the halo exchange
+
+    def _halo_buffers(self):
+        if self._halo is None:
+            d, h = self.dec, self.dec.halo_rows()
+            shape = (3, h, self.params["xsize"])
+            mk = lambda: torch.empty(shape, dtype=torch.float32, device=f"cuda:{d.device}")  # noqa: E731
+            self._halo = dict(up_send=mk(), dn_send=mk(), up_recv=mk(), dn_recv=mk())
+        return self._halo
 
     # -- gather: the final collective of the 16K configuration ------------------
     def alloc_gather(self, stripe):
@@ -122,17 +131,26 @@ class StripeDecoder:
             return d.decode_frame(out)
         d.decode_blocks()
         h = d.halo_rows()
-        if self.world > 1 and h > 0:
-            up_send = d.halo_export(0) if self.rank > 0 else None
-            dn_send = d.halo_export(1) if self.rank + 1 < self.world else None
-            ref = up_send if up_send is not None else dn_send
-            up_recv, dn_recv = torch.empty_like(ref), torch.empty_like(ref)
-            exchange_halos(up_send if up_send is not None else ref,
-                           dn_send if dn_send is not None else ref,
-                           up_recv, dn_recv, self.rank, self.world, self.group)
+        if h > 0:
+            # the boundary rows leave phase 1's planes for dense buffers that live as long as the decoder, travel
+            # to the two neighbours point to point (RCCL over the direct xGMI link) and are installed above / below
+            # this stripe's planes; every step is ordered on streams (an RCCL request's wait() makes the compute
+            # stream wait, not the host)
+            b = self._halo_buffers()
+            ops = []
             if self.rank > 0:
-                d.halo_import(0, up_recv)
+                d.halo_export(0, b["up_send"])
+                ops += [dist.P2POp(dist.isend, b["up_send"], self.rank - 1, self.group),
+                        dist.P2POp(dist.irecv, b["up_recv"], self.rank - 1, self.group)]
             if self.rank + 1 < self.world:
-                d.halo_import(1, dn_recv)
+                d.halo_export(1, b["dn_send"])
+                ops += [dist.P2POp(dist.isend, b["dn_send"], self.rank + 1, self.group),
+                        dist.P2POp(dist.irecv, b["dn_recv"], self.rank + 1, self.group)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if self.rank > 0:
+                d.halo_import(0, b["up_recv"])
+            if self.rank + 1 < self.world:
+                d.halo_import(1, b["dn_recv"])
         d.decode_filters(out)
         return out
