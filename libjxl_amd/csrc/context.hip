@@ -111,6 +111,11 @@ struct jxlhip_ctx {
   int band_rows = 0;  // JXLHIP_BAND_ROWS: group rows per band of decode_frame (0 = whole stripe, the default:
                       // measured on MI355X, bands of 1-9 group rows under-fill the chip and lose 10-70 %)
   bool generic_filters = false;  // JXLHIP_FILTERS=generic: LDS kernel for every stage list
+  int mfma = -1;                 // DCT32X32 on the matrix cores (kernels_mfma.hip).  -1 (default): when the caller's
+                                 // used_acs says DCT32X32 is the only class of the row-per-lane 32-point family in
+                                 // the frame (the class kernel then is a launch of its own anyway; measured on c5:
+                                 // 219 -> 193 us); on mixed frames the butterflies inside the merged launch win
+                                 // (c3: blocks 95 -> 105 us with a separate MFMA launch).  JXLHIP_MFMA=0 / 1 forces.
   bool fuse = true;              // JXLHIP_FUSE=0: jxlhip_decode_frame runs the two phases unfused
   uint2* cell_info = nullptr;    // fused mode: per-cell coefficient offset + quant / CfL word (k_prepare)
   size_t cell_info_items = 0;
@@ -293,6 +298,8 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
     if (b) c->nblock_streams = atoi(b);
     const char* fu = getenv("JXLHIP_FUSE");
     if (fu) c->fuse = atoi(fu) != 0;
+    const char* mf = getenv("JXLHIP_MFMA");
+    if (mf) c->mfma = atoi(mf) != 0 ? 1 : 0;
     const char* br = getenv("JXLHIP_BAND_ROWS");
     if (br) c->band_rows = atoi(br);
     if (c->band_rows < 0) c->band_rows = 0;
@@ -321,7 +328,7 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
     return fail(JXLHIP_ERR_HIP);
   if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kCountStride * kMaxBands) != hipSuccess ||
       hipMalloc((void**)&c->error_flag, sizeof(int32_t) * 2) != hipSuccess ||
-      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024)) != hipSuccess ||
+      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024 + 2048)) != hipSuccess ||
       hipMalloc((void**)&c->quant_enc, sizeof(jxlhip_quant_encoding) * JXLHIP_NUM_QUANT_TABLES) != hipSuccess)
     return fail(JXLHIP_ERR_OUT_OF_MEMORY);
   if (hipMemset(c->error_flag, 0, sizeof(int32_t) * 2) != hipSuccess ||
@@ -331,6 +338,12 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
       hipMemcpy(c->tables + 576, kDitherPattern, sizeof(float) * 1024, hipMemcpyHostToDevice) !=
           hipSuccess)
     return fail(JXLHIP_ERR_HIP);
+  {
+    float mfma_tab[2048];
+    MfmaDct32Constants(mfma_tab);
+    if (hipMemcpy(c->tables + 1600, mfma_tab, sizeof(mfma_tab), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(JXLHIP_ERR_HIP);
+  }
   *out = c;
   return JXLHIP_OK;
 }
@@ -904,6 +917,11 @@ int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, bool fus
   f.band_g1 = g1;
   f.fused = fused ? 1u : 0u;
   f.cell_info = c->cell_info;
+  {
+    constexpr uint32_t kOthers32 = (1u << 8) | (1u << 9) | (1u << 10) | (1u << 11);  // 32x8 .. 16x32
+    const bool lone32 = (f.used_acs & (1u << 5)) && !(f.used_acs & kOthers32);
+    f.mfma32 = (c->mfma > 0 || (c->mfma < 0 && lone32)) ? c->tables + 1600 : nullptr;
+  }
   if (fused)  // every cell "from the planes" until k_prepare says otherwise
     HIPCHK(c, hipMemsetAsync(c->cell_info, 0xFF, sizeof(uint2) * (size_t)f.xsb * f.ysb, st));
   WorkLists wl = c->wl;

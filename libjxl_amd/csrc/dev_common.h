@@ -143,6 +143,9 @@ struct DevFrame {
   // other cell holds kCellFromPlanes in .x: its pixels come from the planes)
   uint2* cell_info;
   uint32_t fused;
+  // JXLHIP_MFMA=1 (kernels_mfma.hip): DCT32X32 varblocks go through the matrix-core kernel; operand tables
+  // (2048 floats, MfmaDct32Constants), nullptr = the row-per-lane path decodes them
+  const float* mfma32;
 };
 
 // address of pixel (y, x) of channel c in the block-major planes

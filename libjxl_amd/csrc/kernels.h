@@ -52,6 +52,10 @@ int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_ite
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st);
 
+// Matrix-core 32x32 IDCT (kernels_mfma.hip), opt-in through DevFrame::mfma32
+void MfmaDct32Constants(float* host /* 2048 floats */);
+void LaunchMfma32(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st);
+
 // Fused kernel (kernels_fused.hip): the row march fed from the coefficient stream (DCT8 decoded by the
 // filter wave itself, other classes copied from the planes).  FusedSupported: frames it takes --
 // decided before k_prepare, which routes the DCT8 blocks (DevFrame::fused).

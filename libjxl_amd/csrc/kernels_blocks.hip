@@ -1290,10 +1290,12 @@ static_assert(kMediumStrategy[8] == 18 && kMediumStrategy[9] == 19 && kMediumStr
 // every class's lane-dependent invariants out of this loop.)
 template <int N, typename Body>
 __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const WorkLists& wl,
-                                             Body&& body, uint32_t first_wg = 0, uint32_t num_wgs = 0) {
+                                             Body&& body, uint32_t first_wg = 0, uint32_t num_wgs = 0,
+                                             bool skip_first = false) {
   uint32_t cnt[N];
 #pragma unroll
   for (int i = 0; i < N; i++) cnt[i] = wl.count[fam[i].cls * kCounterPad];
+  if (skip_first) cnt[0] = 0;  // DCT32X32 on the matrix cores (kernels_mfma.hip)
   if (num_wgs == 0) num_wgs = gridDim.x - first_wg;  // workgroups [first_wg, first_wg + num_wgs) share the family
   for (uint32_t u = blockIdx.x - first_wg;; u += num_wgs) {
     const UnitPick pick = PickUnit(fam, cnt, u);
@@ -1343,7 +1345,8 @@ __global__ __launch_bounds__(256) void k_transform_r32(DevFrame f, WorkLists wl)
                    case 3: RowLaneUnit<32, 8, 8, CT>(f, list, first, n); break;
                    default: RowLaneUnit<8, 32, 9, CT>(f, list, first, n); break;
                  }
-               });
+               },
+               0, 0, f.mfma32 != nullptr);
 }
 
 // Both row-per-lane families in one launch, the (few, long, register-heavy) L = 32 units first:
@@ -1394,7 +1397,7 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(De
                    default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
                  }
                },
-               special_wgs + big_wgs, r_wgs);
+               special_wgs + big_wgs, r_wgs, f.mfma32 != nullptr);
 }
 
 // --------------------------------------------------------------- launchers
@@ -1418,7 +1421,7 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
       if (f.used_acs & (1u << st)) return true;
     return false;
   };
-  const bool merged_r = any({4, 6, 7}) && any({5, 8, 9, 10, 11});
+  const bool merged_r = any({4, 6, 7}) && (any({8, 9, 10, 11}) || (!f.mfma32 && any({5})));
   const bool have_big = any({18, 19, 20});
   bool specials_in_r = false;
   uint32_t grid_specials = 0;
@@ -1442,9 +1445,10 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
   } else {
     if (any({4, 6, 7}))
       hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
-    if (any({5, 8, 9, 10, 11}))
+    if (any({8, 9, 10, 11}) || (!f.mfma32 && any({5})))
       hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
   }
+  if (f.mfma32 && any({5})) LaunchMfma32(f, wl, cells, s1);
   if (cells >= 256 && any({21, 22, 23, 24, 25, 26}))
     hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, s1, f, wl.list[kClsLarge],
                        wl.count + kClsLarge * kCounterPad, wc, resample);

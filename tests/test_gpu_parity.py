@@ -338,3 +338,33 @@ def test_fused_kernel_matches_two_phase_and_oracle(dq, oracle, gab, epf, size, m
         d.close()
     assert rel_err(outs["0"], ref) <= TIGHT
     assert rel_err(outs["1"], ref) <= TIGHT, np.argwhere(np.abs(outs["1"] - ref) > 1e-3)[:5]
+
+
+@pytest.mark.parametrize("coeff_type", [0, 1])
+@pytest.mark.parametrize("size,mix", [((8 * 4 + 256, 8 * 4 + 8), {5: 48.0, 0: 1.0}), ((1000, 520), None),
+                                      ((258, 258), None)])
+def test_mfma_dct32_matches_oracle_and_row_lane_path(dq, oracle, size, mix, coeff_type, monkeypatch):
+    """JXLHIP_MFMA=1 sends DCT32X32 varblocks through the matrix-core kernel (kernels_mfma.hip: two
+    v_mfma_f32_32x32x2_f32 products per channel); everything else keeps its kernel.  Same bar as the
+    butterfly path -- and the two must agree with each other to rounding."""
+    xs, ys = size
+    kw = dict(coeff_type=1, amp=200000.0, decay=3.0) if coeff_type else {}
+    params, t, fr = frames.make_case(xs, ys, mix=mix or synth.MIX_ALL, gab=False, epf_iters=0, seed=5 + xs, **kw)
+    acs = t["ac_strategy"].numpy()
+    assert 5 in set((acs[(acs & 1) == 1] >> 1).tolist())
+    ref = fr.decode_groups()
+    outs = {}
+    for mfma in ("1", "0"):
+        monkeypatch.setenv("JXLHIP_MFMA", mfma)
+        d = VarDctDecoder(0)
+        d.begin_frame(params)
+        d.set_inputs(to_dev(t), dq)
+        d.decode_blocks()
+        d.sync()
+        outs[mfma] = d.export_xyb()
+        d.close()
+    for c in range(3):
+        assert rel_err(outs["0"][c], ref[c]) <= TIGHT
+        assert rel_err(outs["1"][c], ref[c]) <= TIGHT, (c, np.argwhere(np.abs(outs["1"][c] - ref[c]) > 1e-3)[:5])
+    # the MFMA kernel really ran: a dense product rounds differently from the butterflies
+    assert any(not np.array_equal(outs["0"][c], outs["1"][c]) for c in range(3))

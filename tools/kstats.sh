@@ -15,5 +15,5 @@ tot=0
 for r in csv.DictReader(open(sys.argv[1])):
     n=r["Name"]
     if "jxlhip" in n:
-        print("%-64s calls %4s avg %8.1f us  min %8.1f" % (n.split("(")[0].replace("void jxlhip::","")[:64] or "k_filters*", r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3))
+        print("%-64s calls %4s avg %8.1f us  min %8.1f" % (n.replace("(anonymous namespace)::","").split("(")[0].replace("void jxlhip::","")[:64], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3))
 PY

@@ -13,7 +13,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
     if "jxlhip" not in n: continue
-    n = n.split("(")[0].replace("void jxlhip::","").replace("(anonymous namespace)::","")[:34]
+    n = n.replace("(anonymous namespace)::","").split("(")[0].replace("void jxlhip::","")[:34]
     acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = sorted({c for k in acc.values() for c in k})
 print("kernel".ljust(36) + " ".join(c[-18:].rjust(19) for c in names))
