@@ -12,7 +12,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 LIB_SOURCES = ["context.hip", "kernels_blocks.hip", "kernels_filters.hip", "kernels_filters_fast.hip",
-               "kernels_fused.hip", "kernels_mfma.hip", "kernels_tables.hip", "entropy.cc"]
+               "kernels_fused.hip", "kernels_mfma.hip", "kernels_epf0.hip", "kernels_tables.hip", "entropy.cc"]
 RUNNER_SOURCES = ["runner.cc"]
 
 

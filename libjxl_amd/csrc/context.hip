@@ -61,6 +61,8 @@ struct jxlhip_ctx {
   // context-owned device memory
   float* planes = nullptr;  // 3 planes
   size_t planes_floats = 0;
+  float* planes2 = nullptr;  // epf_iters == 3: EPF0 output, the EPF1 + EPF2 march's input (kernels_epf0.hip)
+  size_t planes2_floats = 0;
   float* inv_sigma = nullptr;
   size_t sigma_floats = 0;
   WorkItem* lists = nullptr;
@@ -383,7 +385,7 @@ void jxlhip_destroy(jxlhip_ctx* c) {
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
                   c->dc_tmp,     c->quant_enc,  c->dc_prec,      c->cell_info,
-                  c->qdc_dev,    c->host_frame_dev};
+                  c->qdc_dev,    c->host_frame_dev, c->planes2};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -468,6 +470,7 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   int rc;
   if ((rc = Grow(c, &c->planes, &c->planes_floats, 3 * plane_floats))) return rc;
   for (int ch = 0; ch < 3; ch++) f.xyb[ch] = c->planes + ch * plane_floats;
+  if (p->lf.epf_iters == 3 && (rc = Grow(c, &c->planes2, &c->planes2_floats, 3 * plane_floats))) return rc;
   if ((rc = Grow(c, &c->inv_sigma, &c->sigma_floats, (size_t)f.xsb * f.ysb))) return rc;
   f.inv_sigma = c->inv_sigma;
   f.error_flag = c->error_flag;
@@ -966,9 +969,22 @@ int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint3
     HIPCHK(c, hipGetLastError());
     return JXLHIP_OK;
   }
-  const bool fast = !c->generic_filters && fy1 > fy0 &&
-                    LaunchFiltersFast(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters,
-                                      (int)c->p.output_kind, c->stream);
+  bool fast = false;
+  if (!c->generic_filters && fy1 > fy0 && c->p.lf.epf_iters == 3 && c->planes2) {
+    // EPF0 into the second plane set, EPF1 + EPF2 + output from there
+    float* dst[3];
+    const size_t plane_floats = (size_t)f.plane_tile_rows * f.tile_stride * 64;
+    for (int ch = 0; ch < 3; ch++) dst[ch] = c->planes2 + ch * plane_floats;
+    if (LaunchEpf0(f, fp, (int)c->p.lf.gab, dst, c->stream)) {
+      DevFrame f2 = f;
+      for (int ch = 0; ch < 3; ch++) f2.xyb[ch] = dst[ch];
+      f2.linear_stride = f.tile_stride * 32u;
+      fast = LaunchFiltersFast(f2, fp, 0, 2, (int)c->p.output_kind, c->stream);
+      if (!fast) return Fail(c, JXLHIP_ERR_STATE, "EPF1 + EPF2 march refused a frame the EPF0 march accepted");
+    }
+  } else if (!c->generic_filters && fy1 > fy0) {
+    fast = LaunchFiltersFast(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind, c->stream);
+  }
   if (!fast && LaunchFilters(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters,
                              (int)c->p.output_kind, c->stream) != 0)
     return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "unsupported filter configuration");

@@ -166,7 +166,14 @@ struct Lane {
 };
 
 // Row source of the march
-enum RowSource : int { SRC_PLANES = 0, SRC_LDS = 1 };
+// SRC_LINEAR: planes in plain row-major order (DevFrame::linear_stride bytes per row), what k_epf0 writes for
+// the EPF1 + EPF2 march: every load / store instruction of a wave then covers 512 contiguous bytes
+enum RowSource : int { SRC_PLANES = 0, SRC_LDS = 1, SRC_LINEAR = 2 };
+template <int SRC>
+__device__ __forceinline__ uint32_t SrcRowOffset(const DevFrame& f, int y) {
+  if constexpr (SRC == SRC_LINEAR) return (uint32_t)(y - f.plane_y0) * f.linear_stride;
+  else return RowOffset(f, y);
+}
 // per-wave LDS slab of the fused kernel: one block row (8 pixel rows) x 128 columns x 3 channels
 static constexpr int kSlabCols = 128;
 static constexpr int kSlabPlaneFloats = 8 * kSlabCols;
@@ -372,7 +379,7 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
       int pr = r + kAhead + b;
       pr = pr > prefetch_last_row ? prefetch_last_row : pr;
       if constexpr (DBG & 8) pr = y_begin + (pr & 7);  // ablation: reads stay in L1
-      const uint32_t off = RowOffset(f, Mirror1(pr, H));
+      const uint32_t off = SrcRowOffset<SRC>(f, Mirror1(pr, H));
 #pragma unroll
       for (int c = 0; c < 3; c++) s.x[c][(PH + kAhead + b) & 7] = LoadPair<EDGE>((const char*)f.xyb[c] + off, L);
     }

@@ -52,6 +52,10 @@ int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_ite
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st);
 
+// epf_iters = 3 (kernels_epf0.hip): [Gaborish] + EPF0 from f.xyb into a second plane set; the EPF1 + EPF2 march
+// (LaunchFiltersFast with gab = 0, epf_iters = 2 on those planes) follows.  false: geometry not covered.
+bool LaunchEpf0(const DevFrame& f, const FilterParams& p, int gab, float* const dst[3], hipStream_t st);
+
 // Matrix-core 32x32 IDCT (kernels_mfma.hip), opt-in through DevFrame::mfma32
 void MfmaDct32Constants(float* host /* 2048 floats */);
 void LaunchMfma32(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st);

@@ -59,7 +59,7 @@ struct FastGeom {
   static constexpr int USE = 128 - 2 * HXP;       // output columns per wave
 };
 
-template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, int DBG>
+template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, int DBG, int SRC>
 __device__ __forceinline__ void March(const DevFrame& f, const FilterParams& P, Lane& L, int y_begin,
                                       int y_end) {
   constexpr int HX = FastGeom<GAB, EPF>::HX;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void March(const DevFrame& f, const FilterParams& P, 
     const bool fetch = k < kAhead;
     int pr = r_first + k;
     pr = pr > prefetch_last_row ? prefetch_last_row : pr;
-    const uint32_t off = RowOffset(f, Mirror1(pr, H));
+    const uint32_t off = SrcRowOffset<SRC>(f, Mirror1(pr, H));
     LaneOffset(L.byte_off);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -110,8 +110,8 @@ __device__ __forceinline__ void March(const DevFrame& f, const FilterParams& P, 
   const size_t out_row_bytes = OUTK == JXLHIP_OUT_XYB_PLANAR ? P.out_stride * 4 : P.out_stride;
   char* out_row = (char*)P.out + (ptrdiff_t)(r_first - HX - (int)f.y0) * (ptrdiff_t)out_row_bytes;
 #define JXLHIP_STEP(K)                                                                                         \
-  Step<GAB, EPF, OUTK, FMT, K, EDGE, DBG>(s, r + K, f, P, L, prefetch_last_row, y_begin, y_end, inv_sigma_blk, \
-                                          inv_sigma_blk2, out_row, KC);                                        \
+  Step<GAB, EPF, OUTK, FMT, K, EDGE, DBG, SRC>(s, r + K, f, P, L, prefetch_last_row, y_begin, y_end,        \
+                                               inv_sigma_blk, inv_sigma_blk2, out_row, KC);                  \
   out_row += out_row_bytes
   for (int r = r_first; r <= r_last; r += 8) {
     JXLHIP_STEP(0);
@@ -127,7 +127,7 @@ __device__ __forceinline__ void March(const DevFrame& f, const FilterParams& P, 
 #undef JXLHIP_STEP
 }
 
-template <int GAB, int EPF, int OUTK, int FMT, int DBG>
+template <int GAB, int EPF, int OUTK, int FMT, int DBG, int SRC = SRC_PLANES>
 __global__ __launch_bounds__(256, EPF == 2 ? 2 : 3) void k_filters_fast(DevFrame f, FilterParams P, int RH) {
   using G = FastGeom<GAB, EPF>;
   constexpr int HXP = G::HXP, USE = G::USE;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, EPF == 2 ? 2 : 3) void k_filters_fast(DevFrame
   const int base = m0 & ~1;
   L.sel0 = m0 & 1;
   L.sel1 = m1 & 1;
-  L.byte_off = ((uint32_t)(base >> 3) * 64u + (uint32_t)(base & 7)) * 4u;
+  L.byte_off = SRC == SRC_LINEAR ? (uint32_t)base * 4u : ((uint32_t)(base >> 3) * 64u + (uint32_t)(base & 7)) * 4u;
   const bool edge = x_first - HXP < 0 || x_first - HXP + 128 > W;  // wave-uniform
   const bool lane_in = lane >= HXP / 2 && lane < 64 - HXP / 2;
   L.out0 = lane_in && L.gx < W;
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256, EPF == 2 ? 2 : 3) void k_filters_fast(DevFrame
   L.fix_left = L.gx == -2;
   L.fix_right_even = L.gx == W;       // only reached when W is even (gx is even)
   L.fix_right_odd = L.gx == W - 1;    // W odd
-  if (edge) March<GAB, EPF, OUTK, FMT, true, DBG>(f, P, L, y_begin, y_end);
-  else March<GAB, EPF, OUTK, FMT, false, DBG>(f, P, L, y_begin, y_end);
+  if (edge) March<GAB, EPF, OUTK, FMT, true, DBG, SRC>(f, P, L, y_begin, y_end);
+  else March<GAB, EPF, OUTK, FMT, false, DBG, SRC>(f, P, L, y_begin, y_end);
 }
 
 // Rows per wave.  Every wave costs (RH + 2*HX) row steps and all waves of a
@@ -210,6 +210,17 @@ int FilterRowsPerWave(unsigned wgx, unsigned rows, int hx) {
 
 template <int GAB, int EPF, int OUTK, int FMT = -1>
 void LaunchFastT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
+  if constexpr (GAB == 0 && EPF == 2) {
+    if (f.linear_stride) {  // the input is k_epf0's row-major plane set
+      using G = FastGeom<GAB, EPF>;
+      const unsigned strips = (f.xsize + G::USE - 1) / G::USE;
+      const unsigned wgx = (strips + 3) / 4;
+      const int RH = FilterRowsPerWave(wgx, f.fy1 - f.fy0, G::HX);
+      const dim3 grid(wgx, (f.fy1 - f.fy0 + RH - 1) / RH);
+      hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 0, SRC_LINEAR>), grid, dim3(256), 0, st, f, p, RH);
+      return;
+    }
+  }
   using G = FastGeom<GAB, EPF>;
   const unsigned strips = (f.xsize + G::USE - 1) / G::USE;
   const unsigned wgx = (strips + 3) / 4;
@@ -255,10 +266,11 @@ void LaunchPackedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
 
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st) {
-  if (epf_iters > 2) return false;  // three iterations add EPF0 (7x7 reach): generic LDS kernel
+  if (epf_iters > 2) return false;  // three iterations: LaunchEpf0 (kernels_epf0.hip) first, then this with (0, 2)
   if (f.xsize < 16 || f.ysize < 16) return false;  // multiply mirrored columns / rows: generic kernel
   // row offsets inside a plane are 32-bit
   if ((uint64_t)f.plane_tile_rows * f.tile_stride * 256u >= (1ull << 32)) return false;
+  if (f.linear_stride && !(gab == 0 && epf_iters == 2)) return false;
 #define JXLHIP_FAST(G, E)                                  \
   if (gab == G && epf_iters == E) {                        \
     if (output_kind == 0) LaunchFastT<G, E, 0>(f, p, st);  \

@@ -378,9 +378,12 @@ void LaunchFusedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
 
 // Frames the fused kernel takes (decided before k_prepare: it routes the DCT8 blocks).
 bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) {
-  (void)gab;
   (void)output_kind;
-  if (epf_iters > 2) return false;                 // EPF0: generic kernel
+  if (epf_iters > 2) return false;                 // EPF0: k_epf0 + the EPF1 + EPF2 march (kernels_epf0.hip)
+  // Gaborish + EPF1 + EPF2 on top of the in-wave DCT8 decode is past what two waves per SIMD hide: measured
+  // on the 8K d1.0 mix, fused 0.479 ms per frame against 0.431 two-phase (every other stage list gains
+  // 5-15 % from fusion: profiles/r02_fused_vs_twophase.txt)
+  if (gab && epf_iters == 2) return false;
   if (f.xsize < 16 || f.ysize < 16) return false;  // multiply mirrored columns / rows
   const uint32_t tail = f.ysize & 7u;
   if (tail >= 1 && tail <= 3) return false;        // mirror rows below the frame leave the last block row

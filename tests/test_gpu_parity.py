@@ -368,3 +368,19 @@ def test_mfma_dct32_matches_oracle_and_row_lane_path(dq, oracle, size, mix, coef
         assert rel_err(outs["1"][c], ref[c]) <= TIGHT, (c, np.argwhere(np.abs(outs["1"][c] - ref[c]) > 1e-3)[:5])
     # the MFMA kernel really ran: a dense product rounds differently from the butterflies
     assert any(not np.array_equal(outs["0"][c], outs["1"][c]) for c in range(3))
+
+
+@pytest.mark.parametrize("gab", [1, 0])
+@pytest.mark.parametrize("size,okind", [((1000, 520), 1), ((2048, 1029), 1), ((129, 16), 1), ((777, 300), 0)])
+def test_three_epf_iterations_take_the_epf0_march(dec, dq, oracle, gab, size, okind):
+    """epf_iters = 3: k_epf0 ([Gaborish] + EPF0 into the second plane set, kernels_epf0.hip) + the EPF1 + EPF2
+    march, at sizes with several strips / row bands per wave, odd widths and the minimum height."""
+    params, t, fr = frames.make_case(*size, mix=synth.MIX_D1, gab=bool(gab), epf_iters=3, seed=3 + size[0],
+                                     output_kind=okind)
+    dec.begin_frame(params)
+    dec.set_inputs(to_dev(t), dq)
+    out = dec.decode_frame()
+    dec.sync()
+    ref = fr.decode(threads=4)
+    prof = dec.profile() if hasattr(dec, "profile") else None
+    assert rel_err(out.cpu().numpy(), ref) <= TIGHT
