@@ -332,15 +332,22 @@ def ref_dequant_dc(quant_dc, mul_dc, cfl_x_dc, cfl_b_dc, smooth, mul=1.0):
 def ref_threads(xsize, ysize, max_threads):
     """Threads for Frame.decode_ref when its result is the expected value of a test.
 
-    Seen on the 256-core GPU host (tests/test_gpu_vs_reference.py with JXLHIP_TEST_ARBITRATE=1): with
-    several group threads inside the reference's LowMemoryRenderPipeline, a frame whose last group
-    column is narrower than the pipeline's 16-px border strips (533 px wide: 21 px) now and then gets
-    one column of such a strip (x = 527) rendered as NaN -> 0, while the same reference with one
-    thread, the C restatement and the HIP path agree with each other.  It is a property of the
-    threaded reference run (this driver / single-lane shim), not of the expected pixels, so frames
-    with narrow edge groups -- and small frames, where threads buy nothing -- are decoded with one
-    thread; the 4K / 8K frames keep the threads."""
-    narrow = any(0 < (n % 256) < 64 for n in (xsize, ysize))
+    The reference's LowMemoryRenderPipeline is not independent of the order in which groups finish
+    (root-caused in round 2, tools/probes/ref_mirror_fix_probe.py; pinned by
+    tests/test_reference_parity.py::test_reference_group_order_dependence_is_the_mirroring_test).  RenderRect lets a
+    stage run xextra_right columns past its rect (low_memory_render_pipeline.cc:751-757) but ApplyXMirroring
+    (:486-517) mirrors the stage's input at the right image edge only when rect.x1 + border_x >= image_xsize --
+    xextra_right is not part of that test.  A rect that ends within xextra_right + border_x of the edge, but not
+    within border_x of it, makes the stage read columns past the image edge that nobody wrote: stale floats of the
+    thread's stage buffer (small errors, up to 6.5e-4 seen; NaN when the memory was never used).  Such a rect only
+    exists when the LAST group column is narrower than 16 + the stage list's total border (at most 16 + 7) AND
+    finishes before its left neighbour, whose border strip [x1 - 16, x1 + 16) is then rendered on its own: never
+    with one thread (groups finish in index order), now and then with several.  The in-order result equals
+    SimpleRenderPipeline's and the C restatement's bit for bit, and so does the threaded result once the
+    mirroring test includes the extra columns -- so frames with such a last column are decoded with one
+    thread; every other frame (4K / 8K: widths that are multiples of 256) keeps the threads, where 1 and N threads
+    are bit-identical (test_reference_threads_bit_identical_when_last_column_is_wide)."""
+    narrow = 0 < (xsize % 256) < 16 + 8
     small = ((xsize + 255) // 256) * ((ysize + 255) // 256) <= 16
     return 1 if (narrow or small) else max_threads
 

@@ -348,12 +348,34 @@ Status DecodeFrame(const jxo_frame* f, float* out, size_t out_stride_floats, siz
   JXL_ASSIGN_OR_RETURN(AlignedArray<GroupDecCache> caches,
                        AlignedArray<GroupDecCache>::Create(&ref.mm, nthreads));
 
+  // JXR_GROUP_ORDER="2,0,1,...": the order in which the groups are handed out (a permutation of 0..n-1;
+  // missing groups follow in index order).  With one thread this replays any completion order of a threaded
+  // run deterministically (tools/probes/ref_thread_race.py).
+  std::vector<size_t> order;
+  {
+    std::vector<bool> seen(num_groups, false);
+    if (const char* e = getenv("JXR_GROUP_ORDER")) {
+      for (const char* q = e; *q;) {
+        char* end = nullptr;
+        const unsigned long v = strtoul(q, &end, 10);
+        if (end == q) break;
+        if (v < num_groups && !seen[v]) {
+          seen[v] = true;
+          order.push_back(v);
+        }
+        q = *end ? end + 1 : end;
+      }
+    }
+    for (size_t g = 0; g < num_groups; g++)
+      if (!seen[g]) order.push_back(g);
+  }
   std::atomic<size_t> next{0};
   std::atomic<bool> failed{false};
   auto worker = [&](size_t thread) {
     for (;;) {
-      const size_t g = next.fetch_add(1);
-      if (g >= num_groups || failed.load()) return;
+      const size_t gi = next.fetch_add(1);
+      if (gi >= num_groups || failed.load()) return;
+      const size_t g = order[gi];
       Status ok = [&]() -> Status {
         if (fh.loop_filter.epf_iters > 0) {
           JXL_RETURN_IF_ERROR(ComputeSigma(fh.loop_filter, fd.BlockGroupRect(g), dec_state.get()));

@@ -167,3 +167,49 @@ def test_srgb_transfer_function_known_values(ref):
         exact = 1.055 * x ** (1 / 2.4) - 0.055
         assert abs(L.jxo_srgb_from_linear(x) - exact) < 2e-6 * max(1.0, exact)
         assert L.jxo_srgb_from_linear(-x) == -L.jxo_srgb_from_linear(x)
+
+
+def _decode_ref_in_order(ref, fr, order, threads=1):
+    """decode_ref with the workaround of oracle.ref_threads switched off and the groups handed out in `order`
+    (JXR_GROUP_ORDER, oracle/ref_driver.cc)."""
+    import os
+    keep = ref.ref_threads
+    ref.ref_threads = lambda x, y, t: t
+    try:
+        if order:
+            os.environ["JXR_GROUP_ORDER"] = order
+        return fr.decode_ref(threads=threads)
+    finally:
+        os.environ.pop("JXR_GROUP_ORDER", None)
+        ref.ref_threads = keep
+
+
+def test_reference_group_order_dependence_is_the_mirroring_test(ref):
+    """Round 1's "NaN column now and then with threads"  is not a data race in the driver: ONE
+    thread reproduces it whenever the narrow last group column (530 = 2 * 256 + 18 px: narrower than the 16-px
+    border strip + the 3-px filter border) is finished before its left neighbour.  The reference then renders the
+    strip [496, 528) alone, Gaborish runs 2 columns past it (xextra_right) and reads column 530 -- past the image
+    edge, unmirrored, because ApplyXMirroring only looks at rect.x1 + border (low_memory_render_pipeline.cc:496,
+    :510).  In index order the reference equals the restatement bit for bit."""
+    _, _, fr = frames.make_case(530, 300, mix=synth.MIX_ALL, gab=True, epf_iters=1, seed=24)
+    o = fr.decode(threads=4)
+    assert np.array_equal(bits(o), bits(_decode_ref_in_order(ref, fr, None)))
+    assert np.array_equal(bits(o), bits(fr.decode_ref(threads=1, simple_pipeline=True)))
+    swapped = _decode_ref_in_order(ref, fr, "0,2,1")
+    d = np.argwhere(swapped != o)
+    assert len(d) > 0, "the reference no longer depends on the group order: oracle.ref_threads can go"
+    assert set(d[:, 1].tolist()) <= {526, 527}, "only the strip's last columns read the unmirrored column"
+    # a last column of 16 + 3 px or more has no such rect
+    _, _, fr2 = frames.make_case(531, 300, mix=synth.MIX_ALL, gab=True, epf_iters=1, seed=24)
+    assert np.array_equal(bits(fr2.decode(threads=4)), bits(_decode_ref_in_order(ref, fr2, "0,2,1")))
+
+
+@pytest.mark.parametrize("xs,ys,gab,epf", [(540, 300, True, 3), (768, 520, True, 1), (535, 300, True, 3)])
+def test_reference_threads_bit_identical_when_last_column_is_wide(ref, xs, ys, gab, epf):
+    """... and with a last group column of at least 16 + 7 px (or none: widths that are multiples of 256, like the
+    4K / 8K bench frames) any order and any thread count give the in-order bits."""
+    _, _, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=gab, epf_iters=epf, seed=xs)
+    one = _decode_ref_in_order(ref, fr, None)
+    assert np.array_equal(bits(one), bits(_decode_ref_in_order(ref, fr, "2,5,1,4,0,3")))
+    for _ in range(3):
+        assert np.array_equal(bits(one), bits(_decode_ref_in_order(ref, fr, None, threads=8)))
