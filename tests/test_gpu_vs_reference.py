@@ -95,6 +95,62 @@ def test_config4_hdr_dct32_int32(dec, ref):
              intensity_target=4000.0, quant_mul=2.0)
 
 
+@pytest.mark.parametrize("mfma", ["1", "0"])
+def test_config4_8k_full_size(ref, mfma, monkeypatch):
+    """BASELINE configs[4] at its FULL size, as bench.py --config c5 runs it: 7680x4320, every block DCT32X32,
+    int32 coefficients, d0.5-like quantisation, intensity_target 1000 -- through the matrix-core IDCT
+    (kernels_mfma.hip, what the context picks for this frame) and through the row-per-lane butterflies."""
+    monkeypatch.setenv("JXLHIP_MFMA", mfma)
+    d = VarDctDecoder(0)
+    try:
+        run_case(d, ref, 7680, 4320, mix=synth.MIX_DCT32, gab=False, epf_iters=0, coeff_type=1,
+                 intensity_target=1000.0, quant_mul=2.0)
+    finally:
+        d.close()
+
+
+def test_config3_16k_striped_below_the_abi_full_size(ref):
+    """BASELINE configs[3] at its FULL size (15360x8640 d1.0, Gaborish + EPF1), decoded the way --gpus N decodes it:
+    jxlhip_create_multi splits the frame into stripes of AC-group rows (one per visible device; on a 1-GPU box
+    four stripes share device 0), halo rows and the gather are peer copies below the C ABI.  Against the
+    reference's own decode of the whole frame, pixel for pixel."""
+    import ctypes as C
+    xs, ys = 15360, 8640
+    params, t = synth.synth_frame(xs, ys, device="cpu", mix=synth.MIX_D1, gab=True, epf_iters=1, seed=16)
+    L = abi.load_library()
+    one = VarDctDecoder(0)
+    one.begin_frame(params)
+    table_host = one.default_dequant_tables().cpu().numpy()
+    one.sync()
+    one.close()
+    ndev = torch.cuda.device_count()
+    devices = [i % ndev for i in range(max(4, ndev))]
+    ctx = C.c_void_p()
+    assert L.jxlhip_create_multi((C.c_int * len(devices))(*devices), len(devices), None, C.byref(ctx)) == 0
+    try:
+        p = abi.make_params(params)
+        assert L.jxlhip_frame_begin(ctx, C.byref(p)) == 0, L.jxlhip_last_error(ctx)
+        npy = {k: ([x.numpy() for x in v] if isinstance(v, list) else v.numpy()) for k, v in t.items()}
+        dc3 = (C.c_void_p * 3)(*[a.ctypes.data for a in npy["dc"]])
+        assert L.jxlhip_upload_side_info(ctx, npy["ac_strategy"].ctypes.data, npy["raw_quant"].ctypes.data,
+                                         npy["epf_sharpness"].ctypes.data, npy["ytox_map"].ctypes.data,
+                                         npy["ytob_map"].ctypes.data, dc3, table_host.ctypes.data) == 0
+        for g in range(((xs + 255) // 256) * ((ys + 255) // 256)):
+            ptrs = (C.c_void_p * 3)(*[c[g * 65536:].ctypes.data for c in npy["coeffs"]])
+            assert L.jxlhip_submit_group(ctx, g, ptrs, 65536) == 0, L.jxlhip_last_error(ctx)
+        got = np.zeros((ys, xs, 3), np.float32)
+        assert L.jxlhip_decode_frame_host(ctx, got.ctypes.data, xs * 12, 0) == 0, L.jxlhip_last_error(ctx)
+    finally:
+        L.jxlhip_destroy(ctx)
+    fr = ref.Frame(frames.to_oracle_params(abi.make_params(params)), npy["coeffs"], npy["ac_strategy"],
+                   npy["raw_quant"], npy["epf_sharpness"], npy["ytox_map"], npy["ytob_map"], npy["dc"], table_host)
+    want = fr.decode_ref(threads=THREADS)
+    scale = max(1.0, float(np.abs(want).max()))
+    # row blocks: the difference of two 1.6 GB arrays in one piece is another 1.6 GB
+    err = max(float(np.abs(got[y:y + 540] - want[y:y + 540]).max()) for y in range(0, ys, 540)) / scale
+    assert err <= TIGHT, err
+
+
 def test_xyb_planar_output(dec, ref):
     run_case(dec, ref, 600, 300, mix=synth.MIX_ALL, gab=True, epf_iters=2, output_kind=0)
 
