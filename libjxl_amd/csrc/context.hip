@@ -118,7 +118,11 @@ struct jxlhip_ctx {
                                  // the frame (the class kernel then is a launch of its own anyway; measured on c5:
                                  // 219 -> 193 us); on mixed frames the butterflies inside the merged launch win
                                  // (c3: blocks 95 -> 105 us with a separate MFMA launch).  JXLHIP_MFMA=0 / 1 forces.
-  bool fuse = true;              // JXLHIP_FUSE=0: jxlhip_decode_frame runs the two phases unfused
+  int fuse = -1;                 // the fused kernel (kernels_fused.hip) in jxlhip_decode_frame.  -1 (default): for
+                                 // frames of 24 Mpx and more -- a fused wave pays 16 halo rows and a fill per 8 rows,
+                                 // which only amortises when the frame gives every resident wave ~100 rows (8K d1.0:
+                                 // fused 89.9 vs 80 Gpx/s two-phase; 4K: 69.3 vs 80.3; 1024^2: 15.9 vs 18.3;
+                                 // profiles/r02_fused_rows_sweep.txt).  JXLHIP_FUSE=0 / 1 forces.
   uint2* cell_info = nullptr;    // fused mode: per-cell coefficient offset + quant / CfL word (k_prepare)
   size_t cell_info_items = 0;
   // profiling
@@ -299,7 +303,7 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
     const char* b = getenv("JXLHIP_BLOCK_STREAMS");
     if (b) c->nblock_streams = atoi(b);
     const char* fu = getenv("JXLHIP_FUSE");
-    if (fu) c->fuse = atoi(fu) != 0;
+    if (fu) c->fuse = atoi(fu) != 0 ? 1 : 0;
     const char* mf = getenv("JXLHIP_MFMA");
     if (mf) c->mfma = atoi(mf) != 0 ? 1 : 0;
     const char* br = getenv("JXLHIP_BAND_ROWS");
@@ -1117,7 +1121,13 @@ int jxlhip_decode_frame(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_
   // Whole frame on this context, one band: the fused kernel decodes the DCT8 blocks inside the filter
   // march (kernels_fused.hip).  The split calls (jxlhip_decode_blocks / _filters) stay two-phase: a
   // stripe's halo rows must exist in the planes for its neighbours.
-  if (c->fuse && !c->generic_filters && c->band_rows == 0 && f.group_y0 == 0 && f.group_rows == f.ysg &&
+  // auto: with a filter, frames of 24 Mpx and more (see jxlhip_ctx::fuse); without one the fused wave has no
+  // halo rows to pay for and wins at 4K as well (95.8 vs 83.4 Gpx/s); never when the caller's used_acs says the
+  // frame has no DCT8 block -- then the slab is only a detour (configs[4]: 76.1 vs 79.6 Gpx/s)
+  const bool big = (uint64_t)f.xsize * f.ysize >= (24ull << 20) || (c->p.lf.gab == 0 && c->p.lf.epf_iters == 0);
+  const bool has_dct8 = f.used_acs == 0 || (f.used_acs & 1u);
+  if ((c->fuse > 0 || (c->fuse < 0 && big && has_dct8)) && !c->generic_filters && c->band_rows == 0 && f.group_y0 == 0 &&
+      f.group_rows == f.ysg &&
       FusedSupported(f, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind)) {
     if ((rc = Grow(c, &c->cell_info, &c->cell_info_items, (size_t)f.xsb * f.ysb))) return rc;
     rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, 0, true);

@@ -219,7 +219,12 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
                                            int y_begin, int y_end) {
   constexpr int HX = MarchGeom<GAB, EPF>::HX;
   const int H = (int)f.ysize;
-  const int r_first = y_begin - 8;  // y_begin is a multiple of 8: groups of 8 rows = block rows
+  // y_begin is a multiple of 8: groups of 8 rows = block rows.  The stages need HX rows above y_begin and below
+  // y_end: of the block row above only its last HX rows are marched over (a peeled partial group in front of
+  // the loop), of the one below only the first HX (a peeled tail) -- 2 HX steps instead of 16 per wave (10 of
+  // 120 at 8K).  The partial groups are straight-line copies of the steps they run: guarding the steps of the
+  // loop body instead (if (r + K >= r_start) ...) made the register allocator spill 300 bytes per lane.
+  const int r_first = HX ? y_begin - 8 : y_begin;
   const int r_last = y_end + HX - 1;
   const int nb_last = (H - 1) >> 3;
   LdsF* slab = (LdsF*)w->slab;
@@ -255,7 +260,27 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
   Step<GAB, EPF, OUTK, FMT, K, EDGE, 0, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk,      \
                                                   inv_sigma_blk2, out_row, KC, slab_y0);                    \
   out_row += out_row_bytes
-  for (int r = r_first; r <= r_last; r += 8) {
+  if constexpr (HX > 0) {  // the last HX rows of the block row above
+    const int r = r_first;
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    {
+      const int row0 = Mirror1(r + 8 - HX, H) - slab_y0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][8 - HX] = LdsPair<EDGE>(L, c, row0);
+    }
+    out_row += (8 - HX) * out_row_bytes;
+    NextRowRequest(fa, nx, GroupBlockRow(r + 8, nb_last), bc0);
+    if constexpr (HX >= 4) { JXLHIP_FSTEP(4); }
+    if constexpr (HX >= 3) { JXLHIP_FSTEP(5); }
+    NextRowMasks(fa, nx, bc0);
+    DmaPlaneRows(fa, slab, nx, bc0, 0);  // rows 0 .. 3 of this block row are not read at all
+    DmaPlaneRows(fa, slab, nx, bc0, 1);
+    if constexpr (HX >= 2) { JXLHIP_FSTEP(6); }
+    JXLHIP_FSTEP(7);
+    FinishSlab<CT>(fa, w, nx, bc0, 2);
+  }
+  int r = HX ? y_begin : r_first;
+  for (; r_last - r >= HX; r += 8) {  // whole groups (HX = 0: r <= r_last)
     const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
     {
       const int row0 = Mirror1(r, H) - slab_y0;
@@ -282,6 +307,18 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
     DmaPlaneRows(fa, slab, nx, bc0, 2);
     JXLHIP_FSTEP(7);
     if (more) FinishSlab<CT>(fa, w, nx, bc0, 3);
+  }
+  if (HX > 0 && r <= r_last) {  // the first HX rows of the block row below (y_end a multiple of 8)
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    {
+      const int row0 = Mirror1(r, H) - slab_y0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
+    }
+    JXLHIP_FSTEP(0);
+    if constexpr (HX >= 2) { JXLHIP_FSTEP(1); }
+    if constexpr (HX >= 3) { JXLHIP_FSTEP(2); }
+    if constexpr (HX >= 4) { JXLHIP_FSTEP(3); }
   }
 #undef JXLHIP_FSTEP
 }
@@ -353,7 +390,7 @@ int FusedRowsPerWave(unsigned wgx, unsigned rows) {
   for (int rh = 16; rh <= 512; rh += 8) {
     const unsigned wgs = wgx * ((rows + rh - 1) / rh);
     const unsigned gens = (wgs + resident - 1) / resident;
-    const double cost = (double)gens * (rh + 8 + 8);
+    const double cost = (double)gens * (rh + 6 + 10);  // 2 x HX marched rows + three block-row fills' worth
     if (cost < best_cost) {
       best_cost = cost;
       best = rh;
