@@ -1,6 +1,5 @@
 /*
- * jxl_threads_hip.h -- the JxlParallelRunner of the MI355X back-end
- * ("jxl_threads -> HIP stream pool").
+ * jxl_threads_hip.h -- the JxlParallelRunner of the MI355X back-end.
  *
  * libjxl_threads_hip.so exports the SAME nine symbols as libjxl_threads (the four of the
  * thread-pool runner, the five of the resizable runner)
@@ -14,11 +13,13 @@
  * runner is not re-entrant.  An unmodified djxl / JxlDecoder user links it in
  * place of libjxl_threads.
  *
- * What is different is what a worker IS: every worker thread owns one HIP
- * stream of the pool (plus thread_id 0 = the calling thread), so host-side
- * group tasks (entropy decode -> jxlhip_submit_group) issue their H2D copies
- * on independent streams.  The declarations below mirror the reference's so
- * this header can be used without libjxl's headers.
+ * The workers are plain host threads running the group tasks (entropy decode ->
+ * jxlhip_submit_group); the HIP streams and the pinned staging those tasks'
+ * uploads use belong to the jxlhip context, which therefore works under any
+ * JxlParallelRunner.  (Round 1 gave every worker a stream of its own and exported
+ * it through an extension symbol nothing consumed; both are gone.)  The
+ * declarations below mirror the reference's so this header can be used without
+ * libjxl's headers.
  */
 #ifndef JXL_THREADS_HIP_H_
 #define JXL_THREADS_HIP_H_
@@ -79,10 +80,6 @@ JXL_THREADS_HIP_EXPORT void* JxlResizableParallelRunnerCreate(const JxlMemoryMan
 JXL_THREADS_HIP_EXPORT void JxlResizableParallelRunnerSetThreads(void* runner_opaque, size_t num_threads);
 JXL_THREADS_HIP_EXPORT uint32_t JxlResizableParallelRunnerSuggestThreads(uint64_t xsize, uint64_t ysize);
 JXL_THREADS_HIP_EXPORT void JxlResizableParallelRunnerDestroy(void* runner_opaque);
-
-/* Extension: the hipStream_t owned by `thread_id` (0 = caller) of this runner,
- * or NULL when no device is present (the runner itself works without one). */
-JXL_THREADS_HIP_EXPORT void* JxlHipParallelRunnerStream(void* runner_opaque, size_t thread_id);
 
 #ifdef __cplusplus
 }

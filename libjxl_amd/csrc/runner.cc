@@ -1,13 +1,13 @@
-// runner.cc -- libjxl_threads_hip.so: a JxlParallelRunner whose workers each own
-// a HIP stream (see include/jxl_threads_hip.h).  Replaces lib/threads/
-// thread_parallel_runner{.cc,_internal.cc} behind the same four C symbols.
+// runner.cc -- libjxl_threads_hip.so: the JxlParallelRunner shipped with the back-end (see
+// include/jxl_threads_hip.h).  Replaces lib/threads/thread_parallel_runner{.cc,_internal.cc} and
+// resizable_parallel_runner.cc behind the same nine C symbols.  Plain host threads: the streams and the pinned
+// staging that the group tasks' uploads use belong to the jxlhip context (context.hip: jxlhip_submit_group picks
+// a stream of its pool per call), so that the back-end works under ANY JxlParallelRunner, this one included.
 //
 // Scheduling: one shared atomic cursor over [begin, end); every participant
 // claims a chunk of max(1, remaining / (4 * threads)) tasks per grab, so early
 // chunks are large and the tail is fine-grained.  With zero workers the calling
 // thread runs everything as thread 0.
-#include <hip/hip_runtime_api.h>
-
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
@@ -24,8 +24,6 @@ struct Runner {
   JxlMemoryManager mm{};
   size_t num_workers = 0;
   std::vector<std::thread> threads;
-  std::vector<hipStream_t> streams;  // [max(1, num_workers)]
-  bool have_device = false;
 
   std::mutex mu;
   std::condition_variable cv_start, cv_done;
@@ -132,15 +130,6 @@ void* JxlThreadParallelRunnerCreate(const JxlMemoryManager* memory_manager,
   Runner* r = new (mem) Runner();
   r->mm = mm;
   r->num_workers = num_worker_threads;
-  int ndev = 0;
-  r->have_device = hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
-  const size_t nstreams = num_worker_threads ? num_worker_threads : 1;
-  r->streams.assign(nstreams, nullptr);
-  if (r->have_device) {
-    for (size_t i = 0; i < nstreams; i++)
-      if (hipStreamCreateWithFlags(&r->streams[i], hipStreamNonBlocking) != hipSuccess)
-        r->streams[i] = nullptr;
-  }
   r->threads.reserve(num_worker_threads);
   for (size_t i = 0; i < num_worker_threads; i++)
     r->threads.emplace_back([r, i] { r->WorkerMain(i); });
@@ -156,8 +145,6 @@ void JxlThreadParallelRunnerDestroy(void* runner_opaque) {
   }
   r->cv_start.notify_all();
   for (auto& t : r->threads) t.join();
-  for (hipStream_t s : r->streams)
-    if (s) (void)hipStreamDestroy(s);
   const JxlMemoryManager mm = r->mm;
   r->~Runner();
   MMFree(mm, r);
@@ -165,12 +152,6 @@ void JxlThreadParallelRunnerDestroy(void* runner_opaque) {
 
 size_t JxlThreadParallelRunnerDefaultNumWorkerThreads(void) {
   return std::thread::hardware_concurrency();
-}
-
-void* JxlHipParallelRunnerStream(void* runner_opaque, size_t thread_id) {
-  Runner* r = static_cast<Runner*>(runner_opaque);
-  if (!r || thread_id >= r->streams.size()) return nullptr;
-  return r->streams[thread_id];
 }
 
 }  // extern "C"

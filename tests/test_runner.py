@@ -30,8 +30,6 @@ def lib():
     L.JxlThreadParallelRunnerDestroy.restype = None
     L.JxlThreadParallelRunner.argtypes = [C.c_void_p, C.c_void_p, INIT, FUNC, C.c_uint32, C.c_uint32]
     L.JxlThreadParallelRunnerDefaultNumWorkerThreads.restype = C.c_size_t
-    L.JxlHipParallelRunnerStream.restype = C.c_void_p
-    L.JxlHipParallelRunnerStream.argtypes = [C.c_void_p, C.c_size_t]
     return L
 
 
