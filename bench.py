@@ -237,17 +237,17 @@ def main():
         #               definition; a hybrid: the kernel never touches the coefficient stream)
         #   frac_kernel the kernel's OWN algorithmic bytes (12 B/px planes in + output bytes out) over its time
         #   frac_step   the frame's algorithmic bytes over the whole step (all launches) -- the honest end-to-end one
-        dom = "filters" if "filters" in kern else max(kern, key=kern.get)
+        dom = "fused" if "fused" in kern else ("filters" if "filters" in kern else max(kern, key=kern.get))
         y0, y1 = sd.rows[rank]
         b_alg = algorithmic_bytes(xs, y1 - y0, cb)
         b_alg_frame = algorithmic_bytes(xs, ys, cb)
-        b_own = xs * (y1 - y0) * 24
+        b_own = xs * (y1 - y0) * 24  # planes in + pixels out (k_fused: an upper bound, its DCT8 cells come as coefficients)
         achieved = b_alg / (kern[dom] * 1e-3) / 1e9
         traffic, tsrc = None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf) and world == 1 and name == "c3" and not custom:
             try:
-                traffic = json.load(open(tf)).get(dom)
+                traffic = json.load(open(tf)).get("filters")  # pmc_summarize.py files k_fused under "filters"
                 tsrc = "profiles/pmc_traffic.json (replayed: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.sh)"
             except Exception:
                 traffic = None
@@ -269,7 +269,7 @@ def main():
                          "frac_step": round(b_alg_frame / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "frac_kernel": round(b_own / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": tsrc,
-                         "kernel": "k_filters_fast" if dom == "filters" else dom,
+                         "kernel": {"filters": "k_filters_fast", "fused": "k_fused"}.get(dom, dom),
                          "algorithmic_bytes_per_launch": b_alg,
                          "algorithmic_bytes_frame": b_alg_frame,
                          "kernel_own_bytes_per_launch": b_own},

@@ -330,7 +330,11 @@ enum {
   JXLHIP_KERNEL_BLOCKS = 1,   /* dequant+CfL+LLF+inverse transforms: one launch
                                  per strategy class, overlapped on several
                                  streams; the span covers all of them */
-  JXLHIP_KERNEL_FILTERS = 2,  /* fused Gaborish/EPF/XYB->RGB */
+  JXLHIP_KERNEL_FILTERS = 2,  /* Gaborish/EPF/XYB->RGB row march reading the planes (k_filters_fast / k_filters) */
+  JXLHIP_KERNEL_FUSED = 3,    /* ... fed from the coefficient stream instead (k_fused: whole frames, see
+                                 jxlhip_decode_frame); a frame has a FILTERS or a FUSED span, never both */
+  JXLHIP_KERNEL_EPF0 = 4,     /* epf_iters == 3: [Gaborish] + EPF0 into the second plane set (k_epf0); the EPF1 +
+                                 EPF2 + output march that follows is the FILTERS span */
   JXLHIP_KERNEL_COUNT = 8
 };
 JXLHIP_EXPORT int jxlhip_profile_enable(jxlhip_ctx* ctx, int enable);

@@ -8,7 +8,7 @@ _SO = os.environ.get("JXLHIP_SO") or os.path.join(_HERE, "csrc", "libjxl_hip.so"
 _RUNNER_SO = os.path.join(_HERE, "csrc", "libjxl_threads_hip.so")
 
 KERNEL_COUNT = 8
-KERNEL_NAMES = ["prepare", "blocks", "filters", "k3", "k4", "k5", "k6", "k7"]
+KERNEL_NAMES = ["prepare", "blocks", "filters", "fused", "epf0", "k5", "k6", "k7"]
 
 
 class JxlHipError(RuntimeError):

@@ -968,7 +968,7 @@ int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint3
   if (fused) {
     if (!LaunchFused(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind, c->stream))
       return Fail(c, JXLHIP_ERR_STATE, "fused kernel refused a frame FusedSupported accepted");
-    ProfMark(c, JXLHIP_KERNEL_FILTERS);
+    ProfMark(c, JXLHIP_KERNEL_FUSED);
     ProfEnd(c);
     HIPCHK(c, hipGetLastError());
     return JXLHIP_OK;
@@ -980,6 +980,7 @@ int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint3
     const size_t plane_floats = (size_t)f.plane_tile_rows * f.tile_stride * 64;
     for (int ch = 0; ch < 3; ch++) dst[ch] = c->planes2 + ch * plane_floats;
     if (LaunchEpf0(f, fp, (int)c->p.lf.gab, dst, c->stream)) {
+      ProfMark(c, JXLHIP_KERNEL_EPF0);
       DevFrame f2 = f;
       for (int ch = 0; ch < 3; ch++) f2.xyb[ch] = dst[ch];
       f2.linear_stride = f.tile_stride * 32u;

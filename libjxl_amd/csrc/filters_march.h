@@ -357,7 +357,7 @@ template <int GAB, int EPF, int OUTK, int FMT, int PH, bool EDGE, int DBG, int S
 __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const FilterParams& P,
                                      Lane& L, int prefetch_last_row, int y_begin, int y_end,
                                      float& inv_sigma_blk, float& inv_sigma_blk2, char* out_row, const XybConsts& K,
-                                     int slab_y0 = 0) {
+                                     int slab_y0 = 0, float sigma_pre = 0.0f, float sigma_prev = 0.0f) {
   constexpr int S0 = PH & 3, S1 = (PH + 3) & 3, S2 = (PH + 2) & 3;  // r, r-1, r-2 in the 4-slot rings
   constexpr int X0 = PH & 7, X1 = (PH + 7) & 7, X2 = (PH + 6) & 7, X3 = (PH + 5) & 7;  // ... in the input ring
   const int H = (int)f.ysize;
@@ -442,8 +442,14 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
     const float kMinSigma = -3.90524291751269967465540850526868f;
     // first row whose result is used: y_begin, or the row above it when EPF2 reads it
     if ((o & 7) == 0 || o == y_begin - (EPF == 2 ? 1 : 0)) {
-      const int oc = o < 0 ? 0 : (o >= H ? H - 1 : o);
-      const float is = *(const float*)((const char*)(f.inv_sigma + (size_t)(oc >> 3) * f.xsb) + LaneOffset(L.sx4));
+      // fused kernel: the caller loaded the block row's value at the start of the group of 8 rows -- a load
+      // here would wait (in-order vmcnt) for the LDS-DMA copies issued in between.  (Row y_begin - 1, which EPF2
+      // reads as its first "north" row, lies in the block row of the previous group.)
+      float is = (o & 7) == 0 ? sigma_pre : sigma_prev;
+      if constexpr (SRC != SRC_LDS) {
+        const int oc = o < 0 ? 0 : (o >= H ? H - 1 : o);
+        is = *(const float*)((const char*)(f.inv_sigma + (size_t)(oc >> 3) * f.xsb) + LaneOffset(L.sx4));
+      }
       // below the threshold the stage copies its input (stage_epf.cc:258-262):
       // -inf zeroes the four weights, and (c + 0) * rcp(1) == c exactly
       inv_sigma_blk = is < kMinSigma ? -__builtin_inff() : is;
@@ -496,8 +502,11 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
       s.dv[E0] = dv;
       const int o2 = o - 1;
       if ((o2 & 7) == 0 || o2 == y_begin) {
-        const int oc = o2 < 0 ? 0 : (o2 >= H ? H - 1 : o2);
-        const float is = *(const float*)((const char*)(f.inv_sigma + (size_t)(oc >> 3) * f.xsb) + LaneOffset(L.sx4));
+        float is = sigma_pre;
+        if constexpr (SRC != SRC_LDS) {
+          const int oc = o2 < 0 ? 0 : (o2 >= H ? H - 1 : o2);
+          is = *(const float*)((const char*)(f.inv_sigma + (size_t)(oc >> 3) * f.xsb) + LaneOffset(L.sx4));
+        }
         inv_sigma_blk2 = is < kMinSigma ? -__builtin_inff() : is;
       }
       const int iy2 = o2 & 7;

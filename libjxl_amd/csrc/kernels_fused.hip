@@ -90,6 +90,9 @@ __device__ __forceinline__ void NextRowMasks(FrameArgs fa, NextRow& n, int bc0) 
 // consecutive 128-float slab rows are).  Called when rows 2k, 2k+1 of the CURRENT block row have
 // been consumed: the copy overlaps the march over the remaining rows.
 __device__ __forceinline__ void DmaPlaneRows(FrameArgs fa, LdsF* slab, const NextRow& n, int bc0, int k) {
+#ifdef JXLHIP_ABL_NODMA  // ablation builds: what do the plane copies cost?  (8K d1.0: 26 of 240 us)
+  return;
+#endif
   if (n.mp == 0) return;  // wave-uniform
   const FrameArgs f = Fresh(fa);
   const int lane = threadIdx.x & 63;
@@ -119,7 +122,11 @@ __device__ __forceinline__ void FinishSlab(FrameArgs fa, WaveLds* w, const NextR
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int k = first_plane_k; k < 4; k++) DmaPlaneRows(fa, slab, n, bc0, k);
   const uint32_t m8 = n.m8;
+#ifdef JXLHIP_ABL_NODECODE  // ablation builds: what does the in-wave DCT8 decode cost?  (62 of 240 us: its ~650 VALU
+  if (false) {             // instructions per group of 8 rows on top of the march's 944 -- issue-bound, not latency:
+#else                      // requesting the coefficients two steps early or warming the caches changed nothing)
   if (m8) {  // wave-uniform
+#endif
     const bool is_dct8 = lane < 16 && ((m8 >> lane) & 1u);
     if (is_dct8) {
       const uint32_t rank = __builtin_popcount(m8 & ((1u << lane) - 1u));
@@ -214,6 +221,16 @@ __device__ __forceinline__ int GroupBlockRow(int r, int nb_last) {
   return nb > nb_last ? nb_last : nb;
 }
 
+// inv_sigma of the lane's block column in the block row of image row r (clamped into the frame): the value every
+// EPF stage of a group of 8 rows starting at r picks up (Step, SRC_LDS).  Loaded at the start of the group: a load
+// at the point of use waits, in the in-order vmcnt queue, for the LDS-DMA copies issued in between (-3 us at 8K).
+__device__ __forceinline__ float GroupSigma(FrameArgs fa, Lane& L, int r) {
+  const FrameArgs f = Fresh(fa);
+  const int H = (int)f->ysize;
+  const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);
+  return *(const float*)((const char*)(f->inv_sigma + (size_t)(rc >> 3) * f->xsb) + LaneOffset(L.sx4));
+}
+
 template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, typename CT>
 __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, const FilterParams& P, Lane& L, WaveLds* w, int bc0,
                                            int y_begin, int y_end) {
@@ -248,6 +265,7 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
     s.dv[k] = v2f{0.0f, 0.0f};
   }
   float inv_sigma_blk = -1.0f, inv_sigma_blk2 = -1.0f;
+  float sigma_last = -1.0f;  // GroupSigma of the previous group of 8 rows
   const XybConsts KC = MakeXybConsts(P);
   const size_t out_row_bytes = OUTK == JXLHIP_OUT_XYB_PLANAR ? P.out_stride * 4 : P.out_stride;
   char* out_row = (char*)P.out + (ptrdiff_t)(r_first - HX - (int)f.y0) * (ptrdiff_t)out_row_bytes;
@@ -258,11 +276,14 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
   FinishSlab<CT>(fa, w, nx, bc0, 0);
 #define JXLHIP_FSTEP(K)                                                                                     \
   Step<GAB, EPF, OUTK, FMT, K, EDGE, 0, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk,      \
-                                                  inv_sigma_blk2, out_row, KC, slab_y0);                    \
+                                                  inv_sigma_blk2, out_row, KC, slab_y0, sigma_pre, sigma_prev); \
   out_row += out_row_bytes
   if constexpr (HX > 0) {  // the last HX rows of the block row above
     const int r = r_first;
     const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    const float sigma_prev = sigma_last;
+    const float sigma_pre = EPF ? GroupSigma(fa, L, r) : 0.0f;
+    sigma_last = sigma_pre;
     {
       const int row0 = Mirror1(r + 8 - HX, H) - slab_y0;
 #pragma unroll
@@ -282,6 +303,9 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
   int r = HX ? y_begin : r_first;
   for (; r_last - r >= HX; r += 8) {  // whole groups (HX = 0: r <= r_last)
     const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    const float sigma_prev = sigma_last;
+    const float sigma_pre = EPF ? GroupSigma(fa, L, r) : 0.0f;
+    sigma_last = sigma_pre;
     {
       const int row0 = Mirror1(r, H) - slab_y0;
 #pragma unroll
@@ -310,6 +334,9 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
   }
   if (HX > 0 && r <= r_last) {  // the first HX rows of the block row below (y_end a multiple of 8)
     const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    const float sigma_prev = sigma_last;
+    const float sigma_pre = EPF ? GroupSigma(fa, L, r) : 0.0f;
+    sigma_last = sigma_pre;
     {
       const int row0 = Mirror1(r, H) - slab_y0;
 #pragma unroll
@@ -413,6 +440,15 @@ void LaunchFusedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
 
 }  // namespace
 
+// The instantiations are spread over two translation units (this file compiles for minutes): kernels_fused.hip
+// itself (JXLHIP_FUSED_PART 0: the entry points + the stage lists without EPF1 alone) and kernels_fused_b.hip
+// (PART 1, which includes this file: EPF1 with and without Gaborish -- the BASELINE list).
+#ifndef JXLHIP_FUSED_PART
+#define JXLHIP_FUSED_PART 0
+#endif
+bool LaunchFusedB(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st);
+
+#if JXLHIP_FUSED_PART == 0
 // Frames the fused kernel takes (decided before k_prepare: it routes the DCT8 blocks).
 bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) {
   (void)output_kind;
@@ -429,9 +465,8 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) 
   return true;
 }
 
-bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,
-                 hipStream_t st) {
-  if (!FusedSupported(f, gab, epf_iters, output_kind)) return false;
+#endif  // JXLHIP_FUSED_PART == 0
+
 #define JXLHIP_FUSED(G, E)                                      \
   if (gab == G && epf_iters == E) {                             \
     if (output_kind == 0) LaunchFusedT<G, E, 0>(f, p, st);      \
@@ -439,14 +474,36 @@ bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iter
     else LaunchFusedT<G, E, 2>(f, p, st);                       \
     return true;                                                \
   }
+#if JXLHIP_FUSED_PART == 0
+bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,
+                 hipStream_t st) {
+  if (!FusedSupported(f, gab, epf_iters, output_kind)) return false;
+#ifdef JXLHIP_FUSED_LEAN  // experiment builds (tools/build_variant.py): the BASELINE stage list only, seconds to compile
+  if (gab == 1 && epf_iters == 1 && output_kind == 1 && f.coeff_type == JXLHIP_COEFF_I16) {
+    const unsigned strips = (f.xsize + kFusedUse - 1) / kFusedUse;
+    const unsigned wgx = (strips + 3) / 4;
+    const int RH = FusedRowsPerWave(wgx, f.fy1 - f.fy0);
+    const dim3 grid(wgx, (f.fy1 - f.fy0 + RH - 1) / RH);
+    hipLaunchKernelGGL((k_fused<1, 1, 1, -1, int16_t>), grid, dim3(256), 0, st, f, p, RH);
+    return true;
+  }
+  return false;
+#else
   JXLHIP_FUSED(0, 0)
   JXLHIP_FUSED(1, 0)
+  JXLHIP_FUSED(0, 2)
+  return LaunchFusedB(f, p, gab, epf_iters, output_kind, st);
+#endif
+}
+#else
+bool LaunchFusedB(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st) {
+#ifndef JXLHIP_FUSED_LEAN
   JXLHIP_FUSED(0, 1)
   JXLHIP_FUSED(1, 1)
-  JXLHIP_FUSED(0, 2)
-  JXLHIP_FUSED(1, 2)
-#undef JXLHIP_FUSED
+#endif
   return false;
 }
+#endif
+#undef JXLHIP_FUSED
 
 }  // namespace jxlhip

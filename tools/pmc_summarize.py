@@ -21,7 +21,7 @@ def load(path):
 
 
 def short(name):
-    for key, tag in (("k_fused", "filters"), ("k_filters", "filters"), ("k_xyb_only", "filters"), ("k_transform_8", "blocks_8x8"),
+    for key, tag in (("k_fused", "filters"), ("k_filters", "filters"), ("k_xyb_only", "filters"), ("k_epf0", "epf0"), ("k_transform_mfma32", "blocks_mfma32"), ("k_transform_8", "blocks_8x8"),
                      ("k_transform_r16", "blocks_r16"), ("k_transform_r32", "blocks_r32"), ("k_transform_r", "blocks_r"),
                      ("k_transform_a", "blocks_a"), ("k_large", "blocks_large"), ("k_prepare", "prepare")):
         if key in name:
