@@ -122,9 +122,11 @@ __device__ __forceinline__ void FinishSlab(FrameArgs fa, WaveLds* w, const NextR
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int k = first_plane_k; k < 4; k++) DmaPlaneRows(fa, slab, n, bc0, k);
   const uint32_t m8 = n.m8;
-#ifdef JXLHIP_ABL_NODECODE  // ablation builds: what does the in-wave DCT8 decode cost?  (62 of 240 us: its ~650 VALU
-  if (false) {             // instructions per group of 8 rows on top of the march's 944 -- issue-bound, not latency:
-#else                      // requesting the coefficients two steps early or warming the caches changed nothing)
+#ifdef JXLHIP_ABL_NODECODE  // ablation builds: what does the in-wave DCT8 decode cost?  (62 of 240 us.  Neither
+  if (false) {             // requesting the coefficients two march steps early, nor warming the caches, nor running
+#else                      // the X / B channels as packed pairs (-25 % VALU) changed the kernel time: the SIMDs are
+                           // ~50 % busy; a wave cannot overlap its own fill with its own march, and registers + LDS
+                           // cap the SIMD at three waves)
   if (m8) {  // wave-uniform
 #endif
     const bool is_dct8 = lane < 16 && ((m8 >> lane) & 1u);
