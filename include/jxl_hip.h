@@ -157,6 +157,14 @@ typedef struct jxlhip_frame_params {
      kernels of families without a set bit are not launched.  0 = unknown (everything
      is launched; a strategy missing from a non-zero mask is NOT decoded). */
   uint32_t used_acs;
+  /* ImageMetadata::orientation to UNDO while writing (PassesDecoderState::undo_orientation, dec_cache.h:124;
+     WriteToOutputStage's flip_x / flip_y / transpose, stage_write.cc:441-457,486,664-680 -- what JxlDecoder does
+     unless JxlDecoderSetKeepOrientation).  0 or 1 = write in coded orientation.  2..8: jxlhip_decode_frame /
+     jxlhip_decode_frame_host write DISPLAY orientation; for 5..8 the output is ysize pixels wide and xsize rows
+     high (strides refer to that shape).  Interleaved outputs only (JXLHIP_OUT_LINEAR_RGB_F32, JXLHIP_OUT_PACKED;
+     the 8-bit dither pattern follows the flipped coordinates like the reference's); not with stripes / several
+     devices, not with the split calls (JXLHIP_ERR_UNSUPPORTED). */
+  uint32_t undo_orientation;
 } jxlhip_frame_params;
 
 /* Device pointers of one frame's inputs.  Same content the reference keeps in

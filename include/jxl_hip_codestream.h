@@ -33,7 +33,7 @@ extern "C" {
 typedef struct jxlhip_codestream_info {
   uint32_t xsize, ysize;       /* image = frame size */
   uint32_t container;          /* the bytes were an ISOBMFF container (jxlc / jxlp boxes) */
-  uint32_t orientation;        /* 1..8; the pixels are written in CODED orientation (djxl applies it afterwards) */
+  uint32_t orientation;        /* 1..8 (ImageMetadata::orientation); see JXLHIP_OUT_UNDO_ORIENTATION */
   float intensity_target;      /* ImageMetadata::tone_mapping.intensity_target */
   uint32_t bits_per_sample;    /* of the ORIGINAL image (metadata; the decode itself is float) */
   uint32_t transfer_function;  /* enumerated colour encoding of the original: CICP code (13 = sRGB, 8 = linear, 16 = PQ, 18 = HLG ...) */
@@ -53,11 +53,16 @@ JXLHIP_EXPORT int jxlhip_codestream_basic_info(const uint8_t* data, size_t size,
 /* Decodes the (single, VarDCT) frame of a .jxl file or bare codestream into device memory.
  *   runner / runner_opaque : a JxlParallelRunner (include/jxl/parallel_runner.h; e.g. JxlThreadParallelRunner of
  *                            libjxl_threads_hip.so) for the DC groups and the AC groups; NULL = calling thread
- *   output_kind, out_format: as jxlhip_frame_params (out_format only for JXLHIP_OUT_PACKED; NULL otherwise)
+ *   output_kind, out_format: as jxlhip_frame_params (out_format only for JXLHIP_OUT_PACKED; NULL otherwise).
+ *                            output_kind | JXLHIP_OUT_UNDO_ORIENTATION writes the pixels in DISPLAY orientation, as
+ *                            JxlDecoder does by default (jxlhip_frame_params::undo_orientation = the image's
+ *                            orientation: for orientations 5..8 `out` is ysize pixels wide and xsize rows high);
+ *                            without the flag the pixels stay in coded orientation (JxlDecoderSetKeepOrientation)
  *   out, out_stride, out_plane_stride : as jxlhip_decode_frame (device pointer)
  * The call returns after the frame is complete (jxlhip_sync included).  The context is left with the frame's
  * inputs resident: jxlhip_decode_frame can re-render (another output format after a new jxlhip_frame_begin needs
  * the inputs again: call this function again). */
+#define JXLHIP_OUT_UNDO_ORIENTATION 0x100u
 JXLHIP_EXPORT int jxlhip_decode_codestream(jxlhip_ctx* ctx, jxlhip_parallel_runner runner, void* runner_opaque,
                                            const uint8_t* data, size_t size, uint32_t output_kind,
                                            const jxlhip_output_format* out_format, void* out, size_t out_stride,

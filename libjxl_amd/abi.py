@@ -159,7 +159,7 @@ class FrameParams(C.Structure):
                 ("stripe_group_y0", C.c_uint32),
                 ("stripe_group_rows", C.c_uint32),
                 ("out_format", OutputFormat),
-                ("used_acs", C.c_uint32)]
+                ("used_acs", C.c_uint32), ("undo_orientation", C.c_uint32)]
 
 
 class FrameInputs(C.Structure):
@@ -180,6 +180,7 @@ def make_params(d):
               "stripe_group_rows"):
         setattr(p, k, d[k])
     p.used_acs = d.get("used_acs", 0)
+    p.undo_orientation = d.get("undo_orientation", 0)
     p.quant_biases[:] = d["quant_biases"]
     p.opsin_biases[:] = d["opsin_biases"]
     p.inverse_opsin_matrix[:] = d["inverse_opsin_matrix"]

@@ -61,6 +61,8 @@ struct jxlhip_ctx {
   // context-owned device memory
   float* planes = nullptr;  // 3 planes
   size_t planes_floats = 0;
+  unsigned char* orient_dev = nullptr;  // undo_orientation: the frame in coded orientation (jxlhip_decode_frame)
+  size_t orient_bytes = 0;
   float* planes2 = nullptr;  // epf_iters == 3: EPF0 output, the EPF1 + EPF2 march's input (kernels_epf0.hip)
   size_t planes2_floats = 0;
   float* inv_sigma = nullptr;
@@ -389,7 +391,7 @@ void jxlhip_destroy(jxlhip_ctx* c) {
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
                   c->dc_tmp,     c->quant_enc,  c->dc_prec,      c->cell_info,
-                  c->qdc_dev,    c->host_frame_dev, c->planes2};
+                  c->qdc_dev,    c->host_frame_dev, c->planes2, c->orient_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -407,6 +409,7 @@ int jxlhip_set_stream(jxlhip_ctx* c, void* hip_stream, int external) {
 
 // ---- frame set-up -------------------------------------------------------------
 int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
+  if (c && p && p->undo_orientation > 8) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "undo_orientation %u", p->undo_orientation);
   if (!c || !p) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->children.empty()) return MultiFrameBegin(c, p);
   if (p->xsize == 0 || p->ysize == 0 || p->xsize > (1u << 19) || p->ysize > (1u << 19))
@@ -537,6 +540,16 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
     }
   }
   memcpy(c->lut.v, p->lf.epf_sharp_lut, sizeof(c->lut.v));
+  {
+    // undo_orientation: the kernels write coded orientation into a staging frame (DecodeFrame below), only the
+    // 8-bit dither pattern has to follow the flipped coordinates already
+    const uint32_t o = p->undo_orientation;
+    const bool fx = o == 2 || o == 3 || o == 7 || o == 8, fy = o == 3 || o == 4 || o == 6 || o == 7;
+    fp.dither_x0 = fx ? (int32_t)p->xsize - 1 : 0;
+    fp.dither_xs = fx ? -1 : 1;
+    fp.dither_y0 = fy ? (int32_t)p->ysize - 1 : 0;
+    fp.dither_ys = fy ? -1 : 1;
+  }
   c->fp = fp;
   c->f = f;
   c->p = *p;
@@ -1090,6 +1103,7 @@ int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t ou
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   JXLHIP_NO_MULTI(c);
   if (!c->blocks_done) return Fail(c, JXLHIP_ERR_STATE, "decode_filters before decode_blocks");
+  if (c->p.undo_orientation > 1) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "undo_orientation with the split calls");
   int rc = CheckOutArgs(c, out, out_stride, out_plane_stride);
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
@@ -1104,10 +1118,41 @@ int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t ou
 // group rows -- blocks(b) then filters(b-1) -- which was meant to keep a band's
 // XYB planes in the 256 MB Infinity Cache; measured on MI355X it only loses
 // time, so the default is one band = the whole stripe.
+static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride);
+
+// bytes of one interleaved output pixel (0: planar XYB)
+static size_t OutPixelBytes(const jxlhip_ctx* c) {
+  if (c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32) return 12;
+  if (c->p.output_kind != JXLHIP_OUT_PACKED) return 0;
+  const jxlhip_output_format& o = c->p.out_format;
+  return (size_t)o.num_channels * (o.sample_type == JXLHIP_SAMPLE_U8 ? 1 : (o.sample_type == JXLHIP_SAMPLE_F32 ? 4 : 2));
+}
+
 int jxlhip_decode_frame(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->children.empty()) return out ? MultiDecodeFrame(c, out, nullptr, out_stride, out_plane_stride) : JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "decode needs frame_begin + inputs");
+  if (c->p.undo_orientation <= 1) return DecodeFrameCoded(c, out, out_stride, out_plane_stride);
+  // undo_orientation: coded orientation into a staging frame, k_orient into the caller's buffer
+  const DevFrame& f = c->f;
+  const size_t bpp = OutPixelBytes(c);
+  if (!out || bpp == 0) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "undo_orientation needs an interleaved output");
+  if (f.group_y0 != 0 || f.group_rows != f.ysg) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "undo_orientation with stripes");
+  const bool transposed = c->p.undo_orientation >= 5;
+  const size_t need = (size_t)(transposed ? f.ysize : f.xsize) * bpp;
+  if (out_stride < need) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "row stride %zu too small for the oriented frame", out_stride);
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t row = ((size_t)f.xsize * bpp + 255) & ~(size_t)255;
+  int rc;
+  if ((rc = Grow(c, &c->orient_dev, &c->orient_bytes, (size_t)f.ysize * row))) return rc;
+  if ((rc = DecodeFrameCoded(c, c->orient_dev, row, 0))) return rc;
+  if (!LaunchOrient(c->orient_dev, row, f.xsize, f.ysize, (uint32_t)bpp, c->p.undo_orientation, out, out_stride, c->stream))
+    return Fail(c, JXLHIP_ERR_UNSUPPORTED, "undo_orientation %u with %zu-byte pixels", c->p.undo_orientation, bpp);
+  HIPCHK(c, hipGetLastError());
+  return JXLHIP_OK;
+}
+
+static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
   const DevFrame& f = c->f;
   uint32_t br = c->band_rows ? (uint32_t)c->band_rows : f.group_rows;
   while ((f.group_rows + br - 1) / br > (uint32_t)kMaxBands) br++;
@@ -1163,14 +1208,13 @@ int jxlhip_decode_frame_host(jxlhip_ctx* c, void* host_out, size_t out_stride, s
   }
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "decode needs frame_begin + inputs");
   const DevFrame& f = c->f;
-  const size_t rows = f.y1 - f.y0;
+  const bool transposed = c->p.undo_orientation >= 5;  // the oriented frame is ysize wide, xsize high
+  const size_t rows = transposed ? f.xsize : f.y1 - f.y0;
+  const size_t cols = transposed ? f.ysize : f.xsize;
   size_t row_bytes;
-  if (c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32) row_bytes = (size_t)f.xsize * 12;
-  else if (c->p.output_kind == JXLHIP_OUT_PACKED) {
-    const jxlhip_output_format& o = c->p.out_format;
-    row_bytes = (size_t)f.xsize * o.num_channels *
-                (o.sample_type == JXLHIP_SAMPLE_U8 ? 1 : (o.sample_type == JXLHIP_SAMPLE_F32 ? 4 : 2));
-  } else row_bytes = (size_t)f.xsize * 4;
+  if (c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32) row_bytes = cols * 12;
+  else if (c->p.output_kind == JXLHIP_OUT_PACKED) row_bytes = cols * OutPixelBytes(c);
+  else row_bytes = cols * 4;
   const bool planar = c->p.output_kind == JXLHIP_OUT_XYB_PLANAR;
   const size_t host_row = planar ? out_stride * 4 : out_stride;
   if (host_row < row_bytes) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "host row stride %zu too small", out_stride);

@@ -152,7 +152,10 @@ template <typename DitherPtr>
 __device__ __forceinline__ uint32_t ToUnsigned(const FilterParams& P, DitherPtr dither, float v, int x,
                                                int y, int c, bool dithered) {
   v = v * P.sample_mul;
-  if (dithered) v = v + dither[(((uint32_t)y + 13u * c) & 31u) * 32u + (((uint32_t)x + 23u * c) & 31u)];
+  if (dithered) {
+    const uint32_t dx = (uint32_t)(P.dither_x0 + P.dither_xs * x), dy = (uint32_t)(P.dither_y0 + P.dither_ys * y);
+    v = v + dither[((dy + 13u * c) & 31u) * 32u + ((dx + 23u * c) & 31u)];
+  }
   v = __builtin_fminf(__builtin_fmaxf(v, 0.0f), P.sample_mul);
   return (uint32_t)(int32_t)__builtin_rintf(v);
 }

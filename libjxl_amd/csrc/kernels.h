@@ -35,6 +35,9 @@ struct FilterParams {
   float tf_scale;           // PQ: intensity_target / 10000; GAMMA: inverse gamma
   float hlg_exponent;       // HLG: HlgOOTF exponent (gamma - 1), 0 = OOTF not applied
   const float* dither;      // 32x32 pattern (device)
+  // dither coordinates = (dither_x0 + dither_xs * x, dither_y0 + dither_ys * y): the reference dithers AFTER
+  // undo_orientation's flips (stage_write.cc:486-492): identity = (0, 1, 0, 1)
+  int32_t dither_x0, dither_xs, dither_y0, dither_ys;
 };
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,
@@ -55,6 +58,10 @@ bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int ep
 // epf_iters = 3 (kernels_epf0.hip): [Gaborish] + EPF0 from f.xyb into a second plane set; the EPF1 + EPF2 march
 // (LaunchFiltersFast with gab = 0, epf_iters = 2 on those planes) follows.  false: geometry not covered.
 bool LaunchEpf0(const DevFrame& f, const FilterParams& p, int gab, float* const dst[3], hipStream_t st);
+
+// undo_orientation (kernels_tables.hip k_orient): coded xsize x ysize pixels of bytes_per_pixel -> display orientation
+bool LaunchOrient(const void* src, size_t src_stride, uint32_t xsize, uint32_t ysize, uint32_t bytes_per_pixel,
+                  uint32_t orientation, void* dst, size_t dst_stride, hipStream_t st);
 
 // Matrix-core 32x32 IDCT (kernels_mfma.hip), opt-in through DevFrame::mfma32
 void MfmaDct32Constants(float* host /* 2048 floats */);

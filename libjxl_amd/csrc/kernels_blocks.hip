@@ -1361,8 +1361,11 @@ static constexpr FamilyEntry kFamilyR[8] = {{kClsMedium0 + 7, 8},  {kClsMedium0 
 // The 50 KB of LDS every workgroup of this launch then reserves cost the row-per-lane units
 // nothing: three workgroups per CU is what their registers allow anyway.  As a launch of its own
 // family A is ~22 us of pure latency per 8K d1.0 frame.
+#ifndef JXLHIP_R_WAVES
+#define JXLHIP_R_WAVES 3
+#endif
 template <typename CT>
-__global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(DevFrame f, WorkLists wl, uint32_t big_wgs,
+__global__ __launch_bounds__(256, sizeof(CT) == 2 ? JXLHIP_R_WAVES : 2) void k_transform_r(DevFrame f, WorkLists wl, uint32_t big_wgs,
                                                                                uint32_t special_wgs, uint32_t r_wgs) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
   // fused mode: DCT8 is decoded by the fused kernel, and what k_transform_8 would be left with -- the

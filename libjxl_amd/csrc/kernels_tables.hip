@@ -215,6 +215,58 @@ void LaunchRowsCopy(const DevFrame& f, float* dense, int y_first, int nrows, int
                      dense_stride, dense_plane);
 }
 
+// WriteToOutputStage's undo_orientation (stage_write.cc:441-457: flip_x for orientations 2, 3, 7, 8; flip_y for 3, 4,
+// 6, 7; transpose for 5..8; the flips act in the coded frame, the transpose last, :486,:341,:664-680): pixel (x, y)
+// of the coded W x H frame goes to row / column (y', x') -- or (x', y') when transposed -- with x' = W-1-x, y' = H-1-y
+// where flipped.  One thread per pixel; a 32 x 8 tile of threads reads rows and, when transposed, writes columns of
+// 32-byte-or-more pixels: sector-sized pieces either way.  BPP = bytes per pixel (3 .. 16).
+template <int BPP>
+__global__ __launch_bounds__(256) void k_orient(const unsigned char* __restrict__ src, size_t src_stride, int W, int H,
+                                                unsigned char* __restrict__ dst, size_t dst_stride, int flip_x,
+                                                int flip_y, int transpose) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= W || y >= H) return;
+  const int xo = flip_x ? W - 1 - x : x, yo = flip_y ? H - 1 - y : y;
+  const unsigned char* s = src + (size_t)y * src_stride + (size_t)x * BPP;
+  unsigned char* d = transpose ? dst + (size_t)xo * dst_stride + (size_t)yo * BPP
+                               : dst + (size_t)yo * dst_stride + (size_t)xo * BPP;
+  if constexpr (BPP % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < BPP / 4; i++) ((uint32_t*)d)[i] = ((const uint32_t*)s)[i];
+  } else if constexpr (BPP % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < BPP / 2; i++) ((uint16_t*)d)[i] = ((const uint16_t*)s)[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < BPP; i++) d[i] = s[i];
+  }
+}
+
+bool LaunchOrient(const void* src, size_t src_stride, uint32_t xsize, uint32_t ysize, uint32_t bytes_per_pixel,
+                  uint32_t orientation, void* dst, size_t dst_stride, hipStream_t st) {
+  if (orientation < 1 || orientation > 8) return false;
+  const int fx = orientation == 2 || orientation == 3 || orientation == 8 || orientation == 7;
+  const int fy = orientation == 4 || orientation == 3 || orientation == 6 || orientation == 7;
+  const int tr = orientation >= 5;
+  const dim3 grid((xsize + 31) / 32, (ysize + 7) / 8);
+#define JXLHIP_ORIENT(B)                                                                                      \
+  case B:                                                                                                     \
+    hipLaunchKernelGGL((k_orient<B>), grid, dim3(256), 0, st, (const unsigned char*)src, src_stride, (int)xsize, \
+                       (int)ysize, (unsigned char*)dst, dst_stride, fx, fy, tr);                              \
+    return true;
+  switch (bytes_per_pixel) {
+    JXLHIP_ORIENT(3)
+    JXLHIP_ORIENT(4)
+    JXLHIP_ORIENT(6)
+    JXLHIP_ORIENT(8)
+    JXLHIP_ORIENT(12)
+    JXLHIP_ORIENT(16)
+  }
+#undef JXLHIP_ORIENT
+  return false;
+}
+
 void LaunchDequantTables(float* table, const jxlhip_quant_encoding* enc_dev, int32_t* status,
                          hipStream_t st) {
   hipLaunchKernelGGL(k_dequant_tables, dim3((JXLHIP_DEQUANT_TABLE_FLOATS + 255) / 256), dim3(256),

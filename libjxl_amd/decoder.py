@@ -100,11 +100,13 @@ class VarDctDecoder:
         p = self.params
         y0, y1 = self.stripe_rows()
         dev = f"cuda:{self.device}"
+        # undo_orientation 5..8: the display frame is ysize pixels wide and xsize rows high
+        oh, ow = (p.xsize, p.ysize) if p.undo_orientation >= 5 else (y1 - y0, p.xsize)
         if p.output_kind == 1:
-            return torch.empty((y1 - y0, p.xsize, 3), dtype=torch.float32, device=dev)
+            return torch.empty((oh, ow, 3), dtype=torch.float32, device=dev)
         if p.output_kind == 2:  # packed RGB(A): dtype of the sample type (F16 as raw uint16 bits)
             dt = {0: torch.float32, 1: torch.uint8, 2: torch.int16, 3: torch.int16}[p.out_format.sample_type]
-            return torch.empty((y1 - y0, p.xsize, p.out_format.num_channels), dtype=dt, device=dev)
+            return torch.empty((oh, ow, p.out_format.num_channels), dtype=dt, device=dev)
         return torch.empty((3, y1 - y0, p.xsize), dtype=torch.float32, device=dev)
 
     def _out_args(self, out):

@@ -92,7 +92,7 @@ def _layout_streams(blocks, decay, amp):
 def synth_frame(xsize, ysize, *, mix=None, gab=True, epf_iters=1, seed=0x4A584C,
                 device="cpu", coeff_type=0, num_layouts=6, intensity_target=255.0,
                 output_kind=1, quant_mul=1.0, decay=6.0, amp=6.0,
-                custom_lf=False, out_format=None):
+                custom_lf=False, out_format=None, undo_orientation=0):
     """Returns (params: dict of python scalars, tensors: dict of torch tensors).
     params follows jxlhip_frame_params; tensors follows jxlhip_frame_inputs."""
     mix = MIX_D1 if mix is None else mix
@@ -194,7 +194,7 @@ def synth_frame(xsize, ysize, *, mix=None, gab=True, epf_iters=1, seed=0x4A584C,
         epf_border_sad_mul=bsm,
         opsin_biases=[-0.0037930732552754493] * 3,
         inverse_opsin_matrix=[float(f32(f32(v) * mul)) for v in inv],
-        stripe_group_y0=0, stripe_group_rows=0, out_format=out_format,
+        stripe_group_y0=0, stripe_group_rows=0, out_format=out_format, undo_orientation=undo_orientation,
         used_acs=int(np.bitwise_or.reduce(1 << (np.unique(acs[(acs & 1) == 1]) >> 1).astype(np.int64))))
     tensors = dict(
         coeffs=coeffs,

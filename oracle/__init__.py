@@ -18,9 +18,10 @@ DEQUANT_TABLE_FLOATS = 2056 * 64 * 3
 
 def build(force=False):
     """Compile the oracle with gcc (make); a no-op when up to date."""
-    if force or not os.path.exists(_SO) or any(
-            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
-            for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))):
+    inc = os.path.join(_HERE, "..", "include")  # the restatement shares the C ABI's POD structs (jxl_oracle.h)
+    deps = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
+    deps += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")] if os.path.isdir(inc) else []
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO
 
@@ -57,7 +58,7 @@ class FrameParams(C.Structure):
                 ("stripe_group_y0", C.c_uint32),
                 ("stripe_group_rows", C.c_uint32),
                 ("out_format", OutputFormat),
-                ("used_acs", C.c_uint32)]
+                ("used_acs", C.c_uint32), ("undo_orientation", C.c_uint32)]
 
 
 class OracleFrame(C.Structure):
@@ -367,17 +368,19 @@ def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None):
             L.jxr_set_quant_encodings(None)
     p = self.params
     threads = ref_threads(p.xsize, p.ysize, threads)
+    # undo_orientation 5..8: the reference writes an xsize-high, ysize-wide frame (stage_write.cc:664-680)
+    oh, ow = (p.xsize, p.ysize) if p.undo_orientation >= 5 else (p.ysize, p.xsize)
     if p.output_kind == 2:
         # packed RGB(A) through the reference's FromLinearStage + WriteToOutputStage;
         # out_stride is in BYTES for this kind; F16 comes back as raw uint16 bits
         of = p.out_format
         dt = {0: np.float32, 1: np.uint8, 2: np.uint16, 3: np.uint16}[of.sample_type]
-        out = np.zeros((p.ysize, p.xsize, of.num_channels), dt)
+        out = np.zeros((oh, ow, of.num_channels), dt)
         rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), out.strides[0], 0, threads,
                                         int(simple_pipeline))
     elif p.output_kind == 1:
-        out = np.zeros((p.ysize, p.xsize, 3), np.float32)
-        rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), p.xsize * 3, 0, threads, int(simple_pipeline))
+        out = np.zeros((oh, ow, 3), np.float32)
+        rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), ow * 3, 0, threads, int(simple_pipeline))
     else:
         out = np.zeros((3, p.ysize, p.xsize), np.float32)
         rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), p.xsize, p.xsize * p.ysize, threads,

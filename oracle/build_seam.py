@@ -77,8 +77,13 @@ def patched_dec_frame():
 
 
 def _cc(src, obj, extra=()):
-    if os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src) and \
-            os.path.getmtime(obj) > os.path.getmtime(os.path.abspath(__file__)):
+    # the seam's own sources see the C ABI headers (a stale object with an older jxlhip_frame_params is a
+    # silent struct-size mismatch)
+    inc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include")
+    deps = [src, os.path.abspath(__file__)]
+    if not src.startswith(B.REF):
+        deps += [os.path.join(inc, h) for h in os.listdir(inc) if h.endswith(".h")]
+    if os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):
         return
     r = subprocess.run([B.CXX] + FLAGS + list(extra) + ["-c", src, "-o", obj], capture_output=True, text=True)
     if r.returncode:

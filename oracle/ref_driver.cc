@@ -333,7 +333,13 @@ Status DecodeFrame(const jxo_frame* f, float* out, size_t out_stride_floats, siz
         of.sample_type == JXLHIP_SAMPLE_F32 ? 32 : (of.sample_type == JXLHIP_SAMPLE_F16 ? 16 : of.bits_per_sample);
     dec_state->main_output.stride = out_stride_floats;  // bytes
   }
-  dec_state->main_output.buffer_size = dec_state->main_output.stride * p.ysize;
+  // jxlhip_frame_params::undo_orientation = PassesDecoderState::undo_orientation (dec_cache.h:124), what
+  // FrameDecoder::SetImageOutput derives from the metadata unless the caller keeps the coded orientation
+  if (p.undo_orientation > 1) {
+    if (xyb_out) return JXL_FAILURE("undo_orientation needs an interleaved output");
+    dec_state->undo_orientation = static_cast<Orientation>(p.undo_orientation);
+  }
+  dec_state->main_output.buffer_size = dec_state->main_output.stride * (p.undo_orientation >= 5 ? p.xsize : p.ysize);
 
   ImageBundle decoded(&ref.mm, &metadata.m);
   PassesDecoderState::PipelineOptions options;

@@ -183,6 +183,12 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   metadata.m.xyb_encoded = true;
   metadata.m.color_encoding = ColorEncoding::LinearSRGB(/*is_gray=*/false);
   JXL_RETURN_IF_ERROR(metadata.size.Set(xs, ys));
+  // JXR_ORIENTATION=2..8: ImageMetadata::orientation of the written stream (tests of undo_orientation); the
+  // FrameDecoder run below keeps the coded orientation, JxlDecoder (tests/test_seam.py) undoes it
+  if (const char* e = getenv("JXR_ORIENTATION")) {
+    const int o = atoi(e);
+    if (o >= 1 && o <= 8) metadata.m.orientation = static_cast<uint32_t>(o);
+  }
   ImageBundle ib(&mm, &metadata.m);
   {
     JXL_ASSIGN_OR_RETURN(Image3F img, Image3F::Create(&mm, xs, ys));

@@ -97,7 +97,7 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   if (!fh.chroma_subsampling.Is444() || fh.upsampling != 1 || fh.dc_level != 0) return true;
   if (md.num_extra_channels != 0 || fh.custom_size_or_origin || fh.blending_info.mode != BlendMode::kReplace) return true;
   if (!fh.is_last || fh.CanBeReferenced() || fh.frame_type != FrameType::kRegularFrame) return true;
-  if (fd->decoded_->IsJPEG() || ds->undo_orientation != Orientation::kIdentity) return true;
+  if (fd->decoded_->IsJPEG()) return true;
   if (mo.callback.IsPresent() || !mo.buffer || mo.format.data_type != JXL_TYPE_FLOAT ||
       (mo.format.num_channels != 3 && mo.format.num_channels != 4) || mo.format.endianness == JXL_BIG_ENDIAN)
     return true;
@@ -120,6 +120,7 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   p.xsize = dim.xsize;
   p.ysize = dim.ysize;
   p.output_kind = JXLHIP_OUT_PACKED;
+  p.undo_orientation = static_cast<uint32_t>(ds->undo_orientation);  // the back-end writes display orientation
   p.global_scale = sh.quantizer.global_scale_;
   p.quant_dc = sh.quantizer.quant_dc_;
   p.x_dm_multiplier = ds->x_dm_multiplier;

@@ -152,3 +152,45 @@ def test_unsupported_streams_are_refused_not_misdecoded(L, ref):
         assert rc != 0
     finally:
         dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("orientation", [2, 5, 6, 8])
+def test_display_orientation_like_jxldecoder(L, ref, orientation, monkeypatch):
+    """A stream whose metadata carries an EXIF orientation: JxlDecoder writes DISPLAY orientation unless asked to keep
+    the coded one (decode.h JxlDecoderSetKeepOrientation); so does jxlhip_decode_codestream with
+    JXLHIP_OUT_UNDO_ORIENTATION -- against the reference's public decoder (oracle/_ref/libjxl_dec_ref.so, the
+    unpatched half of the seam build), and coded orientation without the flag against FrameDecoder's pixels."""
+    import sys, os
+    import torch
+    from libjxl_amd import VarDctDecoder
+    import test_seam
+    sys.path.insert(0, os.path.join(test_seam.ROOT, "oracle"))
+    import build_seam
+    try:
+        ref_so, _ = build_seam.build()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    monkeypatch.setenv("JXR_ORIENTATION", str(orientation))
+    rs = ref.RealStream(seed=5, xsize=328, ysize=200, distance=1.0, speed_tier=3)
+    monkeypatch.delenv("JXR_ORIENTATION")
+    cs = rs.codestream.tobytes()
+    want = test_seam.jxl_decode(test_seam.load(ref_so), cs)  # display orientation
+    dec = VarDctDecoder(0)
+    try:
+        info = abi.CodestreamInfo()
+        assert L.jxlhip_codestream_basic_info(cs, len(cs), C.byref(info)) == 0
+        assert info.orientation == orientation and (info.xsize, info.ysize) == (328, 200)
+        oh, ow = (328, 200) if orientation >= 5 else (200, 328)
+        assert want.shape == (oh, ow, 3)
+        out = torch.empty((oh, ow, 3), dtype=torch.float32, device="cuda")
+        rc = L.jxlhip_decode_codestream(dec.ctx, None, None, cs, len(cs), 1 | 0x100, None, out.data_ptr(), ow * 12, 0, None)
+        assert rc == 0, L.jxlhip_last_error(dec.ctx)
+        scale = max(1.0, float(np.abs(want).max()))
+        assert float(np.abs(out.cpu().numpy() - want).max()) / scale <= TIGHT
+        coded = torch.empty((200, 328, 3), dtype=torch.float32, device="cuda")
+        rc = L.jxlhip_decode_codestream(dec.ctx, None, None, cs, len(cs), 1, None, coded.data_ptr(), 328 * 12, 0, None)
+        assert rc == 0, L.jxlhip_last_error(dec.ctx)
+        assert float(np.abs(coded.cpu().numpy() - rs.rgb.reshape(200, 328, 3)).max()) / scale <= TIGHT
+    finally:
+        dec.close()

@@ -320,3 +320,47 @@ def test_entropy_decode_submit_end_to_end(dec, ref):
     L.jxlhip_ac_pass_destroy(h)
     assert torch.equal(got, want)
     d2.close()
+
+
+# ---- f3: undo_orientation in the write stage ----------------------------------
+@pytest.mark.parametrize("orientation", [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("kind", ["f32", "u8", "u16"])
+def test_undo_orientation_matches_the_reference_write_stage(ref, orientation, kind):
+    """jxlhip_frame_params::undo_orientation: the frame in DISPLAY orientation like WriteToOutputStage writes it
+    (stage_write.cc:441-457 flips / transpose, and the 8-bit dither pattern at the FLIPPED coordinates,
+    :486-492) -- every EXIF orientation, float and packed outputs, a ragged size."""
+    xs, ys = 333, 212
+    if kind == "f32":
+        kw = dict(output_kind=1)
+    else:
+        fmt = dict(transfer=1, sample_type=1 if kind == "u8" else 2, num_channels=4 if kind == "u8" else 3,
+                   bits_per_sample=8 if kind == "u8" else 16, swap_endianness=0, tf_param=0.0, luminances=[0, 0, 0])
+        kw = dict(output_kind=2, out_format=fmt)
+    params, t = synth.synth_frame(xs, ys, device="cuda", mix=synth.MIX_D1, gab=True, epf_iters=1, seed=70 + orientation,
+                                  undo_orientation=orientation, **kw)
+    d = VarDctDecoder(0)
+    try:
+        d.begin_frame(params)
+        dq = d.default_dequant_tables()
+        d.set_inputs(t, dq)
+        oh, ow = (xs, ys) if orientation >= 5 else (ys, xs)
+        got = d.decode_frame().cpu().numpy()
+        d.sync()
+    finally:
+        d.close()
+    npy = {k: ([x.cpu().numpy() for x in v] if isinstance(v, list) else v.cpu().numpy()) for k, v in t.items()}
+    fr = ref.Frame(frames.to_oracle_params(abi.make_params(params)), npy["coeffs"], npy["ac_strategy"],
+                   npy["raw_quant"], npy["epf_sharpness"], npy["ytox_map"], npy["ytob_map"], npy["dc"],
+                   dq.cpu().numpy())
+    want = fr.decode_ref(threads=1)
+    assert got.shape == want.shape == (oh, ow, want.shape[2])
+    if kind == "f32":
+        assert float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max())) <= TIGHT
+    else:
+        diff = np.abs(got.view(want.dtype).astype(np.int64) - want.astype(np.int64))
+        # the float pipeline in front differs by <= 2e-5 of the range: a sample may land on the other side of a
+        # rounding boundary -- 1 of 255 codes for a few samples in a thousand, 1-2 of 65535 codes more often
+        if kind == "u8":
+            assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+        else:
+            assert diff.max() <= 2 and (diff > 0).mean() < 2e-2, (diff.max(), (diff > 0).mean())

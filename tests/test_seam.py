@@ -143,3 +143,26 @@ def test_reference_jxldecoder_with_hip_backend_matches_unpatched_reference(libs,
             assert float(np.abs(got - want).max()) / scale <= TIGHT
     finally:
         R.JxlThreadParallelRunnerDestroy(pool)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("orientation", [3, 6, 7])
+def test_oriented_stream_through_the_patched_jxldecoder(libs, ref, orientation, monkeypatch):
+    """ImageMetadata::orientation != 1: JxlDecoder undoes it while writing (decode.cc SetImageOutBuffer ->
+    PassesDecoderState::undo_orientation); the patched decoder hands that to the back-end
+    (jxlhip_frame_params::undo_orientation) instead of declining the frame."""
+    Lr, Lh = load(libs[0]), load(libs[1])
+    R, runner, pool = hip_runner()
+    try:
+        monkeypatch.setenv("JXR_ORIENTATION", str(orientation))
+        rs = ref.RealStream(seed=12, xsize=456, ysize=280, distance=1.0, speed_tier=3)
+        monkeypatch.delenv("JXR_ORIENTATION")
+        cs = rs.codestream.tobytes()
+        want = jxl_decode(Lr, cs, runner, pool, 3)
+        assert want.shape == ((456, 280, 3) if orientation >= 5 else (280, 456, 3))
+        before = Lh.jxlhip_seam_frames_decoded()
+        got = jxl_decode(Lh, cs, runner, pool, 3)
+        assert Lh.jxlhip_seam_frames_decoded() == before + 1, "the frame did not go through the HIP back-end"
+        assert float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max())) <= TIGHT
+    finally:
+        R.JxlThreadParallelRunnerDestroy(pool)

@@ -46,14 +46,17 @@ def main():
     runner = C.cast(R.JxlThreadParallelRunner, C.c_void_p) if a.threads else None
     dec = VarDctDecoder(0)
     w, h = info.xsize, info.ysize
+    if info.orientation >= 5:  # display orientation like djxl (JXLHIP_OUT_UNDO_ORIENTATION): transposed frame
+        w, h = h, w
+    UNDO = 0x100
     if packed:
         nc = 4 if ext == ".pam" else 3
         fmt = abi.OutputFormat(1, 1, nc, 8, 0, 0.0, (C.c_float * 3)(0.2126, 0.7152, 0.0722))
         out = torch.empty((h, w, nc), dtype=torch.uint8, device="cuda")
-        args = (2, C.byref(fmt), out.data_ptr(), w * nc, 0)
+        args = (2 | UNDO, C.byref(fmt), out.data_ptr(), w * nc, 0)
     else:
         out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda")
-        args = (1, None, out.data_ptr(), w * 12, 0)
+        args = (1 | UNDO, None, out.data_ptr(), w * 12, 0)
     best = None
     for _ in range(max(1, a.reps)):
         t0 = time.perf_counter()
