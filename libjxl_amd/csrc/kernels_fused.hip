@@ -352,8 +352,11 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
 #undef JXLHIP_FSTEP
 }
 
+#ifndef JXLHIP_FUSED_WAVES
+#define JXLHIP_FUSED_WAVES 3
+#endif
 template <int GAB, int EPF, int OUTK, int FMT, typename CT>
-__global__ __launch_bounds__(256, (EPF == 2 || OUTK == 2) ? 2 : 3) void k_fused(DevFrame f, FilterParams P, int RH) {
+__global__ __launch_bounds__(256, (EPF == 2 || OUTK == 2) ? 2 : JXLHIP_FUSED_WAVES) void k_fused(DevFrame f, FilterParams P, int RH) {
   __shared__ WaveLds lds[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float __attribute__((address_space(3)))* dither_lds = nullptr;
