@@ -930,7 +930,8 @@ namespace {
 
 // k_prepare + the transform kernels for group rows [g0, g1) of the stripe,
 // using counter slot `band`.
-int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, bool fused = false) {
+int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, bool fused = false,
+                     const FilterParams* emit = nullptr) {
   hipStream_t st = c->stream;
   DevFrame f = c->f;
   f.band_g0 = g0;
@@ -956,13 +957,13 @@ int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, bool fus
     HIPCHK(c, hipEventRecord(c->fork_ev, st));
     for (int i = 0; i < c->nblock_streams; i++)
       HIPCHK(c, hipStreamWaitEvent(c->bstreams[i], c->fork_ev, 0));
-    LaunchBlocks(f, wl, cells, c->tables, c->tables + 512, c->bstreams, c->nblock_streams);
+    LaunchBlocks(f, wl, cells, c->tables, c->tables + 512, c->bstreams, c->nblock_streams, emit);
     for (int i = 0; i < c->nblock_streams; i++) {
       HIPCHK(c, hipEventRecord(c->bev[i], c->bstreams[i]));
       HIPCHK(c, hipStreamWaitEvent(st, c->bev[i], 0));
     }
   } else {
-    LaunchBlocks(f, wl, cells, c->tables, c->tables + 512, &st, 1);
+    LaunchBlocks(f, wl, cells, c->tables, c->tables + 512, &st, 1, emit);
   }
   ProfMark(c, JXLHIP_KERNEL_BLOCKS);
   ProfEnd(c);
@@ -1164,6 +1165,15 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   fp.out = out;
   fp.out_stride = out_stride;
   fp.out_plane_stride = out_plane_stride;
+  // A frame of DCT32X32 varblocks only, no loop filter, linear float RGB out (BASELINE configs[4]): the matrix-core
+  // class kernel applies the opsin inverse and writes the pixels itself (kernels_mfma.hip, EMIT) -- no XYB planes,
+  // no second kernel.  used_acs is the caller's promise; k_prepare reports any other strategy it meets.
+  if (c->mfma != 0 && f.used_acs == (1u << 5) && c->p.lf.gab == 0 && c->p.lf.epf_iters == 0 &&
+      c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32 && !c->generic_filters && c->band_rows == 0) {
+    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, 0, false, &fp);
+    c->blocks_done = false;  // nothing in the planes
+    return rc;
+  }
   // Whole frame on this context, one band: the fused kernel decodes the DCT8 blocks inside the filter
   // march (kernels_fused.hip).  The split calls (jxlhip_decode_blocks / _filters) stay two-phase: a
   // stripe's halo rows must exist in the planes for its neighbours.

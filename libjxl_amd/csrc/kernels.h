@@ -44,8 +44,9 @@ void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float
                    const SharpLut& lut, hipStream_t st);
 // Five launches (k_dct8, the row-per-lane families R16 / R32, family A, the large kinds) on
 // streams[0] / streams[1 % nstreams]; `cells` = block cells of the band (bounds the unit count).
+// emit: see LaunchMfma32 (nullptr: every class writes the XYB planes).
 void LaunchBlocks(const DevFrame& f, const WorkLists& wl, uint32_t cells, const float* wc,
-                  const float* resample, hipStream_t* streams, int nstreams);
+                  const float* resample, hipStream_t* streams, int nstreams, const FilterParams* emit = nullptr);
 // Returns 0, or -1 when the (gab, epf_iters, output_kind) combination is invalid.
 int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                   int output_kind, hipStream_t st);
@@ -65,7 +66,9 @@ bool LaunchOrient(const void* src, size_t src_stride, uint32_t xsize, uint32_t y
 
 // Matrix-core 32x32 IDCT (kernels_mfma.hip), opt-in through DevFrame::mfma32
 void MfmaDct32Constants(float* host /* 2048 floats */);
-void LaunchMfma32(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st);
+// emit != nullptr: the frame is DCT32X32 only and has no loop filter -- the kernel writes linear float RGB to
+// emit->out itself (rows f.y0 .. f.y1) instead of XYB planes
+void LaunchMfma32(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st, const FilterParams* emit = nullptr);
 
 // Fused kernel (kernels_fused.hip): the row march fed from the coefficient stream (DCT8 decoded by the
 // filter wave itself, other classes copied from the planes).  FusedSupported: frames it takes --

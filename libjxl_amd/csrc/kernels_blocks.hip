@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? JXLHIP_R_WAVES : 2) void k_t
 // --------------------------------------------------------------- launchers
 template <typename CT>
 static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells, const float* wc,
-                          const float* resample, hipStream_t* streams, int nstreams) {
+                          const float* resample, hipStream_t* streams, int nstreams, const FilterParams* emit) {
   const uint32_t units = cells / 64;
   const uint32_t grid_l = cells / 128 < 512u ? (cells / 128 ? cells / 128 : 1) : 512u;
   constexpr uint32_t kDct8PerWg = Dct8Geom<CT>::kPerWg;
@@ -1451,7 +1451,7 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     if (any({8, 9, 10, 11}) || (!f.mfma32 && any({5})))
       hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
   }
-  if (f.mfma32 && any({5})) LaunchMfma32(f, wl, cells, s1);
+  if (f.mfma32 && any({5})) LaunchMfma32(f, wl, cells, s1, emit);
   if (cells >= 256 && any({21, 22, 23, 24, 25, 26}))
     hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, s1, f, wl.list[kClsLarge],
                        wl.count + kClsLarge * kCounterPad, wc, resample);
@@ -1473,11 +1473,11 @@ void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float
 }
 
 void LaunchBlocks(const DevFrame& f, const WorkLists& wl, uint32_t cells, const float* wc,
-                  const float* resample, hipStream_t* streams, int nstreams) {
+                  const float* resample, hipStream_t* streams, int nstreams, const FilterParams* emit) {
   if (f.coeff_type == JXLHIP_COEFF_I16)
-    LaunchBlocksT<int16_t>(f, wl, cells, wc, resample, streams, nstreams);
+    LaunchBlocksT<int16_t>(f, wl, cells, wc, resample, streams, nstreams, emit);
   else
-    LaunchBlocksT<int32_t>(f, wl, cells, wc, resample, streams, nstreams);
+    LaunchBlocksT<int32_t>(f, wl, cells, wc, resample, streams, nstreams, emit);
 }
 
 }  // namespace jxlhip

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "blocks_common.h"
+#include "emit.h"
 
 namespace jxlhip {
 
@@ -68,10 +69,16 @@ struct Staged {
   float dc;  // lane l < 48: DC value (channel l / 16, row l / 4 % 4, column l % 4) of the varblock's 4x4 patch
 };
 
-template <typename CT>
+// EMIT: a frame made of DCT32X32 varblocks only, without loop filter, written as linear float RGB (BASELINE
+// configs[4]): the class kernel applies the opsin inverse itself and stores the pixels -- no XYB planes, no second
+// kernel.  Product 2 then runs with its operands swapped (A = product 1's accumulator, B = the constant table: the
+// same table, the accumulator layout is an A-operand layout as well), which leaves lane = pixel COLUMN and
+// register i = pixel row 4 h + i % 4 + 8 (i / 4): one 12-byte store per register, 32 lanes = 384 contiguous bytes
+// of an output row.
+template <typename CT, bool EMIT>
 __global__ __launch_bounds__(256, 2) void k_transform_mfma32(DevFrame f, const WorkItem* __restrict__ list,
                                                              const uint32_t* __restrict__ count,
-                                                             const float* __restrict__ bc) {
+                                                             const float* __restrict__ bc, FilterParams P) {
   constexpr int kVec = Staged<CT>::kVec;
   __shared__ float patch_lds[4][48];
   const uint32_t n = *count;
@@ -173,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_transform_mfma32(DevFrame f, const W
         }
       }
     };
+    v16f px[3];  // EMIT: the three channels' pixels
     float vy[16];
     {
       int32_t q[16];
@@ -207,13 +215,34 @@ __global__ __launch_bounds__(256, 2) void k_transform_mfma32(DevFrame f, const W
 #pragma unroll
       for (int kk = 15; kk >= 0; kk--) q = __builtin_amdgcn_mfma_f32_32x32x2f32(v[kk], b1[kk], q, 0, 0, 0);
       v16f p = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if constexpr (EMIT) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) p = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i], q[i], p, 0, 0, 0);
-      // lane (y = m, h): P[y][8 t + 4 h .. + 3] in registers 4 t .. 4 t + 3
+        for (int i = 0; i < 16; i++) p = __builtin_amdgcn_mfma_f32_32x32x2f32(q[i], a2[i], p, 0, 0, 0);
+        px[c] = p;
+      } else {
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        float* dst = TilePtr(f, c, hd.aby + (m >> 3), hd.abx + t) + (m & 7) * 8 + 4 * h;
-        *(float4*)dst = make_float4(p[4 * t], p[4 * t + 1], p[4 * t + 2], p[4 * t + 3]);
+        for (int i = 0; i < 16; i++) p = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i], q[i], p, 0, 0, 0);
+        // lane (y = m, h): P[y][8 t + 4 h .. + 3] in registers 4 t .. 4 t + 3
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          float* dst = TilePtr(f, c, hd.aby + (m >> 3), hd.abx + t) + (m & 7) * 8 + 4 * h;
+          *(float4*)dst = make_float4(p[4 * t], p[4 * t + 1], p[4 * t + 2], p[4 * t + 3]);
+        }
+      }
+    }
+    if constexpr (EMIT) {
+      // lane (x = m, h), register i: pixel (row 4 h + i % 4 + 8 (i / 4), column x) of the varblock
+      const int x = (int)hd.abx * 8 + m;
+      const int y0 = (int)hd.aby * 8 + 4 * h;
+      char* col = (char*)P.out + (size_t)x * 12;
+      typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int y = y0 + (i & 3) + 8 * (i >> 2);
+        float rgb[3];
+        XybToRgb(px[0][i], px[1][i], px[2][i], P, rgb);
+        if (x < (int)f.xsize && y >= (int)f.y0 && y < (int)f.y1)
+          __builtin_nontemporal_store(f3u{rgb[0], rgb[1], rgb[2]}, (f3u*)(col + (size_t)(y - (int)f.y0) * P.out_stride));
       }
     }
     cur = nxt;
@@ -240,17 +269,23 @@ void MfmaDct32Constants(float* host /* 2048 floats */) {
     }
 }
 
-void LaunchMfma32(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st) {
+void LaunchMfma32(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st, const FilterParams* emit) {
   const float* bc = f.mfma32;
   const int cls = kClsMedium0 + 7;  // DCT32X32 (kMediumStrategy[7] == 5)
   uint32_t grid = cells / 16 / 4 + 1;  // varblocks / 4 waves
   if (grid > 2048u) grid = 2048u;
-  if (f.coeff_type == JXLHIP_COEFF_I16)
-    hipLaunchKernelGGL((k_transform_mfma32<int16_t>), dim3(grid), dim3(256), 0, st, f, wl.list[cls],
-                       wl.count + cls * kCounterPad, bc);
-  else
-    hipLaunchKernelGGL((k_transform_mfma32<int32_t>), dim3(grid), dim3(256), 0, st, f, wl.list[cls],
-                       wl.count + cls * kCounterPad, bc);
+  const FilterParams none{};
+#define JXLHIP_MFMA(CT, E)                                                                                  \
+  hipLaunchKernelGGL((k_transform_mfma32<CT, E>), dim3(grid), dim3(256), 0, st, f, wl.list[cls],            \
+                     wl.count + cls * kCounterPad, bc, E ? *emit : none)
+  if (f.coeff_type == JXLHIP_COEFF_I16) {
+    if (emit) JXLHIP_MFMA(int16_t, true);
+    else JXLHIP_MFMA(int16_t, false);
+  } else {
+    if (emit) JXLHIP_MFMA(int32_t, true);
+    else JXLHIP_MFMA(int32_t, false);
+  }
+#undef JXLHIP_MFMA
 }
 
 }  // namespace jxlhip

@@ -109,6 +109,19 @@ def test_config4_8k_full_size(ref, mfma, monkeypatch):
         d.close()
 
 
+@pytest.mark.parametrize("coeff_type", [0, 1])
+def test_dct32_only_frame_written_by_the_class_kernel(ref, coeff_type):
+    """All-DCT32X32, no loop filter, float RGB: k_transform_mfma32<EMIT> writes the pixels itself (no planes, no
+    filter kernel).  A size whose last block column / row is clipped by the image (1020 x 508 = 128 x 64 blocks)."""
+    d = VarDctDecoder(0)
+    try:
+        kw = dict(coeff_type=1, quant_mul=2.0) if coeff_type else {}
+        run_case(d, ref, 1020, 508, mix=synth.MIX_DCT32, gab=False, epf_iters=0, intensity_target=1000.0, seed=32, **kw)
+        prof_ok = True
+    finally:
+        d.close()
+
+
 def test_config3_16k_striped_below_the_abi_full_size(ref):
     """BASELINE configs[3] at its FULL size (15360x8640 d1.0, Gaborish + EPF1), decoded the way --gpus N decodes it:
     jxlhip_create_multi splits the frame into stripes of AC-group rows (one per visible device; on a 1-GPU box
