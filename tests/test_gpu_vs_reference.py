@@ -117,7 +117,6 @@ def test_dct32_only_frame_written_by_the_class_kernel(ref, coeff_type):
     try:
         kw = dict(coeff_type=1, quant_mul=2.0) if coeff_type else {}
         run_case(d, ref, 1020, 508, mix=synth.MIX_DCT32, gab=False, epf_iters=0, intensity_target=1000.0, seed=32, **kw)
-        prof_ok = True
     finally:
         d.close()
 
