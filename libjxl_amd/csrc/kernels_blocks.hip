@@ -107,7 +107,11 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
 #pragma unroll
     for (int w = 0; w < 16; w++) n += wave_cls[w][tid];
     if (f.fused && tid == kClsDct8) n = 0;  // decoded by the fused kernel: no list
+#ifdef JXLHIP_ABL_PREPARE_NOATOMIC  // ablation build (timing only: lists are garbage): what do the contended atomics cost?
+    wg_base[tid] = (n && in_stripe && group_ok) ? blockIdx.x * 8u : 0;
+#else
     wg_base[tid] = (n && in_stripe && group_ok) ? atomicAdd(&wl.count[tid * kCounterPad], n) : 0;
+#endif
   }
   // sigma_quant of each varblock, scattered to the cells it covers
   if (with_sigma && first) {
