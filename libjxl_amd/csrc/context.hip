@@ -121,10 +121,11 @@ struct jxlhip_ctx {
                                  // 219 -> 193 us); on mixed frames the butterflies inside the merged launch win
                                  // (c3: blocks 95 -> 105 us with a separate MFMA launch).  JXLHIP_MFMA=0 / 1 forces.
   int fuse = -1;                 // the fused kernel (kernels_fused.hip) in jxlhip_decode_frame.  -1 (default): for
-                                 // frames of 24 Mpx and more -- a fused wave pays 16 halo rows and a fill per 8 rows,
-                                 // which only amortises when the frame gives every resident wave ~100 rows (8K d1.0:
-                                 // fused 89.9 vs 80 Gpx/s two-phase; 4K: 69.3 vs 80.3; 1024^2: 15.9 vs 18.3;
-                                 // profiles/r02_fused_rows_sweep.txt).  JXLHIP_FUSE=0 / 1 forces.
+                                 // frames of 12 Mpx and more -- a fused wave pays its halo rows and a fill per 8 rows,
+                                 // which only amortises when the frame gives every resident wave enough rows (8K d1.0:
+                                 // fused 89.9 vs 80 Gpx/s two-phase; 6144x3456: 88.5 vs 77.4; 5120x2880: 87.5 vs 82.2;
+                                 // 4K: 71.2 vs 80.3; 1024^2: 16.9 vs 18.3; profiles/r02_fused_rows_sweep*.txt,
+                                 // r02_fused_size_threshold.txt).  JXLHIP_FUSE=0 / 1 forces.
   uint2* cell_info = nullptr;    // fused mode: per-cell coefficient offset + quant / CfL word (k_prepare)
   size_t cell_info_items = 0;
   // profiling
@@ -1177,10 +1178,10 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   // Whole frame on this context, one band: the fused kernel decodes the DCT8 blocks inside the filter
   // march (kernels_fused.hip).  The split calls (jxlhip_decode_blocks / _filters) stay two-phase: a
   // stripe's halo rows must exist in the planes for its neighbours.
-  // auto: with a filter, frames of 24 Mpx and more (see jxlhip_ctx::fuse); without one the fused wave has no
+  // auto: with a filter, frames of 12 Mpx and more (see jxlhip_ctx::fuse); without one the fused wave has no
   // halo rows to pay for and wins at 4K as well (95.8 vs 83.4 Gpx/s); never when the caller's used_acs says the
   // frame has no DCT8 block -- then the slab is only a detour (configs[4]: 76.1 vs 79.6 Gpx/s)
-  const bool big = (uint64_t)f.xsize * f.ysize >= (24ull << 20) || (c->p.lf.gab == 0 && c->p.lf.epf_iters == 0);
+  const bool big = (uint64_t)f.xsize * f.ysize >= (12ull << 20) || (c->p.lf.gab == 0 && c->p.lf.epf_iters == 0);
   const bool has_dct8 = f.used_acs == 0 || (f.used_acs & 1u);
   // Packed outputs: the two-phase filter kernel has the formats djxl writes most (8-bit sRGB RGB / RGBA, 16-bit sRGB
   // RGB) fixed at compile time, the fused kernel only the general per-sample format path -- measured at 8K d1.0:
