@@ -1,6 +1,6 @@
-// kernels_filters_fast.hip -- phase 2 for the stage lists with at most one EPF
-// pass ([Gaborish] [EPF1] XYB->RGB: every stream below distance 1.5, i.e. the
-// BASELINE d1.0 configuration), written for the CDNA4 wavefront instead of LDS:
+// kernels_filters_fast.hip -- phase 2 as a register row march: [Gaborish] [EPF1] [EPF2] XYB->RGB (every
+// stream below distance ~3, i.e. the BASELINE d1.0 configuration; with three EPF iterations this kernel runs
+// the EPF1 + EPF2 + output part behind k_epf0, kernels_epf0.hip), written for the CDNA4 wavefront instead of LDS:
 //
 //   * one wave = 128 adjacent pixel COLUMNS (each lane owns an aligned PAIR of
 //     columns), marching down the rows of its band.  Two pixels per lane turn
@@ -43,7 +43,8 @@
 // mirrored Gaborish output (symmetric kernel, commutative pair sums), so halo
 // lanes/rows outside the image simply run on mirrored input; this kernel is
 // only used when no stage follows an EPF stage, where that identity is all
-// that is needed.  Other stage lists use the generic kernel (kernels_filters.hip).
+// that is needed.  Where EPF2 follows EPF1 the one out-of-image column / row it reads is the mirror = the edge pixel
+// itself (Lane::fix_*).  Frames narrower or lower than 16 px use the generic kernel (kernels_filters.hip).
 #include <stdlib.h>
 
 #include "filters_march.h"
