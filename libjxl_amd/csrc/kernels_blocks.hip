@@ -1294,14 +1294,14 @@ static_assert(kMediumStrategy[8] == 18 && kMediumStrategy[9] == 19 && kMediumStr
 // every class's lane-dependent invariants out of this loop.)
 template <int N, typename Body>
 __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const WorkLists& wl,
-                                             Body&& body, uint32_t first_wg = 0, uint32_t num_wgs = 0,
+                                             Body&& body, uint32_t wg_index, uint32_t num_wgs,
                                              bool skip_first = false) {
   uint32_t cnt[N];
 #pragma unroll
   for (int i = 0; i < N; i++) cnt[i] = wl.count[fam[i].cls * kCounterPad];
   if (skip_first) cnt[0] = 0;  // DCT32X32 on the matrix cores (kernels_mfma.hip)
-  if (num_wgs == 0) num_wgs = gridDim.x - first_wg;  // workgroups [first_wg, first_wg + num_wgs) share the family
-  for (uint32_t u = blockIdx.x - first_wg;; u += num_wgs) {
+  // workgroup wg_index of the num_wgs that share the family
+  for (uint32_t u = wg_index;; u += num_wgs) {
     const UnitPick pick = PickUnit(fam, cnt, u);
     if (pick.index < 0) return;
     body(pick.index, wl.list[pick.cls], pick.first, pick.n);
@@ -1323,7 +1323,8 @@ __global__ __launch_bounds__(192, sizeof(CT) == 2 ? 3 : 2) void k_transform_a(De
                    case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
                    default: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
                  }
-               });
+               },
+               blockIdx.x, gridDim.x);
 }
 
 template <typename CT>
@@ -1335,7 +1336,8 @@ __global__ __launch_bounds__(256) void k_transform_r16(DevFrame f, WorkLists wl)
                    case 1: RowLaneUnit<16, 8, 6, CT>(f, list, first, n); break;
                    default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
                  }
-               });
+               },
+               blockIdx.x, gridDim.x);
 }
 
 template <typename CT>
@@ -1350,7 +1352,7 @@ __global__ __launch_bounds__(256) void k_transform_r32(DevFrame f, WorkLists wl)
                    default: RowLaneUnit<8, 32, 9, CT>(f, list, first, n); break;
                  }
                },
-               0, 0, f.mfma32 != nullptr);
+               blockIdx.x, gridDim.x, f.mfma32 != nullptr);
 }
 
 // Both row-per-lane families in one launch, the (few, long, register-heavy) L = 32 units first:
@@ -1370,15 +1372,36 @@ static constexpr FamilyEntry kFamilyR[8] = {{kClsMedium0 + 7, 8},  {kClsMedium0 
 #endif
 template <typename CT>
 __global__ __launch_bounds__(256, sizeof(CT) == 2 ? JXLHIP_R_WAVES : 2) void k_transform_r(DevFrame f, WorkLists wl, uint32_t big_wgs,
-                                                                               uint32_t special_wgs, uint32_t r_wgs) {
+                                                                               uint32_t special_wgs, uint32_t r_wgs,
+                                                                               uint32_t dct8_wgs) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
-  // fused mode: DCT8 is decoded by the fused kernel, and what k_transform_8 would be left with -- the
-  // special 8x8 kinds -- rides at the head of this launch instead of being a latency-bound launch of its own
+  // The special 8x8 kinds ride at the head of this launch instead of being a latency-bound launch of their own
+  // (fused mode: DCT8 is decoded by the fused kernel; two-phase: the DCT8 rows ride here as well, below)
   if (blockIdx.x < special_wgs) {
     SpecialWorkgroup<CT>(f, wl, blockIdx.x);
     return;
   }
-  if (blockIdx.x < special_wgs + big_wgs) {
+  // Two-phase: the DCT8 workgroups (short, LDS-free, the bulk of a d1.0 frame) alternate with the persistent
+  // workgroups of the other classes in the dispatch order, so that the two kinds run side by side from the first
+  // wave on -- as two launches the second waits for the first's tail, which on frames of a few Mpx is most of it
+  // (1080p: blocks 39 -> ? us; the two-stream form pays ~40 us of fork / join events instead).
+  const uint32_t np = big_wgs + r_wgs;
+  const uint32_t i = blockIdx.x - special_wgs;
+  const uint32_t pairs = np < dct8_wgs ? np : dct8_wgs;
+  bool is_dct8;
+  uint32_t idx;
+  if (i < 2 * pairs) {
+    is_dct8 = (i & 1u) != 0;
+    idx = i >> 1;
+  } else {
+    is_dct8 = dct8_wgs > np;
+    idx = i - pairs;
+  }
+  if (is_dct8) {
+    Dct8Rows<CT>(f, wl.list[kClsDct8], wl.count[kClsDct8 * kCounterPad], idx);
+    return;
+  }
+  if (idx < big_wgs) {
     if (threadIdx.x >= 192) return;
     UnitDispatch(kFamilyA, wl,
                  [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
@@ -1388,7 +1411,7 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? JXLHIP_R_WAVES : 2) void k_t
                      default: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
                    }
                  },
-                 special_wgs, big_wgs);
+                 idx, big_wgs);
     return;
   }
   UnitDispatch(kFamilyR, wl,
@@ -1404,7 +1427,7 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? JXLHIP_R_WAVES : 2) void k_t
                    default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
                  }
                },
-               special_wgs + big_wgs, r_wgs, f.mfma32 != nullptr);
+               idx - big_wgs, r_wgs, f.mfma32 != nullptr);
 }
 
 // --------------------------------------------------------------- launchers
@@ -1430,8 +1453,8 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
   };
   const bool merged_r = any({4, 6, 7}) && (any({8, 9, 10, 11}) || (!f.mfma32 && any({5})));
   const bool have_big = any({18, 19, 20});
-  bool specials_in_r = false;
-  uint32_t grid_specials = 0;
+  bool specials_in_r = false, dct8_in_r = false;
+  uint32_t grid_specials = 0, grid_dct8 = 0;
   if (have_big && !merged_r)
     hipLaunchKernelGGL((k_transform_a<CT>), dim3(grid_a), dim3(192), 0, s1, f, wl);
   {
@@ -1440,15 +1463,20 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     const uint32_t bound_s = specials ? (cells / 64 + kNumSpecial) * 3 / 4 + 1 : 0;
     const uint32_t bound_8 = (any({0}) && !f.fused) ? (cells + kDct8PerWg - 1) / kDct8PerWg : 0;
     const uint32_t grid_8 = (bound_s > bound_8 ? bound_s : bound_8) + (specials ? kNumSpecial : 0);
-    specials_in_r = f.fused && merged_r && specials;
+    // merged_r: the single-block classes ride in k_transform_r's launch (specials at its head, DCT8 workgroups
+    // alternating with the other classes' persistent ones)
+    specials_in_r = merged_r && specials;
+    dct8_in_r = merged_r && !f.fused && bound_8 != 0;
     grid_specials = bound_s + kNumSpecial;
-    if (grid_8 && !specials_in_r) hipLaunchKernelGGL((k_transform_8<CT>), dim3(grid_8), dim3(256), 0, s0, f, wl);
+    grid_dct8 = bound_8;
+    if (grid_8 && !merged_r) hipLaunchKernelGGL((k_transform_8<CT>), dim3(grid_8), dim3(256), 0, s0, f, wl);
   }
   if (merged_r) {  // -10 us per 8K d1.0 frame against two launches, -15 us more with family A inside
     const uint32_t big_wgs = have_big ? (grid_a < 512u ? grid_a : 512u) : 0u;
     const uint32_t special_wgs = specials_in_r ? grid_specials : 0u;
-    hipLaunchKernelGGL((k_transform_r<CT>), dim3(special_wgs + big_wgs + grid_r16), dim3(256), 0, s0, f, wl, big_wgs,
-                       special_wgs, grid_r16);
+    const uint32_t dct8_wgs = dct8_in_r ? grid_dct8 : 0u;
+    hipLaunchKernelGGL((k_transform_r<CT>), dim3(special_wgs + big_wgs + grid_r16 + dct8_wgs), dim3(256), 0, s0, f, wl,
+                       big_wgs, special_wgs, grid_r16, dct8_wgs);
   } else {
     if (any({4, 6, 7}))
       hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
