@@ -318,6 +318,15 @@ JXLHIP_EXPORT int jxlhip_decode_frame_host(jxlhip_ctx* ctx, void* host_out,
                                            size_t out_stride,
                                            size_t out_plane_stride);
 
+/* The same into a context-owned PINNED host frame (grown on demand, reused by later frames, freed with the
+ * context; taken from the caller's JxlMemoryManager when there is one): returns its address and row stride in
+ * bytes once the pixels are there.  The source for a row consumer -- JxlDecoderSetImageOutCallback /
+ * JxlDecoderSetMultithreadedImageOutCallback (lib/include/jxl/decode.h:1040-1100; how WriteToOutputStage
+ * hands row runs to PixelCallback::run, lib/jxl/render_pipeline/stage_write.cc:662-700): the device-to-host
+ * transfer is one DMA into pinned memory and the callbacks then read it in place.  Interleaved outputs
+ * (JXLHIP_OUT_LINEAR_RGB_F32, JXLHIP_OUT_PACKED); valid until the next decode call on this context. */
+JXLHIP_EXPORT int jxlhip_decode_frame_pinned(jxlhip_ctx* ctx, const void** host_frame, size_t* stride);
+
 JXLHIP_EXPORT int jxlhip_sync(jxlhip_ctx* ctx);
 
 /* Debug/test taps on context-owned intermediates (device pointers).

@@ -224,7 +224,7 @@ EXPORTS = [
     "jxlhip_frame_begin", "jxlhip_frame_set_inputs", "jxlhip_upload_side_info",
     "jxlhip_submit_group", "jxlhip_decode_blocks", "jxlhip_halo_rows",
     "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_frame",
-    "jxlhip_decode_frame_host",
+    "jxlhip_decode_frame_host", "jxlhip_decode_frame_pinned",
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
     "jxlhip_profile_enable", "jxlhip_profile_read",
     "jxlhip_dequant_tables", "jxlhip_default_dequant_tables", "jxlhip_dequant_dc",
@@ -303,6 +303,7 @@ def load_library():
     L.jxlhip_decode_filters.argtypes = [vp, vp, sz, sz]
     L.jxlhip_decode_frame.argtypes = [vp, vp, sz, sz]
     L.jxlhip_decode_frame_host.argtypes = [vp, vp, sz, sz]
+    L.jxlhip_decode_frame_pinned.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlhip_sync.argtypes = [vp]
     L.jxlhip_export_xyb.argtypes = [vp, vp * 3, sz]
     L.jxlhip_get_sigma.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]

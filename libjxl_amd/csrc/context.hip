@@ -104,6 +104,8 @@ struct jxlhip_ctx {
   size_t dc_prec_bytes = 0;
   uint8_t* host_frame_dev = nullptr;  // jxlhip_decode_frame_host: the device frame in front of the D2H copy
   size_t host_frame_bytes = 0;
+  void* pinned_frame = nullptr;  // jxlhip_decode_frame_pinned: context-owned pinned host frame (StageAlloc)
+  size_t pinned_frame_bytes = 0;
   int32_t* qdc_dev = nullptr;  // jxlhip_decode_codestream: the quantized DC planes on their way to jxlhip_dequant_dc_groups
   size_t qdc_dev_items = 0;
   // transform-kernel fan-out (JXLHIP_BLOCK_STREAMS: 3 = one stream per family; default 1 = back to back on the
@@ -389,6 +391,7 @@ void jxlhip_destroy(jxlhip_ctx* c) {
     }
     if (c->stage[i]) StageFree(c, c->stage[i]);
   }
+  if (c->pinned_frame) StageFree(c, c->pinned_frame);
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
                   c->dc_tmp,     c->quant_enc,  c->dc_prec,      c->cell_info,
@@ -1252,6 +1255,33 @@ int jxlhip_decode_frame_host(jxlhip_ctx* c, void* host_out, size_t out_stride, s
     HIPCHK(c, hipMemcpy2DAsync((char*)host_out + pl * out_plane_stride * 4, host_row, c->host_frame_dev + pl * rows * dev_row,
                                dev_row, row_bytes, rows, hipMemcpyDeviceToHost, c->stream));
   return jxlhip_sync(c);
+}
+
+int jxlhip_decode_frame_pinned(jxlhip_ctx* c, const void** host_frame, size_t* stride) {
+  if (!c || !host_frame || !stride) return JXLHIP_ERR_INVALID_ARGUMENT;
+  const jxlhip_frame_params& p = c->p;
+  if (p.output_kind == JXLHIP_OUT_XYB_PLANAR) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "pinned frames are interleaved outputs");
+  const bool transposed = p.undo_orientation >= 5;
+  const size_t rows = transposed ? p.xsize : p.ysize;
+  const size_t cols = transposed ? p.ysize : p.xsize;
+  const size_t row_bytes = cols * (p.output_kind == JXLHIP_OUT_PACKED ? OutPixelBytes(c) : 12);
+  const size_t pitch = (row_bytes + 63) & ~(size_t)63;
+  if (rows * pitch > c->pinned_frame_bytes) {
+    if (c->pinned_frame) {
+      int rc0 = jxlhip_sync(c);  // nothing may still be writing the old frame
+      if (rc0) return rc0;
+      StageFree(c, c->pinned_frame);
+      c->pinned_frame = nullptr;
+      c->pinned_frame_bytes = 0;
+    }
+    if (StageAlloc(c, &c->pinned_frame, rows * pitch)) return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned frame of %zu bytes", rows * pitch);
+    c->pinned_frame_bytes = rows * pitch;
+  }
+  const int rc = jxlhip_decode_frame_host(c, c->pinned_frame, pitch, 0);
+  if (rc) return rc;
+  *host_frame = c->pinned_frame;
+  *stride = pitch;
+  return JXLHIP_OK;
 }
 
 int jxlhip_sync(jxlhip_ctx* c) {

@@ -182,6 +182,16 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   metadata.m.SetFloat32Samples();
   metadata.m.xyb_encoded = true;
   metadata.m.color_encoding = ColorEncoding::LinearSRGB(/*is_gray=*/false);
+  // JXR_ORIGINAL=srgb8 | srgb16: the stream DESCRIBES an 8- / 16-bit sRGB original (what cjxl writes for a PNG), so
+  // that JxlDecoder's default output is sRGB-encoded integer samples (tests/test_djxl.py); the pixels handed to the
+  // encoder stay linear either way (no CMS in this build)
+  if (const char* e = getenv("JXR_ORIGINAL")) {
+    if (!strcmp(e, "srgb8") || !strcmp(e, "srgb16")) {
+      metadata.m.SetUintSamples(!strcmp(e, "srgb8") ? 8 : 16);
+      metadata.m.color_encoding = ColorEncoding::SRGB(/*is_gray=*/false);
+    }
+  }
+  const ColorEncoding c_pixels = ColorEncoding::LinearSRGB(/*is_gray=*/false);
   JXL_RETURN_IF_ERROR(metadata.size.Set(xs, ys));
   // JXR_ORIENTATION=2..8: ImageMetadata::orientation of the written stream (tests of undo_orientation); the
   // FrameDecoder run below keeps the coded orientation, JxlDecoder (tests/test_seam.py) undoes it
@@ -193,7 +203,7 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   {
     JXL_ASSIGN_OR_RETURN(Image3F img, Image3F::Create(&mm, xs, ys));
     FillImage(&img, seed);
-    JXL_RETURN_IF_ERROR(ib.SetFromImage(std::move(img), metadata.m.color_encoding));
+    JXL_RETURN_IF_ERROR(ib.SetFromImage(std::move(img), c_pixels));
   }
   CompressParams cparams;
   cparams.butteraugli_distance = distance;

@@ -9,8 +9,9 @@
 // PassesDecoderState (dec_cache.h:86-229, passes_state.h:48-95) into the C ABI of include/jxl_hip.h, hands the
 // AC sections' BYTES to the product's entropy decoder on the decoder's own JxlParallelRunner
 // (jxlhip_ac_groups_decode_submit), runs the HIP back-end and copies the pixels into the caller's
-// JxlDecoderSetImageOutBuffer buffer.  Frames it does not take (Modular, extra channels, blending, callbacks,
-// integer output, colour management ...) fall through to the untouched CPU path.
+// JxlDecoderSetImageOutBuffer buffer or hands them row by row to the JxlDecoderSetImageOutCallback callback, in
+// whatever sample format the caller chose.  Frames it does not take (Modular, extra channels, blending, grey
+// outputs, a CMS stage, tone mapping ...) fall through to the untouched CPU path.
 //
 // FrameDecoder's members are private; a maintainer would add this as a member function.  Here the class
 // definition is taken as is and its access checks are lifted for this translation unit only.
@@ -98,14 +99,48 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   if (md.num_extra_channels != 0 || fh.custom_size_or_origin || fh.blending_info.mode != BlendMode::kReplace) return true;
   if (!fh.is_last || fh.CanBeReferenced() || fh.frame_type != FrameType::kRegularFrame) return true;
   if (fd->decoded_->IsJPEG()) return true;
-  if (mo.callback.IsPresent() || !mo.buffer || mo.format.data_type != JXL_TYPE_FLOAT ||
-      (mo.format.num_channels != 3 && mo.format.num_channels != 4) || mo.format.endianness == JXL_BIG_ENDIAN)
-    return true;
-  if (!oe.color_encoding_is_original || oe.color_encoding.Channels() != 3) return true;
+  // ---- the output: every ImageOutput WriteToOutputStage serves for a colour image without alpha
+  // (stage_write.cc:288-700) -- buffer or row callback, uint8 / uint16 / float16 / float, either endianness,
+  // RGB or RGBA (opaque alpha) -- which is what djxl asks for: image-out callback always
+  // (lib/extras/dec/jxl.h:64, jxl.cc:543-556), uint8 / uint16 for PNG / PPM, big-endian for PNM
+  // (lib/extras/enc/pnm.cc:118-132), float for PFM / NPY
+  const bool to_callback = mo.callback.IsPresent();
+  if (!to_callback && !mo.buffer) return true;
+  if (mo.format.num_channels != 3 && mo.format.num_channels != 4) return true;  // grey outputs: CPU path
+  uint32_t sample_type, bits = 32;
+  switch (mo.format.data_type) {
+    case JXL_TYPE_FLOAT: sample_type = JXLHIP_SAMPLE_F32; break;
+    case JXL_TYPE_FLOAT16: sample_type = JXLHIP_SAMPLE_F16; bits = 16; break;
+    case JXL_TYPE_UINT16: sample_type = JXLHIP_SAMPLE_U16; bits = static_cast<uint32_t>(mo.bits_per_sample); break;
+    case JXL_TYPE_UINT8: sample_type = JXLHIP_SAMPLE_U8; bits = static_cast<uint32_t>(mo.bits_per_sample); break;
+    default: return true;
+  }
+  if (sample_type == JXLHIP_SAMPLE_U8 && (bits < 1 || bits > 8)) return true;
+  if (sample_type == JXLHIP_SAMPLE_U16 && (bits < 1 || bits > 16)) return true;
+  // the stage list behind XYBStage must be FromLinearStage alone (dec_cache.cc:255-345): the output space is an
+  // RGB one, no CMS stage (the encoding is the original one or no CMS was given), no tone mapping
+  // (stage_tone_mapping.cc:33-60)
+  if (oe.color_encoding.Channels() != 3 || oe.color_encoding.GetColorSpace() == ColorSpace::kXYB) return true;
+  if (!oe.color_encoding_is_original && oe.cms_set) return true;
+  {
+    const auto& otf = oe.orig_color_encoding.Tf();
+    if (oe.desired_intensity_target != oe.orig_intensity_target &&
+        ((otf.IsPQ() && oe.desired_intensity_target < oe.orig_intensity_target) ||
+         (otf.IsHLG() && !oe.color_encoding.Tf().IsHLG())))
+      return true;
+  }
   uint32_t transfer;
-  if (oe.color_encoding.Tf().IsSRGB()) transfer = JXLHIP_TF_SRGB;
-  else if (oe.color_encoding.Tf().IsLinear()) transfer = JXLHIP_TF_LINEAR;
-  else return true;
+  float tf_param = 0.0f;
+  {  // GetFromLinearStage's choice (stage_from_linear.cc:161-182)
+    const auto& tf = oe.color_encoding.Tf();
+    if (tf.IsLinear()) transfer = JXLHIP_TF_LINEAR;
+    else if (tf.IsSRGB()) transfer = JXLHIP_TF_SRGB;
+    else if (tf.IsPQ()) transfer = JXLHIP_TF_PQ, tf_param = oe.orig_intensity_target;
+    else if (tf.IsHLG()) transfer = JXLHIP_TF_HLG, tf_param = oe.desired_intensity_target;
+    else if (tf.Is709()) transfer = JXLHIP_TF_709;
+    else if (tf.have_gamma || tf.IsDCI()) transfer = JXLHIP_TF_GAMMA, tf_param = oe.inverse_gamma;
+    else return true;
+  }
   for (size_t g = 0; g < dim.num_groups; g++)  // the whole frame, nothing drawn yet
     if (desired_num_ac_passes[g] != np || fd->decoded_passes_per_ac_group_[g] != 0) return true;
   jxlhip_ctx* ctx = Context();
@@ -143,9 +178,13 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   for (int i = 0; i < 3; i++) p.opsin_biases[i] = oe.opsin_params.opsin_biases[i];
   for (int i = 0; i < 9; i++) p.inverse_opsin_matrix[i] = oe.opsin_params.inverse_opsin_matrix[i * 4];
   p.out_format.transfer = transfer;
-  p.out_format.sample_type = JXLHIP_SAMPLE_F32;
+  p.out_format.sample_type = sample_type;
   p.out_format.num_channels = mo.format.num_channels;
-  p.out_format.bits_per_sample = 32;
+  p.out_format.bits_per_sample = bits;
+  // SwapEndianness (stage_write.cc:238-252): this host is little-endian
+  p.out_format.swap_endianness = (mo.format.endianness == JXL_BIG_ENDIAN && sample_type != JXLHIP_SAMPLE_U8) ? 1 : 0;
+  p.out_format.tf_param = tf_param;
+  for (int i = 0; i < 3; i++) p.out_format.luminances[i] = oe.luminances[i];
   p.used_acs = ds->used_acs;
 
   // ---- side info out of PassesSharedState, as dense arrays
@@ -229,7 +268,43 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     JXL_RETURN_IF_ERROR(check(rc, "AC groups"));
     break;
   }
-  JXL_RETURN_IF_ERROR(check(jxlhip_decode_frame_host(ctx, mo.buffer, mo.stride, 0), "decode_frame"));
+  if (!to_callback) {
+    JXL_RETURN_IF_ERROR(check(jxlhip_decode_frame_host(ctx, mo.buffer, mo.stride, 0), "decode_frame"));
+  } else {
+    // Row callback (JxlDecoderSetImageOutCallback / SetMultithreadedImageOutCallback, decode.cc:2655-2700): the
+    // frame arrives in the context's pinned host frame, already in display orientation, and is handed out as
+    // WriteToOutputStage does it (stage_write.cc:324-338,399-409,662-700): Init(num_threads, chunk) once, row
+    // runs of at most kChunkSize = 1024 pixels from the pool's threads with their thread id, destroy at the end.
+    const void* frame = nullptr;
+    size_t pitch = 0;
+    JXL_RETURN_IF_ERROR(check(jxlhip_decode_frame_pinned(ctx, &frame, &pitch), "decode_frame"));
+    const bool transposed = static_cast<uint32_t>(ds->undo_orientation) >= 5;
+    const size_t ow = transposed ? dim.ysize : dim.xsize, oh = transposed ? dim.xsize : dim.ysize;
+    const size_t px_bytes =
+        mo.format.num_channels * (sample_type == JXLHIP_SAMPLE_F32 ? 4 : sample_type == JXLHIP_SAMPLE_U8 ? 1 : 2);
+    constexpr size_t kChunk = 1024;
+    void* run_opaque = nullptr;
+    const PixelCallback& cb = mo.callback;
+    const auto init = [&](size_t num_threads) -> Status {
+      run_opaque = cb.Init(num_threads, kChunk);
+      return run_opaque != nullptr;
+    };
+    const auto row = [&](uint32_t y, size_t thread) -> Status {
+      const uint8_t* src = static_cast<const uint8_t*>(frame) + static_cast<size_t>(y) * pitch;
+      for (size_t x = 0; x < ow; x += kChunk) {
+        const size_t n = std::min(kChunk, ow - x);
+        cb.run(run_opaque, thread, x, y, n, src + x * px_bytes);
+      }
+      return true;
+    };
+    const Status ok = RunOnPool(fd->pool_, 0, static_cast<uint32_t>(oh), init, row, "jxlhip rows");
+    if (run_opaque) cb.destroy(run_opaque);
+    JXL_RETURN_IF_ERROR(ok);
+  }
+  if (getenv("JXLHIP_SEAM_VERBOSE"))
+    fprintf(stderr, "jxlhip seam: frame %zux%zu decoded on the HIP back-end (%s, %u-bit sample type %u, %u channels)\n",
+            static_cast<size_t>(dim.xsize), static_cast<size_t>(dim.ysize), to_callback ? "callback" : "buffer", bits,
+            sample_type, mo.format.num_channels);
   for (size_t g = 0; g < dim.num_groups; g++) {
     fd->decoded_passes_per_ac_group_[g] = static_cast<uint8_t>(np);
     for (size_t ps = 0; ps < np && !single; ps++) section_status[ac_group_sec[g][ps]] = FrameDecoder::SectionStatus::kDone;

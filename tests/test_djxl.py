@@ -1,0 +1,215 @@
+"""djxl, unmodified, on the HIP back-end (oracle/build_djxl.py).
+
+  oracle/_ref/djxl_ref : tools/djxl_main.cc + lib/extras on the reference decoder + lib/threads
+  oracle/_ref/djxl_hip : the SAME objects on libjxl_dec_hip.so (reference JxlDecoder + the three-statement seam ->
+                         libjxl_hip.so) + libjxl_threads_hip.so (the product's JxlParallelRunner)
+
+djxl always decodes through an image-out CALLBACK (lib/extras/dec/jxl.h:64, jxl.cc:543-556) and asks for the
+sample type of the file it writes: uint8 / big-endian uint16 for PPM (lib/extras/enc/pnm.cc:118-132), float for
+PFM / NPY.  The GPU suite runs both tools on the same .jxl files, compares the files they write (integer samples
+within 1 LSB and < 0.1 % different, float within 2e-5 of the range) and requires the seam's own log line: the frame
+went through the HIP back-end.  A conformance mini-corpus (tools/conformance_hip.py: libjxl's corpus layout and
+checks, tools/conformance/conformance.py:112-238) generated with djxl_ref is then run through djxl_hip.
+CPU suite: both tools build and agree bit for bit without a device (the seam declines: CPU path)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+TIGHT = 2e-5
+
+
+@pytest.fixture(scope="module")
+def tools(oracle):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import build_djxl
+    try:
+        ref, hip = build_djxl.build()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    return ref, hip
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not available")
+    oracle.ref_lib()
+    return oracle
+
+
+def stream(ref, original=None, orientation=None, **kw):
+    """A genuine VarDCT codestream from the reference encoder; `original` = what the stream says its original was."""
+    old = {k: os.environ.get(k) for k in ("JXR_ORIGINAL", "JXR_ORIENTATION")}
+    try:
+        for k, v in (("JXR_ORIGINAL", original), ("JXR_ORIENTATION", orientation)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        return ref.RealStream(**kw).codestream.tobytes()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def run(tool, args, verbose=False):
+    env = dict(os.environ)
+    if verbose:
+        env["JXLHIP_SEAM_VERBOSE"] = "1"
+    r = subprocess.run([tool] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (tool, args, r.stderr[-2000:])
+    return r.stderr
+
+
+def read_pnm(path):
+    """P6 / PF as djxl writes them (lib/extras/enc/pnm.cc): returns [H, W, 3]."""
+    b = open(path, "rb").read()
+    magic, rest = b.split(b"\n", 1)
+    dims, rest = rest.split(b"\n", 1)
+    mx, data = rest.split(b"\n", 1)
+    w, h = (int(v) for v in dims.split())
+    if magic == b"PF":
+        a = np.frombuffer(data, "<f4" if float(mx) < 0 else ">f4").reshape(h, w, 3)
+        return a[::-1]  # PFM rows run bottom to top
+    assert magic == b"P6"
+    dt = np.uint8 if int(mx) < 256 else np.dtype(">u2")
+    return np.frombuffer(data, dt).reshape(h, w, 3), int(mx)
+
+
+def compare(a_path, b_path, ext):
+    if ext == "npy":
+        a, b = np.load(a_path), np.load(b_path)
+    elif ext == "pfm":
+        a, b = read_pnm(a_path), read_pnm(b_path)
+    else:
+        (a, ma), (b, mb) = read_pnm(a_path), read_pnm(b_path)
+        assert ma == mb and a.shape == b.shape
+        d = np.abs(a.astype(np.int64) - b.astype(np.int64))
+        # the float pipeline in front differs by <= 2e-5: a sample may land on the other side of a rounding step
+        assert int(d.max()) <= (1 if ma < 256 else 2), int(d.max())
+        assert float((d != 0).mean()) < (1e-3 if ma < 256 else 0.5)
+        return
+    assert a.shape == b.shape and a.dtype == b.dtype
+    scale = max(1.0, float(np.abs(a).max()))
+    assert float(np.abs(a.astype(np.float64) - b).max()) / scale <= TIGHT
+
+
+def test_both_tools_agree_without_a_device(tools, ref, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: see the GPU suite")
+    djxl_ref, djxl_hip = tools
+    jxl = tmp_path / "a.jxl"
+    jxl.write_bytes(stream(ref, original="srgb8", seed=5, xsize=200, ysize=120, distance=1.0))
+    for ext in ("ppm", "pfm", "npy"):
+        run(djxl_ref, [str(jxl), str(tmp_path / f"r.{ext}")])
+        err = run(djxl_hip, [str(jxl), str(tmp_path / f"h.{ext}")], verbose=True)
+        assert "jxlhip seam" not in err  # no device: libjxl's own path
+        assert (tmp_path / f"r.{ext}").read_bytes() == (tmp_path / f"h.{ext}").read_bytes()
+
+
+def test_conformance_runner_agrees_with_the_reference_script(tools, ref, tmp_path):
+    """Build container only: the corpus tools/conformance_hip.py writes is accepted by libjxl's own conformance.py,
+    the corpus libjxl's generator.py writes is accepted by tools/conformance_hip.py, and both report a damaged
+    expectation."""
+    import conformance_hip as ch
+    script = "/root/reference/tools/conformance/conformance.py"
+    gen = "/root/reference/tools/conformance/generator.py"
+    if not os.path.exists(script):
+        pytest.skip("reference tree not present")
+    djxl_ref, _ = tools
+    jxl = tmp_path / "case_a.jxl"
+    jxl.write_bytes(stream(ref, original="srgb8", seed=9, xsize=200, ysize=120, distance=1.0))
+    env = dict(os.environ, LCMS2_LIB_PATH="/opt/conda/lib/liblcms2.so.2")
+    ours, theirs = str(tmp_path / "ours"), str(tmp_path / "theirs")
+    ch.generate(djxl_ref, ours, [str(jxl)], 1e-4, 2e-5)
+    subprocess.check_call([sys.executable, gen, "--decoder", djxl_ref, "--output", theirs, "--peak_error", "1e-4",
+                           "--rmse", "2e-5", str(jxl)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for name in ("corpus.txt", "case_a/test.json", "case_a/reference.icc", "case_a/reference_image.npy"):
+        assert open(os.path.join(ours, name), "rb").read() == open(os.path.join(theirs, name), "rb").read(), name
+    res, _ = ch.run_corpus(djxl_ref, theirs, log=lambda s: None)
+    assert res == {"case_a": True}
+    assert subprocess.run([sys.executable, script, "--decoder", djxl_ref, "--corpus", ours], env=env,
+                          capture_output=True).returncode == 0
+    # a damaged expectation (one pixel off by 1e-3) must fail in both
+    p = os.path.join(ours, "case_a", "reference_image.npy")
+    a = np.load(p)
+    a[0, 7, 9, 1] += 1e-3
+    np.save(p, a)
+    res, _ = ch.run_corpus(djxl_ref, ours, log=lambda s: None)
+    assert res == {"case_a": False}
+    assert subprocess.run([sys.executable, script, "--decoder", djxl_ref, "--corpus", ours], env=env,
+                          capture_output=True).returncode != 0
+
+
+CASES = [
+    # (stream parameters, what the stream says its original was, EXIF orientation, outputs)
+    (dict(seed=5, xsize=520, ysize=300, distance=1.0, speed_tier=3), "srgb8", None, ("ppm", "pfm", "npy")),
+    (dict(seed=6, xsize=776, ysize=520, distance=2.0, speed_tier=3, progressive=1), "srgb16", None, ("ppm", "npy")),
+    (dict(seed=7, xsize=640, ysize=264, distance=0.5, speed_tier=5), None, None, ("pfm", "npy")),
+    (dict(seed=8, xsize=2200, ysize=264, distance=1.5, speed_tier=4), "srgb8", 6, ("ppm", "pfm")),   # rotate 90
+    (dict(seed=9, xsize=200, ysize=120, distance=1.0, speed_tier=3), "srgb8", 3, ("ppm", "npy")),     # one section
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,original,orientation,outputs", CASES)
+def test_djxl_on_the_hip_backend_writes_what_djxl_writes(tools, ref, tmp_path, kw, original, orientation, outputs):
+    djxl_ref, djxl_hip = tools
+    jxl = tmp_path / "a.jxl"
+    jxl.write_bytes(stream(ref, original=original, orientation=orientation, **kw))
+    for ext in outputs:
+        for threads in (("--num_threads", "0"), ()) if ext == outputs[0] else ((),):
+            run(djxl_ref, [str(jxl), str(tmp_path / f"r.{ext}")] + list(threads))
+            err = run(djxl_hip, [str(jxl), str(tmp_path / f"h.{ext}")] + list(threads), verbose=True)
+            assert "jxlhip seam: frame" in err and "callback" in err, err[-1500:]
+            compare(str(tmp_path / f"r.{ext}"), str(tmp_path / f"h.{ext}"), ext)
+
+
+@pytest.mark.gpu
+def test_djxl_on_a_genuine_4k_stream(tools, tmp_path):
+    """tests/data/real_4k_d1.npz: 3840x2160 d1.0 written by the reference encoder (42 % 64x64, 32 % 32x32 ...)."""
+    djxl_ref, djxl_hip = tools
+    d = np.load(os.path.join(ROOT, "tests", "data", "real_4k_d1.npz"))
+    jxl = tmp_path / "real4k.jxl"
+    jxl.write_bytes(d["codestream"].tobytes())
+    for ext, extra in (("pfm", []), ("ppm", ["--bits_per_sample", "8"]), ("npy", [])):
+        run(djxl_ref, [str(jxl), str(tmp_path / f"r.{ext}")] + extra)
+        err = run(djxl_hip, [str(jxl), str(tmp_path / f"h.{ext}")] + extra, verbose=True)
+        assert "jxlhip seam: frame 3840x2160" in err, err[-1500:]
+        compare(str(tmp_path / f"r.{ext}"), str(tmp_path / f"h.{ext}"), ext)
+
+
+@pytest.mark.gpu
+def test_conformance_mini_corpus_through_djxl_hip(tools, ref, tmp_path):
+    """Expectations = the reference decoder's float pixels (djxl_ref -> reference_image.npy, reference.icc,
+    test.json with rms_error 2e-5 / peak_error 1e-4: tighter than any threshold of the ISO/IEC 18181-3 corpus, which
+    is not available offline); decoder under test = djxl_hip; every test must pass AND have run on the device."""
+    import conformance_hip as ch
+    djxl_ref, djxl_hip = tools
+    inputs = []
+    for i, (kw, original, orientation, _) in enumerate(CASES):
+        p = tmp_path / f"case{i}_{kw['xsize']}x{kw['ysize']}.jxl"
+        p.write_bytes(stream(ref, original=original, orientation=orientation, **kw))
+        inputs.append(str(p))
+    p = tmp_path / "real4k.jxl"
+    p.write_bytes(np.load(os.path.join(ROOT, "tests", "data", "real_4k_d1.npz"))["codestream"].tobytes())
+    inputs.append(str(p))
+    corpus = str(tmp_path / "corpus")
+    ch.generate(djxl_ref, corpus, inputs, peak_error=1e-4, rmse=2e-5)
+    log = []
+    res, errs = ch.run_corpus(djxl_hip, corpus, log=log.append, env=dict(os.environ, JXLHIP_SEAM_VERBOSE="1"))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "conformance_mini_corpus.log"), "w").write("\n".join(log) + "\n")
+    assert len(res) == len(inputs) and all(res.values()), (res, log[-20:])
+    for tid, err in errs.items():
+        assert "jxlhip seam: frame" in err, (tid, err[-800:])
