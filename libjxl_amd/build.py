@@ -12,7 +12,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 LIB_SOURCES = ["context.hip", "kernels_blocks.hip", "kernels_filters.hip", "kernels_filters_fast.hip",
-               "kernels_fused.hip", "kernels_fused_b.hip", "kernels_mfma.hip", "kernels_epf0.hip", "kernels_tables.hip", "entropy.cc"]
+               "kernels_fused.hip", "kernels_fused_b.hip", "kernels_fused_pc.hip", "kernels_mfma.hip", "kernels_epf0.hip", "kernels_tables.hip", "entropy.cc"]
 RUNNER_SOURCES = ["runner.cc"]
 
 
@@ -35,7 +35,7 @@ def _stale(target, sources):
 def _compile(src):
     obj = os.path.join(BUILD, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    extra = [os.path.join(CSRC, "kernels_fused.hip")] if src == "kernels_fused_b.hip" else []  # it #includes it
+    extra = [os.path.join(CSRC, "kernels_fused.hip")] if src in ("kernels_fused_b.hip", "kernels_fused_pc.hip") else []  # they #include it
     if _stale(obj, [path] + extra + _deps()):
         lang = ["-x", "hip"] if src.endswith(".hip") else []
         cmd = [HIPCC] + FLAGS + lang + ["-c", path, "-o", obj]

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <new>
 #include <string.h>
 
 #include <algorithm>
@@ -45,7 +46,7 @@ struct jxlhip_ctx {
   std::vector<size_t> halo_floats;
   std::vector<uint8_t*> stripe_out;                    // per child: its output stripe when the frame goes to another device / the host
   std::vector<size_t> stripe_out_bytes;
-  std::vector<hipEvent_t> ev_blocks, ev_halo[2], ev_done;
+  std::vector<hipEvent_t> ev_halo[2], ev_pull[2], ev_done;
   JxlMemoryManagerHip mm{};                            // jxlhip_create_ex / _multi: who allocated this object
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -86,6 +87,7 @@ struct jxlhip_ctx {
   jxlhip_frame_inputs up_inputs{};
   hipStream_t pool[kPoolStreams] = {nullptr};
   hipEvent_t pool_ev[kPoolStreams] = {nullptr};
+  hipEvent_t frame_ev = nullptr;  // jxlhip_frame_begin: "everything queued for the previous frame", see there
   bool pool_dirty[kPoolStreams] = {false};
   std::mutex pool_mu;
   uint32_t pool_next = 0;
@@ -335,7 +337,8 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
         hipEventCreateWithFlags(&c->bev[i], hipEventDisableTiming) != hipSuccess)
       return fail(JXLHIP_ERR_HIP);
   }
-  if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess)
+  if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->frame_ev, hipEventDisableTiming) != hipSuccess)
     return fail(JXLHIP_ERR_HIP);
   if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kCountStride * kMaxBands) != hipSuccess ||
       hipMalloc((void**)&c->error_flag, sizeof(int32_t) * 2) != hipSuccess ||
@@ -384,6 +387,7 @@ void jxlhip_destroy(jxlhip_ctx* c) {
     if (c->bev[i]) (void)hipEventDestroy(c->bev[i]);
   }
   if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+  if (c->frame_ev) (void)hipEventDestroy(c->frame_ev);
   for (int i = 0; i < kStageSlots; i++) {
     if (c->stage_ev[i]) {
       if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
@@ -553,6 +557,12 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
     fp.dither_xs = fx ? -1 : 1;
     fp.dither_y0 = fy ? (int32_t)p->ysize - 1 : 0;
     fp.dither_ys = fy ? -1 : 1;
+  }
+  // Frames may follow each other without a jxlhip_sync: the group uploads of THIS frame travel on the pool
+  // streams into the same upload buffers the previous frame's kernels (main stream) may still be reading.
+  if (c->up_coeffs[0]) {
+    HIPCHK(c, hipEventRecord(c->frame_ev, c->stream));
+    for (int i = 0; i < kPoolStreams; i++) HIPCHK(c, hipStreamWaitEvent(c->pool[i], c->frame_ev, 0));
   }
   c->fp = fp;
   c->f = f;

@@ -30,6 +30,10 @@
 #include "blocks_common.h"
 #include "filters_march.h"
 
+#ifndef JXLHIP_FUSED_PART
+#define JXLHIP_FUSED_PART 0
+#endif
+
 namespace jxlhip {
 
 namespace {
@@ -111,11 +115,9 @@ __device__ __forceinline__ void DmaPlaneRows(FrameArgs fa, LdsF* slab, const Nex
 // IDCT, two ds_write_b128 per channel.  nb: block row (inside the frame), bc0: block column of slab
 // column 0 (-1 at the left edge; cells outside the frame are skipped: no lane reads their columns).
 template <typename CT>
-__device__ __forceinline__ void FinishSlab(FrameArgs fa, WaveLds* w, const NextRow& n, int bc0, int first_plane_k) {
+__device__ __forceinline__ void FinishSlab(FrameArgs fa, LdsF* slab, LdsU* list, const NextRow& n, int bc0, int first_plane_k) {
   const FrameArgs f = Fresh(fa);
   const int lane = threadIdx.x & 63;
-  LdsF* slab = (LdsF*)w->slab;
-  LdsU* list = (LdsU*)w->list;
   const int nb = n.nb;
   // every row of the previous block row has been read (this wave's own ds_write stay in order behind
   // the reads; the DMA writes come through the vector memory path: wait for the reads explicitly)
@@ -275,7 +277,7 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
   NextRow nx;
   NextRowRequest(fa, nx, GroupBlockRow(r_first, nb_last), bc0);
   NextRowMasks(fa, nx, bc0);
-  FinishSlab<CT>(fa, w, nx, bc0, 0);
+  FinishSlab<CT>(fa, slab, (LdsU*)w->list, nx, bc0, 0);
 #define JXLHIP_FSTEP(K)                                                                                     \
   Step<GAB, EPF, OUTK, FMT, K, EDGE, 0, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk,      \
                                                   inv_sigma_blk2, out_row, KC, slab_y0, sigma_pre, sigma_prev); \
@@ -300,7 +302,7 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
     DmaPlaneRows(fa, slab, nx, bc0, 1);
     if constexpr (HX >= 2) { JXLHIP_FSTEP(6); }
     JXLHIP_FSTEP(7);
-    FinishSlab<CT>(fa, w, nx, bc0, 2);
+    FinishSlab<CT>(fa, slab, (LdsU*)w->list, nx, bc0, 2);
   }
   int r = HX ? y_begin : r_first;
   for (; r_last - r >= HX; r += 8) {  // whole groups (HX = 0: r <= r_last)
@@ -332,7 +334,7 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
     JXLHIP_FSTEP(6);
     DmaPlaneRows(fa, slab, nx, bc0, 2);
     JXLHIP_FSTEP(7);
-    if (more) FinishSlab<CT>(fa, w, nx, bc0, 3);
+    if (more) FinishSlab<CT>(fa, slab, (LdsU*)w->list, nx, bc0, 3);
   }
   if (HX > 0 && r <= r_last) {  // the first HX rows of the block row below (y_end a multiple of 8)
     const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
@@ -351,6 +353,274 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
   }
 #undef JXLHIP_FSTEP
 }
+
+#if JXLHIP_FUSED_PART == 2
+// ------------------------------------------------------------------------------------------------
+// k_fused_pc: the same window march with the two halves of the work on two WAVES of a workgroup.
+//
+// On gfx9 (gfx950 included) a wave has ONE counter, vmcnt, for its vector-memory loads AND stores, and it
+// retires in issue order: waiting for a load that was issued behind N output stores waits for the write
+// acknowledgements of those N stores first.  The single-wave kernel above waits like that once or twice per
+// block row (the inv_sigma load, the vmcnt(0) that ends a fill) -- every group of 8 rows pays the latency of its
+// own output stores on top of its loads, and the fill can only start when the march has let go of the slab.
+// Here
+//   wave 0 (march)  : reads its rows and its inv_sigma values from LDS, computes, stores pixels.  It issues NO
+//                     vector-memory load, so it never waits on vmcnt: the stores just queue.
+//   wave 1 (produce): fills block row i+1 into the other half of a double-buffered slab (cell info, LDS-DMA of
+//                     the plane cells, in-wave DCT8 decode, inv_sigma row) while wave 0 marches over block row i.
+//                     It issues no store, so its vmcnt waits cover loads only.
+// One s_barrier per block row joins the two (fill(i) done / march(i-1) done).  Workgroup = 128 threads = one
+// window; six workgroups per CU (three waves per SIMD by registers, 24.7 KB of LDS each).
+struct __attribute__((aligned(16))) StripLds {
+  float slab[2][3 * kSlabPlaneFloats];  // [buffer][channel][row 0..7][column 0..127]
+  float sigma[2][16];                   // [buffer][cell]: inv_sigma of the block row's 16 cells (columns clamped into the frame)
+  uint32_t list[16 * 4];                // producer scratch: the DCT8 cells of the block row being filled
+};
+
+// groups of 8 rows a window chunk [y_begin, y_end) walks over: [head (HX rows of the block row above)] + whole
+// groups + [tail (HX rows of the block row below)]; group i starts at image row r_first + 8 i
+template <int HX>
+__device__ __forceinline__ int PcGroups(int y_begin, int y_end) {
+  const int whole = (y_end - y_begin + 7) >> 3;
+  const bool tail = HX > 0 && y_begin + 8 * whole <= y_end + HX - 1;
+  return (HX > 0 ? 1 : 0) + whole + (tail ? 1 : 0);
+}
+
+__device__ __forceinline__ void PcBarrierProducer() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void PcBarrierMarch() {  // no vmcnt: the output stores stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int HX, typename CT>
+__device__ __forceinline__ void ProducePC(FrameArgs fa, StripLds* w, int bc0, int y_begin, int y_end, int nb_last) {
+  const int lane = threadIdx.x & 63;
+  const int r_first = HX ? y_begin - 8 : y_begin;
+  const int G = PcGroups<HX>(y_begin, y_end);
+  auto sigma_request = [&](int nb) -> float {
+    const FrameArgs f = Fresh(fa);
+    const int xsb = (int)f->xsb;
+    int col = bc0 + (lane & 15);
+    col = col < 0 ? 0 : (col >= xsb ? xsb - 1 : col);
+    return lane < 16 ? f->inv_sigma[(size_t)nb * xsb + col] : 0.0f;
+  };
+  NextRow nx;
+  int nb = GroupBlockRow(r_first, nb_last);
+  NextRowRequest(fa, nx, nb, bc0);
+  float sg = sigma_request(nb);
+  for (int i = 0; i < G; i++) {
+    NextRowMasks(fa, nx, bc0);  // needs the cell info: the first wait of this fill
+    const NextRow cur = nx;
+    const float sg_cur = sg;
+    if (i + 1 < G) {  // the next block row's cell info / sigma travel while this one is decoded
+      nb = GroupBlockRow(r_first + 8 * (i + 1), nb_last);
+      NextRowRequest(fa, nx, nb, bc0);
+      sg = sigma_request(nb);
+    }
+    LdsF* slab = (LdsF*)w->slab[i & 1];
+    FinishSlab<CT>(fa, slab, (LdsU*)w->list, cur, bc0, 0);  // four plane row pairs by LDS-DMA + the DCT8 cells; ends on vmcnt(0)
+    if (lane < 16) ((LdsF*)w->sigma[i & 1])[lane] = sg_cur;
+    PcBarrierProducer();
+  }
+}
+
+template <int GAB, int EPF, int OUTK, int FMT, bool EDGE>
+__device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P, Lane& L, StripLds* w, int bc0,
+                                        int y_begin, int y_end) {
+  constexpr int HX = MarchGeom<GAB, EPF>::HX;
+  const int H = (int)f.ysize;
+  const int r_first = HX ? y_begin - 8 : y_begin;
+  const int r_last = y_end + HX - 1;
+  const int nb_last = (H - 1) >> 3;
+  const int G = PcGroups<HX>(y_begin, y_end);
+  State s;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) s.x[c][k] = v2f{0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      s.hs[c][k] = v2f{0.0f, 0.0f};
+      s.g[c][k] = v2f{0.0f, 0.0f};
+      s.e[c][k] = v2f{0.0f, 0.0f};
+    }
+    s.du[k] = v2f{0.0f, 0.0f};
+    s.dl[k] = v2f{0.0f, 0.0f};
+    s.pv[k] = v2f{0.0f, 0.0f};
+    s.ph[k] = v2f{0.0f, 0.0f};
+    s.dv[k] = v2f{0.0f, 0.0f};
+  }
+  float inv_sigma_blk = -1.0f, inv_sigma_blk2 = -1.0f;
+  float sigma_last = -1.0f;
+  const XybConsts KC = MakeXybConsts(P);
+  const size_t out_row_bytes = OUTK == JXLHIP_OUT_XYB_PLANAR ? P.out_stride * 4 : P.out_stride;
+  char* out_row = (char*)P.out + (ptrdiff_t)(r_first - HX - (int)f.y0) * (ptrdiff_t)out_row_bytes;
+  const float __attribute__((address_space(3)))* const slab0 = L.slab;
+  // the lane's cell inside the window, for the inv_sigma row the producer leaves in LDS
+  const LdsF* sig0 = (const LdsF*)w->sigma[0] + ((int)(L.sx4 >> 2) - bc0);
+  int i = 0;
+  auto enter_group = [&](int g) -> float {  // after the barrier that publishes buffer g & 1
+    L.slab = slab0 + (g & 1) * (3 * kSlabPlaneFloats);
+    return EPF ? sig0[(g & 1) * 16] : 0.0f;
+  };
+#define JXLHIP_PSTEP(K)                                                                                     \
+  Step<GAB, EPF, OUTK, FMT, K, EDGE, 0, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk,      \
+                                                  inv_sigma_blk2, out_row, KC, slab_y0, sigma_pre, sigma_prev); \
+  out_row += out_row_bytes
+  PcBarrierMarch();  // fill(0)
+  if constexpr (HX > 0) {  // the last HX rows of the block row above
+    const int r = r_first;
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    const float sigma_prev = sigma_last;
+    const float sigma_pre = enter_group(i);
+    sigma_last = sigma_pre;
+    {
+      const int row0 = Mirror1(r + 8 - HX, H) - slab_y0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][8 - HX] = LdsPair<EDGE>(L, c, row0);
+    }
+    out_row += (8 - HX) * out_row_bytes;
+    if constexpr (HX >= 4) { JXLHIP_PSTEP(4); }
+    if constexpr (HX >= 3) { JXLHIP_PSTEP(5); }
+    if constexpr (HX >= 2) { JXLHIP_PSTEP(6); }
+    JXLHIP_PSTEP(7);
+    i++;
+    PcBarrierMarch();  // a whole group always follows
+  }
+  int r = HX ? y_begin : r_first;
+  for (; r_last - r >= HX; r += 8) {
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    const float sigma_prev = sigma_last;
+    const float sigma_pre = enter_group(i);
+    sigma_last = sigma_pre;
+    {
+      const int row0 = Mirror1(r, H) - slab_y0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
+    }
+    JXLHIP_PSTEP(0);
+    JXLHIP_PSTEP(1);
+    JXLHIP_PSTEP(2);
+    JXLHIP_PSTEP(3);
+    JXLHIP_PSTEP(4);
+    JXLHIP_PSTEP(5);
+    JXLHIP_PSTEP(6);
+    JXLHIP_PSTEP(7);
+    i++;
+    if (i < G) PcBarrierMarch();
+  }
+  if (HX > 0 && r <= r_last) {  // the first HX rows of the block row below
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    const float sigma_prev = sigma_last;
+    const float sigma_pre = enter_group(i);
+    sigma_last = sigma_pre;
+    {
+      const int row0 = Mirror1(r, H) - slab_y0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
+    }
+    JXLHIP_PSTEP(0);
+    if constexpr (HX >= 2) { JXLHIP_PSTEP(1); }
+    if constexpr (HX >= 3) { JXLHIP_PSTEP(2); }
+    if constexpr (HX >= 4) { JXLHIP_PSTEP(3); }
+  }
+#undef JXLHIP_PSTEP
+}
+
+// blockIdx.x is dispatched round-robin over the 8 XCDs: logical workgroup = (xcd, slot) -> xcd * per + slot, so
+// that an XCD's L2 sees neighbouring windows of the same rows (they share two block columns of coefficients and
+// plane tiles); the grid is padded to a multiple of 8
+template <int GAB, int EPF, int OUTK, int FMT, typename CT>
+__global__ __launch_bounds__(128, 3) void k_fused_pc(DevFrame f, FilterParams P, int RH, int strips, int nwg) {
+  __shared__ StripLds lds;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float __attribute__((address_space(3)))* dither_lds = nullptr;
+  if constexpr (OUTK == JXLHIP_OUT_PACKED) {
+    __shared__ float s_dither[1024];
+    if (P.fmt.sample_type == JXLHIP_SAMPLE_U8) {  // uniform
+      for (int i = threadIdx.x; i < 1024; i += 128) s_dither[i] = P.dither[i];
+      __syncthreads();
+    }
+    dither_lds = (const float __attribute__((address_space(3)))*)s_dither;
+  }
+  const int per = (int)gridDim.x >> 3;
+  const int logical = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (logical >= nwg) return;
+  const int strip = logical % strips, chunk = logical / strips;
+  const int W = (int)f.xsize;
+  const int x_first = strip * kFusedUse;
+  const int y_begin = (int)f.fy0 + chunk * RH;
+  const int y_end = min(y_begin + RH, (int)f.fy1);
+  if (x_first >= W || y_begin >= y_end) return;  // (both waves)
+  const int x0 = x_first - kFusedHalo;
+  const int bc0 = x0 >> 3;
+  const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  if (wave == 1) {
+    ProducePC<MarchGeom<GAB, EPF>::HX, CT>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
+    return;
+  }
+  Lane L;
+  L.gx = x0 + 2 * lane;
+  L.dither = dither_lds;
+  const int m0 = MirrorF(L.gx, W), m1 = MirrorF(L.gx + 1, W);
+  int base = (m0 & ~1) - x0;
+  base = base < 0 ? 0 : (base > kSlabCols - 2 ? kSlabCols - 2 : base);
+  L.sel0 = m0 & 1;
+  L.sel1 = m1 & 1;
+  L.byte_off = 0;
+  L.slab = (const float __attribute__((address_space(3)))*)lds.slab[0] + base;
+  const bool edge = x0 < 0 || x0 + kSlabCols > W;
+  const bool lane_in = lane >= kFusedHalo / 2 && lane < 64 - kFusedHalo / 2;
+  L.out0 = lane_in && L.gx < W;
+  L.out1 = lane_in && L.gx + 1 < W;
+  const int gxc = L.gx < 0 ? 0 : (L.gx >= W ? W - 1 : L.gx);
+  L.sx4 = (uint32_t)(gxc >> 3) * 4u;
+  L.out_off = (uint32_t)(L.gx < 0 ? 0 : L.gx) * (OUTK == JXLHIP_OUT_LINEAR_RGB_F32 ? 12u : 4u);
+  const int ix = gxc & 7;
+  L.mul = v2f{ix == 0 ? P.bsm[1] : P.sm[1], ix == 6 ? P.bsm[1] : P.sm[1]};
+  L.mul2 = v2f{ix == 0 ? P.bsm[2] : P.sm[2], ix == 6 ? P.bsm[2] : P.sm[2]};
+  L.fix_left = L.gx == -2;
+  L.fix_right_even = L.gx == W;
+  L.fix_right_odd = L.gx == W - 1;
+  if (edge) MarchPC<GAB, EPF, OUTK, FMT, true>(f, P, L, &lds, bc0, y_begin, y_end);
+  else MarchPC<GAB, EPF, OUTK, FMT, false>(f, P, L, &lds, bc0, y_begin, y_end);
+}
+
+// rows per window chunk: a multiple of 8 that fills whole generations of resident workgroups (6 per CU)
+int FusedRowsPC(unsigned strips, unsigned rows) {
+  const char* e = getenv("JXLHIP_FUSED_PC_RH");  // experiments / tests: rows per window chunk
+  const int forced = e ? atoi(e) : 0;
+  if (forced > 0) return (forced + 7) & ~7;
+  const unsigned resident = 256u * 6u;
+  int best = 64;
+  double best_cost = 1e30;
+  for (int rh = 16; rh <= 1024; rh += 8) {
+    const unsigned wgs = strips * ((rows + rh - 1) / rh);
+    const unsigned gens = (wgs + resident - 1) / resident;
+    const double cost = (double)gens * (rh + 6 + 16);  // 2 x HX marched rows + two more block-row fills per chunk
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = rh;
+    }
+  }
+  return best;
+}
+
+template <int GAB, int EPF, int OUTK, int FMT = -1>
+void LaunchFusedPcT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
+  const unsigned strips = (f.xsize + kFusedUse - 1) / kFusedUse;
+  const int RH = FusedRowsPC(strips, f.fy1 - f.fy0);
+  const unsigned nwg = strips * ((f.fy1 - f.fy0 + RH - 1) / RH);
+  const dim3 grid((nwg + 7) & ~7u);
+  if (f.coeff_type == JXLHIP_COEFF_I16)
+    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int16_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg);
+  else
+    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int32_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg);
+}
+#endif  // JXLHIP_FUSED_PART == 2
 
 #ifndef JXLHIP_FUSED_WAVES
 #define JXLHIP_FUSED_WAVES 3
@@ -448,10 +718,9 @@ void LaunchFusedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
 // The instantiations are spread over two translation units (this file compiles for minutes): kernels_fused.hip
 // itself (JXLHIP_FUSED_PART 0: the entry points + the stage lists without EPF1 alone) and kernels_fused_b.hip
 // (PART 1, which includes this file: EPF1 with and without Gaborish -- the BASELINE list).
-#ifndef JXLHIP_FUSED_PART
-#define JXLHIP_FUSED_PART 0
-#endif
 bool LaunchFusedB(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st);
+// kernels_fused_pc.hip (PART 2): the producer / consumer form; false = no instantiation for this stage list / output
+bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st);
 
 #if JXLHIP_FUSED_PART == 0
 // Frames the fused kernel takes (decided before k_prepare: it routes the DCT8 blocks).
@@ -479,10 +748,31 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) 
     else LaunchFusedT<G, E, 2>(f, p, st);                       \
     return true;                                                \
   }
-#if JXLHIP_FUSED_PART == 0
+#ifndef JXLHIP_FUSED_PC_DEFAULT
+#define JXLHIP_FUSED_PC_DEFAULT 0
+#endif
+#if JXLHIP_FUSED_PART == 2
+bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st) {
+  if (output_kind != JXLHIP_OUT_LINEAR_RGB_F32) return false;
+  if (gab == 1 && epf_iters == 1) {
+    LaunchFusedPcT<1, 1, 1>(f, p, st);
+    return true;
+  }
+  if (gab == 0 && epf_iters == 0) {
+    LaunchFusedPcT<0, 0, 1>(f, p, st);
+    return true;
+  }
+  return false;
+}
+#elif JXLHIP_FUSED_PART == 0
 bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,
                  hipStream_t st) {
   if (!FusedSupported(f, gab, epf_iters, output_kind)) return false;
+  {
+    const char* e = getenv("JXLHIP_FUSED_PC");  // read per launch: the tests switch it
+    const int pc = e ? atoi(e) : JXLHIP_FUSED_PC_DEFAULT;
+    if (pc && LaunchFusedPC(f, p, gab, epf_iters, output_kind, st)) return true;
+  }
 #ifdef JXLHIP_FUSED_LEAN  // experiment builds (tools/build_variant.py): the BASELINE stage list only, seconds to compile
   if (gab == 1 && epf_iters == 1 && output_kind == 1 && f.coeff_type == JXLHIP_COEFF_I16) {
     const unsigned strips = (f.xsize + kFusedUse - 1) / kFusedUse;
@@ -500,7 +790,7 @@ bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iter
   return LaunchFusedB(f, p, gab, epf_iters, output_kind, st);
 #endif
 }
-#else
+#elif JXLHIP_FUSED_PART == 1
 bool LaunchFusedB(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st) {
 #ifndef JXLHIP_FUSED_LEAN
   JXLHIP_FUSED(0, 1)

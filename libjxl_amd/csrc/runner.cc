@@ -185,7 +185,13 @@ struct ResizableRunner {
     }
   }
   void WorkerMain(size_t id) {
-    uint64_t seen = 0;
+    // a worker created by a later SetThreads starts from the CURRENT epoch: runs that happened before it
+    // existed are not its to join (it was never counted in `running`)
+    uint64_t seen;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      seen = epoch;
+    }
     for (;;) {
       {
         std::unique_lock<std::mutex> lock(mu);
@@ -249,6 +255,7 @@ JxlParallelRetCode JxlResizableParallelRunner(void* runner_opaque, void* jpegxl_
   r->Drain(0);
   std::unique_lock<std::mutex> lock(r->mu);
   r->cv_done.wait(lock, [&] { return r->running == 0; });
+  r->participants = 0;  // nobody may join this run any more (a worker that had not woken up yet stays asleep)
   return JXL_PARALLEL_RET_SUCCESS;
 }
 

@@ -88,3 +88,64 @@ def test_multi_context_refuses_what_it_does_not_do():
         L.jxlhip_destroy(ctx)
     bad = (C.c_int * 1)(99)
     assert L.jxlhip_create_multi(bad, 1, None, C.byref(ctx)) == -1
+
+
+def _upload(L, ctx, params, t, table_host):
+    p = abi.make_params(params)
+    assert L.jxlhip_frame_begin(ctx, C.byref(p)) == 0, L.jxlhip_last_error(ctx)
+    npy = {k: ([x.numpy() for x in v] if isinstance(v, list) else v.numpy()) for k, v in t.items()}
+    dc3 = (C.c_void_p * 3)(*[a.ctypes.data for a in npy["dc"]])
+    assert L.jxlhip_upload_side_info(ctx, npy["ac_strategy"].ctypes.data, npy["raw_quant"].ctypes.data,
+                                     npy["epf_sharpness"].ctypes.data, npy["ytox_map"].ctypes.data,
+                                     npy["ytob_map"].ctypes.data, dc3, table_host.ctypes.data) == 0
+    xs, ys = params["xsize"], params["ysize"]
+    for g in range(((xs + 255) // 256) * ((ys + 255) // 256)):
+        ptrs = (C.c_void_p * 3)(*[c[g * 65536:].ctypes.data for c in npy["coeffs"]])
+        assert L.jxlhip_submit_group(ctx, g, ptrs, 65536) == 0, L.jxlhip_last_error(ctx)
+
+
+@pytest.mark.parametrize("padded", [False, True])
+def test_multi_context_frames_back_to_back_without_sync(oracle, monkeypatch, padded):
+    """Ten frames (two different ones, alternating) through one multi context with NO jxlhip_sync in between: the
+    persistent halo staging of a stripe may only be overwritten by the next frame's export once the neighbour has
+    pulled the previous frame's rows (ev_pull, multi.inc), and the next frame's uploads must not overtake the
+    previous frame's kernels (frame_ev, jxlhip_frame_begin).  padded: the caller's rows are wider than the pixels --
+    the gather then is a 2-D copy and the padding bytes stay the caller's."""
+    L = abi.load_library()
+    xs, ys = 600, 1100
+    monkeypatch.setenv("JXLHIP_FUSE", "0")
+    monkeypatch.setenv("JXLHIP_MULTI_FORCE_GATHER", "1")
+    cases, singles = [], []
+    table_host = None
+    for seed in (91, 17):
+        params, t, _ = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=True, epf_iters=1, seed=seed)
+        d = VarDctDecoder(0)
+        d.begin_frame(params)
+        dq = d.default_dequant_tables()
+        d.set_inputs({k: ([x.cuda() for x in v] if isinstance(v, list) else v.cuda()) for k, v in t.items()}, dq)
+        singles.append(d.decode_frame().cpu().numpy())
+        d.sync()
+        table_host = dq.cpu().numpy()
+        d.close()
+        cases.append((params, t))
+    assert not np.array_equal(singles[0], singles[1])
+    ndev = torch.cuda.device_count()
+    devices = [i % ndev for i in range(3)]
+    ctx = C.c_void_p()
+    assert L.jxlhip_create_multi((C.c_int * 3)(*devices), 3, None, C.byref(ctx)) == 0
+    row_floats = xs * 3 + (16 if padded else 0)
+    outs = []
+    try:
+        for i in range(10):
+            params, t = cases[i % 2]
+            _upload(L, ctx, params, t, table_host)
+            out = torch.full((ys, row_floats), -7.0, dtype=torch.float32, device=f"cuda:{devices[0]}")
+            assert L.jxlhip_decode_frame(ctx, out.data_ptr(), row_floats * 4, 0) == 0, L.jxlhip_last_error(ctx)
+            outs.append(out)
+        assert L.jxlhip_sync(ctx) == 0, L.jxlhip_last_error(ctx)
+        for i, out in enumerate(outs):
+            a = out.cpu().numpy()
+            assert np.array_equal(a[:, :xs * 3].reshape(ys, xs, 3), singles[i % 2]), i
+            assert (a[:, xs * 3:] == -7.0).all(), i  # row padding untouched
+    finally:
+        L.jxlhip_destroy(ctx)
