@@ -96,6 +96,91 @@ def cpu_baseline(cfg, sample, threads):
             "sample": f"{w}x{h} frame of this workload, {reps} reps, {cores} thread(s) over groups; {what}"}
 
 
+def pcie_inclusive(torch, dec, params, t, dq, out, xs, ys, n):
+    """Host-boundary rates of the bench frame (never `value`)."""
+    from libjxl_amd import VarDctDecoder
+    host_c = [torch.empty(c.shape, dtype=c.dtype, pin_memory=True).copy_(c) for c in t["coeffs"]]
+    h2d = int(sum(c.numel() * c.element_size() for c in host_c))
+    res = {"unit": "Mpixels/s", "h2d_bytes": h2d}
+
+    # serial on one stream, f32
+    host_o = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+
+    def pstep():
+        for d, h in zip(t["coeffs"], host_c):
+            d.copy_(h, non_blocking=True)
+        dec.decode_frame(out)
+        host_o.copy_(out, non_blocking=True)
+
+    pstep()
+    torch.cuda.synchronize()
+    p0 = time.perf_counter()
+    for _ in range(n):
+        pstep()
+    torch.cuda.synchronize()
+    pdt = (time.perf_counter() - p0) / n
+    res["f32_serial"] = {"value": round(xs * ys / pdt / 1e6, 1), "ms_per_step": round(pdt * 1e3, 3),
+                         "d2h_bytes": int(host_o.numel() * host_o.element_size())}
+    del host_o
+
+    def pipelined(make_params):
+        s_in, s_k, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(s_k):
+            d2 = VarDctDecoder(dec.device)  # launches go to s_k
+        d2.begin_frame(make_params)
+        sets = []
+        for _ in range(2):
+            tt = dict(t)
+            tt["coeffs"] = [torch.empty_like(c) for c in t["coeffs"]]
+            o = d2.alloc_output()
+            sets.append(dict(t=tt, out=o, host=torch.empty(o.shape, dtype=o.dtype, pin_memory=True),
+                             ev_in=torch.cuda.Event(), ev_k=torch.cuda.Event(), ev_out=torch.cuda.Event()))
+        torch.cuda.synchronize()
+
+        def frame(k):
+            b = sets[k & 1]
+            with torch.cuda.stream(s_in):
+                s_in.wait_event(b["ev_k"])  # the kernels of frame k-2 no longer read this set's coefficients
+                for d, h in zip(b["t"]["coeffs"], host_c):
+                    d.copy_(h, non_blocking=True)
+                b["ev_in"].record(s_in)
+            with torch.cuda.stream(s_k):
+                s_k.wait_event(b["ev_in"])
+                s_k.wait_event(b["ev_out"])  # frame k-2's pixels have left this set's device frame
+                d2.set_inputs(b["t"], dq)
+                d2.decode_frame(b["out"])
+                b["ev_k"].record(s_k)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(b["ev_k"])
+                b["host"].copy_(b["out"], non_blocking=True)
+                b["ev_out"].record(s_out)
+
+        for k in range(2):
+            frame(k)
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        for k in range(n):
+            frame(k)
+        torch.cuda.synchronize()
+        qdt = (time.perf_counter() - q0) / n
+        d2h = int(sets[0]["host"].numel() * sets[0]["host"].element_size())
+        d2.sync()
+        d2.close()
+        return {"value": round(xs * ys / qdt / 1e6, 1), "ms_per_step": round(qdt * 1e3, 3), "d2h_bytes": d2h,
+                "h2d_GBps": round(h2d / qdt / 1e9, 1), "d2h_GBps": round(d2h / qdt / 1e9, 1)}
+
+    res["f32_pipelined"] = pipelined(dict(params))
+    p8 = dict(params)
+    p8["output_kind"] = 2
+    p8["out_format"] = dict(transfer=1, sample_type=1, num_channels=4, bits_per_sample=8)  # sRGB RGBA8
+    res["rgba8_pipelined"] = pipelined(p8)
+    res["value"] = res["rgba8_pipelined"]["value"]
+    res["what"] = ("pinned H2D of the coefficient stream + kernels + pinned D2H of the pixels.  value = sRGB RGBA8 "
+                   "output, pipelined over three streams and two buffer sets (H2D of frame k+1 || kernels k || D2H k-1); "
+                   "f32_pipelined = the same with the linear f32 frame; f32_serial = one stream, no overlap")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,19 +258,27 @@ def main():
         b.copy_(a)
         torch.cuda.synchronize()
         del a, b
-    for _ in range(args.warmup):
-        step()
-    dec.sync()  # also surfaces stream errors
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        dec.sync()  # also surfaces stream errors
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        fence()
+        t = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([t], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
+
+    dt = timed(step)
+    # N > 1: the same frame with the output stripes left sharded in each GPU's HBM (a consumer on the device, or
+    # every GPU writing its own stripe to the host): the form in which the split scales -- the gather of a 1.59 GB
+    # float frame into ONE GPU is per-link bound
+    dt_sharded = timed(lambda: sd.decode(out)) if gather else None
 
     # per-kernel device time with HIP events on the launch stream (own pass)
     dec.profile(True)
@@ -199,44 +292,26 @@ def main():
     dec.profile(False)
     kern = {k: round(ms / max(n, 1), 4) for k, (ms, n) in prof.items()}
 
-    # the same step when the boundary hands over HOST buffers: pinned H2D of the
-    # coefficient stream, kernels, pinned D2H of the pixels.  Never `value`.
+    # the same step when the boundary hands over HOST buffers: pinned H2D of the coefficient
+    # stream, kernels, pinned D2H of the pixels.  Never `value`.  Serial on one stream (round 2's figure), and
+    # pipelined: H2D of frame k+1 || kernels of frame k || D2H of frame k-1 on three streams over two sets of
+    # buffers -- for the f32 frame and for sRGB RGBA8 (what djxl writes by default: a third of the bytes back).
     pcie = None
     if world == 1 and not args.no_pcie:
-        host_c = [torch.empty(c.shape, dtype=c.dtype, pin_memory=True).copy_(c) for c in t["coeffs"]]
-        host_o = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
-        n_pcie = max(3, min(args.steps, 10))
-
-        def pstep():
-            for d, h in zip(t["coeffs"], host_c):
-                d.copy_(h, non_blocking=True)
-            dec.decode_frame(out)
-            host_o.copy_(out, non_blocking=True)
-
-        pstep()
-        torch.cuda.synchronize()
-        p0 = time.perf_counter()
-        for _ in range(n_pcie):
-            pstep()
-        torch.cuda.synchronize()
-        pdt = (time.perf_counter() - p0) / n_pcie
-        pcie = {"value": round(xs * ys / pdt / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(pdt * 1e3, 3),
-                "h2d_bytes": int(sum(c.numel() * c.element_size() for c in host_c)),
-                "d2h_bytes": int(host_o.numel() * host_o.element_size()),
-                "what": "pinned H2D of the coefficient stream + kernels + pinned D2H of the f32 pixels, serial on one stream"}
-        del host_c, host_o
-
+        pcie = pcie_inclusive(torch, dec, params, t, dq, out, xs, ys, max(4, min(args.steps, 12)))
     if rank == 0:
         px = xs * ys
         ms_step = dt / args.steps * 1e3
         value = px / (dt / args.steps) / 1e6
         cb = 4 if cfg["coeff32"] else 2
-        # dominant SINGLE kernel of this rank's stripe: the fused Gaborish+EPF+XYB (or plane -> RGB) kernel, one
-        # launch per frame.  Three fractions of the 8 TB/s HBM peak:
-        #   frac        SURVEY 8(d)'s figure: the FRAME's algorithmic bytes over that kernel's time (the contract's
-        #               definition; a hybrid: the kernel never touches the coefficient stream)
-        #   frac_kernel the kernel's OWN algorithmic bytes (12 B/px planes in + output bytes out) over its time
-        #   frac_step   the frame's algorithmic bytes over the whole step (all launches) -- the honest end-to-end one
+        # roofline: the FRAME's algorithmic bytes over the whole STEP -- every launch and every gap
+        # between them -- against the 8 TB/s HBM peak (`frac`).  The per-kernel views stay beside it:
+        #   frac_dominant_kernel  the frame's bytes over the dominant kernel's time alone (SURVEY 8(d) read
+        #                         literally; it flatters: that kernel does not move the whole frame's bytes)
+        #   frac_kernel           the dominant kernel's OWN bytes over its time
+        # `traffic` = HBM bytes of ALL the step's launches from the TCC counters (profiles/pmc_traffic.json: separate
+        # FETCH_SIZE / WRITE_SIZE passes of this command, calibrated on a known copy); traffic_kernel = the
+        # dominant kernel's share.
         dom = "fused" if "fused" in kern else ("filters" if "filters" in kern else max(kern, key=kern.get))
         y0, y1 = sd.rows[rank]
         b_alg = algorithmic_bytes(xs, y1 - y0, cb)
@@ -244,13 +319,16 @@ def main():
         b_own = xs * (y1 - y0) * 24  # planes in + pixels out (k_fused: an upper bound, its DCT8 cells come as coefficients)
         if dom == "blocks":  # all-DCT32X32 frame without filters: the class kernel reads coefficients, writes pixels
             b_own = b_alg
-        achieved = b_alg / (kern[dom] * 1e-3) / 1e9
-        traffic, tsrc = None, None
+        achieved = b_alg_frame / (ms_step * 1e-3) / 1e9
+        traffic, traffic_kernel, tsrc = None, None, None
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf) and world == 1 and name == "c3" and not custom:
             try:
-                traffic = json.load(open(tf)).get("filters")  # pmc_summarize.py files k_fused under "filters"
-                tsrc = "profiles/pmc_traffic.json (replayed: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.sh)"
+                tj = json.load(open(tf))
+                traffic_kernel = tj.get("filters")  # pmc_summarize.py files k_fused under "filters"
+                traffic = sum(v for k, v in tj.items() if not k.startswith("_") and isinstance(v, (int, float)))
+                tsrc = ("profiles/pmc_traffic.json (replayed, not measured in this run: rocprofv3 --pmc FETCH_SIZE / "
+                        "WRITE_SIZE passes of this command, tools/pmc_traffic.sh; commit " + str(tj.get("_commit", "?")) + ")")
             except Exception:
                 traffic = None
         line = {
@@ -268,15 +346,21 @@ def main():
                        "kernel_ms": kern},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "frac_step": round(b_alg_frame / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "what": "frame's algorithmic bytes / whole step (all launches + gaps)",
+                         "frac_dominant_kernel": round(b_alg / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "frac_kernel": round(b_own / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": tsrc,
+                         "traffic": traffic, "traffic_kernel": traffic_kernel, "traffic_source": tsrc,
                          "kernel": {"filters": "k_filters_fast", "fused": "k_fused",
                                     "blocks": "k_transform_mfma32<EMIT>"}.get(dom, dom),
+                         "kernel_ms": kern[dom],
                          "algorithmic_bytes_per_launch": b_alg,
                          "algorithmic_bytes_frame": b_alg_frame,
                          "kernel_own_bytes_per_launch": b_own},
         }
+        if dt_sharded is not None:
+            line["sharded"] = {"value": round(px / (dt_sharded / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                               "ms_per_step": round(dt_sharded / args.steps * 1e3, 4),
+                               "what": "the same frame, output stripes left in each GPU's HBM (no gather)"}
         if pcie:
             line["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:

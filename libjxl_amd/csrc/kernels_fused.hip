@@ -419,9 +419,235 @@ __device__ __forceinline__ void ProducePC(FrameArgs fa, StripLds* w, int bc0, in
       sg = sigma_request(nb);
     }
     LdsF* slab = (LdsF*)w->slab[i & 1];
+#ifndef JXLHIP_ABL_PC_NOFILL  // ablation builds (tools/build_variant.py): the marching wave alone
     FinishSlab<CT>(fa, slab, (LdsU*)w->list, cur, bc0, 0);  // four plane row pairs by LDS-DMA + the DCT8 cells; ends on vmcnt(0)
+#else
+    (void)slab;
+    (void)cur;
+#endif
     if (lane < 16) ((LdsF*)w->sigma[i & 1])[lane] = sg_cur;
     PcBarrierProducer();
+  }
+}
+
+// The producer as a software pipeline (16-bit coefficients): the coefficient rows and DC values of block row
+// g+1 are requested -- into a second set of registers -- BEFORE block row g is decoded, and block row g+2's cell
+// info with them, so that a fill is the decode arithmetic plus LDS writes and the vmcnt(0) in front of the
+// barrier finds loads that have had the whole decode to arrive.  (ProducePC above starts every fill with two
+// dependent round trips: cell info, then coefficients.)
+//
+// These loads are issued through inline asm on purpose: for a load it knows, the compiler places the s_waitcnt
+// itself, and across this loop's control flow it falls back to vmcnt(0) in front of the first use -- which would
+// wait for the prefetch that was just issued.  An asm load's result is "ready" as far as the compiler is concerned;
+// the ONLY wait is the vmcnt(0) of PcBarrierProducer, and every loaded register is first used behind it (the two
+// register sets alternate through a loop unrolled by two: no copies).
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u4v AsmLoad4(const void* p) {
+  u4v r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ u2v AsmLoad2(const void* p) {
+  u2v r;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ uint32_t AsmLoad1(const void* p) {
+  uint32_t r;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+
+struct PcStepRegs {  // one decode step = up to 8 DCT8 cells, lane = (cell of the step: bits 0-2, matrix row: bits 3-5)
+  u4v rows[3];       // the lane's row of 8 coefficients, per channel
+  uint32_t dcv[3];   // DC of the lane's block (float bits)
+  uint32_t qc;
+  int cell;          // window cell 0..15 of the lane's block
+};
+struct PcGroupRegs {
+  PcStepRegs st[2];
+  int n8;       // DCT8 cells of the block row (wave-uniform)
+  uint32_t mp;  // cells copied from the planes (wave-uniform)
+  int nb;       // block row
+};
+struct PcNext {  // cell info + inv_sigma of a block row, as requested (valid behind the next barrier)
+  u2v ci;
+  uint32_t sg;
+  int nb;
+};
+
+__device__ __forceinline__ void PcRequest(FrameArgs fa, PcNext& n, int nb, int bc0) {
+  const FrameArgs f = Fresh(fa);
+  const int lane = threadIdx.x & 63;
+  const int xsb = (int)f->xsb;
+  int col = bc0 + (lane & 15);
+  col = col < 0 ? 0 : (col >= xsb ? xsb - 1 : col);  // lanes 16..63 and cells outside the frame: any valid address
+  n.nb = nb;
+  n.ci = AsmLoad2(f->cell_info + (size_t)nb * xsb + col);
+  n.sg = AsmLoad1(f->inv_sigma + (size_t)nb * xsb + col);
+}
+
+// n's registers are valid (a barrier has passed since PcRequest): masks, the DCT8 list, and the loads of the block
+// row's coefficient rows / DC values into R
+__device__ __forceinline__ void PcIssue(FrameArgs fa, LdsU* list, const PcNext& n, int bc0, PcGroupRegs& R) {
+  const FrameArgs f = Fresh(fa);
+  const int lane = threadIdx.x & 63;
+  const int c16 = bc0 + (lane & 15);
+  const bool valid_cell = lane < 16 && c16 >= 0 && c16 < (int)f->xsb;
+  const bool is_dct8 = valid_cell && n.ci.x != kCellFromPlanes;
+  const uint32_t m8 = (uint32_t)__ballot(is_dct8) & 0xffffu;
+  R.mp = (uint32_t)__ballot(valid_cell && !is_dct8) & 0xffffu;
+  R.n8 = __builtin_popcount(m8);
+  R.nb = n.nb;
+  if (m8 == 0) return;  // wave-uniform
+  if (is_dct8) {
+    const uint32_t rank = __builtin_popcount(m8 & ((1u << lane) - 1u));
+    list[rank * 4 + 0] = (uint32_t)lane;
+    list[rank * 4 + 1] = n.ci.x;
+    list[rank * 4 + 2] = n.ci.y;
+  }
+  const int j = lane >> 3;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    if (s * 8 < R.n8) {  // wave-uniform
+      const int b = s * 8 + (lane & 7);
+      const int bb = b < R.n8 ? b : R.n8 - 1;
+      const int cell = (int)list[bb * 4 + 0];
+      const uint32_t off = list[bb * 4 + 1];
+      R.st[s].qc = list[bb * 4 + 2];
+      R.st[s].cell = cell;
+      const size_t elem = (size_t)off * 64u + (size_t)j * 8u;
+      const size_t dc_at = (size_t)n.nb * f->xsb + (size_t)(bc0 + cell);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        R.st[s].rows[c] = AsmLoad4((const int16_t*)f->coeffs[c] + elem);
+        R.st[s].dcv[c] = AsmLoad1(f->dc[c] + dc_at);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void PcDecode(FrameArgs fa, LdsF* slab, const PcGroupRegs& R, const float (&tab)[3][8]) {
+  const FrameArgs f = Fresh(fa);
+  const int lane = threadIdx.x & 63;
+  const int j = lane >> 3;
+  const bool bit3 = (lane & 8) != 0;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    if (s * 8 < R.n8) {  // wave-uniform
+      const PcStepRegs& T = R.st[s];
+      const bool valid = s * 8 + (lane & 7) < R.n8;
+      float sx, sy, sb, x_cc, b_cc;
+      {
+        const int quant = (int)(T.qc & 0xffffu);
+        const float sq = f->inv_global_scale / (float)quant;  // dec_group.cc:164
+        sx = sq * f->x_dm;
+        sy = sq;
+        sb = sq * f->b_dm;
+        x_cc = f->cfl_base_x + (float)(int8_t)((T.qc >> 16) & 0xffu) * f->color_scale;
+        b_cc = f->cfl_base_b + (float)(int8_t)(T.qc >> 24) * f->color_scale;
+      }
+      const float bias0 = f->biases[0], bias1 = f->biases[1], bias2 = f->biases[2], bias3 = f->biases[3];
+      auto unpack = [](const u4v r, int32_t* q) {
+        const uint32_t wv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          q[2 * i] = (int32_t)(int16_t)(wv[i] & 0xffffu);
+          q[2 * i + 1] = (int32_t)wv[i] >> 16;
+        }
+      };
+      int32_t q[8];
+      float vy[8];
+      unpack(T.rows[1], q);
+#pragma unroll
+      for (int k = 0; k < 8; k++) vy[k] = AdjustQuantBias(q[k], bias1, bias3) * (tab[1][k] * sy);
+#pragma unroll
+      for (int ci3 = 0; ci3 < 3; ci3++) {
+        const int c = ci3 == 0 ? 1 : (ci3 == 1 ? 0 : 2);
+        float v[8];
+        if (c == 1) {
+#pragma unroll
+          for (int k = 0; k < 8; k++) v[k] = vy[k];
+        } else {
+          const float sc = c == 0 ? sx : sb;
+          const float cc = c == 0 ? x_cc : b_cc;
+          unpack(T.rows[c], q);
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const float d = AdjustQuantBias(q[k], c == 0 ? bias0 : bias2, bias3) * (tab[c][k] * sc);
+            v[k] = __builtin_fmaf(cc, vy[k], d);
+          }
+        }
+        if (j == 0) v[0] = __uint_as_float(T.dcv[c]);
+        IdctReg<8>(v);
+        Transpose8Lanes(v, bit3);
+        IdctReg<8>(v);
+        if (valid) {
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          typedef f4v __attribute__((address_space(3))) * P4;
+          LdsF* dst = slab + c * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
+          *(P4)dst = f4v{v[0], v[1], v[2], v[3]};
+          *(P4)(dst + 4) = f4v{v[4], v[5], v[6], v[7]};
+        }
+      }
+    }
+  }
+}
+
+template <int HX>
+__device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, int y_begin, int y_end, int nb_last) {
+  const int lane = threadIdx.x & 63;
+  const int r_first = HX ? y_begin - 8 : y_begin;
+  const int G = PcGroups<HX>(y_begin, y_end);
+  // this lane's 8 entries of the three DCT8 dequant matrices, once per wave (DequantLane, dec_group.cc:115-153)
+  float tab[3][8];
+  {
+    const FrameArgs f = Fresh(fa);
+    const int j = lane >> 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float4 t0 = *(const float4*)(f->dequant + c * 64 + j * 8);
+      const float4 t1 = *(const float4*)(f->dequant + c * 64 + j * 8 + 4);
+      tab[c][0] = t0.x, tab[c][1] = t0.y, tab[c][2] = t0.z, tab[c][3] = t0.w;
+      tab[c][4] = t1.x, tab[c][5] = t1.y, tab[c][6] = t1.z, tab[c][7] = t1.w;
+    }
+  }
+  LdsU* list = (LdsU*)w->list;
+  auto group_nb = [&](int g) { return GroupBlockRow(r_first + 8 * (g < G ? g : G - 1), nb_last); };
+  PcGroupRegs A, B;
+  PcNext n0, n1;
+  uint32_t sg_a = 0, sg_b = 0;
+  // prologue: block row 0's loads and block row 1's cell info, then everything has landed
+  PcRequest(fa, n0, group_nb(0), bc0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PcIssue(fa, list, n0, bc0, A);
+  sg_a = n0.sg;
+  PcRequest(fa, n1, group_nb(1), bc0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // one fill: CUR holds block row g (loaded behind an earlier barrier), NXT receives block row g+1,
+  // nn = cell info of block row g+1 (valid), refilled with block row g+2's
+  auto body = [&](int g, PcGroupRegs& CUR, PcGroupRegs& NXT, uint32_t& sg_cur, uint32_t& sg_nxt, PcNext& nn) {
+    LdsF* slab = (LdsF*)w->slab[g & 1];  // free: the march left it before the previous barrier
+    PcIssue(fa, list, nn, bc0, NXT);     // block row g+1 (the last block row again behind the end: harmless)
+    sg_nxt = nn.sg;
+    PcRequest(fa, nn, group_nb(g + 2), bc0);
+    {
+      NextRow cur;  // what DmaPlaneRows reads
+      cur.nb = CUR.nb;
+      cur.mp = CUR.mp;
+      cur.m8 = 0;
+      cur.ci = make_uint2(0u, 0u);
+#pragma unroll
+      for (int k = 0; k < 4; k++) DmaPlaneRows(fa, slab, cur, bc0, k);
+    }
+    PcDecode(fa, slab, CUR, tab);
+    if (lane < 16) ((LdsU*)w->sigma[g & 1])[lane] = sg_cur;
+    PcBarrierProducer();
+  };
+  for (int g = 0; g < G; g += 2) {
+    body(g, A, B, sg_a, sg_b, n1);
+    if (g + 1 < G) body(g + 1, B, A, sg_b, sg_a, n1);
   }
 }
 
@@ -466,10 +692,19 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
     L.slab = slab0 + (g & 1) * (3 * kSlabPlaneFloats);
     return EPF ? sig0[(g & 1) * 16] : 0.0f;
   };
+#ifdef JXLHIP_ABL_PC_NOMARCH  // ablation builds: the producing wave alone
+#define JXLHIP_PSTEP(K) (void)slab_y0, (void)sigma_pre, (void)sigma_prev
+#else
+#ifdef JXLHIP_ABL_PC_NOSTORE  // ablation builds: the march without its output stores
+#define JXLHIP_PC_DBG 4
+#else
+#define JXLHIP_PC_DBG 0
+#endif
 #define JXLHIP_PSTEP(K)                                                                                     \
-  Step<GAB, EPF, OUTK, FMT, K, EDGE, 0, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk,      \
+  Step<GAB, EPF, OUTK, FMT, K, EDGE, JXLHIP_PC_DBG, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk,      \
                                                   inv_sigma_blk2, out_row, KC, slab_y0, sigma_pre, sigma_prev); \
   out_row += out_row_bytes
+#endif
   PcBarrierMarch();  // fill(0)
   if constexpr (HX > 0) {  // the last HX rows of the block row above
     const int r = r_first;
@@ -559,7 +794,11 @@ __global__ __launch_bounds__(128, 3) void k_fused_pc(DevFrame f, FilterParams P,
   const int bc0 = x0 >> 3;
   const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
   if (wave == 1) {
-    ProducePC<MarchGeom<GAB, EPF>::HX, CT>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
+#ifndef JXLHIP_PC_PRODUCER_V1
+    if constexpr (sizeof(CT) == 2) ProducePC2<MarchGeom<GAB, EPF>::HX>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
+    else
+#endif
+      ProducePC<MarchGeom<GAB, EPF>::HX, CT>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
     return;
   }
   Lane L;
@@ -749,19 +988,28 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) 
     return true;                                                \
   }
 #ifndef JXLHIP_FUSED_PC_DEFAULT
-#define JXLHIP_FUSED_PC_DEFAULT 0
+#define JXLHIP_FUSED_PC_DEFAULT 1
 #endif
+// Packed outputs stay with the single-wave kernel (general formats) / the two-phase march (the fixed formats):
+// their emit code doubles the march's instruction count, and k_fused_pc has the march on half of a workgroup's
+// waves -- measured at 8K d1.0: sRGB u16 RGBA / f16 RGBA 1.12 ms against 0.78 ms single-wave, sRGB RGBA8 0.50 ms
+// against 0.42 ms two-phase (profiles/r03_packed_paths.txt).
+#define JXLHIP_FUSED_PCX(G, E)                                    \
+  if (gab == G && epf_iters == E) {                               \
+    if (output_kind == 0) LaunchFusedPcT<G, E, 0>(f, p, st);      \
+    else LaunchFusedPcT<G, E, 1>(f, p, st);                       \
+    return true;                                                  \
+  }
 #if JXLHIP_FUSED_PART == 2
 bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st) {
-  if (output_kind != JXLHIP_OUT_LINEAR_RGB_F32) return false;
-  if (gab == 1 && epf_iters == 1) {
-    LaunchFusedPcT<1, 1, 1>(f, p, st);
-    return true;
-  }
-  if (gab == 0 && epf_iters == 0) {
-    LaunchFusedPcT<0, 0, 1>(f, p, st);
-    return true;
-  }
+  if (output_kind == JXLHIP_OUT_PACKED) return false;
+  JXLHIP_FUSED_PCX(1, 1)
+  JXLHIP_FUSED_PCX(0, 0)
+#ifndef JXLHIP_FUSED_LEAN
+  JXLHIP_FUSED_PCX(0, 1)
+  JXLHIP_FUSED_PCX(1, 0)
+  JXLHIP_FUSED_PCX(0, 2)
+#endif
   return false;
 }
 #elif JXLHIP_FUSED_PART == 0

@@ -184,14 +184,10 @@ struct ResizableRunner {
       func(opaque, t, thread_id);
     }
   }
-  void WorkerMain(size_t id) {
-    // a worker created by a later SetThreads starts from the CURRENT epoch: runs that happened before it
-    // existed are not its to join (it was never counted in `running`)
-    uint64_t seen;
-    {
-      std::lock_guard<std::mutex> lock(mu);
-      seen = epoch;
-    }
+  // seen: the epoch at the moment SetThreads CREATED this worker (read by the creating thread): runs that
+  // happened before it existed are not its to join (it was never counted in `running`), every run started
+  // afterwards counts it -- also when its thread only gets going after that run began
+  void WorkerMain(size_t id, uint64_t seen) {
     for (;;) {
       {
         std::unique_lock<std::mutex> lock(mu);
@@ -208,12 +204,14 @@ struct ResizableRunner {
   }
   void SetThreads(size_t num) {
     if (num > 0) num -= 1;
+    uint64_t now;
     {
       std::lock_guard<std::mutex> lock(mu);
       desired = num;
+      now = epoch;
     }
     cv_start.notify_all();
-    for (size_t i = workers.size(); i < num; i++) workers.emplace_back([this, i] { WorkerMain(i); });
+    for (size_t i = workers.size(); i < num; i++) workers.emplace_back([this, i, now] { WorkerMain(i, now); });
     if (workers.size() > num) {
       for (size_t i = num; i < workers.size(); i++) workers[i].join();
       workers.resize(num);

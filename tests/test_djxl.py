@@ -181,7 +181,8 @@ def test_djxl_on_a_genuine_4k_stream(tools, tmp_path):
     d = np.load(os.path.join(ROOT, "tests", "data", "real_4k_d1.npz"))
     jxl = tmp_path / "real4k.jxl"
     jxl.write_bytes(d["codestream"].tobytes())
-    for ext, extra in (("pfm", []), ("ppm", ["--bits_per_sample", "8"]), ("npy", [])):
+    # (the stream describes a 32-bit float original: djxl itself refuses integer PNM output for it)
+    for ext, extra in (("pfm", []), ("npy", []), ("npy", ["--num_threads", "3"])):
         run(djxl_ref, [str(jxl), str(tmp_path / f"r.{ext}")] + extra)
         err = run(djxl_hip, [str(jxl), str(tmp_path / f"h.{ext}")] + extra, verbose=True)
         assert "jxlhip seam: frame 3840x2160" in err, err[-1500:]
