@@ -55,6 +55,7 @@ struct jxlhip_ctx {
   bool have_frame = false;
   bool have_inputs = false;
   bool blocks_done = false;
+  bool blocks_fused = false;  // jxlhip_decode_blocks ran in fused-stripe mode: the planes lack the inner DCT8 blocks
   jxlhip_frame_params p{};
   DevFrame f{};
   FilterParams fp{};
@@ -944,13 +945,15 @@ namespace {
 
 // k_prepare + the transform kernels for group rows [g0, g1) of the stripe,
 // using counter slot `band`.
-int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, bool fused = false,
+// fused: 0 = two-phase, 1 = the whole frame through the fused kernel, 2 = a STRIPE through it (the DCT8 cells of
+// the stripe's first / last block row are decoded into the planes as well: they are the halo rows its neighbours pull)
+int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, int fused = 0,
                      const FilterParams* emit = nullptr) {
   hipStream_t st = c->stream;
   DevFrame f = c->f;
   f.band_g0 = g0;
   f.band_g1 = g1;
-  f.fused = fused ? 1u : 0u;
+  f.fused = (uint32_t)fused;
   f.cell_info = c->cell_info;
   {
     constexpr uint32_t kOthers32 = (1u << 8) | (1u << 9) | (1u << 10) | (1u << 11);  // 32x8 .. 16x32
@@ -1027,6 +1030,28 @@ int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint3
   return JXLHIP_OK;
 }
 
+// Does this frame (or stripe of it) go through the fused kernel (kernels_fused.hip)?  auto: with a filter, frames
+// of 12 Mpx and more (see jxlhip_ctx::fuse); without one the fused wave has no halo rows to pay for and wins at 4K as
+// well (95.8 vs 83.4 Gpx/s); never when the caller's used_acs says the frame has no DCT8 block -- then the slab is
+// only a detour (configs[4]: 76.1 vs 79.6 Gpx/s).  Packed outputs: the two-phase filter kernel has the formats djxl
+// writes most (8-bit sRGB RGB / RGBA, 16-bit sRGB RGB) fixed at compile time, the fused kernel only the general
+// per-sample format path -- measured at 8K d1.0: 0.42 ms two-phase against 0.74 - 0.82 ms fused
+// (profiles/r03_packed_paths.txt).
+bool WantFused(const jxlhip_ctx* c) {
+  const DevFrame& f = c->f;
+  const bool big = (uint64_t)f.xsize * f.ysize >= (12ull << 20) || (c->p.lf.gab == 0 && c->p.lf.epf_iters == 0);
+  const bool has_dct8 = f.used_acs == 0 || (f.used_acs & 1u);
+  bool packed_fixed = false;
+  if (c->p.output_kind == JXLHIP_OUT_PACKED) {
+    const jxlhip_output_format& o = c->p.out_format;
+    packed_fixed = o.transfer == JXLHIP_TF_SRGB && !o.swap_endianness &&
+                   ((o.sample_type == JXLHIP_SAMPLE_U8 && (o.num_channels == 3 || o.num_channels == 4)) ||
+                    (o.sample_type == JXLHIP_SAMPLE_U16 && o.num_channels == 3));
+  }
+  return (c->fuse > 0 || (c->fuse < 0 && big && has_dct8 && !packed_fixed)) && !c->generic_filters && c->band_rows == 0 &&
+         FusedSupported(f, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind);
+}
+
 int BeginDecode(jxlhip_ctx* c, uint32_t nbands) {
   if (!c->have_frame || !c->have_inputs)
     return Fail(c, JXLHIP_ERR_STATE, "decode needs frame_begin + inputs");
@@ -1072,7 +1097,14 @@ int jxlhip_decode_blocks(jxlhip_ctx* c) {
   JXLHIP_NO_MULTI(c);
   int rc = BeginDecode(c, 1);
   if (rc) return rc;
-  rc = LaunchBlocksBand(c, c->f.group_y0, c->f.group_y0 + c->f.group_rows, 0);
+  // A STRIPE of a frame (what jxlhip_create_multi / libjxl_amd.stripes run per device) takes the fused kernel
+  // by the whole-frame rule: its DCT8 blocks are decoded inside the filter march, except that those of its
+  // first / last block row ALSO reach the planes -- the halo rows the neighbours pull with jxlhip_halo_export.
+  // A whole frame through the split calls stays two-phase (the taps read the planes).
+  const bool stripe = c->f.group_y0 != 0 || c->f.group_rows != c->f.ysg;
+  c->blocks_fused = stripe && WantFused(c);
+  if (c->blocks_fused && (rc = Grow(c, &c->cell_info, &c->cell_info_items, (size_t)c->f.xsb * c->f.ysb))) return rc;
+  rc = LaunchBlocksBand(c, c->f.group_y0, c->f.group_y0 + c->f.group_rows, 0, c->blocks_fused ? 2 : 0);
   if (rc) return rc;
   c->blocks_done = true;
   return JXLHIP_OK;
@@ -1126,7 +1158,7 @@ int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t ou
   fp.out = out;
   fp.out_stride = out_stride;
   fp.out_plane_stride = out_plane_stride;
-  return LaunchFiltersRows(c, fp, c->f.y0, c->f.y1);
+  return LaunchFiltersRows(c, fp, c->f.y0, c->f.y1, c->blocks_fused);
 }
 
 // Both phases.  With JXLHIP_BAND_ROWS = n > 0 the stripe is walked in bands of n
@@ -1169,6 +1201,7 @@ int jxlhip_decode_frame(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_
 
 static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
   const DevFrame& f = c->f;
+  c->blocks_fused = false;
   uint32_t br = c->band_rows ? (uint32_t)c->band_rows : f.group_rows;
   while ((f.group_rows + br - 1) / br > (uint32_t)kMaxBands) br++;
   int rc = BeginDecode(c, (f.group_rows + br - 1) / br);
@@ -1184,7 +1217,7 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   // no second kernel.  used_acs is the caller's promise; k_prepare reports any other strategy it meets.
   if (c->mfma != 0 && f.used_acs == (1u << 5) && c->p.lf.gab == 0 && c->p.lf.epf_iters == 0 &&
       c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32 && !c->generic_filters && c->band_rows == 0) {
-    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, 0, false, &fp);
+    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, 0, 0, &fp);
     c->blocks_done = false;  // nothing in the planes
     return rc;
   }
@@ -1194,24 +1227,9 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   // auto: with a filter, frames of 12 Mpx and more (see jxlhip_ctx::fuse); without one the fused wave has no
   // halo rows to pay for and wins at 4K as well (95.8 vs 83.4 Gpx/s); never when the caller's used_acs says the
   // frame has no DCT8 block -- then the slab is only a detour (configs[4]: 76.1 vs 79.6 Gpx/s)
-  const bool big = (uint64_t)f.xsize * f.ysize >= (12ull << 20) || (c->p.lf.gab == 0 && c->p.lf.epf_iters == 0);
-  const bool has_dct8 = f.used_acs == 0 || (f.used_acs & 1u);
-  // Packed outputs: the two-phase filter kernel has the formats djxl writes most (8-bit sRGB RGB / RGBA, 16-bit sRGB
-  // RGB) fixed at compile time, the fused kernel only the general per-sample format path -- measured at 8K d1.0:
-  // 0.51 / 0.51 / 0.49 ms two-phase against 0.97 / 1.12 / 1.10 ms fused (the other packed formats: 1.1 ms either
-  // way, f16: 3.6 vs 1.1 ms in favour of the fused kernel)
-  bool packed_fixed = false;
-  if (c->p.output_kind == JXLHIP_OUT_PACKED) {
-    const jxlhip_output_format& o = c->p.out_format;
-    packed_fixed = o.transfer == JXLHIP_TF_SRGB && !o.swap_endianness &&
-                   ((o.sample_type == JXLHIP_SAMPLE_U8 && (o.num_channels == 3 || o.num_channels == 4)) ||
-                    (o.sample_type == JXLHIP_SAMPLE_U16 && o.num_channels == 3));
-  }
-  if ((c->fuse > 0 || (c->fuse < 0 && big && has_dct8 && !packed_fixed)) && !c->generic_filters && c->band_rows == 0 && f.group_y0 == 0 &&
-      f.group_rows == f.ysg &&
-      FusedSupported(f, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind)) {
+  if (WantFused(c) && f.group_y0 == 0 && f.group_rows == f.ysg) {
     if ((rc = Grow(c, &c->cell_info, &c->cell_info_items, (size_t)f.xsb * f.ysb))) return rc;
-    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, 0, true);
+    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, 0, 1);
     if (rc) return rc;
     c->blocks_done = false;  // the planes do not hold the whole frame
     return LaunchFiltersRows(c, fp, f.y0, f.y1, true);
@@ -1317,9 +1335,9 @@ int jxlhip_export_xyb(jxlhip_ctx* c, float* const dst[3], size_t dst_stride) {
   if (!c || !dst || !dst[0] || !dst[1] || !dst[2]) return JXLHIP_ERR_INVALID_ARGUMENT;
   JXLHIP_NO_MULTI(c);
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "no frame");
-  if (!c->blocks_done)
-    return Fail(c, JXLHIP_ERR_STATE, "export_xyb needs jxlhip_decode_blocks (jxlhip_decode_frame may run fused: "
-                                     "DCT8 blocks then never reach the planes)");
+  if (!c->blocks_done || c->blocks_fused)
+    return Fail(c, JXLHIP_ERR_STATE, "export_xyb needs a two-phase jxlhip_decode_blocks (a fused decode -- jxlhip_decode_frame, or "
+                                     "a stripe of a frame of 12 Mpx and more -- leaves DCT8 blocks out of the planes; JXLHIP_FUSE=0)");
   const DevFrame& f = c->f;
   const int rows = (int)(f.plane_tile_rows - 2) * 8;
   if (dst_stride < (size_t)f.xsb * 8) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "stride too small");

@@ -77,8 +77,13 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     if ((int)lane >= d) incl += t;
   }
   if (lane == 63) wave_tot[wave] = incl;
-  // per-wave class histogram
-  const int cls = first ? (int)kClassLut.v[s] : -1;
+  // per-wave class histogram.  Fused mode: DCT8 varblocks are decoded by the fused kernel from cell_info and stay off
+  // the work list -- except, in a STRIPE (fused == 2), those of the stripe's first / last block row next to a
+  // neighbouring stripe: they are decoded into the planes as well (the halo rows the neighbour pulls).
+  const int cls_frame = first ? (int)kClassLut.v[s] : -1;
+  const bool edge_row = f.fused == 2 && ((aby == (f.y0 >> 3) && f.group_y0 > 0) ||
+                                         (aby == ((f.y1 - 1) >> 3) && f.group_y0 + f.group_rows < f.ysg));
+  const int cls = (f.fused && cls_frame == kClsDct8 && !edge_row) ? -1 : cls_frame;
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t rank_in_wave = 0;
 #pragma unroll
@@ -106,7 +111,6 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     uint32_t n = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) n += wave_cls[w][tid];
-    if (f.fused && tid == kClsDct8) n = 0;  // decoded by the fused kernel: no list
 #ifdef JXLHIP_ABL_PREPARE_NOATOMIC  // ablation build (timing only: lists are garbage): what do the contended atomics cost?
     wg_base[tid] = (n && in_stripe && group_ok) ? blockIdx.x * 8u : 0;
 #else
@@ -121,16 +125,18 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
       for (uint32_t ix = 0; ix < cx; ix++) cell_sq[(by + iy) * gw + bx + ix] = sigma_quant;
   }
   __syncthreads();
-  if (in_stripe && group_ok && cls >= 0) {
-    uint32_t pos = wg_base[cls] + rank_in_wave;
-    for (uint32_t w = 0; w < wave; w++) pos += wave_cls[w][cls];
+  if (in_stripe && group_ok && cls_frame >= 0) {
     WorkItem it;
     it.pos = (aby << 16) | abx;
     it.off = g * f.coef_stride64 + off64;
     it.qc = ((uint32_t)cell_q & 0xffffu) | cell_cfl;
     it.pad = 0;
-    if (f.fused && cls == kClsDct8) f.cell_info[cell] = make_uint2(it.off, it.qc);
-    else wl.list[cls][pos] = it;
+    if (f.fused && cls_frame == kClsDct8) f.cell_info[cell] = make_uint2(it.off, it.qc);
+    if (cls >= 0) {
+      uint32_t pos = wg_base[cls] + rank_in_wave;
+      for (uint32_t w = 0; w < wave; w++) pos += wave_cls[w][cls];
+      wl.list[cls][pos] = it;
+    }
   }
   // ComputeSigma (epf.cc:69-79), one cell per thread
   if (with_sigma && valid) {
@@ -1461,12 +1467,14 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     // worst cases: all cells special (3 tasks per 64 blocks, 4 tasks per workgroup) or all DCT8
     const bool specials = any({1, 2, 3, 12, 13, 14, 15, 16, 17});
     const uint32_t bound_s = specials ? (cells / 64 + kNumSpecial) * 3 / 4 + 1 : 0;
-    const uint32_t bound_8 = (any({0}) && !f.fused) ? (cells + kDct8PerWg - 1) / kDct8PerWg : 0;
+    // fused == 2 (a stripe): only the DCT8 cells of the two block rows its neighbours pull are on the list
+    const uint32_t cells_8 = f.fused == 0 ? cells : (f.fused == 2 ? 2u * f.xsb : 0u);
+    const uint32_t bound_8 = (any({0}) && cells_8) ? (cells_8 + kDct8PerWg - 1) / kDct8PerWg : 0;
     const uint32_t grid_8 = (bound_s > bound_8 ? bound_s : bound_8) + (specials ? kNumSpecial : 0);
     // merged_r: the single-block classes ride in k_transform_r's launch (specials at its head, DCT8 workgroups
     // alternating with the other classes' persistent ones)
     specials_in_r = merged_r && specials;
-    dct8_in_r = merged_r && !f.fused && bound_8 != 0;
+    dct8_in_r = merged_r && bound_8 != 0;
     grid_specials = bound_s + kNumSpecial;
     grid_dct8 = bound_8;
     if (grid_8 && !merged_r) hipLaunchKernelGGL((k_transform_8<CT>), dim3(grid_8), dim3(256), 0, s0, f, wl);

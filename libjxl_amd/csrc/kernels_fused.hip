@@ -33,6 +33,12 @@
 #ifndef JXLHIP_FUSED_PART
 #define JXLHIP_FUSED_PART 0
 #endif
+#ifndef JXLHIP_FUSED_PC_ROLE_DEFAULT
+#define JXLHIP_FUSED_PC_ROLE_DEFAULT -1
+#endif
+#ifndef JXLHIP_FUSED_PC_DEFAULT
+#define JXLHIP_FUSED_PC_DEFAULT 1
+#endif
 
 namespace jxlhip {
 
@@ -769,9 +775,12 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
 // that an XCD's L2 sees neighbouring windows of the same rows (they share two block columns of coefficients and
 // plane tiles); the grid is padded to a multiple of 8
 template <int GAB, int EPF, int OUTK, int FMT, typename CT>
-__global__ __launch_bounds__(128, 3) void k_fused_pc(DevFrame f, FilterParams P, int RH, int strips, int nwg) {
+__global__ __launch_bounds__(128, 3) void k_fused_pc(DevFrame f, FilterParams P, int RH, int strips, int nwg, int role_shift) {
   __shared__ StripLds lds;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // which of the two waves marches: swapped on every 2^role_shift-th workgroup (in dispatch order), so that the
+  // SIMDs of a CU -- which receive a workgroup's waves in turn -- each get marching and producing waves
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)(threadIdx.x >> 6) ^ (role_shift >= 0 ? ((int)blockIdx.x >> role_shift) & 1 : 0);
   const float __attribute__((address_space(3)))* dither_lds = nullptr;
   if constexpr (OUTK == JXLHIP_OUT_PACKED) {
     __shared__ float s_dither[1024];
@@ -854,10 +863,12 @@ void LaunchFusedPcT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
   const int RH = FusedRowsPC(strips, f.fy1 - f.fy0);
   const unsigned nwg = strips * ((f.fy1 - f.fy0 + RH - 1) / RH);
   const dim3 grid((nwg + 7) & ~7u);
+  const char* e = getenv("JXLHIP_FUSED_PC_ROLE");  // experiments: -1 = wave 0 always marches
+  const int role_shift = e ? atoi(e) : JXLHIP_FUSED_PC_ROLE_DEFAULT;
   if (f.coeff_type == JXLHIP_COEFF_I16)
-    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int16_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg);
+    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int16_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, role_shift);
   else
-    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int32_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg);
+    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int32_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, role_shift);
 }
 #endif  // JXLHIP_FUSED_PART == 2
 
@@ -962,6 +973,10 @@ bool LaunchFusedB(const DevFrame& f, const FilterParams& p, int gab, int epf_ite
 bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st);
 
 #if JXLHIP_FUSED_PART == 0
+static bool FusedPcEnabled() {
+  const char* e = getenv("JXLHIP_FUSED_PC");  // read per launch: the tests switch it
+  return (e ? atoi(e) : JXLHIP_FUSED_PC_DEFAULT) != 0;
+}
 // Frames the fused kernel takes (decided before k_prepare: it routes the DCT8 blocks).
 bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) {
   (void)output_kind;
@@ -969,7 +984,8 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) 
   // Gaborish + EPF1 + EPF2 on top of the in-wave DCT8 decode is past what two waves per SIMD hide: measured
   // on the 8K d1.0 mix, fused 0.479 ms per frame against 0.431 two-phase (every other stage list gains
   // 5-15 % from fusion: profiles/r02_fused_vs_twophase.txt)
-  if (gab && epf_iters == 2) return false;
+  // ... as ONE wave; k_fused_pc takes it for the planar / f32 outputs: 0.367 ms against 0.43 ms (round 3)
+  if (gab && epf_iters == 2 && (output_kind == JXLHIP_OUT_PACKED || !FusedPcEnabled())) return false;
   if (f.xsize < 16 || f.ysize < 16) return false;  // multiply mirrored columns / rows
   const uint32_t tail = f.ysize & 7u;
   if (tail >= 1 && tail <= 3) return false;        // mirror rows below the frame leave the last block row
@@ -987,9 +1003,6 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) 
     else LaunchFusedT<G, E, 2>(f, p, st);                       \
     return true;                                                \
   }
-#ifndef JXLHIP_FUSED_PC_DEFAULT
-#define JXLHIP_FUSED_PC_DEFAULT 1
-#endif
 // Packed outputs stay with the single-wave kernel (general formats) / the two-phase march (the fixed formats):
 // their emit code doubles the march's instruction count, and k_fused_pc has the march on half of a workgroup's
 // waves -- measured at 8K d1.0: sRGB u16 RGBA / f16 RGBA 1.12 ms against 0.78 ms single-wave, sRGB RGBA8 0.50 ms
@@ -1009,6 +1022,7 @@ bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_it
   JXLHIP_FUSED_PCX(0, 1)
   JXLHIP_FUSED_PCX(1, 0)
   JXLHIP_FUSED_PCX(0, 2)
+  JXLHIP_FUSED_PCX(1, 2)
 #endif
   return false;
 }
@@ -1017,9 +1031,7 @@ bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iter
                  hipStream_t st) {
   if (!FusedSupported(f, gab, epf_iters, output_kind)) return false;
   {
-    const char* e = getenv("JXLHIP_FUSED_PC");  // read per launch: the tests switch it
-    const int pc = e ? atoi(e) : JXLHIP_FUSED_PC_DEFAULT;
-    if (pc && LaunchFusedPC(f, p, gab, epf_iters, output_kind, st)) return true;
+    if (FusedPcEnabled() && LaunchFusedPC(f, p, gab, epf_iters, output_kind, st)) return true;
   }
 #ifdef JXLHIP_FUSED_LEAN  // experiment builds (tools/build_variant.py): the BASELINE stage list only, seconds to compile
   if (gab == 1 && epf_iters == 1 && output_kind == 1 && f.coeff_type == JXLHIP_COEFF_I16) {

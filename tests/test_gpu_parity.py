@@ -227,6 +227,50 @@ def test_stripes_with_halo_exchange_equal_whole_frame(dec, dq, oracle, epf):
         d.close()
 
 
+@pytest.mark.parametrize("gab,epf", [(1, 1), (1, 2), (0, 0)])
+def test_stripes_through_the_fused_kernel_equal_whole_frame(dq, oracle, gab, epf, monkeypatch):
+    """The split calls on a STRIPE take the fused kernel when the frame qualifies (forced here: JXLHIP_FUSE=1):
+    k_prepare keeps the DCT8 blocks off the work list except those of the stripe's first / last block row next to a
+    neighbour, which reach the planes too -- the halo rows that are exported.  Three stripes (the middle one has
+    neighbours on both sides), bit-equal to the whole frame through the fused kernel; the profile slots say which
+    kernel ran."""
+    monkeypatch.setenv("JXLHIP_FUSE", "1")
+    params, t, fr = frames.make_case(600, 1100, mix=synth.MIX_D1, gab=bool(gab), epf_iters=epf, seed=19)
+    devt = to_dev(t)
+    d0 = VarDctDecoder(0)
+    d0.begin_frame(params)
+    d0.set_inputs(devt, dq)
+    whole = d0.decode_frame().clone()
+    d0.sync()
+    d0.close()
+    decs = []
+    for (g0, gr) in [(0, 2), (2, 1), (3, 2)]:
+        d = VarDctDecoder(0)
+        d.begin_frame(dict(params, stripe_group_y0=g0, stripe_group_rows=gr))
+        d.set_inputs(devt, dq)
+        d.profile(True)
+        d.decode_blocks()
+        decs.append(d)
+    torch.cuda.synchronize()
+    for i in range(2 if decs[0].halo_rows() else 0):  # (no loop filter: no halo rows to exchange)
+        decs[i + 1].halo_import(0, decs[i].halo_export(1))
+        decs[i].halo_import(1, decs[i + 1].halo_export(0))
+    parts = []
+    for d in decs:
+        out = d.alloc_output()
+        d.decode_filters(out)
+        d.sync()
+        parts.append(out)
+        assert "fused" in d.profile_read() and "filters" not in d.profile_read()
+        with pytest.raises(Exception):
+            d.export_xyb()  # the planes do not hold the inner DCT8 blocks
+    got = torch.cat(parts, dim=0)
+    assert torch.equal(got, whole)
+    assert rel_err(whole.cpu().numpy(), fr.decode(threads=4)) <= TIGHT
+    for d in decs:
+        d.close()
+
+
 def test_upload_path_equals_device_path(dec, dq, oracle):
     """Host-pointer hand-off (upload_side_info + submit_group per group, as a
     FrameDecoder would call it) gives the same pixels as device-resident inputs."""

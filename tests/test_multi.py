@@ -149,3 +149,31 @@ def test_multi_context_frames_back_to_back_without_sync(oracle, monkeypatch, pad
             assert (a[:, xs * 3:] == -7.0).all(), i  # row padding untouched
     finally:
         L.jxlhip_destroy(ctx)
+
+
+@pytest.mark.parametrize("gab,epf", [(1, 1), (0, 0), (1, 2)])
+@pytest.mark.parametrize("nstripes,host_out", [(3, False), (2, True)])
+def test_multi_context_stripes_take_the_fused_kernel(oracle, monkeypatch, nstripes, host_out, gab, epf):
+    """Stripes of a frame that qualifies for the fused kernel (12 Mpx and more; forced here with JXLHIP_FUSE=1) run it
+    too: a stripe's DCT8 blocks are decoded inside its filter march, only those of its first / last block row also
+    reach the planes -- the halo rows the neighbours pull.  Bit-equal to the whole frame through the fused kernel."""
+    L = abi.load_library()
+    xs, ys = 600, 1100
+    params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=bool(gab), epf_iters=epf, seed=57)
+    ref = fr.decode(threads=4)
+    monkeypatch.setenv("JXLHIP_FUSE", "1")
+    monkeypatch.setenv("JXLHIP_MULTI_FORCE_GATHER", "1")
+    d = VarDctDecoder(0)
+    d.begin_frame(params)
+    dq = d.default_dequant_tables()
+    d.set_inputs({k: ([x.cuda() for x in v] if isinstance(v, list) else v.cuda()) for k, v in t.items()}, dq)
+    single = d.decode_frame().cpu().numpy()
+    d.sync()
+    prof_single = None
+    table_host = dq.cpu().numpy()
+    d.close()
+    ndev = torch.cuda.device_count()
+    got = run_multi(L, [i % ndev for i in range(nstripes)], params, t, table_host, host_out)
+    assert rel_err(got, ref) <= TIGHT
+    assert rel_err(single, ref) <= TIGHT
+    assert np.array_equal(got, single)
