@@ -80,7 +80,8 @@ def cpu_baseline(cfg, sample, threads):
                                 coeff_type=int(cfg["coeff32"]), intensity_target=cfg["intensity"],
                                 quant_mul=cfg["quant_mul"])
     use_ref = oracle.ref_available()
-    run = (lambda: fr.decode_ref(threads=cores)) if use_ref else (lambda: fr.decode(threads=cores))
+    fma = use_ref and oracle.ref_lib_fma() is not None
+    run = (lambda: fr.decode_ref(threads=cores, fma_build=True)) if use_ref else (lambda: fr.decode(threads=cores))
     run()  # warm
     reps, t = 0, 0.0
     while reps < 2 or (t < 10.0 and reps < 12):
@@ -89,7 +90,10 @@ def cpu_baseline(cfg, sample, threads):
         t += time.perf_counter() - t0
         reps += 1
     what = ("libjxl reference sources (lib/jxl, DecodeGroupForRoundtrip + LowMemoryRenderPipeline) built with "
-            "the single-lane Highway shim (scalar; not the AVX2/AVX-512 build)") if use_ref else \
+            "the single-lane Highway shim" + (", -O3 -mavx2 -mfma (hardware FMA, compiler auto-vectorisation of the "
+                                              "one-lane loops; bit-identical to the -O2 checker build)" if fma else " (-O2)") +
+            ".  NOT libjxl's AVX2 / AVX-512 Highway build: Highway is not vendored in the reference tree, that "
+            "figure is unknown here") if use_ref else \
         "oracle/ C restatement (libjxl reference library not available)"
     return {"value": round(w * h * reps / t / 1e6, 2), "unit": "Mpixels/s", "cores": cores,
             "kind": "reference" if use_ref else "port",
@@ -350,7 +354,8 @@ def main():
                          "frac_dominant_kernel": round(b_alg / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "frac_kernel": round(b_own / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_kernel": traffic_kernel, "traffic_source": tsrc,
-                         "kernel": {"filters": "k_filters_fast", "fused": "k_fused",
+                         "kernel": {"filters": "k_filters_fast",
+                                    "fused": "k_fused" if os.environ.get("JXLHIP_FUSED_PC", "1") == "0" else "k_fused_pc",
                                     "blocks": "k_transform_mfma32<EMIT>"}.get(dom, dom),
                          "kernel_ms": kern[dom],
                          "algorithmic_bytes_per_launch": b_alg,

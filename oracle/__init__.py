@@ -276,6 +276,29 @@ def ref_lib():
     return _ref
 
 
+_REF_FMA_SO = os.path.join(_HERE, "_ref", "libjxl_ref_fma.so")
+_ref_fma = None
+
+
+def ref_lib_fma():
+    """The same reference sources compiled -O3 -mavx2 -mfma (build_ref.py variant "fma"): bench.py's cpu_baseline
+    only.  Falls back to the checker build when the host CPU has no AVX2 / FMA or the library is absent."""
+    global _ref_fma
+    if _ref_fma is None:
+        from . import build_ref
+        try:
+            flags = open("/proc/cpuinfo").read()
+            if " avx2" not in flags or " fma" not in flags:
+                raise RuntimeError("host CPU without AVX2 / FMA")
+            build_ref.build(variant="fma")
+            L = C.CDLL(_REF_FMA_SO)
+            L.jxr_decode_frame.argtypes = [C.POINTER(OracleFrame), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+            _ref_fma = L
+        except (RuntimeError, OSError):
+            _ref_fma = False
+    return _ref_fma or None
+
+
 def ref_default_dequant_tables():
     t = np.zeros(DEQUANT_TABLE_FLOATS, np.float32)
     assert ref_lib().jxr_default_dequant_tables(_p(t)) == 0
@@ -353,7 +376,7 @@ def ref_threads(xsize, ysize, max_threads):
     return 1 if (narrow or small) else max_threads
 
 
-def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None):
+def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None, fma_build=False):
     """The same frame through the REFERENCE's DecodeGroupForRoundtrip + render
     pipeline (LowMemory executor by default, as djxl; simple_pipeline=True for
     SimpleRenderPipeline).  The reference computes its own dequant tables: the
@@ -368,6 +391,8 @@ def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None):
             L.jxr_set_quant_encodings(None)
     p = self.params
     threads = ref_threads(p.xsize, p.ysize, threads)
+    ref_lib()
+    R = (ref_lib_fma() if fma_build else None) or ref_lib()
     # undo_orientation 5..8: the reference writes an xsize-high, ysize-wide frame (stage_write.cc:664-680)
     oh, ow = (p.xsize, p.ysize) if p.undo_orientation >= 5 else (p.ysize, p.xsize)
     if p.output_kind == 2:
@@ -376,14 +401,14 @@ def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None):
         of = p.out_format
         dt = {0: np.float32, 1: np.uint8, 2: np.uint16, 3: np.uint16}[of.sample_type]
         out = np.zeros((oh, ow, of.num_channels), dt)
-        rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), out.strides[0], 0, threads,
+        rc = R.jxr_decode_frame(C.byref(self.c), _p(out), out.strides[0], 0, threads,
                                         int(simple_pipeline))
     elif p.output_kind == 1:
         out = np.zeros((oh, ow, 3), np.float32)
-        rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), ow * 3, 0, threads, int(simple_pipeline))
+        rc = R.jxr_decode_frame(C.byref(self.c), _p(out), ow * 3, 0, threads, int(simple_pipeline))
     else:
         out = np.zeros((3, p.ysize, p.xsize), np.float32)
-        rc = ref_lib().jxr_decode_frame(C.byref(self.c), _p(out), p.xsize, p.xsize * p.ysize, threads,
+        rc = R.jxr_decode_frame(C.byref(self.c), _p(out), p.xsize, p.xsize * p.ysize, threads,
                                         int(simple_pipeline))
     if rc != 0:
         raise ValueError("reference decode failed")

@@ -62,13 +62,32 @@ def _compile(job):
     return (obj if r.returncode == 0 else None), r.stderr
 
 
-def build(verbose=False, only_compile=False):
-    lib = os.path.join(OUT, "libjxl_ref.so")
+# variant "fma": the same sources and the same single-lane Highway shim compiled -O3 -mavx2 -mfma -- MulAdd (= fmaf) is
+# one instruction instead of a libm call and the compiler may vectorise the one-lane loops.  Only bench.py's
+# cpu_baseline uses it (libjxl_ref_fma.so); the checker stays the portable -O2 build.  Same results bit for bit
+# (IEEE arithmetic either way, -ffp-contract=off; tests/test_reference_parity.py holds the two to equality).
+VARIANT_FLAGS = {"": [], "fma": ["-O3", "-mavx2", "-mfma"]}
+
+
+def build(verbose=False, only_compile=False, variant=""):
+    global FLAGS
+    lib = os.path.join(OUT, "libjxl_ref%s.so" % ("_" + variant if variant else ""))
     if not available():
         if os.path.exists(lib):
             return lib  # prebuilt, travelled with the snapshot
-        raise RuntimeError("reference tree not present and no prebuilt oracle/_ref/libjxl_ref.so")
-    os.makedirs(OBJ, exist_ok=True)
+        raise RuntimeError("reference tree not present and no prebuilt " + lib)
+    obj_dir = OBJ + ("_" + variant if variant else "")
+    os.makedirs(obj_dir, exist_ok=True)
+    base_flags = FLAGS
+    if variant:
+        FLAGS = [f for f in base_flags if f != "-O2"] + VARIANT_FLAGS[variant]
+    try:
+        return _build(lib, obj_dir, verbose, only_compile)
+    finally:
+        FLAGS = base_flags
+
+
+def _build(lib, OBJ, verbose, only_compile):
     jobs = []
     for f in source_list():
         jobs.append((os.path.join(REF, "lib", f), os.path.join(OBJ, f.replace("/", "__")[:-3] + ".o")))
@@ -99,5 +118,5 @@ def build(verbose=False, only_compile=False):
 
 
 if __name__ == "__main__":
-    build(verbose=True, only_compile="--compile-only" in sys.argv)
+    build(verbose=True, only_compile="--compile-only" in sys.argv, variant="fma" if "--fma" in sys.argv else "")
     sys.exit(0)

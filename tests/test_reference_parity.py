@@ -213,3 +213,15 @@ def test_reference_threads_bit_identical_when_last_column_is_wide(ref, xs, ys, g
     assert np.array_equal(bits(one), bits(_decode_ref_in_order(ref, fr, "2,5,1,4,0,3")))
     for _ in range(3):
         assert np.array_equal(bits(one), bits(_decode_ref_in_order(ref, fr, None, threads=8)))
+
+
+def test_fma_build_of_the_reference_is_bit_identical(ref):
+    """bench.py's cpu_baseline times oracle/_ref/libjxl_ref_fma.so: the same reference sources and Highway shim
+    compiled -O3 -mavx2 -mfma.  Same IEEE arithmetic (MulAdd = fmaf either way, -ffp-contract=off): same bits."""
+    if ref.ref_lib_fma() is None:
+        pytest.skip("no AVX2 / FMA on this host")
+    import frames
+    from libjxl_amd import synth
+    for (w, h, gab, epf) in ((520, 300, True, 1), (333, 268, True, 3), (256, 128, False, 0)):
+        _, _, fr = frames.make_case(w, h, mix=synth.MIX_ALL, gab=gab, epf_iters=epf, seed=4)
+        assert np.array_equal(fr.decode_ref(threads=1), fr.decode_ref(threads=1, fma_build=True))
