@@ -377,11 +377,13 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
 //                     It issues no store, so its vmcnt waits cover loads only.
 // One s_barrier per block row joins the two (fill(i) done / march(i-1) done).  Workgroup = 128 threads = one
 // window; six workgroups per CU (three waves per SIMD by registers, 24.7 KB of LDS each).
-struct __attribute__((aligned(16))) StripLds {
-  float slab[2][3 * kSlabPlaneFloats];  // [buffer][channel][row 0..7][column 0..127]
-  float sigma[2][16];                   // [buffer][cell]: inv_sigma of the block row's 16 cells (columns clamped into the frame)
-  uint32_t list[16 * 4];                // producer scratch: the DCT8 cells of the block row being filled
+template <int NB>
+struct __attribute__((aligned(16))) StripLdsT {
+  float slab[NB][3 * kSlabPlaneFloats];  // [buffer][channel][row 0..7][column 0..127]
+  float sigma[NB][16];                   // [buffer][cell]: inv_sigma of the block row's 16 cells (columns clamped into the frame)
+  uint32_t list[NB - 1][16 * 4];         // per producer: the DCT8 cells of the block row being filled
 };
+typedef StripLdsT<2> StripLds;
 
 // groups of 8 rows a window chunk [y_begin, y_end) walks over: [head (HX rows of the block row above)] + whole
 // groups + [tail (HX rows of the block row below)]; group i starts at image row r_first + 8 i
@@ -426,7 +428,7 @@ __device__ __forceinline__ void ProducePC(FrameArgs fa, StripLds* w, int bc0, in
     }
     LdsF* slab = (LdsF*)w->slab[i & 1];
 #ifndef JXLHIP_ABL_PC_NOFILL  // ablation builds (tools/build_variant.py): the marching wave alone
-    FinishSlab<CT>(fa, slab, (LdsU*)w->list, cur, bc0, 0);  // four plane row pairs by LDS-DMA + the DCT8 cells; ends on vmcnt(0)
+    FinishSlab<CT>(fa, slab, (LdsU*)w->list[0], cur, bc0, 0);  // four plane row pairs by LDS-DMA + the DCT8 cells; ends on vmcnt(0)
 #else
     (void)slab;
     (void)cur;
@@ -619,7 +621,7 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
       tab[c][4] = t1.x, tab[c][5] = t1.y, tab[c][6] = t1.z, tab[c][7] = t1.w;
     }
   }
-  LdsU* list = (LdsU*)w->list;
+  LdsU* list = (LdsU*)w->list[0];
   auto group_nb = [&](int g) { return GroupBlockRow(r_first + 8 * (g < G ? g : G - 1), nb_last); };
   PcGroupRegs A, B;
   PcNext n0, n1;
@@ -657,8 +659,8 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
   }
 }
 
-template <int GAB, int EPF, int OUTK, int FMT, bool EDGE>
-__device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P, Lane& L, StripLds* w, int bc0,
+template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, int NB = 2>
+__device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P, Lane& L, StripLdsT<NB>* w, int bc0,
                                         int y_begin, int y_end) {
   constexpr int HX = MarchGeom<GAB, EPF>::HX;
   const int H = (int)f.ysize;
@@ -694,9 +696,10 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
   // the lane's cell inside the window, for the inv_sigma row the producer leaves in LDS
   const LdsF* sig0 = (const LdsF*)w->sigma[0] + ((int)(L.sx4 >> 2) - bc0);
   int i = 0;
-  auto enter_group = [&](int g) -> float {  // after the barrier that publishes buffer g & 1
-    L.slab = slab0 + (g & 1) * (3 * kSlabPlaneFloats);
-    return EPF ? sig0[(g & 1) * 16] : 0.0f;
+  auto enter_group = [&](int g) -> float {  // after the barrier that publishes buffer g % NB
+    const int b = NB == 2 ? (g & 1) : g % NB;
+    L.slab = slab0 + b * (3 * kSlabPlaneFloats);
+    return EPF ? sig0[b * 16] : 0.0f;
   };
 #ifdef JXLHIP_ABL_PC_NOMARCH  // ablation builds: the producing wave alone
 #define JXLHIP_PSTEP(K) (void)slab_y0, (void)sigma_pre, (void)sigma_prev
@@ -838,11 +841,11 @@ __global__ __launch_bounds__(128, 3) void k_fused_pc(DevFrame f, FilterParams P,
 }
 
 // rows per window chunk: a multiple of 8 that fills whole generations of resident workgroups (6 per CU)
-int FusedRowsPC(unsigned strips, unsigned rows) {
+int FusedRowsPC(unsigned strips, unsigned rows, unsigned per_cu = 6) {
   const char* e = getenv("JXLHIP_FUSED_PC_RH");  // experiments / tests: rows per window chunk
   const int forced = e ? atoi(e) : 0;
   if (forced > 0) return (forced + 7) & ~7;
-  const unsigned resident = 256u * 6u;
+  const unsigned resident = 256u * per_cu;
   int best = 64;
   double best_cost = 1e30;
   for (int rh = 16; rh <= 1024; rh += 8) {
