@@ -377,9 +377,20 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
 //                     It issues no store, so its vmcnt waits cover loads only.
 // One s_barrier per block row joins the two (fill(i) done / march(i-1) done).  Workgroup = 128 threads = one
 // window; six workgroups per CU (three waves per SIMD by registers, 24.7 KB of LDS each).
+#ifdef JXLHIP_ABL_PC_ONEBUF  // ablation builds (timing only, garbage pixels): both "buffers" are the same 12 KB, eight
+#define JXLHIP_PC_SLABS 1    // workgroups per CU fit the LDS -- what would twice as many, shorter marches per CU buy?
+#define JXLHIP_PC_SLAB(b) 0
+#define JXLHIP_PC_WAVES 4
+#define JXLHIP_PC_PER_CU 8
+#else
+#define JXLHIP_PC_SLABS NB
+#define JXLHIP_PC_SLAB(b) (b)
+#define JXLHIP_PC_WAVES 3
+#define JXLHIP_PC_PER_CU 6
+#endif
 template <int NB>
 struct __attribute__((aligned(16))) StripLdsT {
-  float slab[NB][3 * kSlabPlaneFloats];  // [buffer][channel][row 0..7][column 0..127]
+  float slab[JXLHIP_PC_SLABS][3 * kSlabPlaneFloats];  // [buffer][channel][row 0..7][column 0..127]
   float sigma[NB][16];                   // [buffer][cell]: inv_sigma of the block row's 16 cells (columns clamped into the frame)
   uint32_t list[NB - 1][16 * 4];         // per producer: the DCT8 cells of the block row being filled
 };
@@ -426,7 +437,7 @@ __device__ __forceinline__ void ProducePC(FrameArgs fa, StripLds* w, int bc0, in
       NextRowRequest(fa, nx, nb, bc0);
       sg = sigma_request(nb);
     }
-    LdsF* slab = (LdsF*)w->slab[i & 1];
+    LdsF* slab = (LdsF*)w->slab[JXLHIP_PC_SLAB(i & 1)];
 #ifndef JXLHIP_ABL_PC_NOFILL  // ablation builds (tools/build_variant.py): the marching wave alone
     FinishSlab<CT>(fa, slab, (LdsU*)w->list[0], cur, bc0, 0);  // four plane row pairs by LDS-DMA + the DCT8 cells; ends on vmcnt(0)
 #else
@@ -636,7 +647,7 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
   // one fill: CUR holds block row g (loaded behind an earlier barrier), NXT receives block row g+1,
   // nn = cell info of block row g+1 (valid), refilled with block row g+2's
   auto body = [&](int g, PcGroupRegs& CUR, PcGroupRegs& NXT, uint32_t& sg_cur, uint32_t& sg_nxt, PcNext& nn) {
-    LdsF* slab = (LdsF*)w->slab[g & 1];  // free: the march left it before the previous barrier
+    LdsF* slab = (LdsF*)w->slab[JXLHIP_PC_SLAB(g & 1)];  // free: the march left it before the previous barrier
     PcIssue(fa, list, nn, bc0, NXT);     // block row g+1 (the last block row again behind the end: harmless)
     sg_nxt = nn.sg;
     PcRequest(fa, nn, group_nb(g + 2), bc0);
@@ -698,7 +709,7 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
   int i = 0;
   auto enter_group = [&](int g) -> float {  // after the barrier that publishes buffer g % NB
     const int b = NB == 2 ? (g & 1) : g % NB;
-    L.slab = slab0 + b * (3 * kSlabPlaneFloats);
+    L.slab = slab0 + JXLHIP_PC_SLAB(b) * (3 * kSlabPlaneFloats);
     return EPF ? sig0[b * 16] : 0.0f;
   };
 #ifdef JXLHIP_ABL_PC_NOMARCH  // ablation builds: the producing wave alone
@@ -778,7 +789,7 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
 // that an XCD's L2 sees neighbouring windows of the same rows (they share two block columns of coefficients and
 // plane tiles); the grid is padded to a multiple of 8
 template <int GAB, int EPF, int OUTK, int FMT, typename CT>
-__global__ __launch_bounds__(128, 3) void k_fused_pc(DevFrame f, FilterParams P, int RH, int strips, int nwg, int role_shift) {
+__global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, FilterParams P, int RH, int strips, int nwg, int role_shift) {
   __shared__ StripLds lds;
   // which of the two waves marches: swapped on every 2^role_shift-th workgroup (in dispatch order), so that the
   // SIMDs of a CU -- which receive a workgroup's waves in turn -- each get marching and producing waves
@@ -841,7 +852,7 @@ __global__ __launch_bounds__(128, 3) void k_fused_pc(DevFrame f, FilterParams P,
 }
 
 // rows per window chunk: a multiple of 8 that fills whole generations of resident workgroups (6 per CU)
-int FusedRowsPC(unsigned strips, unsigned rows, unsigned per_cu = 6) {
+int FusedRowsPC(unsigned strips, unsigned rows, unsigned per_cu = JXLHIP_PC_PER_CU) {
   const char* e = getenv("JXLHIP_FUSED_PC_RH");  // experiments / tests: rows per window chunk
   const int forced = e ? atoi(e) : 0;
   if (forced > 0) return (forced + 7) & ~7;
