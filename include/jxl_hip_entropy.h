@@ -134,6 +134,20 @@ JXLHIP_EXPORT int jxlhip_ac_group_decode(const jxlhip_ac_pass* pass, uint32_t xs
                                          size_t* bit_pos, uint32_t shift, uint32_t coeff_type,
                                          void* const coeffs[3], size_t* ncoeffs);
 
+/* The same group as NON-ZERO coefficients only: entries[c][i] = (position << 16) | (uint16_t)value, position =
+ * the coefficient's index in the group's channel stream (what jxlhip_ac_group_decode would have written to
+ * coeffs[c][position]), in decode order; counts[c] entries per channel, at most capacity[c].  Single pass
+ * only (values are not accumulated).  JXLHIP_ERR_RANGE: a value does not fit 16 bits or a channel has more than
+ * capacity[c] non-zeros -- decode the group densely instead.  Nine out of ten coefficients of a d1.0 frame are zero:
+ * this is the form in which jxlhip_ac_group_decode_submit sends a group over PCIe (JXLHIP_SPARSE_UPLOAD=0 turns it
+ * off); the context expands it into the dense block stream on the device. */
+JXLHIP_EXPORT int jxlhip_ac_group_decode_sparse(const jxlhip_ac_pass* pass, uint32_t xsize_blocks,
+                                                uint32_t ysize_blocks, uint32_t group_x, uint32_t group_y,
+                                                const uint8_t* ac_strategy, const int32_t* raw_quant,
+                                                const uint8_t* quant_dc, const uint8_t* data, size_t size,
+                                                size_t* bit_pos, uint32_t shift, uint32_t* const entries[3],
+                                                const uint32_t capacity[3], uint32_t counts[3], size_t* ncoeffs);
+
 /* Entropy-decode a single-pass group straight into a pinned staging buffer of
  * the context and queue its upload (jxlhip_submit_group): the call a
  * JxlParallelRunner worker makes per AC group.  Thread-safe.  Side info

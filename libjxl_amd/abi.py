@@ -231,7 +231,7 @@ EXPORTS = [
     "jxlhip_dequant_dc_groups",
     # include/jxl_hip_entropy.h
     "jxlhip_ac_pass_decode", "jxlhip_ac_pass_destroy", "jxlhip_ac_pass_max_num_bits",
-    "jxlhip_ac_pass_used_orders", "jxlhip_ac_pass_order", "jxlhip_ac_group_decode",
+    "jxlhip_ac_pass_used_orders", "jxlhip_ac_pass_order", "jxlhip_ac_group_decode", "jxlhip_ac_group_decode_sparse",
     "jxlhip_ac_group_decode_submit", "jxlhip_block_ctx_map_decode", "jxlhip_quant_dc_contexts",
     "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode", "jxlhip_ac_group_decode_submit_passes",
     "jxlhip_ac_groups_decode_submit", "jxlhip_num_toc_entries", "jxlhip_toc_decode", "jxlhip_ac_global_decode_at",
@@ -276,6 +276,8 @@ def load_library():
     L.jxlhip_ac_pass_used_orders.restype = u32
     L.jxlhip_ac_group_decode.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, vp, sz, C.POINTER(sz), u32, u32,
                                          vp * 3, C.POINTER(sz)]
+    L.jxlhip_ac_group_decode_sparse.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, vp, sz, C.POINTER(sz), u32,
+                                                vp * 3, u32 * 3, u32 * 3, C.POINTER(sz)]
     L.jxlhip_ac_group_decode_submit.argtypes = [vp, vp, u32, vp, vp, vp, vp, sz, C.POINTER(sz)]
     L.jxlhip_ac_group_decode_submit_passes.argtypes = [vp, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp]
     L.jxlhip_ac_groups_decode_submit.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]

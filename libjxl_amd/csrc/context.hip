@@ -86,6 +86,21 @@ struct jxlhip_ctx {
   uint8_t* up_side = nullptr;  // one slab: acs, quant, sharp, ytox, ytob, dc*3, dequant
   size_t up_side_bytes = 0;
   jxlhip_frame_inputs up_inputs{};
+  // sparse coefficient hand-off (jxlhip_ac_group_decode_submit, single-pass 16-bit frames): a group's non-zero
+  // coefficients go up as (position << 16 | value) words into sp_dev + group * kSparseStride; BeginDecode expands the
+  // groups whose sp_mode byte is set into the dense upload buffer (k_expand_sparse)
+  bool sparse_upload = true;  // JXLHIP_SPARSE_UPLOAD=0 turns it off
+  uint8_t* sp_dev = nullptr;
+  size_t sp_bytes = 0;
+  uint32_t frame_serial = 0;
+  std::atomic<bool> sp_any{false};
+  std::atomic<size_t> sp_arena_used{0};   // sp_dev is a per-frame bump arena: a staging slot's worth of groups per copy
+  uint32_t* sp_off_host[2] = {nullptr, nullptr};  // pinned, per frame parity: arena offset / 16 of every group's header,
+  size_t sp_off_items = 0;                        // 0xFFFFFFFF = the group was handed over densely
+  hipEvent_t sp_off_ev[2] = {nullptr, nullptr};   // "the copy of sp_off_host[parity] has executed"
+  bool sp_off_pending[2] = {false, false};
+  uint32_t* sp_off_dev = nullptr;
+  size_t sp_off_dev_items = 0;
   hipStream_t pool[kPoolStreams] = {nullptr};
   hipEvent_t pool_ev[kPoolStreams] = {nullptr};
   hipEvent_t frame_ev = nullptr;  // jxlhip_frame_begin: "everything queued for the previous frame", see there
@@ -310,6 +325,8 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
     c->generic_filters = e && !strcmp(e, "generic");
     const char* b = getenv("JXLHIP_BLOCK_STREAMS");
     if (b) c->nblock_streams = atoi(b);
+    const char* su = getenv("JXLHIP_SPARSE_UPLOAD");
+    if (su) c->sparse_upload = atoi(su) != 0;
     const char* fu = getenv("JXLHIP_FUSE");
     if (fu) c->fuse = atoi(fu) != 0 ? 1 : 0;
     const char* mf = getenv("JXLHIP_MFMA");
@@ -397,6 +414,12 @@ void jxlhip_destroy(jxlhip_ctx* c) {
     if (c->stage[i]) StageFree(c, c->stage[i]);
   }
   if (c->pinned_frame) StageFree(c, c->pinned_frame);
+  if (c->sp_dev) (void)hipFree(c->sp_dev);
+  if (c->sp_off_dev) (void)hipFree(c->sp_off_dev);
+  for (int i = 0; i < 2; i++) {
+    if (c->sp_off_host[i]) StageFree(c, c->sp_off_host[i]);
+    if (c->sp_off_ev[i]) (void)hipEventDestroy(c->sp_off_ev[i]);
+  }
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
                   c->dc_tmp,     c->quant_enc,  c->dc_prec,      c->cell_info,
@@ -417,6 +440,41 @@ int jxlhip_set_stream(jxlhip_ctx* c, void* hip_stream, int external) {
 }
 
 // ---- frame set-up -------------------------------------------------------------
+// A new hand-over of a frame's data begins (jxlhip_frame_begin, and jxlhip_upload_side_info: the same frame may be
+// handed over again without a new frame_begin).  Frames may follow each other without a jxlhip_sync: the group
+// uploads travel on the pool streams into buffers the previous decode's kernels (main stream) may still be reading,
+// so the pool streams wait for everything queued on the main stream; the sparse arena and its offset table start empty.
+static int BeginHandover(jxlhip_ctx* c) {
+  const DevFrame& f = c->f;
+  c->frame_serial++;
+  c->sp_any.store(false);
+  c->sp_arena_used.store(0);
+  if (c->sparse_upload && f.coeff_type == JXLHIP_COEFF_I16) {
+    const size_t ng = (size_t)f.xsg * f.ysg;
+    const int par = (int)(c->frame_serial & 1u);
+    if (c->sp_off_items < ng) {
+      for (int i = 0; i < 2; i++) {
+        if (c->sp_off_pending[i]) (void)hipEventSynchronize(c->sp_off_ev[i]);
+        c->sp_off_pending[i] = false;
+        if (c->sp_off_host[i]) StageFree(c, c->sp_off_host[i]);
+        c->sp_off_host[i] = nullptr;
+        if (StageAlloc(c, (void**)&c->sp_off_host[i], ng * 4)) return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "sparse offset table");
+        if (!c->sp_off_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->sp_off_ev[i], hipEventDisableTiming));
+      }
+      c->sp_off_items = ng;
+    }
+    // the table of two hand-overs ago has long been copied; make sure before it is overwritten
+    if (c->sp_off_pending[par]) HIPCHK(c, hipEventSynchronize(c->sp_off_ev[par]));
+    c->sp_off_pending[par] = false;
+    memset(c->sp_off_host[par], 0xFF, ng * 4);
+  }
+  if (c->up_coeffs[0]) {
+    HIPCHK(c, hipEventRecord(c->frame_ev, c->stream));
+    for (int i = 0; i < kPoolStreams; i++) HIPCHK(c, hipStreamWaitEvent(c->pool[i], c->frame_ev, 0));
+  }
+  return JXLHIP_OK;
+}
+
 int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   if (c && p && p->undo_orientation > 8) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "undo_orientation %u", p->undo_orientation);
   if (!c || !p) return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -559,15 +617,13 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
     fp.dither_y0 = fy ? (int32_t)p->ysize - 1 : 0;
     fp.dither_ys = fy ? -1 : 1;
   }
-  // Frames may follow each other without a jxlhip_sync: the group uploads of THIS frame travel on the pool
-  // streams into the same upload buffers the previous frame's kernels (main stream) may still be reading.
-  if (c->up_coeffs[0]) {
-    HIPCHK(c, hipEventRecord(c->frame_ev, c->stream));
-    for (int i = 0; i < kPoolStreams; i++) HIPCHK(c, hipStreamWaitEvent(c->pool[i], c->frame_ev, 0));
-  }
   c->fp = fp;
   c->f = f;
   c->p = *p;
+  {
+    const int rc = BeginHandover(c);
+    if (rc) return rc;
+  }
   c->have_frame = true;
   c->have_inputs = false;
   c->blocks_done = false;
@@ -644,6 +700,17 @@ static int EnsureUploadBuffers(jxlhip_ctx* c) {
     HIPCHK(c, hipMalloc(&c->up_coeffs[0], cbytes));
     c->up_coeff_bytes = cbytes;
   }
+  if (c->sparse_upload && esz == 2) {  // the landing zone of the sparse hand-off (see SubmitSparse)
+    const size_t need = (size_t)f.xsg * f.ysg * 3 * JXLHIP_GROUP_COEFFS * 2;
+    if (c->sp_bytes < need) {
+      if (c->sp_dev) HIPCHK(c, hipFree(c->sp_dev));
+      c->sp_dev = nullptr;
+      c->sp_bytes = 0;
+      HIPCHK(c, hipMalloc((void**)&c->sp_dev, need));
+      HIPCHK(c, hipMemset(c->sp_dev, 0, need));  // no header carries a frame serial yet
+      c->sp_bytes = need;
+    }
+  }
   c->up_groups = f.xsg * f.ysg;
   c->up_esz = esz;
   c->up_coeffs[1] = (char*)c->up_coeffs[0] + (size_t)JXLHIP_GROUP_COEFFS * esz;
@@ -686,6 +753,7 @@ int jxlhip_upload_side_info(jxlhip_ctx* c, const uint8_t* ac_strategy, const int
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = EnsureUploadBuffers(c))) return rc;
+  if ((rc = BeginHandover(c))) return rc;  // (again when the frame is handed over a second time)
   const DevFrame& f = c->f;
   const size_t nb = (size_t)f.xsb * f.ysb;
   const size_t nt = (size_t)f.xtiles * ((f.ysb + 7) / 8);
@@ -767,6 +835,107 @@ static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void*
   return JXLHIP_OK;
 }
 
+// ---- sparse hand-off ------------------------------------------------------------------------------------------
+// A single-pass, 16-bit group crosses PCIe as its NON-ZERO coefficients: 16 header bytes (three counts) + one
+// (position << 16 | value) word per non-zero, the three channels' lists back to back -- nine out of ten
+// coefficients of a d1.0 frame are zero, and the dense stream is 384 KB per group whatever it holds (8K: 196 MB per
+// frame).  The compact groups of one runner thread are collected in a staging slot and go up TOGETHER: one
+// hipMemcpyAsync costs ~15 us inside the runtime whatever thread issues it, serialised -- 510 per-group copies
+// were an 8 ms floor under an 8K frame however many threads decoded.  sp_dev is a per-frame bump arena;
+// sp_off_host[parity][g] says where group g's header landed (0xFFFFFFFF: handed over densely); BeginDecode uploads
+// that table and k_expand_sparse rebuilds the dense block stream (zero + scatter) behind the uploads.
+// entries per channel (X, Y, B), one slot's worth in total: the luma list can take EVERY coefficient of the group (a
+// noise patch at d1.0 has 45 000 non-zero luma coefficients in a group), the chroma lists a quarter each
+static constexpr uint32_t kSparseCap[3] = {16382u, 65536u, 16382u};
+static constexpr size_t kSparseStride = 3u * (size_t)JXLHIP_GROUP_COEFFS * 2u;     // arena bytes per group, worst case
+static constexpr int kBatchGroups = 96;
+
+struct SparseBatch {  // what one runner thread has collected (in its own heap buffer: a pinned staging slot is only
+  std::vector<uint8_t> buf;  // held for the moment of the copy -- more threads than slots must not starve each other)
+  size_t used = 0;
+  int n = 0;
+  uint32_t group[kBatchGroups];
+  uint32_t at[kBatchGroups];  // byte offset of the group's header inside the slot
+};
+
+static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out);
+static void ReleaseSlot(jxlhip_ctx* c, int slot, bool uploaded);
+
+// the batch goes up as one copy through a pinned staging slot; its groups' headers are entered into the offset table
+static int SparseFlush(jxlhip_ctx* c, SparseBatch* b) {
+  if (b->n == 0) return JXLHIP_OK;
+  int slot = -1;
+  int rc = AcquireSlot(c, kSparseStride, &slot);
+  if (rc) return rc;
+  memcpy(c->stage[slot], b->buf.data(), b->used);
+  const size_t bytes = (b->used + 255) & ~(size_t)255;
+  const size_t off = c->sp_arena_used.fetch_add(bytes);
+  int stream;
+  {
+    std::lock_guard<std::mutex> lock(c->pool_mu);
+    stream = (int)(c->pool_next++ % kPoolStreams);
+    c->pool_dirty[stream] = true;
+  }
+  if (off + bytes > c->sp_bytes) rc = Fail(c, JXLHIP_ERR_STATE, "sparse arena overflow");
+  if (!rc && hipSetDevice(c->device) != hipSuccess) rc = JXLHIP_ERR_HIP;
+  if (!rc) {
+    hipError_t e = hipMemcpyAsync(c->sp_dev + off, c->stage[slot], b->used, hipMemcpyHostToDevice, c->pool[stream]);
+    if (e != hipSuccess) rc = Fail(c, JXLHIP_ERR_HIP, "sparse submit: %s", hipGetErrorString(e));
+    else if (hipEventRecord(c->stage_ev[slot], c->pool[stream]) != hipSuccess) rc = Fail(c, JXLHIP_ERR_HIP, "sparse submit: event record failed");
+  }
+  if (!rc) {
+    uint32_t* table = c->sp_off_host[c->frame_serial & 1u];
+    for (int i = 0; i < b->n; i++) table[b->group[i]] = (uint32_t)((off + b->at[i]) >> 4);
+    c->sp_any.store(true);
+  }
+  ReleaseSlot(c, slot, rc == JXLHIP_OK);
+  b->used = 0;
+  b->n = 0;
+  return rc;
+}
+
+// One group, single pass, decoded into `scratch` (kSparseStride bytes) and appended to the batch.
+// JXLHIP_ERR_RANGE: not representable (a chroma channel with more than kSparseCap non-zeros, a value outside 16 bits):
+// the caller hands the group over densely.
+static int SparseAppend(jxlhip_ctx* c, SparseBatch* b, uint8_t* scratch, const jxlhip_ac_pass* pass, uint32_t shift,
+                        uint32_t group_idx, const uint8_t* ac_strategy, const int32_t* raw_quant, const uint8_t* quant_dc,
+                        const uint8_t* data, size_t size, size_t* bit_pos) {
+  const DevFrame& f = c->f;
+  uint32_t* const ent[3] = {(uint32_t*)(scratch + 16), (uint32_t*)(scratch + 16) + kSparseCap[0],
+                            (uint32_t*)(scratch + 16) + kSparseCap[0] + kSparseCap[1]};
+  uint32_t cnt[3] = {0, 0, 0};
+  size_t pos = *bit_pos, ncoeffs = 0;
+  int rc = jxlhip_ac_group_decode_sparse(pass, f.xsb, f.ysb, group_idx % f.xsg, group_idx / f.xsg, ac_strategy, raw_quant, quant_dc,
+                                         data, size, &pos, shift, ent, kSparseCap, cnt, &ncoeffs);
+  if (rc) return rc;
+  *bit_pos = pos;
+  const size_t bytes = 16 + 4 * ((size_t)cnt[0] + cnt[1] + cnt[2]);
+  if (b->buf.size() < kSparseStride) b->buf.resize(kSparseStride);
+  if (b->n && (b->used + bytes > kSparseStride || b->n == kBatchGroups)) {
+    if ((rc = SparseFlush(c, b))) return rc;
+  }
+  uint8_t* dst = b->buf.data() + b->used;
+  uint32_t* hdr = (uint32_t*)dst;
+  hdr[0] = cnt[0], hdr[1] = cnt[1], hdr[2] = cnt[2], hdr[3] = 0;
+  memcpy(dst + 16, ent[0], (size_t)cnt[0] * 4);
+  memcpy(dst + 16 + (size_t)cnt[0] * 4, ent[1], (size_t)cnt[1] * 4);
+  memcpy(dst + 16 + ((size_t)cnt[0] + cnt[1]) * 4, ent[2], (size_t)cnt[2] * 4);
+  b->group[b->n] = group_idx;
+  b->at[b->n] = (uint32_t)b->used;
+  b->n++;
+  b->used += (bytes + 15) & ~(size_t)15;
+  return JXLHIP_OK;
+}
+
+static bool SparseEligible(const jxlhip_ctx* c, uint32_t num_passes) {
+  return c->sparse_upload && num_passes == 1 && c->f.coeff_type == JXLHIP_COEFF_I16 && c->sp_dev &&
+         c->sp_bytes >= (size_t)c->f.xsg * c->f.ysg * kSparseStride && c->sp_off_items >= (size_t)c->f.xsg * c->f.ysg;
+}
+
+static int SubmitPassesImpl(jxlhip_ctx* c, uint32_t num_passes, const jxlhip_ac_pass* const* passes, const uint32_t* shifts,
+                            uint32_t group_idx, const uint8_t* ac_strategy, const int32_t* raw_quant, const uint8_t* quant_dc,
+                            const uint8_t* const* data, const size_t* sizes, size_t* bit_pos, bool allow_sparse);
+
 // f1: entropy-decode all passes of one AC group into a pinned staging slot and
 // queue its upload.  The slot is reused only after its copies completed.
 int jxlhip_ac_group_decode_submit_passes(jxlhip_ctx* c, uint32_t num_passes,
@@ -787,75 +956,101 @@ int jxlhip_ac_group_decode_submit_passes(jxlhip_ctx* c, uint32_t num_passes,
     return MultiCheck(c, c->children[o], jxlhip_ac_group_decode_submit_passes(c->children[o], num_passes, passes, shifts, group_idx, ac_strategy,
                                                                               raw_quant, quant_dc, data, sizes, bit_pos));
   }
+  return SubmitPassesImpl(c, num_passes, passes, shifts, group_idx, ac_strategy, raw_quant, quant_dc, data, sizes, bit_pos, true);
+}
+
+// A free pinned staging slot (state 1 = owned by the caller); blocks while all are in flight / owned.
+static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out) {
+  int slot = -1;
+  std::unique_lock<std::mutex> lock(c->stage_mu);
+  if (hipSetDevice(c->device) != hipSuccess) return JXLHIP_ERR_HIP;
+  if (c->stage_bytes < slot_bytes) {
+    // (re)allocation: only when no thread owns a slot
+    c->stage_cv.wait(lock, [&] {
+      for (int i = 0; i < kStageSlots; i++)
+        if (c->stage_state[i] == 1) return false;
+      return true;
+    });
+    if (c->stage_bytes < slot_bytes) {
+      for (int i = 0; i < kStageSlots; i++) {
+        if (c->stage[i]) {
+          if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
+          StageFree(c, c->stage[i]);
+          c->stage[i] = nullptr;
+        }
+        c->stage_state[i] = 0;
+        if (StageAlloc(c, &c->stage[i], slot_bytes) != JXLHIP_OK)
+          return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
+        if (!c->stage_ev[i] &&
+            hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess)
+          return Fail(c, JXLHIP_ERR_HIP, "event creation failed");
+      }
+      c->stage_bytes = slot_bytes;
+    }
+  }
+  while (slot < 0) {
+    int pending = -1;
+    for (int i = 0; i < kStageSlots && slot < 0; i++) {
+      if (c->stage_state[i] == 0) slot = i;
+      else if (c->stage_state[i] == 2) {
+        if (hipEventQuery(c->stage_ev[i]) == hipSuccess) slot = i;
+        else if (pending < 0) pending = i;
+      }
+    }
+    if (slot >= 0) break;
+    if (pending >= 0) {  // every slot is in flight: wait for one upload
+      if (hipEventSynchronize(c->stage_ev[pending]) != hipSuccess) return JXLHIP_ERR_HIP;
+      if (c->stage_state[pending] == 2) slot = pending;
+    } else {  // every slot is owned by another decoding thread
+      c->stage_cv.wait(lock);
+    }
+  }
+  c->stage_state[slot] = 1;
+  *out = slot;
+  return JXLHIP_OK;
+}
+
+static void ReleaseSlot(jxlhip_ctx* c, int slot, bool uploaded) {
+  {
+    std::lock_guard<std::mutex> lock(c->stage_mu);
+    c->stage_state[slot] = uploaded ? 2 : 0;
+  }
+  c->stage_cv.notify_all();
+}
+
+static int SubmitPassesImpl(jxlhip_ctx* c, uint32_t num_passes, const jxlhip_ac_pass* const* passes, const uint32_t* shifts,
+                            uint32_t group_idx, const uint8_t* ac_strategy, const int32_t* raw_quant, const uint8_t* quant_dc,
+                            const uint8_t* const* data, const size_t* sizes, size_t* bit_pos, bool allow_sparse) {
   const DevFrame& f = c->f;
   if (group_idx >= f.xsg * f.ysg) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad group %u", group_idx);
   const size_t esz = f.coeff_type == JXLHIP_COEFF_I16 ? 2 : 4;
   const size_t slot_bytes = 3 * (size_t)JXLHIP_GROUP_COEFFS * esz;
-  int slot = -1;
-  {
-    std::unique_lock<std::mutex> lock(c->stage_mu);
-    if (hipSetDevice(c->device) != hipSuccess) return JXLHIP_ERR_HIP;
-    if (c->stage_bytes < slot_bytes) {
-      // (re)allocation: only when no thread owns a slot
-      c->stage_cv.wait(lock, [&] {
-        for (int i = 0; i < kStageSlots; i++)
-          if (c->stage_state[i] == 1) return false;
-        return true;
-      });
-      if (c->stage_bytes < slot_bytes) {
-        for (int i = 0; i < kStageSlots; i++) {
-          if (c->stage[i]) {
-            if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
-            StageFree(c, c->stage[i]);
-            c->stage[i] = nullptr;
-          }
-          c->stage_state[i] = 0;
-          if (StageAlloc(c, &c->stage[i], slot_bytes) != JXLHIP_OK)
-            return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
-          if (!c->stage_ev[i] &&
-              hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess)
-            return Fail(c, JXLHIP_ERR_HIP, "event creation failed");
-        }
-        c->stage_bytes = slot_bytes;
-      }
+  int rc = JXLHIP_ERR_RANGE;
+  if (allow_sparse && SparseEligible(c, num_passes)) {  // one group = one batch (callers that submit groups one by one)
+    SparseBatch b;
+    std::vector<uint8_t> scratch(kSparseStride);
+    rc = SparseAppend(c, &b, scratch.data(), passes[0], shifts ? shifts[0] : 0, group_idx, ac_strategy, raw_quant, quant_dc,
+                      data[0], sizes[0], &bit_pos[0]);
+    const int rf = SparseFlush(c, &b);
+    if (rc == JXLHIP_OK) rc = rf;
+  }
+  if (rc == JXLHIP_ERR_RANGE) {  // the dense form
+    int slot = -1;
+    if ((rc = AcquireSlot(c, slot_bytes, &slot))) return rc;
+    char* base = (char*)c->stage[slot];
+    void* const ch[3] = {base, base + (size_t)JXLHIP_GROUP_COEFFS * esz, base + 2 * (size_t)JXLHIP_GROUP_COEFFS * esz};
+    size_t ncoeffs = 0;
+    memset(base, 0, slot_bytes);  // coefficients are accumulated (dec_group.cc:527-531)
+    for (uint32_t p = 0; p < num_passes && rc == JXLHIP_OK; p++)
+      rc = jxlhip_ac_group_decode(passes[p], f.xsb, f.ysb, group_idx % f.xsg, group_idx / f.xsg, ac_strategy,
+                                  raw_quant, quant_dc, data[p], sizes[p], &bit_pos[p], shifts ? shifts[p] : 0,
+                                  f.coeff_type, ch, &ncoeffs);
+    if (rc == JXLHIP_OK) {
+      const void* const src[3] = {ch[0], ch[1], ch[2]};
+      rc = jxlhip_submit_group_ev(c, group_idx, src, ncoeffs, c->stage_ev[slot]);
     }
-    while (slot < 0) {
-      int pending = -1;
-      for (int i = 0; i < kStageSlots && slot < 0; i++) {
-        if (c->stage_state[i] == 0) slot = i;
-        else if (c->stage_state[i] == 2) {
-          if (hipEventQuery(c->stage_ev[i]) == hipSuccess) slot = i;
-          else if (pending < 0) pending = i;
-        }
-      }
-      if (slot >= 0) break;
-      if (pending >= 0) {  // every slot is in flight: wait for one upload
-        if (hipEventSynchronize(c->stage_ev[pending]) != hipSuccess) return JXLHIP_ERR_HIP;
-        if (c->stage_state[pending] == 2) slot = pending;
-      } else {  // every slot is owned by another decoding thread
-        c->stage_cv.wait(lock);
-      }
-    }
-    c->stage_state[slot] = 1;
+    ReleaseSlot(c, slot, rc == JXLHIP_OK);
   }
-  char* base = (char*)c->stage[slot];
-  void* const ch[3] = {base, base + (size_t)JXLHIP_GROUP_COEFFS * esz, base + 2 * (size_t)JXLHIP_GROUP_COEFFS * esz};
-  memset(base, 0, slot_bytes);  // coefficients are accumulated (dec_group.cc:527-531)
-  size_t ncoeffs = 0;
-  int rc = JXLHIP_OK;
-  for (uint32_t p = 0; p < num_passes && rc == JXLHIP_OK; p++)
-    rc = jxlhip_ac_group_decode(passes[p], f.xsb, f.ysb, group_idx % f.xsg, group_idx / f.xsg, ac_strategy,
-                                raw_quant, quant_dc, data[p], sizes[p], &bit_pos[p], shifts ? shifts[p] : 0,
-                                f.coeff_type, ch, &ncoeffs);
-  if (rc == JXLHIP_OK) {
-    const void* const src[3] = {ch[0], ch[1], ch[2]};
-    rc = jxlhip_submit_group_ev(c, group_idx, src, ncoeffs, c->stage_ev[slot]);
-  }
-  {
-    std::lock_guard<std::mutex> lock(c->stage_mu);
-    c->stage_state[slot] = rc == JXLHIP_OK ? 2 : 0;
-  }
-  c->stage_cv.notify_all();
   if (rc == JXLHIP_ERR_BAD_STREAM) return Fail(c, rc, "AC group %u: invalid entropy-coded data", group_idx);
   return rc;
 }
@@ -872,9 +1067,20 @@ struct GroupsJob {
   const uint8_t* const* sections;
   const size_t* sizes;
   std::atomic<int> status{JXLHIP_OK};
+  // sparse hand-off: one open staging slot + one decode scratch per runner thread
+  bool sparse = false;
+  std::vector<SparseBatch> batch;
+  std::vector<std::vector<uint8_t>> scratch;
 };
-int GroupsInit(void*, size_t) { return 0; }
-void GroupsFunc(void* opaque, uint32_t g, size_t /*thread*/) {
+int GroupsInit(void* opaque, size_t num_threads) {
+  GroupsJob* j = static_cast<GroupsJob*>(opaque);
+  if (j->sparse) {
+    j->batch.assign(num_threads ? num_threads : 1, SparseBatch());
+    j->scratch.assign(num_threads ? num_threads : 1, std::vector<uint8_t>());
+  }
+  return 0;
+}
+void GroupsFunc(void* opaque, uint32_t g, size_t thread) {
   GroupsJob* j = static_cast<GroupsJob*>(opaque);
   if (j->status.load(std::memory_order_relaxed) != JXLHIP_OK) return;
   const DevFrame& f = j->c->f;
@@ -887,8 +1093,15 @@ void GroupsFunc(void* opaque, uint32_t g, size_t /*thread*/) {
     sizes[p] = j->sizes[(size_t)p * j->num_groups + g];
     pos[p] = 0;
   }
-  const int rc = jxlhip_ac_group_decode_submit_passes(j->c, j->num_passes, j->passes, j->shifts, g, j->acs,
-                                                      j->raw_quant, j->quant_dc, data, sizes, pos);
+  int rc = JXLHIP_ERR_RANGE;
+  if (j->sparse && thread < j->batch.size()) {
+    if (j->scratch[thread].empty()) j->scratch[thread].resize(kSparseStride);
+    rc = SparseAppend(j->c, &j->batch[thread], j->scratch[thread].data(), j->passes[0], j->shifts ? j->shifts[0] : 0, g, j->acs,
+                      j->raw_quant, j->quant_dc, data[0], sizes[0], &pos[0]);
+    if (rc == JXLHIP_ERR_BAD_STREAM) Fail(j->c, rc, "AC group %u: invalid entropy-coded data", g);
+  }
+  if (rc == JXLHIP_ERR_RANGE)
+    rc = SubmitPassesImpl(j->c, j->num_passes, j->passes, j->shifts, g, j->acs, j->raw_quant, j->quant_dc, data, sizes, pos, false);
   if (rc != JXLHIP_OK) {
     int expected = JXLHIP_OK;
     j->status.compare_exchange_strong(expected, rc);
@@ -923,11 +1136,20 @@ int jxlhip_ac_groups_decode_submit(jxlhip_ctx* c, jxlhip_parallel_runner runner,
   job.quant_dc = quant_dc;
   job.sections = sections;
   job.sizes = sizes;
+  job.sparse = SparseEligible(c, num_passes);
   if (runner) {
     if (runner(runner_opaque, &job, GroupsInit, GroupsFunc, 0, job.num_groups) != 0)
       return Fail(c, JXLHIP_ERR_STATE, "parallel runner failed");
   } else {
+    GroupsInit(&job, 1);
     for (uint32_t g = 0; g < job.num_groups; g++) GroupsFunc(&job, g, 0);
+  }
+  for (SparseBatch& b : job.batch) {  // what the threads still hold
+    const int rc = SparseFlush(c, &b);
+    if (rc != JXLHIP_OK) {
+      int expected = JXLHIP_OK;
+      job.status.compare_exchange_strong(expected, rc);
+    }
   }
   return job.status.load();
 }
@@ -1065,6 +1287,18 @@ int BeginDecode(jxlhip_ctx* c, uint32_t nbands) {
       HIPCHK(c, hipStreamWaitEvent(st, c->pool_ev[i], 0));
       c->pool_dirty[i] = false;
     }
+  }
+  if (c->sp_any.load() && c->f.coeffs[0] == c->up_coeffs[0]) {
+    // the groups that came up as non-zero lists: their offset table, then zero + scatter into the dense upload
+    // buffer, behind the uploads.  (Idempotent: a second decode of the same frame repeats it.)
+    const size_t ng = (size_t)c->f.xsg * c->f.ysg;
+    const int par = (int)(c->frame_serial & 1u);
+    int rc;
+    if ((rc = Grow(c, &c->sp_off_dev, &c->sp_off_dev_items, ng))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->sp_off_dev, c->sp_off_host[par], ng * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->sp_off_ev[par], st));
+    c->sp_off_pending[par] = true;
+    LaunchExpandSparse(c->sp_dev, c->sp_off_dev, (int16_t*)c->up_coeffs[0], c->f.group_y0 * c->f.xsg, c->f.group_rows * c->f.xsg, st);
   }
   if (nbands > (uint32_t)kMaxBands) nbands = kMaxBands;
   HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kCountStride * nbands, st));

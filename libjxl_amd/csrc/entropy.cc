@@ -966,10 +966,48 @@ const ZeroDensityLut& ZdLut() {
   return l;
 }
 
-template <typename T, bool kPlainAns>
+// Where the decoded coefficients of a group go: the reference's dense block stream (DenseSink: values are ADDED,
+// dec_group.cc:527-531 -- progressive passes accumulate), or the non-zero ones as (position << 16 | value) words
+// per channel (SparseSink, single-pass frames: nine out of ten coefficients of a d1.0 frame are zero, and the
+// dense stream is what crosses PCIe otherwise).
+template <typename T>
+struct DenseSink {
+  static constexpr bool kSparse = false;
+  T* const* coeffs;
+  bool out_of_range = false;  // 16-bit buffers only
+  bool overflow = false;
+  inline void Put(int c, size_t pos, int32_t coeff) {
+    if constexpr (sizeof(T) == 2) {
+      const int32_t sum = (int32_t)coeffs[c][pos] + coeff;
+      out_of_range |= sum != (int32_t)(int16_t)sum;
+      coeffs[c][pos] = (T)sum;
+    } else {
+      coeffs[c][pos] = (T)(coeffs[c][pos] + (T)coeff);
+    }
+  }
+};
+struct SparseSink {
+  static constexpr bool kSparse = true;
+  uint32_t* ent[3];
+  uint32_t cnt[3] = {0, 0, 0};
+  uint32_t cap[3];
+  bool out_of_range = false;
+  bool overflow = false;
+  inline void Put(int c, size_t pos, int32_t coeff) {
+    if (coeff == 0) return;
+    out_of_range |= coeff != (int32_t)(int16_t)coeff;
+    if (cnt[c] >= cap[c]) {
+      overflow = true;
+      return;
+    }
+    ent[c][cnt[c]++] = ((uint32_t)pos << 16) | (uint32_t)(uint16_t)(int16_t)coeff;
+  }
+};
+
+template <typename Sink, bool kPlainAns>
 int DecodeGroupImpl(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
                     const uint8_t* acs_map, const int32_t* raw_quant, const uint8_t* quant_dc, BitReader* br,
-                    uint32_t shift, T* const coeffs[3], size_t* ncoeffs) {
+                    uint32_t shift, Sink& sink, size_t* ncoeffs) {
   const uint32_t bx0 = gx * 32, by0 = gy * 32;
   if (bx0 >= xsb || by0 >= ysb) return JXLHIP_ERR_INVALID_ARGUMENT;
   const uint32_t gw = std::min(32u, xsb - bx0), gh = std::min(32u, ysb - by0);
@@ -991,7 +1029,6 @@ int DecodeGroupImpl(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint
   // device by k_prepare; here it only has to be harmless.
   int32_t nz[3][32][32];
   memset(nz, 0, sizeof(nz));
-  bool out_of_range = false;  // 16-bit buffers only
   size_t offset = 0;
   for (uint32_t by = 0; by < gh; by++) {
     for (uint32_t bx = 0; bx < gw; bx++) {
@@ -1034,8 +1071,16 @@ int DecodeGroupImpl(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint
         // DecodeACVarBlock's coefficient loop (dec_group.cc:510-538)
         const uint8_t* hmap = cmap + ctx_offset + nb * 37 + 458 * block_ctx;
         const uint32_t* order = pass->orders.data() + L.offset[ord][c];
-        T* block = coeffs[c] + offset;
         uint32_t prev = nzeros > size / 16 ? 0 : 1;
+        // sparse sink: the write cursor lives in locals for the block (through the sink it would be reloaded after
+        // every store: the entries and the counts are both uint32_t)
+        uint32_t* w = nullptr;
+        uint32_t* wend = nullptr;
+        bool oor = false;
+        if constexpr (Sink::kSparse) {
+          w = sink.ent[c] + sink.cnt[c];
+          wend = sink.ent[c] + sink.cap[c];
+        }
         for (uint32_t k = covered; k < size && nzeros != 0; k++) {
           const uint32_t left = (nzeros + covered - 1) >> log2c;
           if (left >= 64) return kBad;  // more non-zeros than positions: invalid stream
@@ -1043,15 +1088,21 @@ int DecodeGroupImpl(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint
           const uint32_t u = kPlainAns ? reader.ReadHybridUintAns(hmap[ctx], br) : reader.ReadHybridUint(hmap[ctx], br);
           const uint32_t magnitude = u >> 1, neg = (~u) & 1;  // UnpackSigned
           const int32_t coeff = (int32_t)((magnitude ^ (neg - 1)) << shift);
-          if constexpr (sizeof(T) == 2) {
-            const int32_t sum = (int32_t)block[order[k]] + coeff;
-            out_of_range |= sum != (int32_t)(int16_t)sum;
-            block[order[k]] = (T)sum;
+          if constexpr (Sink::kSparse) {
+            if (u != 0) {
+              oor |= coeff != (int32_t)(int16_t)coeff;
+              if (w < wend) *w++ = ((uint32_t)(offset + order[k]) << 16) | (uint32_t)(uint16_t)(int16_t)coeff;
+              else sink.overflow = true;
+            }
           } else {
-            block[order[k]] = (T)(block[order[k]] + (T)coeff);
+            sink.Put(c, offset + order[k], coeff);
           }
           prev = u != 0;
           nzeros -= prev;
+        }
+        if constexpr (Sink::kSparse) {
+          sink.cnt[c] = (uint32_t)(w - sink.ent[c]);
+          sink.out_of_range |= oor;
         }
         if (nzeros != 0) return kBad;
       }
@@ -1060,18 +1111,27 @@ int DecodeGroupImpl(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint
   }
   if (reader.Corrupt() || !reader.FinalStateOk()) return kBad;
   if (!br->Healthy()) return kBad;
-  if (out_of_range) return JXLHIP_ERR_RANGE;
+  if (sink.out_of_range || sink.overflow) return JXLHIP_ERR_RANGE;
   if (ncoeffs) *ncoeffs = offset;
   return kOk;
+}
+
+template <typename Sink>
+int DecodeGroupS(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
+                 const uint8_t* acs_map, const int32_t* raw_quant, const uint8_t* quant_dc, BitReader* br,
+                 uint32_t shift, Sink& sink, size_t* ncoeffs) {
+  if (!pass->code.use_prefix && !pass->code.lz77.enabled)
+    return DecodeGroupImpl<Sink, true>(pass, xsb, ysb, gx, gy, acs_map, raw_quant, quant_dc, br, shift, sink, ncoeffs);
+  return DecodeGroupImpl<Sink, false>(pass, xsb, ysb, gx, gy, acs_map, raw_quant, quant_dc, br, shift, sink, ncoeffs);
 }
 
 template <typename T>
 int DecodeGroupT(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
                  const uint8_t* acs_map, const int32_t* raw_quant, const uint8_t* quant_dc, BitReader* br,
                  uint32_t shift, T* const coeffs[3], size_t* ncoeffs) {
-  if (!pass->code.use_prefix && !pass->code.lz77.enabled)
-    return DecodeGroupImpl<T, true>(pass, xsb, ysb, gx, gy, acs_map, raw_quant, quant_dc, br, shift, coeffs, ncoeffs);
-  return DecodeGroupImpl<T, false>(pass, xsb, ysb, gx, gy, acs_map, raw_quant, quant_dc, br, shift, coeffs, ncoeffs);
+  DenseSink<T> sink;
+  sink.coeffs = coeffs;
+  return DecodeGroupS(pass, xsb, ysb, gx, gy, acs_map, raw_quant, quant_dc, br, shift, sink, ncoeffs);
 }
 
 }  // namespace
@@ -2168,6 +2228,22 @@ int jxlhip_ac_group_decode(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ys
     int32_t* const c32[3] = {(int32_t*)coeffs[0], (int32_t*)coeffs[1], (int32_t*)coeffs[2]};
     rc = DecodeGroupT<int32_t>(pass, xsb, ysb, gx, gy, acs, raw_quant, quant_dc, &br, shift, c32, ncoeffs);
   }
+  if (rc == kOk) *bit_pos = br.BitsConsumed();
+  return rc;
+}
+
+int jxlhip_ac_group_decode_sparse(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
+                                  const uint8_t* acs, const int32_t* raw_quant, const uint8_t* quant_dc,
+                                  const uint8_t* data, size_t size, size_t* bit_pos, uint32_t shift,
+                                  uint32_t* const entries[3], const uint32_t capacity[3], uint32_t counts[3], size_t* ncoeffs) {
+  if (!pass || !acs || !raw_quant || !data || !bit_pos || !entries || !entries[0] || !entries[1] || !entries[2] ||
+      !counts || !capacity || shift > 24)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  BitReader br(data, size, *bit_pos);
+  SparseSink sink;
+  for (int c = 0; c < 3; c++) sink.ent[c] = entries[c], sink.cap[c] = capacity[c];
+  const int rc = DecodeGroupS(pass, xsb, ysb, gx, gy, acs, raw_quant, quant_dc, &br, shift, sink, ncoeffs);
+  for (int c = 0; c < 3; c++) counts[c] = sink.cnt[c];
   if (rc == kOk) *bit_pos = br.BitsConsumed();
   return rc;
 }

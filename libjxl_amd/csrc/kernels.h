@@ -60,6 +60,12 @@ bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int ep
 // (LaunchFiltersFast with gab = 0, epf_iters = 2 on those planes) follows.  false: geometry not covered.
 bool LaunchEpf0(const DevFrame& f, const FilterParams& p, int gab, float* const dst[3], hipStream_t st);
 
+// Sparse coefficient hand-off (kernels_tables.hip k_expand_sparse): group g of [g0, g0 + n) whose entry in `offsets`
+// is not 0xFFFFFFFF is expanded from `sparse + 16 * offsets[g]` -- three counts + pad, then the (position << 16 |
+// value) lists of the three channels back to back -- into the dense int16 block stream `dense`
+// ([group][channel][65536], zero-filled first)
+void LaunchExpandSparse(const uint8_t* sparse, const uint32_t* offsets, int16_t* dense, uint32_t g0, uint32_t n, hipStream_t st);
+
 // undo_orientation (kernels_tables.hip k_orient): coded xsize x ysize pixels of bytes_per_pixel -> display orientation
 bool LaunchOrient(const void* src, size_t src_stride, uint32_t xsize, uint32_t ysize, uint32_t bytes_per_pixel,
                   uint32_t orientation, void* dst, size_t dst_stride, hipStream_t st);

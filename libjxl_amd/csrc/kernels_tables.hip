@@ -294,4 +294,31 @@ void LaunchDequantDC(uint32_t xsb, uint32_t ysb, const int32_t* const q[3], floa
   }
 }
 
+// ---------------------------------------------------------------- sparse coefficient hand-off
+// One workgroup per AC group: zero the group's dense block stream (3 x 65536 int16 = 384 KB), then scatter its
+// non-zero coefficients.  What crosses PCIe is 4 bytes per NON-ZERO coefficient instead of 2 bytes per coefficient.
+__global__ __launch_bounds__(1024) void k_expand_sparse(const uint8_t* __restrict__ sparse, const uint32_t* __restrict__ offsets,
+                                                       int16_t* __restrict__ dense, uint32_t g0) {
+  const uint32_t g = g0 + blockIdx.x;
+  const uint32_t off = offsets[g];
+  if (off == 0xFFFFFFFFu) return;  // handed over densely (progressive passes, a channel with too many non-zeros)
+  const uint32_t* hdr = (const uint32_t*)(sparse + (size_t)off * 16u);
+  const uint32_t n0 = hdr[0], n1 = hdr[1], n2 = hdr[2];
+  int16_t* d = dense + (size_t)g * 3 * 65536;
+  uint4* d4 = (uint4*)d;
+  for (uint32_t i = threadIdx.x; i < 3u * 65536u * 2u / 16u; i += 1024) d4[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  const uint32_t* e = hdr + 4;
+  const uint32_t total = n0 + n1 + n2;
+  for (uint32_t i = threadIdx.x; i < total; i += 1024) {
+    const uint32_t c = (i >= n0 ? 1u : 0u) + (i >= n0 + n1 ? 1u : 0u);
+    const uint32_t v = e[i];
+    d[c * 65536u + (v >> 16)] = (int16_t)(v & 0xffffu);
+  }
+}
+
+void LaunchExpandSparse(const uint8_t* sparse, const uint32_t* offsets, int16_t* dense, uint32_t g0, uint32_t n, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_expand_sparse, dim3(n), dim3(1024), 0, st, sparse, offsets, dense, g0);
+}
+
 }  // namespace jxlhip

@@ -94,14 +94,23 @@ def available():
     return B.available()
 
 
+# Both decoder libraries are compiled like bench.py's cpu_baseline build of the same sources: -O3 -mavx2 -mfma over
+# the one-lane Highway shim (build_ref.py variant "fma": hardware FMA for MulAdd; bit-identical to the -O2 checker
+# build, tests/test_reference_parity.py) -- djxl_ref should not be slower than it has to be when its MP/s stand next
+# to djxl_hip's.
+VARIANT = "fma"
+
+
 def build(verbose=False):
+    global FLAGS
     ref_so = os.path.join(B.OUT, "libjxl_dec_ref.so")
     hip_so = os.path.join(B.OUT, "libjxl_dec_hip.so")
     if not B.available():
         if os.path.exists(ref_so) and os.path.exists(hip_so):
             return ref_so, hip_so  # prebuilt, travelled with the snapshot
         raise RuntimeError("reference tree not present and no prebuilt seam libraries")
-    objs = B.build(only_compile=True)
+    objs = B.build(only_compile=True, variant=VARIANT)
+    FLAGS = [f for f in B.FLAGS if f != "-O2"] + B.VARIANT_FLAGS[VARIANT] + ["-DJPEGXL_ENABLE_BOXES=0", "-DJPEGXL_ENABLE_TRANSCODE_JPEG=0"]
     os.makedirs(SEAM, exist_ok=True)
     extra_objs = []
     for f in EXTRA_TUS:

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cinttypes>
 #include <cmath>
 #include <cstddef>
@@ -146,6 +147,10 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   jxlhip_ctx* ctx = Context();
   if (!ctx) return true;  // no device: CPU path
 
+  const bool verbose = getenv("JXLHIP_SEAM_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  double t_side = 0, t_entropy = 0, t_decode = 0;
   auto check = [&](int rc, const char* what) -> Status {
     if (rc == JXLHIP_OK) return true;
     return JXL_FAILURE("jxlhip %s: %s (%s)", what, jxlhip_status_string(rc), jxlhip_last_error(ctx));
@@ -210,6 +215,7 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   const float* dc3[3] = {dc.data(), dc.data() + nb, dc.data() + 2 * nb};
   const float* table = sh.matrices.Matrix(AcStrategyType::DCT, 0);  // = table_ (quant_weights.h:364-367), EnsureComputed by ProcessACGlobal
 
+  t_side = now();
   // ---- AC global once more, from its bytes, into the product's pass objects (histograms, coefficient orders)
   jxlhip_block_ctx_map bcm = {};
   for (int c = 0; c < 3; c++) {
@@ -268,8 +274,10 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     JXL_RETURN_IF_ERROR(check(rc, "AC groups"));
     break;
   }
+  t_entropy = now();
   if (!to_callback) {
     JXL_RETURN_IF_ERROR(check(jxlhip_decode_frame_host(ctx, mo.buffer, mo.stride, 0), "decode_frame"));
+    t_decode = now();
   } else {
     // Row callback (JxlDecoderSetImageOutCallback / SetMultithreadedImageOutCallback, decode.cc:2655-2700): the
     // frame arrives in the context's pinned host frame, already in display orientation, and is handed out as
@@ -278,6 +286,7 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     const void* frame = nullptr;
     size_t pitch = 0;
     JXL_RETURN_IF_ERROR(check(jxlhip_decode_frame_pinned(ctx, &frame, &pitch), "decode_frame"));
+    t_decode = now();
     const bool transposed = static_cast<uint32_t>(ds->undo_orientation) >= 5;
     const size_t ow = transposed ? dim.ysize : dim.xsize, oh = transposed ? dim.xsize : dim.ysize;
     const size_t px_bytes =
@@ -301,10 +310,11 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     if (run_opaque) cb.destroy(run_opaque);
     JXL_RETURN_IF_ERROR(ok);
   }
-  if (getenv("JXLHIP_SEAM_VERBOSE"))
-    fprintf(stderr, "jxlhip seam: frame %zux%zu decoded on the HIP back-end (%s, %u-bit sample type %u, %u channels)\n",
+  if (verbose)
+    fprintf(stderr, "jxlhip seam: frame %zux%zu decoded on the HIP back-end (%s, %u-bit sample type %u, %u channels); ms: "
+                    "side info %.2f, AC global + entropy decode + uploads %.2f, kernels + copy out %.2f, row callbacks %.2f\n",
             static_cast<size_t>(dim.xsize), static_cast<size_t>(dim.ysize), to_callback ? "callback" : "buffer", bits,
-            sample_type, mo.format.num_channels);
+            sample_type, mo.format.num_channels, t_side - t_begin, t_entropy - t_side, t_decode - t_entropy, now() - t_decode);
   for (size_t g = 0; g < dim.num_groups; g++) {
     fd->decoded_passes_per_ac_group_[g] = static_cast<uint8_t>(np);
     for (size_t ps = 0; ps < np && !single; ps++) section_status[ac_group_sec[g][ps]] = FrameDecoder::SectionStatus::kDone;

@@ -115,6 +115,53 @@ def test_roundtrip_d1_mix_1024_int16(L, ref):
         assert np.array_equal(out[c], npy["coeffs"][c]), c
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(force_huffman=True), dict(histo_sets=2), dict(lz77_method=1)])
+def test_sparse_group_decode_equals_the_dense_stream(L, ref, opts):
+    """jxlhip_ac_group_decode_sparse: the group's NON-ZERO coefficients as (position << 16 | value) words per channel
+    -- the form that crosses PCIe (jxlhip_ac_group_decode_submit; k_expand_sparse rebuilds the dense stream on the
+    device).  Expanded on the host it is the reference encoder's coefficient buffer bit for bit, it consumes the same
+    bits, and a capacity that is too small is reported as JXLHIP_ERR_RANGE (the caller then decodes densely)."""
+    xs, ys = 520, 300
+    params, fr, npy = case(xs, ys, mix=synth.MIX_ALL, gab=True, epf_iters=1, seed=31)
+    glob, groups, used_acs, used_orders = fr.encode_ac_ref(**opts)
+    L.jxlhip_ac_group_decode_sparse.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                                C.c_uint32, C.c_void_p * 3, C.c_uint32 * 3, C.c_uint32 * 3,
+                                                C.POINTER(C.c_size_t)]
+    rc, h, pos = open_pass(L, glob, used_acs, opts.get("histo_sets", 1))
+    assert rc == 0
+    xsb, ysb, xsg = (xs + 7) // 8, (ys + 7) // 8, (xs + 255) // 256
+    cap = 32766
+    try:
+        for gi, data in enumerate(groups):
+            d = np.frombuffer(data, np.uint8) if len(data) else np.zeros(1, np.uint8)
+            ent = [np.zeros(cap, np.uint32) for _ in range(3)]
+            cnt = (C.c_uint32 * 3)()
+            gp, n = C.c_size_t(0), C.c_size_t(0)
+            args = (h, xsb, ysb, gi % xsg, gi // xsg, npy["ac_strategy"].ctypes.data, npy["raw_quant"].ctypes.data, None,
+                    d.ctypes.data, len(data), C.byref(gp), 0, (C.c_void_p * 3)(*[e.ctypes.data for e in ent]))
+            assert L.jxlhip_ac_group_decode_sparse(*args, (C.c_uint32 * 3)(cap, cap, cap), cnt, C.byref(n)) == 0
+            assert (gp.value + 7) // 8 == len(data)
+            for c in range(3):
+                want = npy["coeffs"][c][gi * 65536:(gi + 1) * 65536]
+                got = np.zeros(65536, np.int16)
+                e = ent[c][:cnt[c]]
+                assert len(np.unique(e >> 16)) == len(e)  # one entry per position
+                got[e >> 16] = (e & 0xFFFF).astype(np.uint16).view(np.int16)
+                assert np.array_equal(got, want), (gi, c)
+                assert cnt[c] == np.count_nonzero(want)
+            # too small a capacity: reported, nothing written past it
+            small = max(1, int(max(cnt)) // 2)
+            ent2 = [np.full(small + 1, 0xDEADBEEF, np.uint32) for _ in range(3)]
+            gp2 = C.c_size_t(0)
+            args2 = args[:10] + (C.byref(gp2), 0, (C.c_void_p * 3)(*[e.ctypes.data for e in ent2]))
+            if max(cnt) > 1:
+                assert L.jxlhip_ac_group_decode_sparse(*args2, (C.c_uint32 * 3)(small, small, small), cnt, C.byref(n)) == -8  # JXLHIP_ERR_RANGE
+                assert all(e[small] == 0xDEADBEEF for e in ent2)
+    finally:
+        L.jxlhip_ac_pass_destroy(h)
+
+
 def test_roundtrip_int32_large_values(L, ref):
     # d0.5-like quantisation with int32 buffers: long hybrid-uint tokens
     xs, ys = 520, 264

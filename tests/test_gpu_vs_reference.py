@@ -283,9 +283,15 @@ def test_packed_8k_srgb_u8_rgba_full_size(dec, ref):
 # the product decodes them on host threads into pinned staging, uploads them group
 # by group and renders; the result must equal the decode from device-resident
 # coefficients bit for bit (entropy coding is lossless).
-def test_entropy_decode_submit_end_to_end(dec, ref):
+@pytest.mark.parametrize("sparse", ["1", "0"])
+def test_entropy_decode_submit_end_to_end(dec, ref, sparse, monkeypatch):
+    """sparse = 1 (the default): a group crosses PCIe as its non-zero coefficients and k_expand_sparse rebuilds the
+    dense block stream on the device; 0: the dense staging slot.  Either way the pixels of the device-resident path,
+    bit for bit -- and a later frame that is handed over DENSELY (jxlhip_submit_group) in the same context must not
+    see the earlier frame's sparse groups."""
     import ctypes as C
     import threading
+    monkeypatch.setenv("JXLHIP_SPARSE_UPLOAD", sparse)
     xs, ys = 1000, 700
     params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=True, epf_iters=1, seed=77)
     dq = dec.default_dequant_tables()
@@ -331,6 +337,27 @@ def test_entropy_decode_submit_end_to_end(dec, ref):
     d2.sync()
     L.jxlhip_ac_pass_destroy(h)
     assert torch.equal(got, want)
+    assert torch.equal(d2.decode_frame(), want)  # a second decode of the same frame
+    d2.sync()
+    # another frame, same context, dense hand-over of (other) coefficients
+    params2, t2, _ = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=True, epf_iters=1, seed=78)
+    dec.begin_frame(params2)
+    dec.set_inputs({k: ([x.cuda() for x in v] if isinstance(v, list) else v.cuda()) for k, v in t2.items()}, dq)
+    want2 = dec.decode_frame().clone()
+    dec.sync()
+    assert not torch.equal(want2, want)
+    d2.begin_frame(params2)
+    npy2 = {k: ([x.numpy() for x in v] if isinstance(v, list) else v.numpy()) for k, v in t2.items()}
+    dc3b = (C.c_void_p * 3)(*[x.ctypes.data for x in npy2["dc"]])
+    assert L.jxlhip_upload_side_info(d2.ctx, npy2["ac_strategy"].ctypes.data, npy2["raw_quant"].ctypes.data,
+                                     npy2["epf_sharpness"].ctypes.data, npy2["ytox_map"].ctypes.data,
+                                     npy2["ytob_map"].ctypes.data, dc3b, dqh.ctypes.data) == 0
+    for gi in range(ng):
+        ptrs = (C.c_void_p * 3)(*[npy2["coeffs"][c][gi * 65536:].ctypes.data for c in range(3)])
+        assert L.jxlhip_submit_group(d2.ctx, gi, ptrs, 65536) == 0
+    got2 = d2.decode_frame()
+    d2.sync()
+    assert torch.equal(got2, want2)
     d2.close()
 
 

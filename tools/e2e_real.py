@@ -39,7 +39,8 @@ t0 = time.perf_counter()
 assert L.jxlhip_ac_global_decode(glob.ctypes.data, len(glob), ng, 1, int(d["used_acs"]), C.byref(bctx), C.byref(encs),
                                  C.byref(nh), hs, C.byref(used)) == 0
 t_global = time.perf_counter() - t0
-params = abi.FrameParams.from_buffer_copy(d["params"].tobytes())
+_pb = d["params"].tobytes()  # (files written before a field was appended to jxlhip_frame_params: zero-padded)
+params = abi.FrameParams.from_buffer_copy(_pb + b"\0" * max(0, C.sizeof(abi.FrameParams) - len(_pb)))
 params.output_kind = 1
 # 16-bit buffers optimistically (jxl_hip_entropy.h): JXLHIP_ERR_RANGE would ask for a redo with --i32
 params.coeff_type = 1 if "--i32" in sys.argv else 0
