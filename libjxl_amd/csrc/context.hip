@@ -135,7 +135,8 @@ struct jxlhip_ctx {
   int band_rows = 0;  // JXLHIP_BAND_ROWS: group rows per band of decode_frame (0 = whole stripe, the default:
                       // measured on MI355X, bands of 1-9 group rows under-fill the chip and lose 10-70 %)
   bool generic_filters = false;  // JXLHIP_FILTERS=generic: LDS kernel for every stage list
-  int mfma = -1;                 // DCT32X32 on the matrix cores (kernels_mfma.hip).  -1 (default): when the caller's
+  int mfma = -1;                 // DCT32X32 / DCT16X16 on the matrix cores (kernels_mfma.hip; the 16x16 rule is in
+                                 // LaunchBlocksBand).  -1 (default): when the caller's
                                  // used_acs says DCT32X32 is the only class of the row-per-lane 32-point family in
                                  // the frame (the class kernel then is a launch of its own anyway; measured on c5:
                                  // 219 -> 193 us); on mixed frames the butterflies inside the merged launch win
@@ -360,7 +361,7 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
     return fail(JXLHIP_ERR_HIP);
   if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kCountStride * kMaxBands) != hipSuccess ||
       hipMalloc((void**)&c->error_flag, sizeof(int32_t) * 2) != hipSuccess ||
-      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024 + 2048)) != hipSuccess ||
+      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024 + 2048 + 256)) != hipSuccess ||
       hipMalloc((void**)&c->quant_enc, sizeof(jxlhip_quant_encoding) * JXLHIP_NUM_QUANT_TABLES) != hipSuccess)
     return fail(JXLHIP_ERR_OUT_OF_MEMORY);
   if (hipMemset(c->error_flag, 0, sizeof(int32_t) * 2) != hipSuccess ||
@@ -371,8 +372,9 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
           hipSuccess)
     return fail(JXLHIP_ERR_HIP);
   {
-    float mfma_tab[2048];
+    float mfma_tab[2048 + 256];
     MfmaDct32Constants(mfma_tab);
+    MfmaDct16Constants(mfma_tab + 2048);
     if (hipMemcpy(c->tables + 1600, mfma_tab, sizeof(mfma_tab), hipMemcpyHostToDevice) != hipSuccess)
       return fail(JXLHIP_ERR_HIP);
   }
@@ -1181,6 +1183,14 @@ int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, int fuse
     constexpr uint32_t kOthers32 = (1u << 8) | (1u << 9) | (1u << 10) | (1u << 11);  // 32x8 .. 16x32
     const bool lone32 = (f.used_acs & (1u << 5)) && !(f.used_acs & kOthers32);
     f.mfma32 = (c->mfma > 0 || (c->mfma < 0 && lone32)) ? c->tables + 1600 : nullptr;
+    // DCT16X16: the same rule against the 16-point row-per-lane family (16x8, 8x16), only when no 32-point class
+    // pulls the merged launch in anyway, and on frames of 16 Mpx and more (measured, all-DCT16X16 frames: 8K blocks
+    // 132 -> 118 us, 16x16 + 32x32 176 -> 161 us; 4K 33.6 -> 37.6 us: the butterflies stay; on the mixed c3 frame a
+    // launch of its own costs 97 -> 117 us, like DCT32X32)
+    constexpr uint32_t kOthers16 = (1u << 6) | (1u << 7);
+    const bool lone16 = (f.used_acs & (1u << 4)) && !(f.used_acs & (kOthers16 | kOthers32)) &&
+                        (!(f.used_acs & (1u << 5)) || f.mfma32) && (uint64_t)f.xsize * f.ysize >= (16u << 20);
+    f.mfma16 = (c->mfma > 0 || (c->mfma < 0 && lone16)) ? c->tables + 1600 + 2048 : nullptr;
   }
   if (fused)  // every cell "from the planes" until k_prepare says otherwise
     HIPCHK(c, hipMemsetAsync(c->cell_info, 0xFF, sizeof(uint2) * (size_t)f.xsb * f.ysb, st));

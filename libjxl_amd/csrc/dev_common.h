@@ -146,6 +146,8 @@ struct DevFrame {
   // JXLHIP_MFMA=1 (kernels_mfma.hip): DCT32X32 varblocks go through the matrix-core kernel; operand tables
   // (2048 floats, MfmaDct32Constants), nullptr = the row-per-lane path decodes them
   const float* mfma32;
+  // the same for DCT16X16 (256 floats, MfmaDct16Constants)
+  const float* mfma16;
   // != 0: xyb[] are plain row-major planes of this many bytes per row, first row plane_y0 (k_epf0's output
   // as the EPF1 + EPF2 march reads it, filters_march.h SRC_LINEAR)
   uint32_t linear_stride;

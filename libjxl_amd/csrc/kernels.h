@@ -72,9 +72,12 @@ bool LaunchOrient(const void* src, size_t src_stride, uint32_t xsize, uint32_t y
 
 // Matrix-core 32x32 IDCT (kernels_mfma.hip), opt-in through DevFrame::mfma32
 void MfmaDct32Constants(float* host /* 2048 floats */);
+void MfmaDct16Constants(float* host /* 256 floats */);
 // emit != nullptr: the frame is DCT32X32 only and has no loop filter -- the kernel writes linear float RGB to
 // emit->out itself (rows f.y0 .. f.y1) instead of XYB planes
 void LaunchMfma32(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st, const FilterParams* emit = nullptr);
+// Matrix-core 16x16 IDCT, opt-in through DevFrame::mfma16
+void LaunchMfma16(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st);
 
 // Fused kernel (kernels_fused.hip): the row march fed from the coefficient stream (DCT8 decoded by the
 // filter wave itself, other classes copied from the planes).  FusedSupported: frames it takes --

@@ -1301,11 +1301,11 @@ static_assert(kMediumStrategy[8] == 18 && kMediumStrategy[9] == 19 && kMediumStr
 template <int N, typename Body>
 __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const WorkLists& wl,
                                              Body&& body, uint32_t wg_index, uint32_t num_wgs,
-                                             bool skip_first = false) {
+                                             uint32_t skip_mask = 0) {
   uint32_t cnt[N];
 #pragma unroll
-  for (int i = 0; i < N; i++) cnt[i] = wl.count[fam[i].cls * kCounterPad];
-  if (skip_first) cnt[0] = 0;  // DCT32X32 on the matrix cores (kernels_mfma.hip)
+  for (int i = 0; i < N; i++)  // skip_mask: classes decoded on the matrix cores (kernels_mfma.hip)
+    cnt[i] = (skip_mask >> i) & 1u ? 0u : wl.count[fam[i].cls * kCounterPad];
   // workgroup wg_index of the num_wgs that share the family
   for (uint32_t u = wg_index;; u += num_wgs) {
     const UnitPick pick = PickUnit(fam, cnt, u);
@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(256) void k_transform_r16(DevFrame f, WorkLists wl)
                    default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
                  }
                },
-               blockIdx.x, gridDim.x);
+               blockIdx.x, gridDim.x, f.mfma16 != nullptr ? 1u : 0u);
 }
 
 template <typename CT>
@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_transform_r32(DevFrame f, WorkLists wl)
                    default: RowLaneUnit<8, 32, 9, CT>(f, list, first, n); break;
                  }
                },
-               blockIdx.x, gridDim.x, f.mfma32 != nullptr);
+               blockIdx.x, gridDim.x, f.mfma32 != nullptr ? 1u : 0u);
 }
 
 // Both row-per-lane families in one launch, the (few, long, register-heavy) L = 32 units first:
@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? JXLHIP_R_WAVES : 2) void k_t
                    default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
                  }
                },
-               idx - big_wgs, r_wgs, f.mfma32 != nullptr);
+               idx - big_wgs, r_wgs, (f.mfma32 != nullptr ? 1u : 0u) | (f.mfma16 != nullptr ? 1u << 5 : 0u));
 }
 
 // --------------------------------------------------------------- launchers
@@ -1457,7 +1457,9 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
       if (f.used_acs & (1u << st)) return true;
     return false;
   };
-  const bool merged_r = any({4, 6, 7}) && (any({8, 9, 10, 11}) || (!f.mfma32 && any({5})));
+  const bool need_r16 = any({6, 7}) || (!f.mfma16 && any({4}));
+  const bool need_r32 = any({8, 9, 10, 11}) || (!f.mfma32 && any({5}));
+  const bool merged_r = need_r16 && need_r32;
   const bool have_big = any({18, 19, 20});
   bool specials_in_r = false, dct8_in_r = false;
   uint32_t grid_specials = 0, grid_dct8 = 0;
@@ -1486,12 +1488,11 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     hipLaunchKernelGGL((k_transform_r<CT>), dim3(special_wgs + big_wgs + grid_r16 + dct8_wgs), dim3(256), 0, s0, f, wl,
                        big_wgs, special_wgs, grid_r16, dct8_wgs);
   } else {
-    if (any({4, 6, 7}))
-      hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
-    if (any({8, 9, 10, 11}) || (!f.mfma32 && any({5})))
-      hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
+    if (need_r16) hipLaunchKernelGGL((k_transform_r16<CT>), dim3(grid_r16), dim3(256), 0, s0, f, wl);
+    if (need_r32) hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
   }
   if (f.mfma32 && any({5})) LaunchMfma32(f, wl, cells, s1, emit);
+  if (f.mfma16 && any({4})) LaunchMfma16(f, wl, cells, s1);
   if (cells >= 256 && any({21, 22, 23, 24, 25, 26}))
     hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, s1, f, wl.list[kClsLarge],
                        wl.count + kClsLarge * kCounterPad, wc, resample);

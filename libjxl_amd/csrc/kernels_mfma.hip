@@ -1,6 +1,6 @@
-// kernels_mfma.hip -- the 32x32 inverse DCT as two dense matrix products on the matrix cores
-// (v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate -- an fmaf chain, so the arithmetic stays fp32 like the
-// rest of the path).  BASELINE configs[4] ("MFMA large-DCT path") / north_star: "MFMA only for the 16x16 /
+// kernels_mfma.hip -- the 32x32 and 16x16 inverse DCTs as two dense matrix products on the matrix cores
+// (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: fp32 in, fp32 accumulate -- an fmaf chain, so the arithmetic
+// stays fp32 like the rest of the path).  BASELINE configs[4] ("MFMA large-DCT path") / north_star: "MFMA only for the 16x16 /
 // 32x32 DCT tiles where it is a true dense matmul".  Replaces, for DCT32X32 varblocks, what RowLaneUnit<32, 32>
 // (kernels_blocks.hip) does with butterflies and register transposes: ComputeScaledIDCT<32, 32>
 // (lib/jxl/dct-inl.h:376-397) = IDCT1D along both axes (dct-inl.h:191-232, scales dct_scales.h:237-369).
@@ -22,8 +22,18 @@
 //   result     register i of lane (n, h) = P^T[x][y = n], x = 4 h + i % 4 + 8 (i / 4): four runs of four
 //              consecutive pixels of image row y -> four 16-byte stores into the block-major tiles.
 // 32 MFMAs per channel (64 cycles each on one SIMD) = 2 cycles per pixel and channel; the VALU only dequantises.
+//
+// DCT16X16 (k_transform_mfma16, below) is the same scheme on v_mfma_f32_16x16x4_f32: lane (m = lane % 16,
+// h = lane / 16) holds M[m][4 h .. 4 h + 3] (8 or 16 contiguous bytes of the stream: one load per lane and channel,
+// the wave fetches the whole block), step kk of lane quarter h is k = 4 h + kk; product 1's accumulator (register i
+// of lane (n, h) = Q[4 h + i][n]) is product 2's B operand as it stands, and ONE constant table serves both
+// products (B operand of product 1 = A operand of product 2 = B[4 h + step][lane % 16]).  The result is four
+// consecutive pixels of image row m per lane: one 16-byte store.  8 MFMAs (32 cycles each) per channel = 1 cycle
+// per pixel and channel.
 #include <math.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "blocks_common.h"
 #include "emit.h"
@@ -249,7 +259,168 @@ __global__ __launch_bounds__(256, 2) void k_transform_mfma32(DevFrame f, const W
   }
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <typename CT>
+struct Staged16 {
+  typedef typename std::conditional<sizeof(CT) == 2, uint2, uint4>::type Raw;  // M[m][4 h .. 4 h + 3]
+  WorkItem it;
+  Raw raw[3];
+  float dc;  // lane l < 12: DC value (channel l / 4, row l / 2 % 2, column l % 2) of the varblock's 2x2 patch
+};
+
+template <typename CT>
+__global__ __launch_bounds__(256, 4) void k_transform_mfma16(DevFrame f, const WorkItem* __restrict__ list,
+                                                             const uint32_t* __restrict__ count,
+                                                             const float* __restrict__ bc) {
+  typedef typename Staged16<CT>::Raw Raw;
+  // the class's dequant matrices in LDS, rows padded to 20 floats (a 16-lane group's 16-byte reads then cover all
+  // banks); as global loads they would share the in-order vmcnt queue with the prefetch below
+  __shared__ __attribute__((aligned(16))) float tab_lds[3 * 16 * 20];
+  for (int i = threadIdx.x; i < 3 * 256; i += 256) tab_lds[(i >> 4) * 20 + (i & 15)] = f.dequant[DequantOffset(4) + i];
+  __syncthreads();
+  const uint32_t n = *count;
+  const int lane = threadIdx.x & 63;
+  const int m = lane & 15, h = lane >> 4;
+  float b1[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) b1[i] = bc[i * 64 + lane];
+  const uint32_t stride = gridDim.x * 4;
+  uint32_t vb = blockIdx.x * 4 + (threadIdx.x >> 6);
+  auto item = [&](uint32_t i) { return list[i < n ? i : n - 1]; };
+  auto fetch = [&](const WorkItem it, Staged16<CT>& s) {
+    s.it = it;
+    const size_t coef = (size_t)it.off * 64u + (size_t)m * 16 + 4 * h;
+#pragma unroll
+    for (int c = 0; c < 3; c++) s.raw[c] = *(const Raw*)((const CT*)f.coeffs[c] + coef);
+    const int l = lane < 12 ? lane : 11;
+    s.dc = f.dc[l >> 2][(size_t)((it.pos >> 16) + ((l >> 1) & 1)) * f.xsb + (it.pos & 0xffffu) + (l & 1)];
+  };
+  if (vb >= n) return;
+  Staged16<CT> cur;
+  fetch(item(vb), cur);
+  WorkItem it_next = item(vb + stride);
+  const float rx = m == 0 ? kResampleUpHost[2] : kResampleUpHost[3];
+  const bool llf_lane = h == 0 && m < 2;
+  for (; vb < n; vb += stride) {
+    Staged16<CT> nxt;
+    fetch(it_next, nxt);  // (a repeat of the last varblock past the end of the list: loaded, never used)
+    it_next = item(vb + 2 * stride);
+    const BlockHdr hd = MakeHdr(f, cur.it);
+    int tab_at = m * 20 + 4 * h;
+    asm volatile("" : "+v"(tab_at));
+    const float* tab = tab_lds + tab_at;
+    // lowest frequencies from the 2x2 DC patch (LowestFrequenciesFromDC, dec_transforms-inl.h:691-818), the twelve
+    // DC values broadcast from the lanes that loaded them: lane (m = x < 2, h = 0) holds the corner M[x][0..1]
+    float llf[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      float d[2][2];
+#pragma unroll
+      for (int y = 0; y < 2; y++)
+#pragma unroll
+        for (int x = 0; x < 2; x++)
+          d[y][x] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cur.dc), c * 4 + y * 2 + x));
+      float dp[2][2];
+#pragma unroll
+      for (int x = 0; x < 2; x++) {
+        float v[2] = {d[0][x], d[1][x]};
+        DctReg<2>(v);
+        dp[0][x] = 0.5f * v[0];
+        dp[1][x] = 0.5f * v[1];
+      }
+#pragma unroll
+      for (int y = 0; y < 2; y++) {
+        float v[2] = {dp[y][0], dp[y][1]};
+        DctReg<2>(v);
+        const float val = 0.5f * (m == 0 ? v[0] : v[1]);
+        llf[c][y] = val * rx * kResampleUpHost[2 + y];
+      }
+    }
+    auto unpack = [&](const Raw& r, int32_t* q) {
+      if constexpr (sizeof(CT) == 2) {
+        q[0] = (int32_t)(int16_t)(r.x & 0xffffu);
+        q[1] = (int32_t)r.x >> 16;
+        q[2] = (int32_t)(int16_t)(r.y & 0xffffu);
+        q[3] = (int32_t)r.y >> 16;
+      } else {
+        q[0] = (int32_t)r.x;
+        q[1] = (int32_t)r.y;
+        q[2] = (int32_t)r.z;
+        q[3] = (int32_t)r.w;
+      }
+    };
+    float vy[4];
+    {
+      int32_t q[4];
+      unpack(cur.raw[1], q);
+      const float4 t = *(const float4*)(tab + 16 * 20);
+      const float tk[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) vy[k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tk[k] * hd.sy);
+    }
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+      float v[4];
+      if (c == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = vy[k];
+      } else {
+        const float sc = c == 0 ? hd.sx : hd.sb;
+        const float cc = c == 0 ? hd.x_cc : hd.b_cc;
+        int32_t q[4];
+        unpack(cur.raw[c], q);
+        const float4 t = *(const float4*)(tab + c * 16 * 20);
+        const float tk[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const float d = AdjustQuantBias(q[k], f.biases[c], f.biases[3]) * (tk[k] * sc);
+          v[k] = __builtin_fmaf(cc, vy[k], d);
+        }
+      }
+      if (llf_lane) {
+        v[0] = llf[c][0];
+        v[1] = llf[c][1];
+      }
+      v4f q = {0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 3; kk >= 0; kk--) q = __builtin_amdgcn_mfma_f32_16x16x4f32(v[kk], b1[kk], q, 0, 0, 0);
+      v4f p = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; i++) p = __builtin_amdgcn_mfma_f32_16x16x4f32(b1[i], q[i], p, 0, 0, 0);
+      // lane (y = m, h): pixels (row y, columns 4 h .. 4 h + 3)
+      float* dst = TilePtr(f, c, hd.aby + (m >> 3), hd.abx + (h >> 1)) + (m & 7) * 8 + 4 * (h & 1);
+      *(float4*)dst = make_float4(p[0], p[1], p[2], p[3]);
+    }
+    cur = nxt;
+  }
+}
+
 }  // namespace
+
+// bc16[step * 64 + lane]: B[4 h + step][n] of the 16-point IDCT, lane = (n = lane % 16, h = lane / 16) -- the B
+// operand of product 1 and the A operand of product 2
+void MfmaDct16Constants(float* host /* 256 floats */) {
+  for (int k = 0; k < 16; k++) {
+    double v[16] = {0};
+    v[k] = 1.0;
+    IdctHost(v, 16);
+    for (int n = 0; n < 16; n++) host[(k & 3) * 64 + (k >> 2) * 16 + n] = (float)v[n];
+  }
+}
+
+void LaunchMfma16(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st) {
+  const int cls = kClsMedium0 + 2;  // DCT16X16 (kMediumStrategy[2] == 4)
+  uint32_t grid = cells / 4 / 4 + 1;  // varblocks / 4 waves
+  if (grid > 4096u) grid = 4096u;
+  if (f.coeff_type == JXLHIP_COEFF_I16)
+    hipLaunchKernelGGL((k_transform_mfma16<int16_t>), dim3(grid), dim3(256), 0, st, f, wl.list[cls],
+                       wl.count + cls * kCounterPad, f.mfma16);
+  else
+    hipLaunchKernelGGL((k_transform_mfma16<int32_t>), dim3(grid), dim3(256), 0, st, f, wl.list[cls],
+                       wl.count + cls * kCounterPad, f.mfma16);
+}
 
 // bc[0 .. 1023]: B operand of product 1, step kk: lane (n, h) -> B[16 h + kk][n]
 // bc[1024 ..  ]: A operand of product 2, step i : lane (x, h) -> B[4 h + i % 4 + 8 (i / 4)][x]

@@ -414,17 +414,19 @@ def test_fused_producer_consumer_form_is_bit_identical(dq, oracle, gab, epf, siz
 
 
 @pytest.mark.parametrize("coeff_type", [0, 1])
-@pytest.mark.parametrize("size,mix", [((8 * 4 + 256, 8 * 4 + 8), {5: 48.0, 0: 1.0}), ((1000, 520), None),
-                                      ((258, 258), None)])
-def test_mfma_dct32_matches_oracle_and_row_lane_path(dq, oracle, size, mix, coeff_type, monkeypatch):
-    """JXLHIP_MFMA=1 sends DCT32X32 varblocks through the matrix-core kernel (kernels_mfma.hip: two
-    v_mfma_f32_32x32x2_f32 products per channel); everything else keeps its kernel.  Same bar as the
-    butterfly path -- and the two must agree with each other to rounding."""
+@pytest.mark.parametrize("size,mix,want", [((8 * 4 + 256, 8 * 4 + 8), {5: 48.0, 0: 1.0}, (5,)),
+                                           ((8 * 4 + 256, 8 * 4 + 8), {4: 48.0, 0: 1.0}, (4,)),
+                                           ((1000, 520), {4: 8.0, 5: 8.0, 0: 1.0, 6: 1.0}, (4, 5)),
+                                           ((1000, 520), None, (4, 5)), ((258, 258), None, (4, 5))])
+def test_mfma_dct32_dct16_match_oracle_and_row_lane_path(dq, oracle, size, mix, want, coeff_type, monkeypatch):
+    """JXLHIP_MFMA=1 sends DCT32X32 and DCT16X16 varblocks through the matrix-core kernels (kernels_mfma.hip: two
+    v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 products per channel); everything else keeps its kernel.
+    Same bar as the butterfly path -- and the two must agree with each other to rounding."""
     xs, ys = size
     kw = dict(coeff_type=1, amp=200000.0, decay=3.0) if coeff_type else {}
     params, t, fr = frames.make_case(xs, ys, mix=mix or synth.MIX_ALL, gab=False, epf_iters=0, seed=5 + xs, **kw)
     acs = t["ac_strategy"].numpy()
-    assert 5 in set((acs[(acs & 1) == 1] >> 1).tolist())
+    assert set(want) <= set((acs[(acs & 1) == 1] >> 1).tolist())
     ref = fr.decode_groups()
     outs = {}
     for mfma in ("1", "0"):
@@ -441,6 +443,28 @@ def test_mfma_dct32_matches_oracle_and_row_lane_path(dq, oracle, size, mix, coef
         assert rel_err(outs["1"][c], ref[c]) <= TIGHT, (c, np.argwhere(np.abs(outs["1"][c] - ref[c]) > 1e-3)[:5])
     # the MFMA kernel really ran: a dense product rounds differently from the butterflies
     assert any(not np.array_equal(outs["0"][c], outs["1"][c]) for c in range(3))
+
+
+def test_all_dct16_frame_of_16_mpx_takes_the_matrix_cores_by_default(dq, oracle, monkeypatch):
+    """The context's own rule (LaunchBlocksBand): DCT16X16 alone in the row-per-lane families, 16 Mpx and more ->
+    k_transform_mfma16.  Checked against the oracle, and against the butterflies to see that the rule engaged."""
+    params, t, fr = frames.make_case(4096, 4096, mix={4: 1.0}, gab=False, epf_iters=0, seed=77)
+    ref = fr.decode(threads=8)
+    outs = {}
+    for mfma in (None, "0"):
+        if mfma is None:
+            monkeypatch.delenv("JXLHIP_MFMA", raising=False)
+        else:
+            monkeypatch.setenv("JXLHIP_MFMA", mfma)
+        d = VarDctDecoder(0)
+        d.begin_frame(params)
+        d.set_inputs(to_dev(t), dq)
+        outs[mfma] = d.decode_frame().cpu().numpy()
+        d.sync()
+        d.close()
+    assert rel_err(outs[None], ref) <= TIGHT
+    assert rel_err(outs["0"], ref) <= TIGHT
+    assert not np.array_equal(outs[None], outs["0"])
 
 
 @pytest.mark.parametrize("gab", [1, 0])

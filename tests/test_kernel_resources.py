@@ -66,6 +66,6 @@ def test_fused_pc_kernels_have_no_scratch():
 def test_metadata_reader_sees_the_known_kernels():
     ks = kernels()
     names = " ".join(ks)
-    for k in ("k_prepare", "k_transform_r", "k_filters_fast", "k_fused", "k_epf0", "k_transform_mfma32"):
+    for k in ("k_prepare", "k_transform_r", "k_filters_fast", "k_fused", "k_epf0", "k_transform_mfma32", "k_transform_mfma16"):
         assert k in names
     assert all(1 <= v["vgprs"] <= 512 for v in ks.values())
