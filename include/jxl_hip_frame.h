@@ -164,10 +164,11 @@ typedef struct jxlhip_frame_header {
   uint32_t xsize_groups, ysize_groups;
   uint64_t num_groups, num_dc_groups, num_toc_entries; /* 64-bit: a custom frame size may reach 2^30 squared */
   float x_dm_multiplier, b_dm_multiplier;
-  /* copied from jxlhip_image_info: the Modular parts of the frame carry the extra channels (alpha, depth, ...),
-     which this front-end does not decode -- jxlhip_modular_global_decode / jxlhip_dc_group_decode return
-     JXLHIP_ERR_UNSUPPORTED when it is non-zero (dec_modular.cc:230-262) */
+  /* copied from jxlhip_image_info: the Modular parts of the frame carry the extra channels (alpha, depth, ...;
+     dec_modular.cc:230-262).  jxlhip_modular_global_decode / jxlhip_modular_ac_group_decode take up to four of them,
+     each at the frame's own resolution (ec_upsampling == upsampling == 1); JXLHIP_ERR_UNSUPPORTED otherwise */
   uint32_t num_extra_channels;
+  uint32_t ec_upsampling[4];   /* FrameHeader::extra_channel_upsampling of the first four (dim_shift applied) */
 } jxlhip_frame_header;
 
 /* ReadFrameHeader (frame_header.cc:212-215): reads the header at bit *bit_pos of data (advanced to
@@ -209,6 +210,21 @@ typedef struct jxlhip_modular_tree jxlhip_modular_tree;
 JXLHIP_EXPORT int jxlhip_modular_global_decode(const uint8_t* data, size_t size, size_t* bit_pos,
                                                const jxlhip_frame_header* frame, jxlhip_modular_tree** tree);
 JXLHIP_EXPORT void jxlhip_modular_tree_destroy(jxlhip_modular_tree* tree);
+
+/* Extra channels (alpha, depth, ...) of a VarDCT frame.  jxlhip_modular_global_decode has read the global part
+ * (group header, transforms, channels that fit one group) into the handle; this call reads what follows the VarDCT
+ * coefficients of pass `pass` in AC group `group` -- ModularFrameDecoder::DecodeGroup for
+ * ModularStreamId::ModularAC(group, pass), dec_modular.cc:330-425, dec_frame.cc:497-530 -- from bit *bit_pos of the
+ * section (advanced): the group's rectangle of every larger extra channel.  Thread-safe for different groups.  A
+ * frame without extra channels (tree may be NULL) reads nothing. */
+JXLHIP_EXPORT int jxlhip_modular_ac_group_decode(jxlhip_modular_tree* tree, const jxlhip_frame_header* frame,
+                                                 uint32_t group, uint32_t pass, const uint8_t* data, size_t size,
+                                                 size_t* bit_pos);
+/* Once every group is in: extra channel `ec` as float samples, out[y * stride_floats + x] = v / (2^ec_bits - 1)
+ * (ModularImageToDecodedRect, dec_modular.cc:686-737; image_bits = the IMAGE's bits_per_sample, which picks the
+ * float or the double multiply, :726-731). */
+JXLHIP_EXPORT int jxlhip_modular_extra_channel_f32(const jxlhip_modular_tree* tree, uint32_t ec, uint32_t ec_bits,
+                                                   uint32_t image_bits, float* out, size_t stride_floats);
 
 /* One DC group section (section 1 + dc_group of the TOC).  All outputs are FRAME-level arrays in the
  * layouts jxlhip_upload_side_info / jxlhip_dequant_dc take, of which this call fills the group's

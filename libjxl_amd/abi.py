@@ -133,7 +133,7 @@ class FrameHeader(C.Structure):
                 ("group_dim", C.c_uint32), ("xsize_groups", C.c_uint32), ("ysize_groups", C.c_uint32),
                 ("num_groups", C.c_uint64), ("num_dc_groups", C.c_uint64), ("num_toc_entries", C.c_uint64),
                 ("x_dm_multiplier", C.c_float), ("b_dm_multiplier", C.c_float),
-                ("num_extra_channels", C.c_uint32)]
+                ("num_extra_channels", C.c_uint32), ("ec_upsampling", C.c_uint32 * 4)]
 
 
 class CodestreamInfo(C.Structure):
@@ -238,6 +238,7 @@ EXPORTS = [
     # include/jxl_hip_frame.h
     "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode",
     "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
+    "jxlhip_modular_ac_group_decode", "jxlhip_modular_extra_channel_f32",
     # include/jxl_hip_codestream.h
     "jxlhip_codestream_basic_info", "jxlhip_decode_codestream",
 ]
@@ -289,6 +290,8 @@ def load_library():
     L.jxlhip_modular_global_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(FrameHeader), C.POINTER(vp)]
     L.jxlhip_modular_tree_destroy.argtypes = [vp]
     L.jxlhip_modular_tree_destroy.restype = None
+    L.jxlhip_modular_ac_group_decode.argtypes = [vp, C.POINTER(FrameHeader), u32, u32, vp, sz, C.POINTER(sz)]
+    L.jxlhip_modular_extra_channel_f32.argtypes = [vp, u32, u32, u32, vp, sz]
     L.jxlhip_dc_group_decode.argtypes = [vp, vp, sz, C.POINTER(sz), C.POINTER(FrameHeader), C.c_uint32,
                                          C.POINTER(vp), C.POINTER(C.c_uint32), vp, vp, vp, vp, vp,
                                          C.POINTER(C.c_uint32)]

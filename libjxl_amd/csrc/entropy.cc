@@ -1480,6 +1480,7 @@ int jxlhip_frame_header_decode(const uint8_t* data, size_t size, size_t* bit_pos
   h->x_qm_scale = 3;
   h->b_qm_scale = 2;
   h->num_passes = 1;
+  for (uint32_t& u : h->ec_upsampling) u = 1;
   h->is_last = 1;
   h->color_transform = JXLHIP_CT_XYB;
   const bool xyb = im->xyb_encoded != 0;
@@ -1519,6 +1520,7 @@ int jxlhip_frame_header_decode(const uint8_t* data, size_t size, size_t* bit_pos
         ec <<= ds;
         if (ec < h->upsampling || ec > 8) return kBad;
         if (!br.Healthy()) return kBad;
+        if (i < 4) h->ec_upsampling[i] = ec;
       }
     }
     if (h->is_modular) h->group_size_shift = r.Bits(2);

@@ -475,9 +475,11 @@ class RealStream:
                  epf_sharpness=(3, np.uint8), ytox_map=(4, np.int8), ytob_map=(5, np.int8),
                  dc_x=(6, np.float32), dc_y=(7, np.float32), dc_b=(8, np.float32), quant_dc=(9, np.uint8),
                  block_ctx_bytes=(10, np.uint8), rgb=(11, np.float32), section_offset=(12, np.uint64),
-                 section_size=(13, np.uint64), params=(14, np.uint8), dequant_table=(15, np.float32))
+                 section_size=(13, np.uint64), params=(14, np.uint8), dequant_table=(15, np.float32),
+                 alpha=(16, np.float32))
 
-    def __init__(self, xsize, ysize, seed=1, distance=1.0, speed_tier=3, epf=-1, progressive=0):
+    def __init__(self, xsize, ysize, seed=1, distance=1.0, speed_tier=3, epf=-1, progressive=0, alpha_bits=0,
+                 alpha_levels=0):
         L = ref_lib()
         L.jxr_real_case_create.restype = C.c_void_p
         L.jxr_real_case_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int, C.c_int]
@@ -486,7 +488,20 @@ class RealStream:
         L.jxr_real_case_data.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.jxr_real_case_info.restype = C.c_uint64
         L.jxr_real_case_info.argtypes = [C.c_void_p, C.c_int]
-        h = L.jxr_real_case_create(xsize, ysize, seed, distance, speed_tier, epf, progressive)
+        knobs = {"JXR_ALPHA": alpha_bits, "JXR_ALPHA_LEVELS": alpha_levels}
+        old = {k: os.environ.get(k) for k in knobs}
+        for k, v in knobs.items():
+            if v:
+                os.environ[k] = str(v)
+        try:
+            h = L.jxr_real_case_create(xsize, ysize, seed, distance, speed_tier, epf, progressive)
+        finally:
+            for k, v in knobs.items():
+                if v:
+                    if old[k] is None:
+                        del os.environ[k]
+                    else:
+                        os.environ[k] = old[k]
         if not h:
             raise ValueError("reference encode/decode failed")
         try:
@@ -507,6 +522,7 @@ class RealStream:
         for name in ("ac_strategy", "raw_quant", "epf_sharpness", "dc_x", "dc_y", "dc_b", "quant_dc"):
             setattr(self, name, getattr(self, name).reshape(ysb, xsb))
         self.rgb = self.rgb.reshape(ysize, xsize, 3)
+        self.alpha = self.alpha.reshape(ysize, xsize) if alpha_bits else None
         self.frame_params = FrameParams.from_buffer_copy(self.params.tobytes())
 
     def section(self, logical_id):

@@ -104,6 +104,7 @@ struct RealCase {
   std::vector<int8_t> ytox, ytob;
   std::vector<float> dc[3];
   std::vector<float> rgb;     // reference decoder output, interleaved linear RGB
+  std::vector<float> alpha;   // ... and its alpha channel (JXR_ALPHA streams)
   std::vector<float> dequant; // the frame's DequantMatrices table (JXLHIP_DEQUANT_TABLE_FLOATS)
 };
 
@@ -193,6 +194,11 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   }
   const ColorEncoding c_pixels = ColorEncoding::LinearSRGB(/*is_gray=*/false);
   JXL_RETURN_IF_ERROR(metadata.size.Set(xs, ys));
+  // JXR_ALPHA=8 | 16: an alpha channel of that many bits (the encoder codes it losslessly in the frame's Modular
+  // sub-bitstream, like cjxl does for an RGBA PNG): soft-edged disc, a ramp, a hard-edged box, a noisy band
+  uint32_t alpha_bits = 0;
+  if (const char* e = getenv("JXR_ALPHA")) alpha_bits = static_cast<uint32_t>(atoi(e));
+  if (alpha_bits) metadata.m.SetAlphaBits(alpha_bits);
   // JXR_ORIENTATION=2..8: ImageMetadata::orientation of the written stream (tests of undo_orientation); the
   // FrameDecoder run below keeps the coded orientation, JxlDecoder (tests/test_seam.py) undoes it
   if (const char* e = getenv("JXR_ORIENTATION")) {
@@ -204,6 +210,32 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
     JXL_ASSIGN_OR_RETURN(Image3F img, Image3F::Create(&mm, xs, ys));
     FillImage(&img, seed);
     JXL_RETURN_IF_ERROR(ib.SetFromImage(std::move(img), c_pixels));
+  }
+  if (alpha_bits) {
+    JXL_ASSIGN_OR_RETURN(ImageF alpha, ImageF::Create(&mm, xs, ys));
+    uint32_t s = seed * 747796405u + 2891336453u;
+    const float levels = static_cast<float>((1u << alpha_bits) - 1);
+    // JXR_ALPHA_LEVELS=n: only n distinct alpha values (a cut-out mask has 2): the encoder then codes the channel
+    // through a palette transform
+    const char* lv = getenv("JXR_ALPHA_LEVELS");
+    const float coarse = lv && atoi(lv) > 1 ? static_cast<float>(atoi(lv) - 1) : 0.0f;
+    for (size_t y = 0; y < ys; y++) {
+      float* row = alpha.Row(y);
+      for (size_t x = 0; x < xs; x++) {
+        const float dx = (x - 0.55f * xs) / (0.35f * xs), dy = (y - 0.45f * ys) / (0.4f * ys);
+        float a = 1.2f - std::sqrt(dx * dx + dy * dy);                   // soft-edged disc
+        a = std::min(1.0f, std::max(0.0f, a * 2.0f));
+        if (y < ys / 6) a = static_cast<float>(x) / xs;                    // ramp
+        if (x > xs * 0.1f && x < xs * 0.25f && y > ys * 0.5f && y < ys * 0.8f) a = 0.0f;  // hard-edged hole
+        if (y > ys * 0.9f) {                                               // noise
+          s = s * 1664525u + 1013904223u;
+          a = (s >> 8) / 16777216.0f;
+        }
+        if (coarse != 0.0f) a = std::floor(a * coarse + 0.5f) / coarse;
+        row[x] = std::floor(a * levels + 0.5f) / levels;
+      }
+    }
+    JXL_RETURN_IF_ERROR(ib.SetAlpha(std::move(alpha)));
   }
   CompressParams cparams;
   cparams.butteraugli_distance = distance;
@@ -236,7 +268,8 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   // ---- 2. decode with the reference's FrameDecoder (the body of jxl::DecodeFrame, dec_frame.cc:82-133)
   auto dec_state = jxl::make_unique<PassesDecoderState>(&mm);
   JXL_RETURN_IF_ERROR(dec_state->output_encoding_info.SetFromMetadata(metadata));
-  out->rgb.assign(static_cast<size_t>(xs) * ys * 3, 0.0f);
+  const uint32_t nch = alpha_bits ? 4 : 3;
+  out->rgb.assign(static_cast<size_t>(xs) * ys * nch, 0.0f);
   ImageBundle decoded(&mm, &metadata.m);
   FrameDecoder fd(dec_state.get(), metadata, nullptr, /*use_slow_rendering_pipeline=*/false);
   const uint8_t* in = out->codestream.data() + out->frame_offset;
@@ -246,7 +279,7 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   JXL_RETURN_IF_ERROR(fd.InitFrameOutput());
   // PassesDecoderState::Init (from InitFrameOutput) clears main_output: set it now, as decode.cc:1470 does
   JXL_RETURN_IF_ERROR(fd.SetImageOutput(PixelCallback(), out->rgb.data(), out->rgb.size() * sizeof(float), xs, ys,
-                                        JxlPixelFormat{3, JXL_TYPE_FLOAT, JXL_NATIVE_ENDIAN, 0}, 32,
+                                        JxlPixelFormat{nch, JXL_TYPE_FLOAT, JXL_NATIVE_ENDIAN, 0}, 32,
                                         /*unpremul_alpha=*/false, /*undo_orientation=*/false));
   const size_t header_bytes = reader.TotalBitsConsumed() / kBitsPerByte;
   JXL_RETURN_IF_ERROR(reader.Close());
@@ -288,6 +321,15 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
     JXL_RETURN_IF_ERROR(close_ok);
   }
   JXL_RETURN_IF_ERROR(fd.FinalizeFrame());
+  if (alpha_bits) {  // split the interleaved RGBA
+    out->alpha.resize(static_cast<size_t>(xs) * ys);
+    std::vector<float> rgb(static_cast<size_t>(xs) * ys * 3);
+    for (size_t i = 0; i < static_cast<size_t>(xs) * ys; i++) {
+      for (int c = 0; c < 3; c++) rgb[i * 3 + c] = out->rgb[i * 4 + c];
+      out->alpha[i] = out->rgb[i * 4 + 3];
+    }
+    out->rgb.swap(rgb);
+  }
 
   // ---- 3. the inputs of the product's boundary, from the decoder's state
   if (fh.encoding != FrameEncoding::kVarDCT || fh.upsampling != 1 ||
@@ -394,7 +436,7 @@ JXR_EXPORT void jxr_real_case_destroy(void* h) { delete static_cast<RealCase*>(h
 
 // what = 0 codestream, 1 acs, 2 raw_quant, 3 sharpness, 4 ytox, 5 ytob, 6..8 dc x/y/b, 9 quant_dc,
 // 10 block-ctx-map bytes, 11 rgb, 12 section offsets (u64), 13 section sizes (u64), 14 frame params,
-// 15 dequant table
+// 15 dequant table, 16 alpha (JXR_ALPHA)
 JXR_EXPORT const void* jxr_real_case_data(void* h, int what, size_t* bytes) {
   RealCase* c = static_cast<RealCase*>(h);
   auto ret = [&](const void* p, size_t n) {
@@ -416,6 +458,7 @@ JXR_EXPORT const void* jxr_real_case_data(void* h, int what, size_t* bytes) {
     case 13: return ret(c->section_size.data(), c->section_size.size() * 8);
     case 14: return ret(&c->params, sizeof(c->params));
     case 15: return ret(c->dequant.data(), c->dequant.size() * 4);
+    case 16: return ret(c->alpha.data(), c->alpha.size() * 4);
     default: *bytes = 0; return static_cast<const void*>(nullptr);
   }
 }

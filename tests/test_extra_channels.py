@@ -1,0 +1,153 @@
+"""Extra channels (alpha) of a VarDCT frame: the Modular side of the host front-end beyond the DC groups --
+jxlhip_modular_global_decode (group header, transforms, channels that fit one group), jxlhip_modular_ac_group_decode
+(what follows the VarDCT coefficients in every AC-group section) and jxlhip_modular_extra_channel_f32
+(FinalizeDecoding + ModularImageToDecodedRect) -- against the alpha plane the REFERENCE decoder produced for the same
+bytes (oracle.RealStream(alpha_bits=...): the reference's own encoder writes the stream, lossless alpha like cjxl).
+
+  CPU suite : bytes -> alpha plane, bit-exact; multi-group, single-section (the channel is coded globally),
+              two DC groups, 8 and 16 bit, few-valued alpha (a mask); the squeezed alpha of a progressive
+              stream is refused.
+  GPU suite : jxlhip_decode_codestream with a 4-channel packed output -- RGB as before, alpha = that plane."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from libjxl_amd import abi
+
+TIGHT = 2e-5
+
+
+@pytest.fixture(scope="module")
+def ref(oracle):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not available")
+    oracle.ref_lib()
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def L():
+    return abi.load_library()
+
+
+def decode_alpha_on_host(L, rs):
+    """The product's host parsers only; returns (alpha plane, image header, frame header)."""
+    cs = np.ascontiguousarray(rs.codestream)
+    base, n = cs.ctypes.data, len(cs)
+    ih, pos = abi.ImageHeader(), C.c_size_t(0)
+    extra = (abi.ExtraChannel * 4)()
+    assert L.jxlhip_image_header_decode(base, n, C.byref(pos), extra, 4, C.byref(ih)) == 0
+    assert ih.num_extra_channels == 1 and extra[0].type == 0  # JXLHIP_EC_ALPHA
+    info = abi.ImageInfo(ih.xsize, ih.ysize, ih.xyb_encoded, ih.num_extra_channels, None, 0, 0, 0)
+    fh = abi.FrameHeader()
+    assert L.jxlhip_frame_header_decode(base, n, C.byref(pos), C.byref(info), C.byref(fh)) == 0
+    assert fh.num_extra_channels == 1 and fh.ec_upsampling[0] == 1
+    nt = int(fh.num_toc_entries)
+    off, sz, total = np.zeros(nt, np.uint64), np.zeros(nt, np.uint32), C.c_uint64(0)
+    assert L.jxlhip_toc_decode(base, n, C.byref(pos), nt, off.ctypes.data, sz.ctypes.data, C.byref(total)) == 0
+    start = pos.value // 8
+    sections = [cs[start + int(o): start + int(o) + int(s)] for o, s in zip(off, sz)]
+    single = nt == 1
+    ng, ndc, npass = int(fh.num_groups), int(fh.num_dc_groups), fh.num_passes
+    xsb, ysb, xsg = fh.xsize_blocks, fh.ysize_blocks, int(fh.xsize_groups)
+
+    s0 = sections[0]
+    dcg, spos = abi.DcGlobal(), C.c_size_t(0)
+    assert L.jxlhip_dc_global_decode(s0.ctypes.data, len(s0), C.byref(spos), fh.flags, C.byref(dcg)) == 0
+    tree = C.c_void_p()
+    assert L.jxlhip_modular_global_decode(s0.ctypes.data, len(s0), C.byref(spos), C.byref(fh), C.byref(tree)) == 0
+    hs = (C.c_void_p * npass)()
+    try:
+        # (libjxl's encoder ends the global stream with the ANS state of an EMPTY token list when every channel is
+        # left to the groups, which no decoder reads: the section may be 4 bytes longer than what is consumed)
+        assert (spos.value + 7) // 8 <= len(s0)
+        qdc = [np.zeros(xsb * ysb, np.int32) for _ in range(3)]
+        acs, rq, sharp = np.zeros(xsb * ysb, np.uint8), np.zeros(xsb * ysb, np.int32), np.zeros(xsb * ysb, np.uint8)
+        cw, chh = (xsb + 7) // 8, (ysb + 7) // 8
+        ytox, ytob = np.zeros(cw * chh, np.int8), np.zeros(cw * chh, np.int8)
+        used = C.c_uint32(0)
+        for g in range(ndc):
+            d = s0 if single else sections[1 + g]
+            gp, ep = (spos if single else C.c_size_t(0)), C.c_uint32(0)
+            ptrs = (C.c_void_p * 3)(*[q.ctypes.data for q in qdc])
+            assert L.jxlhip_dc_group_decode(tree, d.ctypes.data, len(d), C.byref(gp), C.byref(fh), g, ptrs, C.byref(ep),
+                                            acs.ctypes.data, rq.ctypes.data, sharp.ctypes.data, ytox.ctypes.data,
+                                            ytob.ctypes.data, C.byref(used)) == 0
+            if not single:
+                assert (gp.value + 7) // 8 == len(d)
+        assert np.array_equal(acs, rs.ac_strategy.ravel())
+        qctx = np.zeros(xsb * ysb, np.uint8)
+        qp = (C.c_void_p * 3)(*[q.ctypes.data for q in qdc])
+        assert L.jxlhip_quant_dc_contexts(C.byref(dcg.block_ctx_map), xsb * ysb, qp, qctx.ctypes.data) == 0
+        encs, nh, bits = abi.QuantEncodings(), C.c_uint32(0), C.c_size_t(0)
+        if single:
+            assert L.jxlhip_ac_global_decode_at(s0.ctypes.data, len(s0), C.byref(spos), ng, npass, used.value,
+                                                C.byref(dcg.block_ctx_map), C.byref(encs), C.byref(nh), hs) == 0
+        else:
+            glob = sections[1 + ndc]
+            assert L.jxlhip_ac_global_decode(glob.ctypes.data, len(glob), ng, npass, used.value,
+                                             C.byref(dcg.block_ctx_map), C.byref(encs), C.byref(nh), hs,
+                                             C.byref(bits)) == 0
+        scratch = [np.zeros(65536, np.int32) for _ in range(3)]
+        ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in scratch])
+        for g in range(ng):
+            for ps in range(npass):
+                d = s0 if single else sections[2 + ndc + ps * ng + g]
+                gp, cnt = (spos if single else C.c_size_t(0)), C.c_size_t(0)
+                assert L.jxlhip_ac_group_decode(hs[ps], xsb, ysb, g % xsg, g // xsg, acs.ctypes.data, rq.ctypes.data,
+                                                qctx.ctypes.data, d.ctypes.data, len(d), C.byref(gp), fh.shift[ps], 1,
+                                                ptrs, C.byref(cnt)) == 0
+                # ... and behind the coefficients, the group's part of the Modular image
+                assert L.jxlhip_modular_ac_group_decode(tree, C.byref(fh), g, ps, d.ctypes.data, len(d), C.byref(gp)) == 0
+                assert (gp.value + 7) // 8 == len(d), (g, ps, gp.value, len(d))  # the section is consumed exactly
+        alpha = np.full((fh.ysize, fh.xsize), -1.0, np.float32)
+        assert L.jxlhip_modular_extra_channel_f32(tree, 0, extra[0].bit_depth.bits_per_sample, ih.bit_depth.bits_per_sample,
+                                                  alpha.ctypes.data, fh.xsize) == 0
+    finally:
+        for h in hs:
+            if h:
+                L.jxlhip_ac_pass_destroy(h)
+        L.jxlhip_modular_tree_destroy(tree)
+    return alpha, ih, fh
+
+
+CASES = [
+    dict(xsize=520, ysize=300, alpha_bits=8),
+    dict(xsize=520, ysize=300, alpha_bits=16),
+    dict(xsize=200, ysize=120, alpha_bits=8),                      # one section: the alpha channel is coded globally
+    dict(xsize=776, ysize=520, alpha_bits=8, distance=3.0),
+    dict(xsize=520, ysize=300, alpha_bits=8, alpha_levels=2),      # a mask: two values
+    dict(xsize=520, ysize=300, alpha_bits=16, alpha_levels=5),
+    dict(xsize=200, ysize=120, alpha_bits=8, alpha_levels=3),
+    dict(xsize=2200, ysize=264, alpha_bits=8, speed_tier=4),       # two DC groups
+    dict(xsize=300, ysize=300, alpha_bits=8, speed_tier=7),
+]
+
+
+@pytest.mark.parametrize("kw", CASES)
+def test_alpha_plane_from_the_codestream_bytes(L, ref, kw):
+    rs = ref.RealStream(seed=29, **dict(dict(distance=1.0, speed_tier=3), **kw))
+    alpha, ih, fh = decode_alpha_on_host(L, rs)
+    assert np.array_equal(alpha, rs.alpha), float(np.abs(alpha - rs.alpha).max())
+
+
+@pytest.mark.parametrize("progressive", [1, 2])
+def test_squeezed_alpha_of_progressive_streams_is_refused(L, ref, progressive):
+    """cjxl -p codes the extra channels through the Squeeze transform (responsive Modular): outside this front-end,
+    and said so before anything is decoded (the caller falls back to the reference decoder)."""
+    rs = ref.RealStream(seed=29, xsize=520, ysize=300, alpha_bits=8, progressive=progressive, distance=2.0)
+    cs = np.ascontiguousarray(rs.codestream)
+    ih, pos = abi.ImageHeader(), C.c_size_t(0)
+    assert L.jxlhip_image_header_decode(cs.ctypes.data, len(cs), C.byref(pos), None, 0, C.byref(ih)) == 0
+    info = abi.ImageInfo(ih.xsize, ih.ysize, ih.xyb_encoded, ih.num_extra_channels, None, 0, 0, 0)
+    fh = abi.FrameHeader()
+    assert L.jxlhip_frame_header_decode(cs.ctypes.data, len(cs), C.byref(pos), C.byref(info), C.byref(fh)) == 0
+    nt = int(fh.num_toc_entries)
+    off, sz, total = np.zeros(nt, np.uint64), np.zeros(nt, np.uint32), C.c_uint64(0)
+    assert L.jxlhip_toc_decode(cs.ctypes.data, len(cs), C.byref(pos), nt, off.ctypes.data, sz.ctypes.data, C.byref(total)) == 0
+    s0 = cs[pos.value // 8 + int(off[0]):][:int(sz[0])]
+    dcg, spos, tree = abi.DcGlobal(), C.c_size_t(0), C.c_void_p()
+    assert L.jxlhip_dc_global_decode(s0.ctypes.data, len(s0), C.byref(spos), fh.flags, C.byref(dcg)) == 0
+    assert L.jxlhip_modular_global_decode(s0.ctypes.data, len(s0), C.byref(spos), C.byref(fh), C.byref(tree)) == -7
+    assert not tree.value
