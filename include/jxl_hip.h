@@ -256,6 +256,12 @@ JXLHIP_EXPORT int jxlhip_upload_side_info(
     const uint8_t* epf_sharpness, const int8_t* ytox_map,
     const int8_t* ytob_map, const float* const dc[3],
     const float* dequant_table);
+/* The frame's alpha channel for 4-channel JXLHIP_OUT_PACKED outputs: a dense host plane of xsize x ysize floats
+ * (stride_floats per row; 1.0 = opaque), copied into context-owned HBM.  It is written to the output like a
+ * colour channel without the transfer function -- what WriteToOutputStage does with input channel alpha_c
+ * (stage_write.cc:350-366); not un-premultiplied.  Without this call (jxlhip_frame_begin resets it) alpha is the
+ * opaque 1.0 the reference substitutes (:355-360).  Single-device contexts. */
+JXLHIP_EXPORT int jxlhip_set_alpha(jxlhip_ctx* ctx, const float* host_plane, size_t stride_floats);
 /* Replaces GetBlockFromEncoder/GetBlockFromBitstream -> DequantBlock hand-off
  * (dec_group.cc:334-359,662-706): the group's quantized coefficient stream, as
  * produced by DecodeACVarBlock, ncoeffs <= 65536 elements per channel.

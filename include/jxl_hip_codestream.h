@@ -44,6 +44,9 @@ typedef struct jxlhip_codestream_info {
   uint32_t used_acs;
   uint32_t coeff_type;         /* JXLHIP_COEFF_I16, or I32 after the JXLHIP_ERR_RANGE redo */
   uint32_t fused;              /* reserved */
+  /* headers: the image's extra channels (this front-end takes up to four, full resolution, integer samples) and the
+     first one of type alpha: its bit depth (0 = the image has no alpha channel), whether it is premultiplied */
+  uint32_t num_extra_channels, alpha_bits, alpha_premultiplied;
 } jxlhip_codestream_info;
 
 /* Headers only (no device needed): size and colour metadata of the first frame's image.  JXLHIP_ERR_BAD_STREAM /
@@ -51,6 +54,9 @@ typedef struct jxlhip_codestream_info {
 JXLHIP_EXPORT int jxlhip_codestream_basic_info(const uint8_t* data, size_t size, jxlhip_codestream_info* info);
 
 /* Decodes the (single, VarDCT) frame of a .jxl file or bare codestream into device memory.
+ *   alpha                  : an alpha channel of the image is decoded (host, Modular) and written as the fourth
+ *                            channel of a 4-channel JXLHIP_OUT_PACKED output; every other output ignores it (its bytes
+ *                            are skipped), and a frame without one gives the opaque value.  Not un-premultiplied.
  *   runner / runner_opaque : a JxlParallelRunner (include/jxl/parallel_runner.h; e.g. JxlThreadParallelRunner of
  *                            libjxl_threads_hip.so) for the DC groups and the AC groups; NULL = calling thread
  *   output_kind, out_format: as jxlhip_frame_params (out_format only for JXLHIP_OUT_PACKED; NULL otherwise).

@@ -199,6 +199,15 @@ JXLHIP_EXPORT int jxlhip_ac_groups_decode_submit(jxlhip_ctx* ctx, jxlhip_paralle
                                                  const uint8_t* ac_strategy, const int32_t* raw_quant,
                                                  const uint8_t* quant_dc, const uint8_t* const* sections,
                                                  const size_t* sizes);
+/* The same; end_bits (optional, [num_passes * num_groups], indexed like sections) receives the bit position in each
+ * section right behind the VarDCT coefficients -- where the group's part of the frame's Modular image starts
+ * (jxlhip_modular_ac_group_decode, dec_frame.cc:497-530).  Entries of groups outside the stripe are left alone. */
+JXLHIP_EXPORT int jxlhip_ac_groups_decode_submit_ex(jxlhip_ctx* ctx, jxlhip_parallel_runner runner,
+                                                    void* runner_opaque, uint32_t num_passes,
+                                                    const jxlhip_ac_pass* const* passes, const uint32_t* shifts,
+                                                    const uint8_t* ac_strategy, const int32_t* raw_quant,
+                                                    const uint8_t* quant_dc, const uint8_t* const* sections,
+                                                    const size_t* sizes, size_t* end_bits);
 
 #ifdef __cplusplus
 }

@@ -221,9 +221,10 @@ JXLHIP_EXPORT int jxlhip_modular_ac_group_decode(jxlhip_modular_tree* tree, cons
                                                  uint32_t group, uint32_t pass, const uint8_t* data, size_t size,
                                                  size_t* bit_pos);
 /* Once every group is in: extra channel `ec` as float samples, out[y * stride_floats + x] = v / (2^ec_bits - 1)
- * (ModularImageToDecodedRect, dec_modular.cc:686-737; image_bits = the IMAGE's bits_per_sample, which picks the
- * float or the double multiply, :726-731). */
-JXLHIP_EXPORT int jxlhip_modular_extra_channel_f32(const jxlhip_modular_tree* tree, uint32_t ec, uint32_t ec_bits,
+ * (FinalizeDecoding + ModularImageToDecodedRect, dec_modular.cc:686-737,739-760; image_bits = the IMAGE's
+ * bits_per_sample, which picks the float or the double multiply, :726-731).  The first call undoes the global
+ * image's transforms; not thread-safe, and no group may be decoded afterwards. */
+JXLHIP_EXPORT int jxlhip_modular_extra_channel_f32(jxlhip_modular_tree* tree, uint32_t ec, uint32_t ec_bits,
                                                    uint32_t image_bits, float* out, size_t stride_floats);
 
 /* One DC group section (section 1 + dc_group of the TOC).  All outputs are FRAME-level arrays in the

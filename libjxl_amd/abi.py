@@ -142,7 +142,8 @@ class CodestreamInfo(C.Structure):
                 ("intensity_target", C.c_float), ("bits_per_sample", C.c_uint32), ("transfer_function", C.c_uint32),
                 ("primaries", C.c_uint32), ("white_point", C.c_uint32), ("num_passes", C.c_uint32),
                 ("num_groups", C.c_uint32), ("num_dc_groups", C.c_uint32), ("epf_iters", C.c_uint32),
-                ("gab", C.c_uint32), ("used_acs", C.c_uint32), ("coeff_type", C.c_uint32), ("fused", C.c_uint32)]
+                ("gab", C.c_uint32), ("used_acs", C.c_uint32), ("coeff_type", C.c_uint32), ("fused", C.c_uint32),
+                ("num_extra_channels", C.c_uint32), ("alpha_bits", C.c_uint32), ("alpha_premultiplied", C.c_uint32)]
 
 
 class FrameParams(C.Structure):
@@ -222,7 +223,7 @@ EXPORTS = [
     "jxlhip_dequant_table_offset", "jxlhip_status_string", "jxlhip_create", "jxlhip_create_ex", "jxlhip_create_multi",
     "jxlhip_destroy", "jxlhip_last_error", "jxlhip_set_stream",
     "jxlhip_frame_begin", "jxlhip_frame_set_inputs", "jxlhip_upload_side_info",
-    "jxlhip_submit_group", "jxlhip_decode_blocks", "jxlhip_halo_rows",
+    "jxlhip_submit_group", "jxlhip_set_alpha", "jxlhip_decode_blocks", "jxlhip_halo_rows",
     "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_frame",
     "jxlhip_decode_frame_host", "jxlhip_decode_frame_pinned",
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
@@ -234,7 +235,7 @@ EXPORTS = [
     "jxlhip_ac_pass_used_orders", "jxlhip_ac_pass_order", "jxlhip_ac_group_decode", "jxlhip_ac_group_decode_sparse",
     "jxlhip_ac_group_decode_submit", "jxlhip_block_ctx_map_decode", "jxlhip_quant_dc_contexts",
     "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode", "jxlhip_ac_group_decode_submit_passes",
-    "jxlhip_ac_groups_decode_submit", "jxlhip_num_toc_entries", "jxlhip_toc_decode", "jxlhip_ac_global_decode_at",
+    "jxlhip_ac_groups_decode_submit", "jxlhip_ac_groups_decode_submit_ex", "jxlhip_num_toc_entries", "jxlhip_toc_decode", "jxlhip_ac_global_decode_at",
     # include/jxl_hip_frame.h
     "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode",
     "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
@@ -282,6 +283,7 @@ def load_library():
     L.jxlhip_ac_group_decode_submit.argtypes = [vp, vp, u32, vp, vp, vp, vp, sz, C.POINTER(sz)]
     L.jxlhip_ac_group_decode_submit_passes.argtypes = [vp, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp]
     L.jxlhip_ac_groups_decode_submit.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
+    L.jxlhip_ac_groups_decode_submit_ex.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.jxlhip_num_toc_entries.argtypes = [u32, u32, u32]
     L.jxlhip_num_toc_entries.restype = u32
     L.jxlhip_toc_decode.argtypes = [vp, sz, C.POINTER(sz), u32, vp, vp, vp]
@@ -301,6 +303,7 @@ def load_library():
     L.jxlhip_frame_set_inputs.argtypes = [vp, C.POINTER(FrameInputs)]
     L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]
     L.jxlhip_submit_group.argtypes = [vp, u32, vp * 3, sz]
+    L.jxlhip_set_alpha.argtypes = [vp, vp, sz]
     L.jxlhip_decode_blocks.argtypes = [vp]
     L.jxlhip_halo_rows.argtypes = [vp]
     L.jxlhip_halo_export.argtypes = [vp, i32, vp]

@@ -124,6 +124,8 @@ struct jxlhip_ctx {
   size_t host_frame_bytes = 0;
   void* pinned_frame = nullptr;  // jxlhip_decode_frame_pinned: context-owned pinned host frame (StageAlloc)
   size_t pinned_frame_bytes = 0;
+  float* alpha_dev = nullptr;  // jxlhip_set_alpha: the frame's alpha plane (xsize floats per row)
+  size_t alpha_items = 0;
   int32_t* qdc_dev = nullptr;  // jxlhip_decode_codestream: the quantized DC planes on their way to jxlhip_dequant_dc_groups
   size_t qdc_dev_items = 0;
   // transform-kernel fan-out (JXLHIP_BLOCK_STREAMS: 3 = one stream per family; default 1 = back to back on the
@@ -425,7 +427,8 @@ void jxlhip_destroy(jxlhip_ctx* c) {
   void* bufs[] = {c->planes, c->inv_sigma, c->lists,        c->counts,
                   c->error_flag, c->tables, c->up_coeffs[0], c->up_side,
                   c->dc_tmp,     c->quant_enc,  c->dc_prec,      c->cell_info,
-                  c->qdc_dev,    c->host_frame_dev, c->planes2, c->orient_dev};
+                  c->qdc_dev,    c->host_frame_dev, c->planes2, c->orient_dev,
+                  c->alpha_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -708,8 +711,10 @@ static int EnsureUploadBuffers(jxlhip_ctx* c) {
       if (c->sp_dev) HIPCHK(c, hipFree(c->sp_dev));
       c->sp_dev = nullptr;
       c->sp_bytes = 0;
+      // (never cleared: k_expand_sparse reads only what the offset table points at, and those bytes were uploaded.
+      // A hipMemset here runs on the NULL stream, unordered against the uploads on the non-blocking pool streams: it
+      // once landed AFTER the first batch and turned a frame into its DC image.)
       HIPCHK(c, hipMalloc((void**)&c->sp_dev, need));
-      HIPCHK(c, hipMemset(c->sp_dev, 0, need));  // no header carries a frame serial yet
       c->sp_bytes = need;
     }
   }
@@ -733,6 +738,24 @@ static int EnsureUploadBuffers(jxlhip_ctx* c) {
   in.ytob_map = (const int8_t*)(c->up_side + off[4]);
   in.dequant_table = (const float*)(c->up_side + off[8]);
   c->up_inputs = in;
+  return JXLHIP_OK;
+}
+
+// The alpha channel of the current frame for 4-channel packed outputs (what reaches WriteToOutputStage as
+// input channel alpha_c, stage_write.cc:350-366); frame_begin resets to "opaque".
+int jxlhip_set_alpha(jxlhip_ctx* c, const float* host_plane, size_t stride_floats) {
+  if (!c || !host_plane) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->children.empty()) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "alpha on a multi-device context");
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "set_alpha before frame_begin");
+  const size_t w = c->f.xsize, h = c->f.ysize;
+  if (stride_floats < w) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "alpha stride %zu < xsize", stride_floats);
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rc = Grow(c, &c->alpha_dev, &c->alpha_items, w * h);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpy2DAsync(c->alpha_dev, w * sizeof(float), host_plane, stride_floats * sizeof(float), w * sizeof(float), h,
+                             hipMemcpyHostToDevice, c->stream));
+  c->fp.alpha = c->alpha_dev;
+  c->fp.alpha_stride = (uint32_t)w;
   return JXLHIP_OK;
 }
 
@@ -1068,6 +1091,7 @@ struct GroupsJob {
   const uint8_t* quant_dc;
   const uint8_t* const* sections;
   const size_t* sizes;
+  size_t* end_bits = nullptr;
   std::atomic<int> status{JXLHIP_OK};
   // sparse hand-off: one open staging slot + one decode scratch per runner thread
   bool sparse = false;
@@ -1107,6 +1131,8 @@ void GroupsFunc(void* opaque, uint32_t g, size_t thread) {
   if (rc != JXLHIP_OK) {
     int expected = JXLHIP_OK;
     j->status.compare_exchange_strong(expected, rc);
+  } else if (j->end_bits) {
+    for (uint32_t p = 0; p < j->num_passes; p++) j->end_bits[(size_t)p * j->num_groups + g] = pos[p];
   }
 }
 }  // namespace
@@ -1116,13 +1142,22 @@ int jxlhip_ac_groups_decode_submit(jxlhip_ctx* c, jxlhip_parallel_runner runner,
                                    const uint32_t* shifts, const uint8_t* ac_strategy,
                                    const int32_t* raw_quant, const uint8_t* quant_dc,
                                    const uint8_t* const* sections, const size_t* sizes) {
+  return jxlhip_ac_groups_decode_submit_ex(c, runner, runner_opaque, num_passes, passes, shifts, ac_strategy, raw_quant, quant_dc,
+                                           sections, sizes, nullptr);
+}
+
+int jxlhip_ac_groups_decode_submit_ex(jxlhip_ctx* c, jxlhip_parallel_runner runner, void* runner_opaque,
+                                      uint32_t num_passes, const jxlhip_ac_pass* const* passes,
+                                      const uint32_t* shifts, const uint8_t* ac_strategy,
+                                      const int32_t* raw_quant, const uint8_t* quant_dc,
+                                      const uint8_t* const* sections, const size_t* sizes, size_t* end_bits) {
   if (!c || !passes || !ac_strategy || !raw_quant || !sections || !sizes || num_passes == 0 || num_passes > 11)
     return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "ac_groups_decode_submit before frame_begin");
   if (!c->children.empty()) {  // every child takes the groups of its stripe (GroupsFunc skips the others)
     for (jxlhip_ctx* k : c->children) {
-      const int rc = jxlhip_ac_groups_decode_submit(k, runner, runner_opaque, num_passes, passes, shifts, ac_strategy, raw_quant,
-                                                    quant_dc, sections, sizes);
+      const int rc = jxlhip_ac_groups_decode_submit_ex(k, runner, runner_opaque, num_passes, passes, shifts, ac_strategy, raw_quant,
+                                                       quant_dc, sections, sizes, end_bits);
       if (rc) return MultiCheck(c, k, rc);
     }
     return JXLHIP_OK;
@@ -1138,6 +1173,7 @@ int jxlhip_ac_groups_decode_submit(jxlhip_ctx* c, jxlhip_parallel_runner runner,
   job.quant_dc = quant_dc;
   job.sections = sections;
   job.sizes = sizes;
+  job.end_bits = end_bits;
   job.sparse = SparseEligible(c, num_passes);
   if (runner) {
     if (runner(runner_opaque, &job, GroupsInit, GroupsFunc, 0, job.num_groups) != 0)

@@ -176,6 +176,8 @@ __device__ __forceinline__ void PackSamples(const FilterParams& P, DitherPtr dit
   const uint32_t st = Sel::sample_type(F);
   const uint32_t tf = Sel::transfer(F);
   float v[4] = {rgb[0], rgb[1], rgb[2], 1.0f};
+  // the alpha channel goes to the output like a colour channel, minus the transfer function (stage_write.cc:350-366)
+  if (Sel::channels(F) == 4 && P.alpha) v[3] = P.alpha[(size_t)y * P.alpha_stride + x];
   if (tf == JXLHIP_TF_HLG) HlgOotf(P, v);
 #pragma unroll
   for (int c = 0; c < 3; c++) v[c] = ApplyTransfer(tf, v[c], P.tf_scale);
@@ -202,8 +204,9 @@ __device__ __forceinline__ void PackSamples(const FilterParams& P, DitherPtr dit
 }
 
 // One pixel of the JXLHIP_OUT_PACKED output: rgb are LINEAR samples; alpha (4
-// channels) is the opaque 1.0 the reference substitutes when the frame has no
-// alpha channel (stage_write.cc:355-360).  `row` = first byte of output row y.
+// channels) is FilterParams::alpha at (x, y), or the opaque 1.0 the reference
+// substitutes when the frame has no alpha channel (stage_write.cc:355-360).
+// `row` = first byte of output row y.
 template <typename Sel, typename DitherPtr>
 __device__ __forceinline__ void StorePackedPixel(const FilterParams& P, DitherPtr dither, char* row,
                                                  int x, int y, const float* rgb) {

@@ -38,6 +38,10 @@ struct FilterParams {
   // dither coordinates = (dither_x0 + dither_xs * x, dither_y0 + dither_ys * y): the reference dithers AFTER
   // undo_orientation's flips (stage_write.cc:486-492): identity = (0, 1, 0, 1)
   int32_t dither_x0, dither_xs, dither_y0, dither_ys;
+  // 4-channel packed output: the frame's alpha channel (floats, image coordinates, alpha_stride floats per row);
+  // nullptr = the opaque 1.0 the reference substitutes (stage_write.cc:355-360)
+  const float* alpha;
+  uint32_t alpha_stride;
 };
 
 void LaunchPrepare(const DevFrame& f, const WorkLists& wl, int with_sigma, float epf_quant_mul,

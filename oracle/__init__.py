@@ -479,7 +479,7 @@ class RealStream:
                  alpha=(16, np.float32))
 
     def __init__(self, xsize, ysize, seed=1, distance=1.0, speed_tier=3, epf=-1, progressive=0, alpha_bits=0,
-                 alpha_levels=0):
+                 alpha_levels=0, original=None):
         L = ref_lib()
         L.jxr_real_case_create.restype = C.c_void_p
         L.jxr_real_case_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int, C.c_int]
@@ -488,7 +488,8 @@ class RealStream:
         L.jxr_real_case_data.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.jxr_real_case_info.restype = C.c_uint64
         L.jxr_real_case_info.argtypes = [C.c_void_p, C.c_int]
-        knobs = {"JXR_ALPHA": alpha_bits, "JXR_ALPHA_LEVELS": alpha_levels}
+        # original = "srgb8" | "srgb16": the stream describes an integer sRGB original, like a file cjxl made from a PNG
+        knobs = {"JXR_ALPHA": alpha_bits, "JXR_ALPHA_LEVELS": alpha_levels, "JXR_ORIGINAL": original}
         old = {k: os.environ.get(k) for k in knobs}
         for k, v in knobs.items():
             if v:

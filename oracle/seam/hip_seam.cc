@@ -10,8 +10,10 @@
 // AC sections' BYTES to the product's entropy decoder on the decoder's own JxlParallelRunner
 // (jxlhip_ac_groups_decode_submit), runs the HIP back-end and copies the pixels into the caller's
 // JxlDecoderSetImageOutBuffer buffer or hands them row by row to the JxlDecoderSetImageOutCallback callback, in
-// whatever sample format the caller chose.  Frames it does not take (Modular, extra channels, blending, grey
-// outputs, a CMS stage, tone mapping ...) fall through to the untouched CPU path.
+// whatever sample format the caller chose.  An alpha channel going to an RGBA output is decoded from the frame's
+// Modular bytes by the product's host front-end (jxlhip_modular_*) and written by the back-end.  Frames it does not
+// take (Modular, separate extra-channel outputs, blending, grey outputs, a CMS stage, tone mapping ...) fall through
+// to the untouched CPU path.
 //
 // FrameDecoder's members are private; a maintainer would add this as a member function.  Here the class
 // definition is taken as is and its access checks are lifted for this translation unit only.
@@ -49,6 +51,7 @@
 
 #include "jxl_hip.h"
 #include "jxl_hip_entropy.h"
+#include "jxl_hip_frame.h"
 
 extern "C" {
 static std::atomic<int> g_frames{0};
@@ -84,6 +87,12 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
                          size_t ac_global_bit, FrameDecoder::SectionStatus* section_status, bool* done) {
   *done = false;
   if (getenv("JXLHIP_SEAM_DISABLE")) return true;
+  const bool verbose = getenv("JXLHIP_SEAM_VERBOSE") != nullptr;
+  auto decline = [&](const char* why) -> Status {  // the CPU path takes the frame
+    if (verbose) fprintf(stderr, "jxlhip seam declines the frame: %s\n", why);
+    return true;
+  };
+
   const FrameHeader& fh = fd->frame_header_;
   PassesDecoderState* ds = fd->dec_state_;
   const PassesSharedState& sh = *ds->shared;
@@ -94,41 +103,57 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   const size_t np = fh.passes.num_passes;
   // ---- frames the back-end takes; everything else keeps the CPU path
   if (!fd->decoded_ac_global_ || ac_global_sec == num) return true;  // AC global must arrive with the groups
-  if (fh.encoding != FrameEncoding::kVarDCT || fh.color_transform != ColorTransform::kXYB || !md.xyb_encoded) return true;
-  if (fh.flags & (FrameHeader::kNoise | FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kUseDcFrame)) return true;
-  if (!fh.chroma_subsampling.Is444() || fh.upsampling != 1 || fh.dc_level != 0) return true;
-  if (md.num_extra_channels != 0 || fh.custom_size_or_origin || fh.blending_info.mode != BlendMode::kReplace) return true;
-  if (!fh.is_last || fh.CanBeReferenced() || fh.frame_type != FrameType::kRegularFrame) return true;
-  if (fd->decoded_->IsJPEG()) return true;
+  if (fh.encoding != FrameEncoding::kVarDCT || fh.color_transform != ColorTransform::kXYB || !md.xyb_encoded) return decline("not an XYB VarDCT frame");
+  if (fh.flags & (FrameHeader::kNoise | FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kUseDcFrame)) return decline("noise / patches / splines / DC frame");
+  if (!fh.chroma_subsampling.Is444() || fh.upsampling != 1 || fh.dc_level != 0) return decline("chroma subsampling / upsampling / DC level");
+  if (fh.custom_size_or_origin || fh.blending_info.mode != BlendMode::kReplace) return decline("frame origin / blending");
+  // extra channels: only the first alpha channel is ever written, and only into an RGBA main output
+  // (WriteToOutputStage, stage_write.cc:288-366); separate extra-channel outputs and un-premultiplication: CPU path
+  int alpha_ec = -1;
+  if (md.num_extra_channels > 4) return decline("more than four extra channels");
+  for (size_t i = 0; i < md.num_extra_channels; i++) {
+    const ExtraChannelInfo& e = md.extra_channel_info[i];
+    if (e.dim_shift != 0 || e.bit_depth.floating_point_sample || e.bit_depth.bits_per_sample > 24)
+      return decline("extra channel format");
+    if (fh.extra_channel_upsampling[i] != 1) return decline("extra channel upsampling");
+    if (fh.extra_channel_blending_info[i].mode != BlendMode::kReplace) return decline("extra channel blending");
+    if (e.type == ExtraChannel::kAlpha && alpha_ec < 0) alpha_ec = static_cast<int>(i);
+  }
+  for (const ImageOutput& eo : ds->extra_output)
+    if (eo.callback.IsPresent() || eo.buffer) return decline("separate extra-channel outputs");
+  if (alpha_ec >= 0 && ds->unpremul_alpha) return decline("un-premultiplied alpha");
+  const bool want_alpha = alpha_ec >= 0 && mo.format.num_channels == 4;
+  if (!fh.is_last || fh.CanBeReferenced() || fh.frame_type != FrameType::kRegularFrame) return decline("not a single regular frame");
+  if (fd->decoded_->IsJPEG()) return decline("JPEG reconstruction");
   // ---- the output: every ImageOutput WriteToOutputStage serves for a colour image without alpha
   // (stage_write.cc:288-700) -- buffer or row callback, uint8 / uint16 / float16 / float, either endianness,
   // RGB or RGBA (opaque alpha) -- which is what djxl asks for: image-out callback always
   // (lib/extras/dec/jxl.h:64, jxl.cc:543-556), uint8 / uint16 for PNG / PPM, big-endian for PNM
   // (lib/extras/enc/pnm.cc:118-132), float for PFM / NPY
   const bool to_callback = mo.callback.IsPresent();
-  if (!to_callback && !mo.buffer) return true;
-  if (mo.format.num_channels != 3 && mo.format.num_channels != 4) return true;  // grey outputs: CPU path
+  if (!to_callback && !mo.buffer) return decline("no image output set");
+  if (mo.format.num_channels != 3 && mo.format.num_channels != 4) return decline("grey output");
   uint32_t sample_type, bits = 32;
   switch (mo.format.data_type) {
     case JXL_TYPE_FLOAT: sample_type = JXLHIP_SAMPLE_F32; break;
     case JXL_TYPE_FLOAT16: sample_type = JXLHIP_SAMPLE_F16; bits = 16; break;
     case JXL_TYPE_UINT16: sample_type = JXLHIP_SAMPLE_U16; bits = static_cast<uint32_t>(mo.bits_per_sample); break;
     case JXL_TYPE_UINT8: sample_type = JXLHIP_SAMPLE_U8; bits = static_cast<uint32_t>(mo.bits_per_sample); break;
-    default: return true;
+    default: return decline("output sample type");
   }
-  if (sample_type == JXLHIP_SAMPLE_U8 && (bits < 1 || bits > 8)) return true;
-  if (sample_type == JXLHIP_SAMPLE_U16 && (bits < 1 || bits > 16)) return true;
+  if (sample_type == JXLHIP_SAMPLE_U8 && (bits < 1 || bits > 8)) return decline("output bit depth");
+  if (sample_type == JXLHIP_SAMPLE_U16 && (bits < 1 || bits > 16)) return decline("output bit depth");
   // the stage list behind XYBStage must be FromLinearStage alone (dec_cache.cc:255-345): the output space is an
   // RGB one, no CMS stage (the encoding is the original one or no CMS was given), no tone mapping
   // (stage_tone_mapping.cc:33-60)
-  if (oe.color_encoding.Channels() != 3 || oe.color_encoding.GetColorSpace() == ColorSpace::kXYB) return true;
-  if (!oe.color_encoding_is_original && oe.cms_set) return true;
+  if (oe.color_encoding.Channels() != 3 || oe.color_encoding.GetColorSpace() == ColorSpace::kXYB) return decline("output colour space is not RGB");
+  if (!oe.color_encoding_is_original && oe.cms_set) return decline("a CMS stage is needed");
   {
     const auto& otf = oe.orig_color_encoding.Tf();
     if (oe.desired_intensity_target != oe.orig_intensity_target &&
         ((otf.IsPQ() && oe.desired_intensity_target < oe.orig_intensity_target) ||
          (otf.IsHLG() && !oe.color_encoding.Tf().IsHLG())))
-      return true;
+      return decline("tone mapping");
   }
   uint32_t transfer;
   float tf_param = 0.0f;
@@ -140,21 +165,59 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     else if (tf.IsHLG()) transfer = JXLHIP_TF_HLG, tf_param = oe.desired_intensity_target;
     else if (tf.Is709()) transfer = JXLHIP_TF_709;
     else if (tf.have_gamma || tf.IsDCI()) transfer = JXLHIP_TF_GAMMA, tf_param = oe.inverse_gamma;
-    else return true;
+    else return decline("transfer function of the output");
   }
   for (size_t g = 0; g < dim.num_groups; g++)  // the whole frame, nothing drawn yet
-    if (desired_num_ac_passes[g] != np || fd->decoded_passes_per_ac_group_[g] != 0) return true;
+    if (desired_num_ac_passes[g] != np || fd->decoded_passes_per_ac_group_[g] != 0) return decline("not every pass of every AC group at once");
   jxlhip_ctx* ctx = Context();
-  if (!ctx) return true;  // no device: CPU path
+  if (!ctx) return decline("no device");
 
-  const bool verbose = getenv("JXLHIP_SEAM_VERBOSE") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();
   double t_side = 0, t_entropy = 0, t_decode = 0;
   auto check = [&](int rc, const char* what) -> Status {
     if (rc == JXLHIP_OK) return true;
+    if (verbose) fprintf(stderr, "jxlhip seam: %s failed: %s (%s)\n", what, jxlhip_status_string(rc), jxlhip_last_error(ctx));
     return JXL_FAILURE("jxlhip %s: %s (%s)", what, jxlhip_status_string(rc), jxlhip_last_error(ctx));
   };
+  // ---- alpha: the global part of the frame's Modular image once more, from the DC-global section's bytes, into the
+  // product's own state (the reference's copy lives in ModularFrameDecoder and feeds its render pipeline directly)
+  struct TreeOwner {
+    jxlhip_modular_tree* t = nullptr;
+    ~TreeOwner() { jxlhip_modular_tree_destroy(t); }
+  } mtree;
+  jxlhip_frame_header mfh = {};
+  if (want_alpha) {
+    const BitReader* dbr = nullptr;
+    for (size_t i = 0; i < num; i++)
+      if (sections[i].id == 0) dbr = sections[i].br;  // DC global (or the frame's only section)
+    if (!dbr) return decline("DC global arrived in an earlier call");
+    mfh.upsampling = fh.upsampling;
+    mfh.flags = fh.flags;
+    mfh.num_passes = static_cast<uint32_t>(np);
+    mfh.num_downsample = fh.passes.num_downsample;
+    for (uint32_t i = 0; i < fh.passes.num_downsample; i++) {
+      mfh.downsample[i] = fh.passes.downsample[i];
+      mfh.last_pass[i] = fh.passes.last_pass[i];
+    }
+    mfh.xsize = static_cast<uint32_t>(dim.xsize);
+    mfh.ysize = static_cast<uint32_t>(dim.ysize);
+    mfh.xsize_blocks = static_cast<uint32_t>(dim.xsize_blocks);
+    mfh.ysize_blocks = static_cast<uint32_t>(dim.ysize_blocks);
+    mfh.group_dim = static_cast<uint32_t>(dim.group_dim);
+    mfh.xsize_groups = static_cast<uint32_t>(dim.xsize_groups);
+    mfh.ysize_groups = static_cast<uint32_t>(dim.ysize_groups);
+    mfh.num_groups = dim.num_groups;
+    mfh.num_dc_groups = dim.num_dc_groups;
+    mfh.num_extra_channels = md.num_extra_channels;
+    for (size_t i = 0; i < md.num_extra_channels; i++) mfh.ec_upsampling[i] = fh.extra_channel_upsampling[i];
+    jxlhip_dc_global dcg;
+    size_t mpos = 0;
+    int rc = jxlhip_dc_global_decode(dbr->FirstByte(), dbr->TotalBytes(), &mpos, fh.flags, &dcg);
+    if (rc == JXLHIP_OK) rc = jxlhip_modular_global_decode(dbr->FirstByte(), dbr->TotalBytes(), &mpos, &mfh, &mtree.t);
+    if (rc == JXLHIP_ERR_UNSUPPORTED) return decline("extra channels coded with transforms (e.g. squeezed, progressive)");
+    JXL_RETURN_IF_ERROR(check(rc, "modular global"));
+  }
   // ---- per-frame parameters
   jxlhip_frame_params p = {};
   p.xsize = dim.xsize;
@@ -251,6 +314,7 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
       sec_size[ps * dim.num_groups + g] = br->TotalBytes();
     }
 
+  std::vector<size_t> end_bits(want_alpha ? np * dim.num_groups : 0, 0);
   const jxlhip_ac_pass* pp[11];
   for (size_t i = 0; i < np; i++) pp[i] = passes.p[i];
   JxlParallelRunner runner = fd->pool_ ? fd->pool_->runner() : nullptr;
@@ -265,14 +329,46 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
       const uint8_t* d1[1] = {gbr->FirstByte()};
       size_t s1[1] = {gbr->TotalBytes()}, b1[1] = {gpos};
       rc = jxlhip_ac_group_decode_submit_passes(ctx, 1, pp, shifts.data(), 0, acs.data(), rq.data(), qctx.data(), d1, s1, b1);
+      if (want_alpha) {
+        end_bits[0] = b1[0];
+        sec[0] = d1[0];
+        sec_size[0] = s1[0];
+      }
     } else {
-      rc = jxlhip_ac_groups_decode_submit(ctx, reinterpret_cast<jxlhip_parallel_runner>(runner), runner_opaque,
-                                          static_cast<uint32_t>(np), pp, shifts.data(), acs.data(), rq.data(), qctx.data(),
-                                          sec.data(), sec_size.data());
+      rc = jxlhip_ac_groups_decode_submit_ex(ctx, reinterpret_cast<jxlhip_parallel_runner>(runner), runner_opaque,
+                                             static_cast<uint32_t>(np), pp, shifts.data(), acs.data(), rq.data(), qctx.data(),
+                                             sec.data(), sec_size.data(), want_alpha ? end_bits.data() : nullptr);
     }
     if (rc == JXLHIP_ERR_RANGE && ct == JXLHIP_COEFF_I16) continue;  // a coefficient needs 32 bits: redo
     JXL_RETURN_IF_ERROR(check(rc, "AC groups"));
     break;
+  }
+  std::vector<float> alpha;
+  if (want_alpha) {
+    // what follows the coefficients in every AC-group section (ProcessACGroup's second half, dec_frame.cc:497-530),
+    // on the decoder's pool; then the samples as floats, as ModularImageToDecodedRect makes them
+    std::atomic<int> status{JXLHIP_OK};
+    const auto group = [&](uint32_t g, size_t /*thread*/) -> Status {
+      for (size_t ps = 0; ps < np; ps++) {
+        const size_t i = ps * dim.num_groups + g;
+        size_t pos = end_bits[i];
+        const int rc = jxlhip_modular_ac_group_decode(mtree.t, &mfh, g, static_cast<uint32_t>(ps), sec[i], sec_size[i], &pos);
+        if (rc != JXLHIP_OK) {
+          int expected = JXLHIP_OK;
+          status.compare_exchange_strong(expected, rc);
+          break;
+        }
+      }
+      return true;
+    };
+    JXL_RETURN_IF_ERROR(RunOnPool(fd->pool_, 0, static_cast<uint32_t>(dim.num_groups), ThreadPool::NoInit, group, "jxlhip modular"));
+    JXL_RETURN_IF_ERROR(check(status.load(), "modular AC groups"));
+    alpha.resize(dim.xsize * dim.ysize);
+    JXL_RETURN_IF_ERROR(check(jxlhip_modular_extra_channel_f32(mtree.t, static_cast<uint32_t>(alpha_ec),
+                                                               md.extra_channel_info[alpha_ec].bit_depth.bits_per_sample,
+                                                               md.bit_depth.bits_per_sample, alpha.data(), dim.xsize),
+                              "alpha samples"));
+    JXL_RETURN_IF_ERROR(check(jxlhip_set_alpha(ctx, alpha.data(), dim.xsize), "set_alpha"));
   }
   t_entropy = now();
   if (!to_callback) {
@@ -319,6 +415,11 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     fd->decoded_passes_per_ac_group_[g] = static_cast<uint8_t>(np);
     for (size_t ps = 0; ps < np && !single; ps++) section_status[ac_group_sec[g][ps]] = FrameDecoder::SectionStatus::kDone;
   }
+  // The frame's pixels are out.  A Modular image the reference kept whole (extra channels of a frame that fits one
+  // group are coded globally: ModularFrameDecoder::use_full_image) would be rendered by FinalizeFrame ->
+  // FinalizeDecoding (dec_modular.cc:739-790) through the CPU pipeline -- whose colour buffers were never filled --
+  // and handed to the output a second time.
+  fd->modular_frame_decoder_.use_full_image = false;
   g_frames.fetch_add(1);
   *done = true;
   return true;

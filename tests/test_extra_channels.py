@@ -5,8 +5,8 @@ jxlhip_modular_global_decode (group header, transforms, channels that fit one gr
 bytes (oracle.RealStream(alpha_bits=...): the reference's own encoder writes the stream, lossless alpha like cjxl).
 
   CPU suite : bytes -> alpha plane, bit-exact; multi-group, single-section (the channel is coded globally),
-              two DC groups, 8 and 16 bit, few-valued alpha (a mask); the squeezed alpha of a progressive
-              stream is refused.
+              two DC groups, 8 and 16 bit, the single-channel palettes libjxl's encoder applies (per group, global,
+              global with the indices in the groups: a mask); the squeezed alpha of a progressive stream is refused.
   GPU suite : jxlhip_decode_codestream with a 4-channel packed output -- RGB as before, alpha = that plane."""
 import ctypes as C
 
@@ -122,6 +122,14 @@ CASES = [
     dict(xsize=200, ysize=120, alpha_bits=8, alpha_levels=3),
     dict(xsize=2200, ysize=264, alpha_bits=8, speed_tier=4),       # two DC groups
     dict(xsize=300, ysize=300, alpha_bits=8, speed_tier=7),
+    # 8- / 16-bit integer originals (what cjxl writes for a PNG): the encoder compacts the channel's values through a
+    # single-channel palette -- per group, in the global image of a small frame, or globally with the indices left to
+    # the groups (a mask)
+    dict(xsize=520, ysize=300, alpha_bits=8, original="srgb8"),
+    dict(xsize=776, ysize=520, alpha_bits=16, original="srgb16", distance=2.0, speed_tier=4),
+    dict(xsize=200, ysize=120, alpha_bits=8, original="srgb8"),
+    dict(xsize=520, ysize=300, alpha_bits=8, alpha_levels=2, original="srgb8"),
+    dict(xsize=2200, ysize=264, alpha_bits=16, alpha_levels=2, original="srgb16", speed_tier=4),
 ]
 
 
@@ -151,3 +159,84 @@ def test_squeezed_alpha_of_progressive_streams_is_refused(L, ref, progressive):
     assert L.jxlhip_dc_global_decode(s0.ctypes.data, len(s0), C.byref(spos), fh.flags, C.byref(dcg)) == 0
     assert L.jxlhip_modular_global_decode(s0.ctypes.data, len(s0), C.byref(spos), C.byref(fh), C.byref(tree)) == -7
     assert not tree.value
+
+
+GPU_CASES = [
+    dict(xsize=520, ysize=300, alpha_bits=8),
+    dict(xsize=200, ysize=120, alpha_bits=8),                      # one section, bit-chained
+    dict(xsize=776, ysize=520, alpha_bits=16, distance=2.0, epf=1),
+    dict(xsize=2200, ysize=520, alpha_bits=8, speed_tier=4),       # two DC groups, 27 AC groups
+    dict(xsize=520, ysize=300, alpha_bits=8, alpha_levels=2, original="srgb8"),   # a mask: global palette
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [0, 6])
+@pytest.mark.parametrize("kw", GPU_CASES)
+def test_rgba_outputs_of_the_codestream_decoder(L, ref, kw, workers):
+    """jxlhip_decode_codestream on RGBA streams: float RGBA (RGB to the usual bar, alpha EXACTLY the reference's
+    plane), 8-bit sRGB RGBA (alpha = the coded 8-bit values; a 16-bit alpha rounds), and the 3-channel outputs, which
+    skip the alpha bytes."""
+    import torch
+    from libjxl_amd import VarDctDecoder
+    rs = ref.RealStream(seed=31, **dict(dict(distance=1.0, speed_tier=3), **kw))
+    cs = rs.codestream.tobytes()
+    R = C.CDLL(abi.runner_library_path())
+    R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    pool = R.JxlThreadParallelRunnerCreate(None, workers) if workers else None
+    runner = C.cast(R.JxlThreadParallelRunner, C.c_void_p) if workers else None
+    dec = VarDctDecoder(0)
+    try:
+        info = abi.CodestreamInfo()
+        assert L.jxlhip_codestream_basic_info(cs, len(cs), C.byref(info)) == 0
+        assert (info.num_extra_channels, info.alpha_bits, info.alpha_premultiplied) == (1, kw["alpha_bits"], 0)
+        W, H = info.xsize, info.ysize
+        scale = max(1.0, float(np.abs(rs.rgb).max()))
+        lum = (C.c_float * 3)(0.2126, 0.7152, 0.0722)
+        # float RGBA.  (torch.full leaves a kernel pending on the stream the decoder shares with torch: the hand-over
+        # of the first frame of a context must not depend on that stream being idle -- it once did, see
+        # EnsureUploadBuffers)
+        # (a stream that describes an sRGB original decodes to sRGB samples in the reference: rs.rgb is then encoded)
+        encoded = kw.get("original") is not None
+        fmt = abi.OutputFormat(1 if encoded else 0, 0, 4, 32, 0, 0.0, lum)
+        out = torch.full((H, W, 4), -7.0, dtype=torch.float32, device="cuda")
+        rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, cs, len(cs), 2, C.byref(fmt), out.data_ptr(), W * 16, 0, None)
+        assert rc == 0, (rc, L.jxlhip_last_error(dec.ctx))
+        got = out.cpu().numpy()
+        err = np.abs(got[..., :3] - rs.rgb).max(axis=2) / scale
+        assert float(err.max()) <= TIGHT, [(gy, gx, int((err[gy * 256:gy * 256 + 256, gx * 256:gx * 256 + 256] > TIGHT).sum()))
+                                           for gy in range((H + 255) // 256) for gx in range((W + 255) // 256)]
+        assert np.array_equal(got[..., 3], rs.alpha), float(np.abs(got[..., 3] - rs.alpha).max())
+        # 8-bit sRGB RGBA
+        fmt8 = abi.OutputFormat(1, 1, 4, 8, 0, 0.0, lum)
+        out8 = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, cs, len(cs), 2, C.byref(fmt8), out8.data_ptr(), W * 4, 0, None)
+        assert rc == 0, L.jxlhip_last_error(dec.ctx)
+        g8 = out8.cpu().numpy()
+        lin = np.clip(rs.rgb, 0, 1)
+        srgb = (lin if encoded else np.where(lin <= 0.0031308, lin * 12.92, 1.055 * np.power(lin, 1 / 2.4) - 0.055)) * 255.0
+        assert np.abs(g8[..., :3].astype(np.float32) - srgb).max() <= 1.6
+        a8 = rs.alpha * 255.0
+        if kw["alpha_bits"] == 8:
+            assert np.array_equal(g8[..., 3], np.rint(a8).astype(np.uint8))
+        else:
+            assert np.abs(g8[..., 3].astype(np.float32) - a8).max() <= 1.0   # ordered dither
+        # the same frame without room for alpha: 3-channel float, then 4-channel again (no state left behind)
+        out3 = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, cs, len(cs), 1, None, out3.data_ptr(), W * 12, 0, None)
+        assert rc == 0, L.jxlhip_last_error(dec.ctx)
+        if not encoded:
+            assert float(np.abs(out3.cpu().numpy() - rs.rgb).max()) / scale <= TIGHT
+        # a stream WITHOUT alpha after one with: opaque again
+        rs0 = ref.RealStream(seed=31, xsize=264, ysize=200, distance=1.0, speed_tier=3)
+        cs0 = rs0.codestream.tobytes()
+        o0 = torch.zeros((200, 264, 4), dtype=torch.float32, device="cuda")
+        rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, cs0, len(cs0), 2, C.byref(fmt), o0.data_ptr(), 264 * 16, 0, None)
+        assert rc == 0, L.jxlhip_last_error(dec.ctx)
+        assert (o0.cpu().numpy()[..., 3] == 1.0).all()
+    finally:
+        dec.close()
+        if pool:
+            R.JxlThreadParallelRunnerDestroy(pool)
