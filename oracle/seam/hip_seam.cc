@@ -10,10 +10,11 @@
 // AC sections' BYTES to the product's entropy decoder on the decoder's own JxlParallelRunner
 // (jxlhip_ac_groups_decode_submit), runs the HIP back-end and copies the pixels into the caller's
 // JxlDecoderSetImageOutBuffer buffer or hands them row by row to the JxlDecoderSetImageOutCallback callback, in
-// whatever sample format the caller chose.  An alpha channel going to an RGBA output is decoded from the frame's
-// Modular bytes by the product's host front-end (jxlhip_modular_*) and written by the back-end.  Frames it does not
-// take (Modular, separate extra-channel outputs, blending, grey outputs, a CMS stage, tone mapping ...) fall through
-// to the untouched CPU path.
+// whatever sample format the caller chose.  Extra channels are decoded from the frame's Modular bytes by the
+// product's host front-end (jxlhip_modular_*): an alpha channel going to an RGBA output is written by the back-end,
+// float extra-channel buffers (JxlDecoderSetExtraChannelBuffer) are filled here.  Frames it does not take (Modular,
+// integer extra-channel buffers, blending, grey outputs, a CMS stage, tone mapping ...) fall through to the
+// untouched CPU path.
 //
 // FrameDecoder's members are private; a maintainer would add this as a member function.  Here the class
 // definition is taken as is and its access checks are lifted for this translation unit only.
@@ -119,10 +120,22 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     if (fh.extra_channel_blending_info[i].mode != BlendMode::kReplace) return decline("extra channel blending");
     if (e.type == ExtraChannel::kAlpha && alpha_ec < 0) alpha_ec = static_cast<int>(i);
   }
-  for (const ImageOutput& eo : ds->extra_output)
-    if (eo.callback.IsPresent() || eo.buffer) return decline("separate extra-channel outputs");
+  // extra channels asked for in buffers of their own (JxlDecoderSetExtraChannelBuffer: what djxl does with the alpha
+  // channel for .ppm / .npy, lib/extras/dec/jxl.cc:574-607): float samples are handed out by this function from the
+  // planes the host front-end decodes; integer conversions stay with the CPU path
+  bool extra_buffers = false;
+  for (size_t i = 0; i < ds->extra_output.size(); i++) {
+    const ImageOutput& eo = ds->extra_output[i];
+    if (eo.callback.IsPresent()) return decline("extra-channel callback");
+    if (!eo.buffer) continue;
+    if (i >= md.num_extra_channels || eo.format.data_type != JXL_TYPE_FLOAT || eo.format.num_channels != 1 ||
+        eo.format.endianness == JXL_BIG_ENDIAN)
+      return decline("extra-channel buffer that is not native float");
+    extra_buffers = true;
+  }
   if (alpha_ec >= 0 && ds->unpremul_alpha) return decline("un-premultiplied alpha");
-  const bool want_alpha = alpha_ec >= 0 && mo.format.num_channels == 4;
+  const bool alpha_in_main = alpha_ec >= 0 && mo.format.num_channels == 4;
+  const bool want_alpha = alpha_in_main || extra_buffers;  // = the frame's Modular image is needed
   if (!fh.is_last || fh.CanBeReferenced() || fh.frame_type != FrameType::kRegularFrame) return decline("not a single regular frame");
   if (fd->decoded_->IsJPEG()) return decline("JPEG reconstruction");
   // ---- the output: every ImageOutput WriteToOutputStage serves for a colour image without alpha
@@ -364,11 +377,39 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     JXL_RETURN_IF_ERROR(RunOnPool(fd->pool_, 0, static_cast<uint32_t>(dim.num_groups), ThreadPool::NoInit, group, "jxlhip modular"));
     JXL_RETURN_IF_ERROR(check(status.load(), "modular AC groups"));
     alpha.resize(dim.xsize * dim.ysize);
-    JXL_RETURN_IF_ERROR(check(jxlhip_modular_extra_channel_f32(mtree.t, static_cast<uint32_t>(alpha_ec),
-                                                               md.extra_channel_info[alpha_ec].bit_depth.bits_per_sample,
-                                                               md.bit_depth.bits_per_sample, alpha.data(), dim.xsize),
-                              "alpha samples"));
-    JXL_RETURN_IF_ERROR(check(jxlhip_set_alpha(ctx, alpha.data(), dim.xsize), "set_alpha"));
+    // extra-channel buffers: the plane in display orientation (WriteToOutputStage's flips / transpose,
+    // stage_write.cc:441-457,664-680), rows of `stride` bytes
+    const uint32_t o = static_cast<uint32_t>(ds->undo_orientation);
+    const bool fx = o == 2 || o == 3 || o == 7 || o == 8, fy = o == 3 || o == 4 || o == 6 || o == 7, tr = o >= 5;
+    for (size_t i = 0; i < ds->extra_output.size(); i++) {
+      const ImageOutput& eo = ds->extra_output[i];
+      if (!eo.buffer) continue;
+      JXL_RETURN_IF_ERROR(check(jxlhip_modular_extra_channel_f32(mtree.t, static_cast<uint32_t>(i),
+                                                                 md.extra_channel_info[i].bit_depth.bits_per_sample,
+                                                                 md.bit_depth.bits_per_sample, alpha.data(), dim.xsize),
+                                "extra channel samples"));
+      const size_t ow = tr ? dim.ysize : dim.xsize, oh = tr ? dim.xsize : dim.ysize;
+      if (eo.stride < ow * sizeof(float) || eo.buffer_size < (oh - 1) * eo.stride + ow * sizeof(float))
+        return JXL_FAILURE("extra channel buffer too small");
+      const auto row = [&](uint32_t y, size_t /*thread*/) -> Status {
+        const float* src = alpha.data() + static_cast<size_t>(y) * dim.xsize;
+        const size_t yo = fy ? dim.ysize - 1 - y : y;
+        for (size_t x = 0; x < dim.xsize; x++) {
+          const size_t xo = fx ? dim.xsize - 1 - x : x;
+          char* d = static_cast<char*>(eo.buffer) + (tr ? xo * eo.stride + yo * sizeof(float) : yo * eo.stride + xo * sizeof(float));
+          memcpy(d, &src[x], sizeof(float));
+        }
+        return true;
+      };
+      JXL_RETURN_IF_ERROR(RunOnPool(fd->pool_, 0, static_cast<uint32_t>(dim.ysize), ThreadPool::NoInit, row, "jxlhip extra channel"));
+    }
+    if (alpha_in_main) {
+      JXL_RETURN_IF_ERROR(check(jxlhip_modular_extra_channel_f32(mtree.t, static_cast<uint32_t>(alpha_ec),
+                                                                 md.extra_channel_info[alpha_ec].bit_depth.bits_per_sample,
+                                                                 md.bit_depth.bits_per_sample, alpha.data(), dim.xsize),
+                                "alpha samples"));
+      JXL_RETURN_IF_ERROR(check(jxlhip_set_alpha(ctx, alpha.data(), dim.xsize), "set_alpha"));
+    }
   }
   t_entropy = now();
   if (!to_callback) {
