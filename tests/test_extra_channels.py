@@ -240,3 +240,35 @@ def test_rgba_outputs_of_the_codestream_decoder(L, ref, kw, workers):
         dec.close()
         if pool:
             R.JxlThreadParallelRunnerDestroy(pool)
+
+
+def test_damaged_modular_bytes_never_crash(L, ref):
+    """Bit flips in the DC-global section and at the tail of the AC-group sections (where the alpha channel's bytes
+    are): every call returns -- a status, or pixels that merely differ.  (Run under ASan + UBSan while developing:
+    clean.)"""
+    import random
+    rng = random.Random(11)
+    streams = [ref.RealStream(264, 200, seed=3, distance=1.0, speed_tier=3, alpha_bits=8, original="srgb8"),
+               ref.RealStream(300, 264, seed=5, distance=2.0, speed_tier=3, alpha_bits=8, alpha_levels=2, original="srgb8")]
+
+    class Damaged:
+        pass
+
+    outcomes = {"decoded": 0, "refused": 0}
+    for it in range(160):
+        rs = streams[it % len(streams)]
+        cs = rs.codestream.copy()
+        for _ in range(rng.choice((1, 1, 2, 4))):
+            k = rng.randrange(len(rs.section_offset))
+            o, s = int(rs.section_offset[k]), int(rs.section_size[k])
+            pos = o + max(0, s - 1 - rng.randrange(min(s, 300))) if s else o
+            cs[min(pos, len(cs) - 1)] ^= 1 << rng.randrange(8)
+        d = Damaged()
+        d.__dict__.update(rs.__dict__)
+        d.codestream = cs
+        try:
+            decode_alpha_on_host(L, d)
+            outcomes["decoded"] += 1
+        except AssertionError:
+            outcomes["refused"] += 1
+    assert outcomes["refused"] > 20, outcomes
