@@ -11,7 +11,8 @@ BUILD = os.path.join(CSRC, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
-LIB_SOURCES = ["context.hip", "kernels_blocks.hip", "kernels_filters.hip", "kernels_filters_fast.hip",
+LIB_SOURCES = ["context.hip", "kernels_blocks.hip", "kernels_filters.hip", "kernels_filters_fast.hip", "kernels_filters_fast_b.hip", "kernels_filters_fast_c.hip",
+               "kernels_filters_fast_d.hip",
                "kernels_fused.hip", "kernels_fused_b.hip", "kernels_fused_pc.hip", "kernels_mfma.hip", "kernels_epf0.hip", "kernels_tables.hip", "entropy.cc"]
 RUNNER_SOURCES = ["runner.cc"]
 
@@ -36,6 +37,8 @@ def _compile(src):
     obj = os.path.join(BUILD, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     extra = [os.path.join(CSRC, "kernels_fused.hip")] if src in ("kernels_fused_b.hip", "kernels_fused_pc.hip") else []  # they #include it
+    if src.startswith("kernels_filters_fast_"):
+        extra = [os.path.join(CSRC, "kernels_filters_fast.hip")]
     if _stale(obj, [path] + extra + _deps()):
         lang = ["-x", "hip"] if src.endswith(".hip") else []
         cmd = [HIPCC] + FLAGS + lang + ["-c", path, "-o", obj]

@@ -1312,9 +1312,7 @@ bool WantFused(const jxlhip_ctx* c) {
   bool packed_fixed = false;
   if (c->p.output_kind == JXLHIP_OUT_PACKED) {
     const jxlhip_output_format& o = c->p.out_format;
-    packed_fixed = o.transfer == JXLHIP_TF_SRGB && !o.swap_endianness &&
-                   ((o.sample_type == JXLHIP_SAMPLE_U8 && (o.num_channels == 3 || o.num_channels == 4)) ||
-                    (o.sample_type == JXLHIP_SAMPLE_U16 && o.num_channels == 3));
+    packed_fixed = FastFixedFormat(o);
   }
   return (c->fuse > 0 || (c->fuse < 0 && big && has_dct8 && !packed_fixed)) && !c->generic_filters && c->band_rows == 0 &&
          FusedSupported(f, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind);

@@ -126,22 +126,24 @@ __device__ __forceinline__ float ApplyTransfer(uint32_t tf, float v, float tf_sc
 // Output format as seen by the emit code: FmtSel<-1> reads it from the launch
 // parameters (wave-uniform branches per sample -- correct for every format, but
 // the scalar branches cost as much as the arithmetic); FmtSel<ID> with
-// ID = FormatId(transfer, sample_type, channels) fixes it at compile time for
-// the formats the launchers specialise.
-__host__ __device__ constexpr int FormatId(int transfer, int sample_type, int channels) {
-  return transfer | (sample_type << 1) | ((channels - 3) << 3);
+// ID = FormatId(transfer, sample_type, channels, swap_endianness) fixes it at compile time for
+// the formats the launchers specialise (tf_param, the bit depth and the HLG luminances stay launch parameters).
+__host__ __device__ constexpr int FormatId(int transfer, int sample_type, int channels, int swap = 0) {
+  return transfer | (sample_type << 3) | ((channels - 3) << 5) | (swap << 6);
 }
 template <int ID>
 struct FmtSel {
-  static __device__ __forceinline__ uint32_t transfer(const jxlhip_output_format&) { return ID & 1; }  // linear / sRGB
-  static __device__ __forceinline__ uint32_t sample_type(const jxlhip_output_format&) { return (ID >> 1) & 3; }
-  static __device__ __forceinline__ uint32_t channels(const jxlhip_output_format&) { return 3 + ((ID >> 3) & 1); }
+  static __device__ __forceinline__ uint32_t transfer(const jxlhip_output_format&) { return ID & 7; }  // JXLHIP_TF_*
+  static __device__ __forceinline__ uint32_t sample_type(const jxlhip_output_format&) { return (ID >> 3) & 3; }
+  static __device__ __forceinline__ uint32_t channels(const jxlhip_output_format&) { return 3 + ((ID >> 5) & 1); }
+  static __device__ __forceinline__ bool swap(const jxlhip_output_format&) { return ((ID >> 6) & 1) != 0; }
 };
 template <>
 struct FmtSel<-1> {
   static __device__ __forceinline__ uint32_t transfer(const jxlhip_output_format& F) { return F.transfer; }
   static __device__ __forceinline__ uint32_t sample_type(const jxlhip_output_format& F) { return F.sample_type; }
   static __device__ __forceinline__ uint32_t channels(const jxlhip_output_format& F) { return F.num_channels; }
+  static __device__ __forceinline__ bool swap(const jxlhip_output_format& F) { return F.swap_endianness != 0; }
 };
 
 // MakeUnsigned (stage_write.cc:263-284): scale, ordered dither for 8-bit types,
@@ -196,7 +198,7 @@ __device__ __forceinline__ void PackSamples(const FilterParams& P, DitherPtr dit
 #pragma unroll
     for (int c = 0; c < 4; c++) q[c] = __float_as_uint(v[c]);
   }
-  if (F.swap_endianness) {  // rare: one uniform branch
+  if (Sel::swap(F)) {  // (general format: one uniform branch)
 #pragma unroll
     for (int c = 0; c < 4; c++)
       q[c] = st == JXLHIP_SAMPLE_F32 ? __builtin_bswap32(q[c]) : (uint32_t)Bswap16((uint16_t)q[c]);
@@ -263,7 +265,9 @@ __device__ __forceinline__ void StorePackedPair(const FilterParams& P, DitherPtr
       __builtin_nontemporal_store(u4{a[0], a[1], a[2], a[3]}, (u4*)d);
       __builtin_nontemporal_store(u4{b[0], b[1], b[2], b[3]}, (u4*)(d + 4));
     } else {
+      // (the fence keeps the pair of stores a pair: merged and re-split into two 12-byte stores they are 6x slower)
       __builtin_nontemporal_store(u4{a[0], a[1], a[2], b[0]}, (u4*)d);
+      asm volatile("" ::: "memory");
       __builtin_nontemporal_store(u2{b[1], b[2]}, (u2*)(d + 4));
     }
   } else {  // 16-bit samples
@@ -274,6 +278,7 @@ __device__ __forceinline__ void StorePackedPair(const FilterParams& P, DitherPtr
                                   (u4*)d);
     } else {  // 12 bytes as 8 + 4 (a 12-byte vector store measured 8x slower here)
       __builtin_nontemporal_store(u2{a[0] | (a[1] << 16), a[2] | (b[0] << 16)}, (u2*)d);
+      asm volatile("" ::: "memory");  // (or the compiler merges the two into that 12-byte store)
       __builtin_nontemporal_store(b[1] | (b[2] << 16), d + 2);
     }
   }

@@ -59,6 +59,8 @@ int LaunchFilters(const DevFrame& f, const FilterParams& p, int gab, int epf_ite
 // when the configuration is not covered (caller falls back to LaunchFilters).
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st);
+// the packed formats LaunchFiltersFast has a kernel with the format fixed at compile time for
+bool FastFixedFormat(const jxlhip_output_format& o);
 
 // epf_iters = 3 (kernels_epf0.hip): [Gaborish] + EPF0 from f.xyb into a second plane set; the EPF1 + EPF2 march
 // (LaunchFiltersFast with gab = 0, epf_iters = 2 on those planes) follows.  false: geometry not covered.

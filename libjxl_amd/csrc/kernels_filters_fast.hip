@@ -49,6 +49,13 @@
 
 #include "filters_march.h"
 
+// This file is compiled four times: as itself (part 0: the entry points, the float / planar outputs, the general
+// packed format and the three fixed formats of round 2) and, through kernels_filters_fast_{b,c,d}.hip, for three
+// more sets of packed formats fixed at compile time (parts 1..3) -- six stage lists each, in parallel.
+#ifndef JXLHIP_FAST_PART
+#define JXLHIP_FAST_PART 0
+#endif
+
 namespace jxlhip {
 
 namespace {
@@ -246,24 +253,94 @@ void LaunchFastT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
   hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 0>), grid, dim3(256), 0, st, f, p, RH);
 }
 
-// The formats djxl writes most (8-bit sRGB for PNG / PPM / JPEG-like consumers,
-// 16-bit sRGB) get a kernel with the format fixed at compile time; everything
-// else takes the one that reads the format from its launch parameters.
+// Packed formats with a kernel of their own (the format fixed at compile time): what djxl writes most -- 8-bit sRGB
+// for PNG / PPM, 16-bit sRGB (round 2, part 0) -- and, round 3: 16-bit sRGB RGBA and the BIG-ENDIAN 16-bit forms
+// (PNG / PNM are big-endian), float sRGB / linear (PFM, NPY, API clients), half-float RGBA (HDR canvases), 16-bit PQ
+// (HDR PNG).  Everything else takes the kernel that reads the format from its launch parameters -- at twice the time
+// (per-sample wave-uniform branches, 256 VGPRs and spills; profiles/r03_packed_fixed_formats.txt).
+#define JXLHIP_FIXED_FORMATS_0(X)                    \
+  X(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U8, 3, 0)          \
+  X(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U8, 4, 0)          \
+  X(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U16, 3, 0)
+#define JXLHIP_FIXED_FORMATS_1(X)                    \
+  X(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U16, 4, 0)         \
+  X(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U16, 3, 1)         \
+  X(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U16, 4, 1)
+#define JXLHIP_FIXED_FORMATS_2(X)                    \
+  X(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_F32, 3, 0)         \
+  X(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_F32, 4, 0)         \
+  X(JXLHIP_TF_LINEAR, JXLHIP_SAMPLE_F32, 4, 0)
+#define JXLHIP_FIXED_FORMATS_3(X)                    \
+  X(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_F16, 4, 0)         \
+  X(JXLHIP_TF_LINEAR, JXLHIP_SAMPLE_F16, 4, 0)       \
+  X(JXLHIP_TF_PQ, JXLHIP_SAMPLE_U16, 3, 1)           \
+  X(JXLHIP_TF_PQ, JXLHIP_SAMPLE_U16, 4, 1)
+#if JXLHIP_FAST_PART == 0
+#define JXLHIP_FIXED_FORMATS(X) JXLHIP_FIXED_FORMATS_0(X)
+#elif JXLHIP_FAST_PART == 1
+#define JXLHIP_FIXED_FORMATS(X) JXLHIP_FIXED_FORMATS_1(X)
+#elif JXLHIP_FAST_PART == 2
+#define JXLHIP_FIXED_FORMATS(X) JXLHIP_FIXED_FORMATS_2(X)
+#else
+#define JXLHIP_FIXED_FORMATS(X) JXLHIP_FIXED_FORMATS_3(X)
+#endif
+
+// this part's fixed formats: launches and returns true when p.fmt is one of them
 template <int GAB, int EPF>
-void LaunchPackedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
+bool LaunchFixedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
   const jxlhip_output_format& o = p.fmt;
-  if (o.transfer == JXLHIP_TF_SRGB && !o.swap_endianness) {
-    if (o.sample_type == JXLHIP_SAMPLE_U8 && o.num_channels == 3)
-      return LaunchFastT<GAB, EPF, 2, FormatId(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U8, 3)>(f, p, st);
-    if (o.sample_type == JXLHIP_SAMPLE_U8 && o.num_channels == 4)
-      return LaunchFastT<GAB, EPF, 2, FormatId(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U8, 4)>(f, p, st);
-    if (o.sample_type == JXLHIP_SAMPLE_U16 && o.num_channels == 3)
-      return LaunchFastT<GAB, EPF, 2, FormatId(JXLHIP_TF_SRGB, JXLHIP_SAMPLE_U16, 3)>(f, p, st);
+#define JXLHIP_TRY(TF, ST, NC, SW)                                                                              \
+  if (o.transfer == TF && o.sample_type == ST && o.num_channels == NC && (o.swap_endianness != 0) == (SW != 0)) { \
+    LaunchFastT<GAB, EPF, 2, FormatId(TF, ST, NC, SW)>(f, p, st);                                               \
+    return true;                                                                                                \
   }
-  LaunchFastT<GAB, EPF, 2, -1>(f, p, st);
+  JXLHIP_FIXED_FORMATS(JXLHIP_TRY)
+#undef JXLHIP_TRY
+  return false;
+}
+
+bool LaunchFixedPart(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, hipStream_t st) {
+#define JXLHIP_FAST(G, E) \
+  if (gab == G && epf_iters == E) return LaunchFixedT<G, E>(f, p, st);
+  JXLHIP_FAST(0, 0)
+  JXLHIP_FAST(1, 0)
+  JXLHIP_FAST(0, 1)
+  JXLHIP_FAST(1, 1)
+  JXLHIP_FAST(0, 2)
+  JXLHIP_FAST(1, 2)
+#undef JXLHIP_FAST
+  return false;
 }
 
 }  // namespace
+
+#if JXLHIP_FAST_PART == 1
+bool LaunchFastFixedB(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, hipStream_t st) {
+  return LaunchFixedPart(f, p, gab, epf_iters, st);
+}
+#elif JXLHIP_FAST_PART == 2
+bool LaunchFastFixedC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, hipStream_t st) {
+  return LaunchFixedPart(f, p, gab, epf_iters, st);
+}
+#elif JXLHIP_FAST_PART == 3
+bool LaunchFastFixedD(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, hipStream_t st) {
+  return LaunchFixedPart(f, p, gab, epf_iters, st);
+}
+#else
+bool LaunchFastFixedB(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, hipStream_t st);
+bool LaunchFastFixedC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, hipStream_t st);
+bool LaunchFastFixedD(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, hipStream_t st);
+
+bool FastFixedFormat(const jxlhip_output_format& o) {
+#define JXLHIP_IS(TF, ST, NC, SW) \
+  if (o.transfer == TF && o.sample_type == ST && o.num_channels == NC && (o.swap_endianness != 0) == (SW != 0)) return true;
+  JXLHIP_FIXED_FORMATS_0(JXLHIP_IS)
+  JXLHIP_FIXED_FORMATS_1(JXLHIP_IS)
+  JXLHIP_FIXED_FORMATS_2(JXLHIP_IS)
+  JXLHIP_FIXED_FORMATS_3(JXLHIP_IS)
+#undef JXLHIP_IS
+  return false;
+}
 
 bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int epf_iters,
                        int output_kind, hipStream_t st) {
@@ -272,11 +349,16 @@ bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int ep
   // row offsets inside a plane are 32-bit
   if ((uint64_t)f.plane_tile_rows * f.tile_stride * 256u >= (1ull << 32)) return false;
   if (f.linear_stride && !(gab == 0 && epf_iters == 2)) return false;
+  if (gab < 0 || gab > 1 || epf_iters < 0) return false;
+  if (output_kind == JXLHIP_OUT_PACKED &&
+      (LaunchFixedPart(f, p, gab, epf_iters, st) || LaunchFastFixedB(f, p, gab, epf_iters, st) ||
+       LaunchFastFixedC(f, p, gab, epf_iters, st) || LaunchFastFixedD(f, p, gab, epf_iters, st)))
+    return true;
 #define JXLHIP_FAST(G, E)                                  \
   if (gab == G && epf_iters == E) {                        \
     if (output_kind == 0) LaunchFastT<G, E, 0>(f, p, st);  \
     else if (output_kind == 1) LaunchFastT<G, E, 1>(f, p, st); \
-    else LaunchPackedT<G, E>(f, p, st);                    \
+    else LaunchFastT<G, E, 2, -1>(f, p, st);               \
     return true;                                           \
   }
   JXLHIP_FAST(0, 0)  // no loop filter: the same row march is a streaming block-major -> RGB conversion
@@ -288,5 +370,6 @@ bool LaunchFiltersFast(const DevFrame& f, const FilterParams& p, int gab, int ep
 #undef JXLHIP_FAST
   return false;
 }
+#endif
 
 }  // namespace jxlhip

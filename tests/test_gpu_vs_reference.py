@@ -250,6 +250,40 @@ def test_packed_float_srgb(dec, ref, st, sw):
     assert (g[..., 3] == 1.0).all()
 
 
+@pytest.mark.parametrize("gab,epf", [(True, 1), (False, 0), (True, 2), (False, 1), (True, 3)])
+@pytest.mark.parametrize("tf,st,bits,nc,sw", [(1, 2, 16, 4, 0), (1, 2, 16, 3, 1), (1, 2, 10, 4, 1), (1, 0, 0, 3, 0), (1, 0, 0, 4, 0),
+                                              (0, 0, 0, 4, 0), (1, 3, 0, 4, 0), (0, 3, 0, 4, 0), (2, 2, 16, 3, 1), (2, 2, 16, 4, 1)])
+def test_packed_formats_with_a_kernel_of_their_own(dec, ref, tf, st, bits, nc, sw, gab, epf):
+    """Round 3's fixed-format instantiations of the row march (kernels_filters_fast_{b,c,d}.hip: 16-bit sRGB RGBA and
+    the big-endian 16-bit forms, float sRGB / linear, half-float RGBA, big-endian 16-bit PQ) against the reference's
+    FromLinearStage + WriteToOutputStage, over the stage lists."""
+    hdr = tf == 2
+    got, want = run_packed(dec, ref, 520, 264, dict(transfer=tf, sample_type=st, num_channels=nc, bits_per_sample=bits,
+                                                    swap_endianness=sw, tf_param=1000.0 if hdr else 0.0),
+                           mix=synth.MIX_D1, gab=gab, epf_iters=epf, intensity_target=1000.0 if hdr else (80.0 if tf else 255.0))
+    if st == 2:
+        g, w = got.view(np.uint16), want.view(np.uint16)
+        if sw:
+            g, w = g.byteswap(), w.byteswap()
+        d = np.abs(g.astype(np.int32) - w.astype(np.int32))
+        if hdr:  # PQ's slope near zero (~1e3 at 1e-4) amplifies the float pipeline's 2e-5
+            assert d[..., :3].max() <= 140 and (d[..., :3] > 8).mean() < 2e-3
+        else:
+            assert d.max() <= max(2, int(TIGHT * 8 * (1 << bits)))
+        if nc == 4:
+            assert (g[..., 3] == (1 << bits) - 1).all()
+        return
+    if st == 3:
+        g, w = got.view(np.uint16).view(np.float16).astype(np.float32), want.view(np.uint16).view(np.float16).astype(np.float32)
+        tol = 2e-3
+    else:
+        g, w = got.view(np.float32), want.view(np.float32)
+        tol = 1e-4 if tf else TIGHT
+    assert float(np.abs(g - w).max()) <= tol * max(1.0, float(np.abs(w).max()))
+    if nc == 4:
+        assert (g[..., 3] == 1.0).all()
+
+
 @pytest.mark.parametrize("tf,par,it", [(2, 1000.0, 1000.0), (3, 0.0, 255.0), (4, 1 / 2.6, 255.0), (5, 1000.0, 1000.0),
                                        (5, 334.0, 334.0)])
 @pytest.mark.parametrize("st,bits", [(1, 8), (2, 16), (0, 0)])
