@@ -262,6 +262,10 @@ JXLHIP_EXPORT int jxlhip_upload_side_info(
  * (stage_write.cc:350-366); not un-premultiplied.  Without this call (jxlhip_frame_begin resets it) alpha is the
  * opaque 1.0 the reference substitutes (:355-360).  Single-device contexts. */
 JXLHIP_EXPORT int jxlhip_set_alpha(jxlhip_ctx* ctx, const float* host_plane, size_t stride_floats);
+/* A pinned host plane of the current frame's size, owned by the context, for the caller to fill and hand to
+ * jxlhip_set_alpha (the copy is then a true asynchronous DMA).  Valid until the next jxlhip_frame_begin of a larger
+ * frame or jxlhip_destroy; the previous frame must have been synchronised before it is written again. */
+JXLHIP_EXPORT int jxlhip_alpha_staging(jxlhip_ctx* ctx, float** plane, size_t* stride_floats);
 /* Replaces GetBlockFromEncoder/GetBlockFromBitstream -> DequantBlock hand-off
  * (dec_group.cc:334-359,662-706): the group's quantized coefficient stream, as
  * produced by DecodeACVarBlock, ncoeffs <= 65536 elements per channel.

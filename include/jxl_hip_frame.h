@@ -220,6 +220,16 @@ JXLHIP_EXPORT void jxlhip_modular_tree_destroy(jxlhip_modular_tree* tree);
 JXLHIP_EXPORT int jxlhip_modular_ac_group_decode(jxlhip_modular_tree* tree, const jxlhip_frame_header* frame,
                                                  uint32_t group, uint32_t pass, const uint8_t* data, size_t size,
                                                  size_t* bit_pos);
+/* The same, with the samples converted on the group's thread and written straight into the caller's float planes --
+ * planes[e] for extra channel e (NULL = not wanted), rows of stride_floats, ec_bits[e] / image_bits as for
+ * jxlhip_modular_extra_channel_f32 -- so that the frame's int32 image is never allocated and nothing is left to
+ * convert afterwards.  Channels that fit one group are coded in the global section and do not pass here: they are
+ * read with jxlhip_modular_extra_channel_f32.  JXLHIP_ERR_UNSUPPORTED: the global image carries a palette of a
+ * palette (use the collecting form above). */
+JXLHIP_EXPORT int jxlhip_modular_ac_group_decode_f32(jxlhip_modular_tree* tree, const jxlhip_frame_header* frame,
+                                                     uint32_t group, uint32_t pass, const uint8_t* data, size_t size,
+                                                     size_t* bit_pos, const uint32_t* ec_bits, uint32_t image_bits,
+                                                     float* const* planes, size_t stride_floats);
 /* Once every group is in: extra channel `ec` as float samples, out[y * stride_floats + x] = v / (2^ec_bits - 1)
  * (FinalizeDecoding + ModularImageToDecodedRect, dec_modular.cc:686-737,739-760; image_bits = the IMAGE's
  * bits_per_sample, which picks the float or the double multiply, :726-731).  The first call undoes the global

@@ -223,7 +223,7 @@ EXPORTS = [
     "jxlhip_dequant_table_offset", "jxlhip_status_string", "jxlhip_create", "jxlhip_create_ex", "jxlhip_create_multi",
     "jxlhip_destroy", "jxlhip_last_error", "jxlhip_set_stream",
     "jxlhip_frame_begin", "jxlhip_frame_set_inputs", "jxlhip_upload_side_info",
-    "jxlhip_submit_group", "jxlhip_set_alpha", "jxlhip_decode_blocks", "jxlhip_halo_rows",
+    "jxlhip_submit_group", "jxlhip_set_alpha", "jxlhip_alpha_staging", "jxlhip_decode_blocks", "jxlhip_halo_rows",
     "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_frame",
     "jxlhip_decode_frame_host", "jxlhip_decode_frame_pinned",
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
@@ -239,7 +239,7 @@ EXPORTS = [
     # include/jxl_hip_frame.h
     "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode",
     "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
-    "jxlhip_modular_ac_group_decode", "jxlhip_modular_extra_channel_f32",
+    "jxlhip_modular_ac_group_decode", "jxlhip_modular_ac_group_decode_f32", "jxlhip_modular_extra_channel_f32",
     # include/jxl_hip_codestream.h
     "jxlhip_codestream_basic_info", "jxlhip_decode_codestream",
 ]
@@ -294,6 +294,7 @@ def load_library():
     L.jxlhip_modular_tree_destroy.restype = None
     L.jxlhip_modular_ac_group_decode.argtypes = [vp, C.POINTER(FrameHeader), u32, u32, vp, sz, C.POINTER(sz)]
     L.jxlhip_modular_extra_channel_f32.argtypes = [vp, u32, u32, u32, vp, sz]
+    L.jxlhip_modular_ac_group_decode_f32.argtypes = [vp, C.POINTER(FrameHeader), u32, u32, vp, sz, C.POINTER(sz), vp, u32, vp, sz]
     L.jxlhip_dc_group_decode.argtypes = [vp, vp, sz, C.POINTER(sz), C.POINTER(FrameHeader), C.c_uint32,
                                          C.POINTER(vp), C.POINTER(C.c_uint32), vp, vp, vp, vp, vp,
                                          C.POINTER(C.c_uint32)]
@@ -304,6 +305,7 @@ def load_library():
     L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]
     L.jxlhip_submit_group.argtypes = [vp, u32, vp * 3, sz]
     L.jxlhip_set_alpha.argtypes = [vp, vp, sz]
+    L.jxlhip_alpha_staging.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlhip_decode_blocks.argtypes = [vp]
     L.jxlhip_halo_rows.argtypes = [vp]
     L.jxlhip_halo_export.argtypes = [vp, i32, vp]

@@ -126,6 +126,8 @@ struct jxlhip_ctx {
   size_t pinned_frame_bytes = 0;
   float* alpha_dev = nullptr;  // jxlhip_set_alpha: the frame's alpha plane (xsize floats per row)
   size_t alpha_items = 0;
+  void* alpha_host = nullptr;  // jxlhip_alpha_staging: pinned plane the caller fills
+  size_t alpha_host_items = 0;
   int32_t* qdc_dev = nullptr;  // jxlhip_decode_codestream: the quantized DC planes on their way to jxlhip_dequant_dc_groups
   size_t qdc_dev_items = 0;
   // transform-kernel fan-out (JXLHIP_BLOCK_STREAMS: 3 = one stream per family; default 1 = back to back on the
@@ -419,6 +421,7 @@ void jxlhip_destroy(jxlhip_ctx* c) {
   }
   if (c->pinned_frame) StageFree(c, c->pinned_frame);
   if (c->sp_dev) (void)hipFree(c->sp_dev);
+  if (c->alpha_host) StageFree(c, c->alpha_host);
   if (c->sp_off_dev) (void)hipFree(c->sp_off_dev);
   for (int i = 0; i < 2; i++) {
     if (c->sp_off_host[i]) StageFree(c, c->sp_off_host[i]);
@@ -738,6 +741,27 @@ static int EnsureUploadBuffers(jxlhip_ctx* c) {
   in.ytob_map = (const int8_t*)(c->up_side + off[4]);
   in.dequant_table = (const float*)(c->up_side + off[8]);
   c->up_inputs = in;
+  return JXLHIP_OK;
+}
+
+int jxlhip_alpha_staging(jxlhip_ctx* c, float** plane, size_t* stride_floats) {
+  if (!c || !plane || !stride_floats) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->children.empty()) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "alpha on a multi-device context");
+  if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "alpha_staging before frame_begin");
+  const size_t need = (size_t)c->f.xsize * c->f.ysize;
+  if (need > c->alpha_host_items) {
+    if (c->alpha_host) {
+      const int rc = jxlhip_sync(c);  // nothing may still be reading the old plane
+      if (rc) return rc;
+      StageFree(c, c->alpha_host);
+      c->alpha_host = nullptr;
+      c->alpha_host_items = 0;
+    }
+    if (StageAlloc(c, &c->alpha_host, need * sizeof(float))) return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned alpha plane");
+    c->alpha_host_items = need;
+  }
+  *plane = (float*)c->alpha_host;
+  *stride_floats = c->f.xsize;
   return JXLHIP_OK;
 }
 

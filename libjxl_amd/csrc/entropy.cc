@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 

@@ -361,11 +361,25 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     // what follows the coefficients in every AC-group section (ProcessACGroup's second half, dec_frame.cc:497-530),
     // on the decoder's pool; then the samples as floats, as ModularImageToDecodedRect makes them
     std::atomic<int> status{JXLHIP_OK};
+    // Alpha for the main output only, in a channel larger than a group: the groups' threads write the float samples
+    // straight into the context's pinned plane.  Otherwise the samples are collected and converted below.
+    const bool direct = alpha_in_main && !extra_buffers && (dim.xsize > dim.group_dim || dim.ysize > dim.group_dim);
+    float* staging = nullptr;
+    size_t staging_stride = 0;
+    uint32_t ec_bits[4] = {8, 8, 8, 8};
+    float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (direct) {
+      JXL_RETURN_IF_ERROR(check(jxlhip_alpha_staging(ctx, &staging, &staging_stride), "alpha_staging"));
+      for (size_t i = 0; i < md.num_extra_channels; i++) ec_bits[i] = md.extra_channel_info[i].bit_depth.bits_per_sample;
+      planes[alpha_ec] = staging;
+    }
     const auto group = [&](uint32_t g, size_t /*thread*/) -> Status {
       for (size_t ps = 0; ps < np; ps++) {
         const size_t i = ps * dim.num_groups + g;
         size_t pos = end_bits[i];
-        const int rc = jxlhip_modular_ac_group_decode(mtree.t, &mfh, g, static_cast<uint32_t>(ps), sec[i], sec_size[i], &pos);
+        const int rc = direct ? jxlhip_modular_ac_group_decode_f32(mtree.t, &mfh, g, static_cast<uint32_t>(ps), sec[i], sec_size[i],
+                                                                   &pos, ec_bits, md.bit_depth.bits_per_sample, planes, staging_stride)
+                              : jxlhip_modular_ac_group_decode(mtree.t, &mfh, g, static_cast<uint32_t>(ps), sec[i], sec_size[i], &pos);
         if (rc != JXLHIP_OK) {
           int expected = JXLHIP_OK;
           status.compare_exchange_strong(expected, rc);
@@ -376,39 +390,43 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     };
     JXL_RETURN_IF_ERROR(RunOnPool(fd->pool_, 0, static_cast<uint32_t>(dim.num_groups), ThreadPool::NoInit, group, "jxlhip modular"));
     JXL_RETURN_IF_ERROR(check(status.load(), "modular AC groups"));
-    alpha.resize(dim.xsize * dim.ysize);
-    // extra-channel buffers: the plane in display orientation (WriteToOutputStage's flips / transpose,
-    // stage_write.cc:441-457,664-680), rows of `stride` bytes
-    const uint32_t o = static_cast<uint32_t>(ds->undo_orientation);
-    const bool fx = o == 2 || o == 3 || o == 7 || o == 8, fy = o == 3 || o == 4 || o == 6 || o == 7, tr = o >= 5;
-    for (size_t i = 0; i < ds->extra_output.size(); i++) {
-      const ImageOutput& eo = ds->extra_output[i];
-      if (!eo.buffer) continue;
-      JXL_RETURN_IF_ERROR(check(jxlhip_modular_extra_channel_f32(mtree.t, static_cast<uint32_t>(i),
-                                                                 md.extra_channel_info[i].bit_depth.bits_per_sample,
-                                                                 md.bit_depth.bits_per_sample, alpha.data(), dim.xsize),
-                                "extra channel samples"));
-      const size_t ow = tr ? dim.ysize : dim.xsize, oh = tr ? dim.xsize : dim.ysize;
-      if (eo.stride < ow * sizeof(float) || eo.buffer_size < (oh - 1) * eo.stride + ow * sizeof(float))
-        return JXL_FAILURE("extra channel buffer too small");
-      const auto row = [&](uint32_t y, size_t /*thread*/) -> Status {
-        const float* src = alpha.data() + static_cast<size_t>(y) * dim.xsize;
-        const size_t yo = fy ? dim.ysize - 1 - y : y;
-        for (size_t x = 0; x < dim.xsize; x++) {
-          const size_t xo = fx ? dim.xsize - 1 - x : x;
-          char* d = static_cast<char*>(eo.buffer) + (tr ? xo * eo.stride + yo * sizeof(float) : yo * eo.stride + xo * sizeof(float));
-          memcpy(d, &src[x], sizeof(float));
-        }
-        return true;
-      };
-      JXL_RETURN_IF_ERROR(RunOnPool(fd->pool_, 0, static_cast<uint32_t>(dim.ysize), ThreadPool::NoInit, row, "jxlhip extra channel"));
-    }
-    if (alpha_in_main) {
-      JXL_RETURN_IF_ERROR(check(jxlhip_modular_extra_channel_f32(mtree.t, static_cast<uint32_t>(alpha_ec),
-                                                                 md.extra_channel_info[alpha_ec].bit_depth.bits_per_sample,
-                                                                 md.bit_depth.bits_per_sample, alpha.data(), dim.xsize),
-                                "alpha samples"));
-      JXL_RETURN_IF_ERROR(check(jxlhip_set_alpha(ctx, alpha.data(), dim.xsize), "set_alpha"));
+    if (direct) {
+      JXL_RETURN_IF_ERROR(check(jxlhip_set_alpha(ctx, staging, staging_stride), "set_alpha"));
+    } else {
+      alpha.resize(dim.xsize * dim.ysize);
+      // extra-channel buffers: the plane in display orientation (WriteToOutputStage's flips / transpose,
+      // stage_write.cc:441-457,664-680), rows of `stride` bytes
+      const uint32_t o = static_cast<uint32_t>(ds->undo_orientation);
+      const bool fx = o == 2 || o == 3 || o == 7 || o == 8, fy = o == 3 || o == 4 || o == 6 || o == 7, tr = o >= 5;
+      for (size_t i = 0; i < ds->extra_output.size(); i++) {
+        const ImageOutput& eo = ds->extra_output[i];
+        if (!eo.buffer) continue;
+        JXL_RETURN_IF_ERROR(check(jxlhip_modular_extra_channel_f32(mtree.t, static_cast<uint32_t>(i),
+                                                                   md.extra_channel_info[i].bit_depth.bits_per_sample,
+                                                                   md.bit_depth.bits_per_sample, alpha.data(), dim.xsize),
+                                  "extra channel samples"));
+        const size_t ow = tr ? dim.ysize : dim.xsize, oh = tr ? dim.xsize : dim.ysize;
+        if (eo.stride < ow * sizeof(float) || eo.buffer_size < (oh - 1) * eo.stride + ow * sizeof(float))
+          return JXL_FAILURE("extra channel buffer too small");
+        const auto row = [&](uint32_t y, size_t /*thread*/) -> Status {
+          const float* src = alpha.data() + static_cast<size_t>(y) * dim.xsize;
+          const size_t yo = fy ? dim.ysize - 1 - y : y;
+          for (size_t x = 0; x < dim.xsize; x++) {
+            const size_t xo = fx ? dim.xsize - 1 - x : x;
+            char* d = static_cast<char*>(eo.buffer) + (tr ? xo * eo.stride + yo * sizeof(float) : yo * eo.stride + xo * sizeof(float));
+            memcpy(d, &src[x], sizeof(float));
+          }
+          return true;
+        };
+        JXL_RETURN_IF_ERROR(RunOnPool(fd->pool_, 0, static_cast<uint32_t>(dim.ysize), ThreadPool::NoInit, row, "jxlhip extra channel"));
+      }
+      if (alpha_in_main) {
+        JXL_RETURN_IF_ERROR(check(jxlhip_modular_extra_channel_f32(mtree.t, static_cast<uint32_t>(alpha_ec),
+                                                                   md.extra_channel_info[alpha_ec].bit_depth.bits_per_sample,
+                                                                   md.bit_depth.bits_per_sample, alpha.data(), dim.xsize),
+                                  "alpha samples"));
+        JXL_RETURN_IF_ERROR(check(jxlhip_set_alpha(ctx, alpha.data(), dim.xsize), "set_alpha"));
+      }
     }
   }
   t_entropy = now();

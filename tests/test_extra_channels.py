@@ -31,8 +31,10 @@ def L():
     return abi.load_library()
 
 
-def decode_alpha_on_host(L, rs):
-    """The product's host parsers only; returns (alpha plane, image header, frame header)."""
+def decode_alpha_on_host(L, rs, direct=False):
+    """The product's host parsers only; returns (alpha plane, image header, frame header).  direct: the groups write
+    their float samples straight into the plane (jxlhip_modular_ac_group_decode_f32) instead of being collected in
+    the frame's int32 image and converted at the end."""
     cs = np.ascontiguousarray(rs.codestream)
     base, n = cs.ctypes.data, len(cs)
     ih, pos = abi.ImageHeader(), C.c_size_t(0)
@@ -91,6 +93,10 @@ def decode_alpha_on_host(L, rs):
                                              C.byref(bits)) == 0
         scratch = [np.zeros(65536, np.int32) for _ in range(3)]
         ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in scratch])
+        alpha = np.full((fh.ysize, fh.xsize), -1.0, np.float32)
+        in_groups = fh.xsize > fh.group_dim or fh.ysize > fh.group_dim
+        ec_bits = (C.c_uint32 * 4)(extra[0].bit_depth.bits_per_sample, 8, 8, 8)
+        planes = (C.c_void_p * 4)(alpha.ctypes.data, None, None, None)
         for g in range(ng):
             for ps in range(npass):
                 d = s0 if single else sections[2 + ndc + ps * ng + g]
@@ -99,11 +105,18 @@ def decode_alpha_on_host(L, rs):
                                                 qctx.ctypes.data, d.ctypes.data, len(d), C.byref(gp), fh.shift[ps], 1,
                                                 ptrs, C.byref(cnt)) == 0
                 # ... and behind the coefficients, the group's part of the Modular image
-                assert L.jxlhip_modular_ac_group_decode(tree, C.byref(fh), g, ps, d.ctypes.data, len(d), C.byref(gp)) == 0
+                if direct:
+                    assert L.jxlhip_modular_ac_group_decode_f32(tree, C.byref(fh), g, ps, d.ctypes.data, len(d), C.byref(gp),
+                                                                ec_bits, ih.bit_depth.bits_per_sample, planes, fh.xsize) == 0
+                else:
+                    assert L.jxlhip_modular_ac_group_decode(tree, C.byref(fh), g, ps, d.ctypes.data, len(d), C.byref(gp)) == 0
                 assert (gp.value + 7) // 8 == len(d), (g, ps, gp.value, len(d))  # the section is consumed exactly
-        alpha = np.full((fh.ysize, fh.xsize), -1.0, np.float32)
-        assert L.jxlhip_modular_extra_channel_f32(tree, 0, extra[0].bit_depth.bits_per_sample, ih.bit_depth.bits_per_sample,
-                                                  alpha.ctypes.data, fh.xsize) == 0
+        rc = L.jxlhip_modular_extra_channel_f32(tree, 0, extra[0].bit_depth.bits_per_sample, ih.bit_depth.bits_per_sample,
+                                                alpha.ctypes.data, fh.xsize) if not (direct and in_groups) else 0
+        assert rc == 0
+        if direct and in_groups:  # the int32 image was never allocated: the collecting reader says so
+            tmp = np.zeros((fh.ysize, fh.xsize), np.float32)
+            assert L.jxlhip_modular_extra_channel_f32(tree, 0, 8, 8, tmp.ctypes.data, fh.xsize) == -6  # JXLHIP_ERR_STATE
     finally:
         for h in hs:
             if h:
@@ -133,10 +146,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("kw", CASES)
-def test_alpha_plane_from_the_codestream_bytes(L, ref, kw):
+def test_alpha_plane_from_the_codestream_bytes(L, ref, kw, direct):
     rs = ref.RealStream(seed=29, **dict(dict(distance=1.0, speed_tier=3), **kw))
-    alpha, ih, fh = decode_alpha_on_host(L, rs)
+    alpha, ih, fh = decode_alpha_on_host(L, rs, direct)
     assert np.array_equal(alpha, rs.alpha), float(np.abs(alpha - rs.alpha).max())
 
 
