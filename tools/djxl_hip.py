@@ -6,8 +6,8 @@ jxlhip_decode_codestream (include/jxl_hip_codestream.h) and writes the pixels th
 extensions (tools/djxl_main.cc, lib/extras/enc/pnm.cc):
   .pfm  linear-light float RGB, bottom-up rows, little endian (scale -1.0)
   .npy  float32 [H, W, 3] linear RGB (what tools/conformance/conformance.py reads, conformance.py:34-66)
-  .ppm  8-bit sRGB RGB          .pam  8-bit sRGB RGBA
-Streams outside the back-end (Modular, alpha, ICC, animation ...) exit with status 3 and the error text so that a
+  .ppm  8-bit sRGB RGB          .pam  8-bit sRGB RGBA (the image's alpha channel, opaque without one)
+Streams outside the back-end (Modular frames, squeezed extra channels, ICC, animation ...) exit with status 3 and the error text so that a
 wrapper can fall back to libjxl's djxl.  Prints Mpx/s of the decode call like djxl's SpeedStats."""
 import argparse
 import ctypes as C
