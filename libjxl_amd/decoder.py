@@ -117,6 +117,15 @@ class VarDctDecoder:
             return C.c_void_p(out.data_ptr()), out.stride(0) * out.element_size(), 0
         return C.c_void_p(out.data_ptr()), out.stride(1), out.stride(0)
 
+    def set_alpha(self, plane):
+        """The frame's alpha channel for 4-channel packed outputs: a host float32 array [ysize, xsize] (1.0 = opaque),
+        jxlhip_set_alpha; begin_frame resets to opaque."""
+        import numpy as np
+        a = np.ascontiguousarray(plane, dtype=np.float32)
+        assert a.shape == (self.params.ysize, self.params.xsize), a.shape
+        _check(self.L, self.ctx, self.L.jxlhip_set_alpha(self.ctx, a.ctypes.data, a.shape[1]), "set_alpha")
+        self.sync()  # (the array may go away as soon as this returns)
+
     # -- decode ----------------------------------------------------------------
     def decode_blocks(self):
         _check(self.L, self.ctx, self.L.jxlhip_decode_blocks(self.ctx), "decode_blocks")

@@ -481,3 +481,62 @@ def test_three_epf_iterations_take_the_epf0_march(dec, dq, oracle, gab, size, ok
     ref = fr.decode(threads=4)
     prof = dec.profile() if hasattr(dec, "profile") else None
     assert rel_err(out.cpu().numpy(), ref) <= TIGHT
+
+
+@pytest.mark.parametrize("size,gab,epf", [((520, 300), True, 1), ((777, 300), False, 0), ((1000, 520), True, 2), ((520, 264), True, 3),
+                                          ((4096, 3200), True, 1)])
+@pytest.mark.parametrize("st,bits,nc_tf", [(1, 8, 1), (2, 16, 1), (2, 12, 1), (3, 0, 1), (0, 0, 1), (0, 0, 0), (2, 16, 2)])
+def test_alpha_plane_in_every_packed_path(dq, size, gab, epf, st, bits, nc_tf, monkeypatch):
+    """jxlhip_set_alpha (FilterParams::alpha): the fourth sample of a 4-channel packed output is the plane's value
+    through MakeUnsigned / the float conversions -- like a colour sample, without the transfer function
+    (stage_write.cc:350-366) -- whichever kernel writes the frame: the fixed-format and general row marches, the generic
+    LDS kernel, k_epf0 + march, and (13 Mpx) the fused kernels; the colour samples do not change."""
+    xs, ys = size
+    tf = nc_tf  # 0 linear, 1 sRGB, 2 PQ
+    if xs > 2000 and (st, tf) not in ((2, 2), (1, 1), (0, 0)):
+        pytest.skip("the 13 Mpx frame: one format per kernel family")
+    fmt = dict(transfer=tf, sample_type=st, num_channels=4, bits_per_sample=bits, tf_param=1000.0 if tf == 2 else 0.0)
+    params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=gab, epf_iters=epf, seed=7 + xs, output_kind=2,
+                                     out_format=fmt, intensity_target=1000.0 if tf == 2 else 80.0)
+    rng = np.random.default_rng(xs + st)
+    levels = 255 if st == 1 else 65535
+    alpha = rng.integers(0, levels + 1, size=(ys, xs)).astype(np.float32) * np.float32(1.0 / levels)
+    alpha[: ys // 4] = 1.0
+    alpha[ys // 4: ys // 2, : xs // 3] = 0.0
+    outs = {}
+    for generic in ("", "generic"):
+        if generic:
+            monkeypatch.setenv("JXLHIP_FILTERS", generic)
+        else:
+            monkeypatch.delenv("JXLHIP_FILTERS", raising=False)
+        if generic and xs > 2000:
+            continue
+        d = VarDctDecoder(0)
+        d.begin_frame(params)
+        d.set_inputs(to_dev(t), dq)
+        opaque = d.decode_frame().cpu().numpy().copy()
+        d.set_alpha(alpha)
+        got = d.decode_frame().cpu().numpy().copy()
+        d.begin_frame(params)           # a new frame: opaque again
+        d.set_inputs(to_dev(t), dq)
+        again = d.decode_frame().cpu().numpy().copy()
+        d.sync()
+        d.close()
+        assert np.array_equal(again, opaque)
+        assert np.array_equal(got[..., :3], opaque[..., :3])
+        a = got[..., 3]
+        if st == 1:
+            assert (opaque[..., 3] == 255).all()
+            assert np.array_equal(a, np.rint(alpha * 255.0).astype(np.uint8))      # the dither never crosses .5
+        elif st == 2:
+            full = (1 << bits) - 1
+            au = a.view(np.uint16)
+            assert (opaque[..., 3].view(np.uint16) == full).all()
+            assert np.abs(au.astype(np.int32) - np.rint(alpha.astype(np.float64) * full)).max() <= (0 if bits == 16 else 1)
+        elif st == 3:
+            assert np.array_equal(a.view(np.uint16).view(np.float16), alpha.astype(np.float16))
+        else:
+            assert np.array_equal(a, alpha)
+        outs[generic] = got
+    if "generic" in outs:
+        assert np.array_equal(outs[""][..., 3], outs["generic"][..., 3])
