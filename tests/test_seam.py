@@ -61,11 +61,14 @@ def load(path):
     L.JxlDecoderGetBasicInfo.argtypes = [C.c_void_p, C.c_void_p]
     L.JxlDecoderImageOutBufferSize.argtypes = [C.c_void_p, C.POINTER(PixelFormat), C.POINTER(C.c_size_t)]
     L.JxlDecoderSetImageOutBuffer.argtypes = [C.c_void_p, C.POINTER(PixelFormat), C.c_void_p, C.c_size_t]
+    L.JxlDecoderExtraChannelBufferSize.argtypes = [C.c_void_p, C.POINTER(PixelFormat), C.POINTER(C.c_size_t), C.c_uint32]
+    L.JxlDecoderSetExtraChannelBuffer.argtypes = [C.c_void_p, C.POINTER(PixelFormat), C.c_void_p, C.c_size_t, C.c_uint32]
     return L
 
 
-def jxl_decode(L, data, runner=None, runner_opaque=None, channels=3):
-    """JxlDecoder event loop of lib/extras/dec/jxl.cc, float output.  Returns [H, W, channels] float32."""
+def jxl_decode(L, data, runner=None, runner_opaque=None, channels=3, extra_channel=None):
+    """JxlDecoder event loop of lib/extras/dec/jxl.cc, float output.  Returns [H, W, channels] float32 -- and, with
+    extra_channel = index, that extra channel in a buffer of its own (JxlDecoderSetExtraChannelBuffer): a tuple."""
     dec = L.JxlDecoderCreate(None)
     assert dec
     try:
@@ -85,16 +88,22 @@ def jxl_decode(L, data, runner=None, runner_opaque=None, channels=3):
             elif st == JXL_DEC_NEED_IMAGE_OUT_BUFFER:
                 n = C.c_size_t(0)
                 assert L.JxlDecoderImageOutBufferSize(dec, C.byref(fmt), C.byref(n)) == JXL_DEC_SUCCESS
-                assert n.value == int(w) * int(h) * channels * 4
-                out = np.zeros((int(h), int(w), channels), np.float32)
+                out = np.zeros((n.value // (int(w) * channels * 4), int(w), channels), np.float32)
                 assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), out.ctypes.data, n.value) == JXL_DEC_SUCCESS
+                if extra_channel is not None:
+                    efmt, en = PixelFormat(1, 0, 0, 0), C.c_size_t(0)
+                    assert L.JxlDecoderExtraChannelBufferSize(dec, C.byref(efmt), C.byref(en), extra_channel) == JXL_DEC_SUCCESS
+                    ec = np.full((out.shape[0], out.shape[1]), -3.0, np.float32)
+                    assert en.value == ec.nbytes
+                    assert L.JxlDecoderSetExtraChannelBuffer(dec, C.byref(efmt), ec.ctypes.data, en.value,
+                                                             extra_channel) == JXL_DEC_SUCCESS
             elif st == JXL_DEC_FULL_IMAGE:
                 continue
             elif st == JXL_DEC_SUCCESS:
                 break
             else:
                 raise AssertionError(f"JxlDecoderProcessInput -> {st}")
-        return out
+        return (out, ec) if extra_channel is not None else out
     finally:
         L.JxlDecoderDestroy(dec)
 
@@ -164,5 +173,42 @@ def test_oriented_stream_through_the_patched_jxldecoder(libs, ref, orientation, 
         got = jxl_decode(Lh, cs, runner, pool, 3)
         assert Lh.jxlhip_seam_frames_decoded() == before + 1, "the frame did not go through the HIP back-end"
         assert float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max())) <= TIGHT
+    finally:
+        R.JxlThreadParallelRunnerDestroy(pool)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,orientation", [
+    (dict(xsize=520, ysize=300, alpha_bits=8, original="srgb8"), None),
+    (dict(xsize=200, ysize=120, alpha_bits=8, original="srgb8"), None),          # one group: alpha coded globally
+    (dict(xsize=456, ysize=280, alpha_bits=16, original="srgb16"), 6),             # rotated while written
+    (dict(xsize=520, ysize=300, alpha_bits=8, alpha_levels=2, original="srgb8"), None),   # a mask: global palette
+])
+def test_rgba_stream_through_the_patched_jxldecoder(libs, ref, kw, orientation, monkeypatch):
+    """An image with an alpha channel: RGBA in the main buffer (the back-end writes the alpha plane the host front-end
+    decoded), RGB only (the Modular bytes are skipped; FinalizeFrame must not render the frame a second time), and RGB
+    plus the alpha channel in a float buffer of its own (JxlDecoderSetExtraChannelBuffer, display orientation)."""
+    Lr, Lh = load(libs[0]), load(libs[1])
+    R, runner, pool = hip_runner()
+    try:
+        if orientation:
+            monkeypatch.setenv("JXR_ORIENTATION", str(orientation))
+        rs = ref.RealStream(seed=43, distance=1.0, speed_tier=3, **kw)
+        monkeypatch.delenv("JXR_ORIENTATION", raising=False)
+        cs = rs.codestream.tobytes()
+        for channels, ec in ((4, None), (3, None), (3, 0), (4, 0)):
+            want = jxl_decode(Lr, cs, runner, pool, channels, ec)
+            before = Lh.jxlhip_seam_frames_decoded()
+            got = jxl_decode(Lh, cs, runner, pool, channels, ec)
+            assert Lh.jxlhip_seam_frames_decoded() == before + 1, ("the frame did not go through the HIP back-end", channels, ec)
+            if ec is not None:
+                (want, want_ec), (got, got_ec) = want, got
+                assert np.array_equal(got_ec, want_ec), float(np.abs(got_ec - want_ec).max())
+                assert want_ec.min() >= 0.0 and len(np.unique(want_ec)) > 1
+            assert got.shape == want.shape
+            scale = max(1.0, float(np.abs(want[..., :3]).max()))
+            assert float(np.abs(got[..., :3] - want[..., :3]).max()) / scale <= 1e-4   # (sRGB-encoded samples: slope 12.92)
+            if channels == 4:
+                assert np.array_equal(got[..., 3], want[..., 3])
     finally:
         R.JxlThreadParallelRunnerDestroy(pool)
