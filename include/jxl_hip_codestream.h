@@ -47,6 +47,12 @@ typedef struct jxlhip_codestream_info {
   /* headers: the image's extra channels (this front-end takes up to four, full resolution, integer samples) and the
      first one of type alpha: its bit depth (0 = the image has no alpha channel), whether it is premultiplied */
   uint32_t num_extra_channels, alpha_bits, alpha_premultiplied;
+  /* headers: the pixels are produced in the image's ORIGINAL colour space (primaries / white_point above; the inverse
+     opsin matrix is adapted like OutputEncodingInfo::SetColorEncoding, dec_xyb.cc:180-249).  luminances: the
+     luminance weights of that space, for jxlhip_output_format::luminances (HLG OOTF); gamma: the original's gamma
+     exponent when its transfer function is a gamma curve (tf_param of JXLHIP_TF_GAMMA), else 0 */
+  float luminances[3];
+  float gamma;
 } jxlhip_codestream_info;
 
 /* Headers only (no device needed): size and colour metadata of the first frame's image.  JXLHIP_ERR_BAD_STREAM /

@@ -116,6 +116,15 @@ JXLHIP_EXPORT int jxlhip_image_header_decode(const uint8_t* data, size_t size, s
                                              jxlhip_extra_channel* extra, size_t extra_capacity,
                                              jxlhip_image_header* out);
 
+/* The inverse opsin matrix (unscaled: multiply by 255 / intensity_target for jxlhip_frame_params) that makes the
+ * back-end's pixels come out in the image's ORIGINAL colour space -- what OutputEncodingInfo::SetFromMetadata /
+ * SetColorEncoding derive (dec_xyb.cc:144-165,180-249): the coded matrix for sRGB / D65 originals, the coded matrix
+ * followed by sRGB -> XYZ(D50) -> original primaries / white point otherwise (P3, Rec.2100, custom xy) -- and the
+ * luminance weights of that space (jxlhip_output_format::luminances, the HLG OOTF).  JXLHIP_ERR_UNSUPPORTED: an ICC
+ * original, a grey original, a transfer function outside the enumerated ones, an image that is not XYB encoded. */
+JXLHIP_EXPORT int jxlhip_output_opsin_matrix(const jxlhip_image_header* header, float inverse_matrix[9],
+                                             float luminances[3]);
+
 /* What the frame header's conditions read from the image header (CodecMetadata). */
 typedef struct jxlhip_image_info {
   uint32_t xsize, ysize;          /* image size, or the preview size when is_preview */

@@ -143,7 +143,8 @@ class CodestreamInfo(C.Structure):
                 ("primaries", C.c_uint32), ("white_point", C.c_uint32), ("num_passes", C.c_uint32),
                 ("num_groups", C.c_uint32), ("num_dc_groups", C.c_uint32), ("epf_iters", C.c_uint32),
                 ("gab", C.c_uint32), ("used_acs", C.c_uint32), ("coeff_type", C.c_uint32), ("fused", C.c_uint32),
-                ("num_extra_channels", C.c_uint32), ("alpha_bits", C.c_uint32), ("alpha_premultiplied", C.c_uint32)]
+                ("num_extra_channels", C.c_uint32), ("alpha_bits", C.c_uint32), ("alpha_premultiplied", C.c_uint32),
+                ("luminances", C.c_float * 3), ("gamma", C.c_float)]
 
 
 class FrameParams(C.Structure):
@@ -237,7 +238,7 @@ EXPORTS = [
     "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode", "jxlhip_ac_group_decode_submit_passes",
     "jxlhip_ac_groups_decode_submit", "jxlhip_ac_groups_decode_submit_ex", "jxlhip_num_toc_entries", "jxlhip_toc_decode", "jxlhip_ac_global_decode_at",
     # include/jxl_hip_frame.h
-    "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode",
+    "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode", "jxlhip_output_opsin_matrix",
     "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
     "jxlhip_modular_ac_group_decode", "jxlhip_modular_ac_group_decode_f32", "jxlhip_modular_extra_channel_f32",
     # include/jxl_hip_codestream.h
@@ -300,6 +301,7 @@ def load_library():
                                          C.POINTER(C.c_uint32)]
     L.jxlhip_image_header_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(ExtraChannel), sz,
                                              C.POINTER(ImageHeader)]
+    L.jxlhip_output_opsin_matrix.argtypes = [C.POINTER(ImageHeader), C.c_float * 9, C.c_float * 3]
     L.jxlhip_frame_begin.argtypes = [vp, C.POINTER(FrameParams)]
     L.jxlhip_frame_set_inputs.argtypes = [vp, C.POINTER(FrameInputs)]
     L.jxlhip_upload_side_info.argtypes = [vp, vp, vp, vp, vp, vp, vp * 3, vp]

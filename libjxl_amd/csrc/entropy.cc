@@ -1930,6 +1930,58 @@ bool ReadColorEncoding(FieldReader* r, jxlhip_color_encoding* c) {  // color_enc
 }
 }  // namespace
 
+// OutputEncodingInfo::SetFromMetadata + SetColorEncoding (dec_xyb.cc:144-165,180-249) for an XYB image decoded into
+// its ORIGINAL colour space: the inverse opsin matrix lands in linear sRGB (D65); for other primaries / white points
+// it is followed by sRGB -> XYZ(D50) -> the original space, so that the kernels' 3x3 product comes out in the
+// original primaries; luminances = the Y row of the original space's RGB -> XYZ matrix (the HLG OOTF's weights).
+int jxlhip_output_opsin_matrix(const jxlhip_image_header* ih, float inverse_matrix[9], float luminances[3]) {
+  if (!ih || !inverse_matrix || !luminances) return JXLHIP_ERR_INVALID_ARGUMENT;
+  const jxlhip_color_encoding& c = ih->color_encoding;
+  memcpy(inverse_matrix, ih->inverse_opsin_matrix, 9 * sizeof(float));
+  luminances[0] = 0.2126f, luminances[1] = 0.7152f, luminances[2] = 0.0722f;
+  if (!ih->xyb_encoded || c.want_icc) return JXLHIP_ERR_UNSUPPORTED;  // (an ICC original: the reference needs a CMS)
+  if (c.all_default) return kOk;
+  if (c.color_space != JXLHIP_CS_RGB) return JXLHIP_ERR_UNSUPPORTED;   // grey: a 1-channel pipeline in the reference
+  // CanOutputToColorEncoding: every enumerated transfer function the kernels have (the caller picks it)
+  if (!c.have_gamma && c.transfer_function != 1 && c.transfer_function != 8 && c.transfer_function != 13 &&
+      c.transfer_function != 16 && c.transfer_function != 17 && c.transfer_function != 18)
+    return JXLHIP_ERR_UNSUPPORTED;
+  if (c.primaries == JXLHIP_PRIM_SRGB && c.white_point == JXLHIP_WP_D65) return kOk;
+  double wx, wy;
+  switch (c.white_point) {
+    case JXLHIP_WP_CUSTOM: wx = c.white_xy[0] * (1.0 / 1000000), wy = c.white_xy[1] * (1.0 / 1000000); break;
+    case JXLHIP_WP_DCI: wx = 0.314, wy = 0.351; break;
+    case JXLHIP_WP_E: wx = wy = 1.0 / 3; break;
+    default: wx = 0.3127, wy = 0.3290; break;
+  }
+  static const double kSrgb[6] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204};
+  static const double k2100[6] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046};
+  static const double kP3[6] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060};
+  float ps[6], po[6];
+  for (int i = 0; i < 6; i++) {
+    ps[i] = (float)kSrgb[i];
+    po[i] = (float)(c.primaries == JXLHIP_PRIM_CUSTOM ? c.primaries_xy[i] * (1.0 / 1000000)
+                    : c.primaries == JXLHIP_PRIM_2100 ? k2100[i]
+                    : c.primaries == JXLHIP_PRIM_P3   ? kP3[i]
+                                                      : kSrgb[i]);
+  }
+  Mat3 srgb_xyz, srgb_d50, srgb_to_xyzd50, original_to_xyz, adapt, xyzd50_to_original, srgb_to_original, orig, out;
+  if (!PrimariesToXyz(ps, 0.3127f, 0.3290f, srgb_xyz) || !AdaptToXyzD50(0.3127f, 0.3290f, srgb_d50)) return kBad;
+  MulMat(srgb_d50, srgb_xyz, srgb_to_xyzd50);
+  if (!PrimariesToXyz(po, (float)wx, (float)wy, original_to_xyz)) return kBad;
+  for (int i = 0; i < 3; i++) luminances[i] = original_to_xyz[1][i];
+  if (!AdaptToXyzD50((float)wx, (float)wy, adapt)) return kBad;
+  MulMat(adapt, original_to_xyz, xyzd50_to_original);
+  if (!InvMat(xyzd50_to_original)) return kBad;
+  MulMat(xyzd50_to_original, srgb_to_xyzd50, srgb_to_original);
+  for (int j = 0; j < 3; j++)
+    for (int i = 0; i < 3; i++) orig[j][i] = ih->inverse_opsin_matrix[j * 3 + i];
+  MulMat(srgb_to_original, orig, out);
+  for (int j = 0; j < 3; j++)
+    for (int i = 0; i < 3; i++) inverse_matrix[j * 3 + i] = out[j][i];
+  return kOk;
+}
+
 int jxlhip_image_header_decode(const uint8_t* data, size_t size, size_t* bit_pos, jxlhip_extra_channel* extra,
                                size_t extra_capacity, jxlhip_image_header* h) {
   if (!data || !bit_pos || !h || (extra_capacity && !extra)) return JXLHIP_ERR_INVALID_ARGUMENT;

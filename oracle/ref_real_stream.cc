@@ -191,6 +191,36 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
       metadata.m.SetUintSamples(!strcmp(e, "srgb8") ? 8 : 16);
       metadata.m.color_encoding = ColorEncoding::SRGB(/*is_gray=*/false);
     }
+    // other enumerated originals: the decoder adapts the inverse opsin matrix to their primaries / white point
+    // (OutputEncodingInfo::SetColorEncoding) and applies their transfer function
+    ColorEncoding c;
+    c.SetColorSpace(ColorSpace::kRGB);
+    if (!strcmp(e, "p3")) {  // Display P3
+      JXL_RETURN_IF_ERROR(c.SetWhitePointType(WhitePoint::kD65));
+      JXL_RETURN_IF_ERROR(c.SetPrimariesType(Primaries::kP3));
+      c.Tf().SetTransferFunction(TransferFunction::kSRGB);
+      metadata.m.color_encoding = c;
+    } else if (!strcmp(e, "rec2100pq")) {  // HDR10-like, 1000 nits
+      JXL_RETURN_IF_ERROR(c.SetWhitePointType(WhitePoint::kD65));
+      JXL_RETURN_IF_ERROR(c.SetPrimariesType(Primaries::k2100));
+      c.Tf().SetTransferFunction(TransferFunction::kPQ);
+      metadata.m.color_encoding = c;
+      metadata.m.SetIntensityTarget(1000.0f);
+    } else if (!strcmp(e, "customxy")) {  // Adobe-RGB-like primaries, a D50 white point, gamma 2.2
+      JxlColorEncoding ext = {};
+      ext.color_space = JXL_COLOR_SPACE_RGB;
+      ext.white_point = JXL_WHITE_POINT_CUSTOM;
+      ext.white_point_xy[0] = 0.3457, ext.white_point_xy[1] = 0.3585;
+      ext.primaries = JXL_PRIMARIES_CUSTOM;
+      ext.primaries_red_xy[0] = 0.64, ext.primaries_red_xy[1] = 0.33;
+      ext.primaries_green_xy[0] = 0.21, ext.primaries_green_xy[1] = 0.71;
+      ext.primaries_blue_xy[0] = 0.15, ext.primaries_blue_xy[1] = 0.06;
+      ext.transfer_function = JXL_TRANSFER_FUNCTION_GAMMA;
+      ext.gamma = 1.0 / 2.2;
+      ext.rendering_intent = JXL_RENDERING_INTENT_RELATIVE;
+      JXL_RETURN_IF_ERROR(c.FromExternal(ext));
+      metadata.m.color_encoding = c;
+    }
   }
   const ColorEncoding c_pixels = ColorEncoding::LinearSRGB(/*is_gray=*/false);
   JXL_RETURN_IF_ERROR(metadata.size.Set(xs, ys));
@@ -205,7 +235,15 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
     const int o = atoi(e);
     if (o >= 1 && o <= 8) metadata.m.orientation = static_cast<uint32_t>(o);
   }
-  ImageBundle ib(&mm, &metadata.m);
+  // The ENCODER works from a copy of the metadata that says "linear sRGB": with the original's own primaries it would
+  // call the CMS (absent from this build) to bring the pixels there.  The frame's bytes depend on the metadata only
+  // through xyb_encoded / the intensity target / the extra channels, which the copy shares; the headers written to
+  // the stream and the decoder below carry the original's colour encoding.
+  CodecMetadata metadata_enc = metadata;
+  if (!(metadata.m.color_encoding.GetPrimariesType() == Primaries::kSRGB &&
+        metadata.m.color_encoding.GetWhitePointType() == WhitePoint::kD65))
+    metadata_enc.m.color_encoding = ColorEncoding::LinearSRGB(/*is_gray=*/false);
+  ImageBundle ib(&mm, &metadata_enc.m);
   {
     JXL_ASSIGN_OR_RETURN(Image3F img, Image3F::Create(&mm, xs, ys));
     FillImage(&img, seed);
@@ -259,7 +297,9 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   FrameInfo info;
   info.is_last = true;
   JxlCmsInterface no_cms{};  // never used: the input already is linear sRGB
-  JXL_RETURN_IF_ERROR(EncodeFrame(&mm, cparams, info, &metadata, ib, no_cms, nullptr, &writer, nullptr));
+  if (getenv("JXR_TRACE")) fprintf(stderr, "before EncodeFrame\n");
+  JXL_RETURN_IF_ERROR(EncodeFrame(&mm, cparams, info, &metadata_enc, ib, no_cms, nullptr, &writer, nullptr));
+  if (getenv("JXR_TRACE")) fprintf(stderr, "after EncodeFrame\n");
   {
     PaddedBytes bytes = std::move(writer).TakeBytes();
     out->codestream.assign(bytes.data(), bytes.data() + bytes.size());
@@ -275,6 +315,7 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   const uint8_t* in = out->codestream.data() + out->frame_offset;
   const size_t avail = out->codestream.size() - out->frame_offset;
   BitReader reader(Bytes(in, avail));
+  if (getenv("JXR_TRACE")) fprintf(stderr, "before InitFrame\n");
   JXL_RETURN_IF_ERROR(fd.InitFrame(&reader, &decoded, false));
   JXL_RETURN_IF_ERROR(fd.InitFrameOutput());
   // PassesDecoderState::Init (from InitFrameOutput) clears main_output: set it now, as decode.cc:1470 does
@@ -320,6 +361,7 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
     closers.clear();
     JXL_RETURN_IF_ERROR(close_ok);
   }
+  if (getenv("JXR_TRACE")) fprintf(stderr, "before FinalizeFrame\n");
   JXL_RETURN_IF_ERROR(fd.FinalizeFrame());
   if (alpha_bits) {  // split the interleaved RGBA
     out->alpha.resize(static_cast<size_t>(xs) * ys);

@@ -194,3 +194,59 @@ def test_display_orientation_like_jxldecoder(L, ref, orientation, monkeypatch):
         assert float(np.abs(coded.cpu().numpy() - rs.rgb.reshape(200, 328, 3)).max()) / scale <= TIGHT
     finally:
         dec.close()
+
+
+ORIGINALS = [None, "srgb8", "p3", "rec2100pq", "customxy"]
+
+
+@pytest.mark.parametrize("original", ORIGINALS)
+def test_inverse_opsin_matrix_for_the_original_colour_space(L, ref, original):
+    """jxlhip_output_opsin_matrix = OutputEncodingInfo::SetFromMetadata / SetColorEncoding (dec_xyb.cc:144-249): for an
+    original with other primaries or white point than sRGB / D65 the coded matrix is followed by sRGB -> XYZ(D50) ->
+    original.  Held, bit for bit, to the matrix the REFERENCE decoder derived for the same stream (Display P3,
+    Rec.2100 PQ at 1000 nits, custom primaries with a D50 white point and a gamma curve)."""
+    rs = ref.RealStream(264, 200, seed=3, original=original)
+    cs = np.ascontiguousarray(rs.codestream)
+    ih, pos = abi.ImageHeader(), C.c_size_t(0)
+    assert L.jxlhip_image_header_decode(cs.ctypes.data, len(cs), C.byref(pos), None, 0, C.byref(ih)) == 0
+    m, lum = (C.c_float * 9)(), (C.c_float * 3)()
+    assert L.jxlhip_output_opsin_matrix(C.byref(ih), m, lum) == 0
+    scale = np.float32(255.0) / np.float32(ih.intensity_target)
+    mine = np.array([np.float32(v) * scale for v in m], np.float32)
+    assert np.array_equal(mine, np.array(rs.frame_params.inverse_opsin_matrix, np.float32))
+    assert abs(sum(lum) - 1.0) < 1e-5
+    info = abi.CodestreamInfo()
+    blob = cs.tobytes()
+    assert L.jxlhip_codestream_basic_info(blob, len(blob), C.byref(info)) == 0
+    want = {None: (8, 1, 1, 0.0), "srgb8": (13, 1, 1, 0.0), "p3": (13, 11, 1, 0.0), "rec2100pq": (16, 9, 1, 0.0),
+            "customxy": (None, 2, 2, 1 / 2.2)}[original]
+    assert (info.primaries, info.white_point) == want[1:3] and abs(info.gamma - want[3]) < 1e-6
+    if want[0] is not None:
+        assert info.transfer_function == want[0]
+    assert list(info.luminances) == list(lum)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("original", ["p3", "rec2100pq", "customxy"])
+def test_pixels_in_the_original_colour_space(L, ref, original):
+    """Display P3, Rec.2100 PQ and custom-primaries originals: jxlhip_decode_codestream with the transfer function the
+    info struct names -> the pixels the reference decoder wrote (its default: the original space)."""
+    import torch
+    from libjxl_amd import VarDctDecoder
+    rs = ref.RealStream(520, 300, seed=19, original=original, distance=1.0, speed_tier=3)
+    cs = rs.codestream.tobytes()
+    info = abi.CodestreamInfo()
+    assert L.jxlhip_codestream_basic_info(cs, len(cs), C.byref(info)) == 0
+    tf, par = {"p3": (1, 0.0), "rec2100pq": (2, info.intensity_target), "customxy": (4, info.gamma)}[original]
+    fmt = abi.OutputFormat(tf, 0, 3, 32, 0, par, info.luminances)
+    dec = VarDctDecoder(0)
+    try:
+        out = torch.full((300, 520, 3), -7.0, dtype=torch.float32, device="cuda")
+        rc = L.jxlhip_decode_codestream(dec.ctx, None, None, cs, len(cs), 2, C.byref(fmt), out.data_ptr(), 520 * 12, 0, None)
+        assert rc == 0, L.jxlhip_last_error(dec.ctx)
+        got = out.cpu().numpy()
+        # the encoded samples: steep curves near zero amplify the float pipeline's 2e-5 (as in the packed-format tests)
+        assert float(np.abs(got - rs.rgb).max()) <= (2e-3 if original == "rec2100pq" else 2e-4)
+        assert float(np.abs(got - rs.rgb).mean()) <= 2e-5
+    finally:
+        dec.close()
