@@ -6,7 +6,8 @@ jxlhip_decode_codestream (include/jxl_hip_codestream.h) and writes the pixels th
 extensions (tools/djxl_main.cc, lib/extras/enc/pnm.cc):
   .pfm  linear-light float RGB, bottom-up rows, little endian (scale -1.0)
   .npy  float32 [H, W, 3] linear RGB (what tools/conformance/conformance.py reads, conformance.py:34-66)
-  .ppm  8-bit sRGB RGB          .pam  8-bit sRGB RGBA (the image's alpha channel, opaque without one)
+  .ppm  8-bit RGB               .pam  8-bit RGBA (the image's alpha channel, opaque without one)
+        -- both in the image's original colour encoding (its transfer function over its primaries)
 Streams outside the back-end (Modular frames, squeezed extra channels, ICC, animation ...) exit with status 3 and the error text so that a
 wrapper can fall back to libjxl's djxl.  Prints Mpx/s of the decode call like djxl's SpeedStats."""
 import argparse
@@ -51,7 +52,14 @@ def main():
     UNDO = 0x100
     if packed:
         nc = 4 if ext == ".pam" else 3
-        fmt = abi.OutputFormat(1, 1, nc, 8, 0, 0.0, (C.c_float * 3)(0.2126, 0.7152, 0.0722))
+        # 8-bit samples in the ORIGINAL colour encoding, like djxl: the original's transfer function over pixels in the
+        # original's primaries (jxlhip_decode_codestream adapts the opsin inverse; the info struct names the rest)
+        if info.gamma > 0:
+            tf, par = 4, info.gamma
+        else:
+            tf, par = {8: (0, 0.0), 13: (1, 0.0), 16: (2, info.intensity_target), 1: (3, 0.0), 17: (4, 1 / 2.6),
+                       18: (5, info.intensity_target)}.get(info.transfer_function, (1, 0.0))
+        fmt = abi.OutputFormat(tf, 1, nc, 8, 0, par, info.luminances)
         out = torch.empty((h, w, nc), dtype=torch.uint8, device="cuda")
         args = (2 | UNDO, C.byref(fmt), out.data_ptr(), w * nc, 0)
     else:
