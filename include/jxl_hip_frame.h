@@ -119,9 +119,10 @@ JXLHIP_EXPORT int jxlhip_image_header_decode(const uint8_t* data, size_t size, s
 /* The inverse opsin matrix (unscaled: multiply by 255 / intensity_target for jxlhip_frame_params) that makes the
  * back-end's pixels come out in the image's ORIGINAL colour space -- what OutputEncodingInfo::SetFromMetadata /
  * SetColorEncoding derive (dec_xyb.cc:144-165,180-249): the coded matrix for sRGB / D65 originals, the coded matrix
- * followed by sRGB -> XYZ(D50) -> original primaries / white point otherwise (P3, Rec.2100, custom xy) -- and the
- * luminance weights of that space (jxlhip_output_format::luminances, the HLG OOTF).  JXLHIP_ERR_UNSUPPORTED: an ICC
- * original, a grey original, a transfer function outside the enumerated ones, an image that is not XYB encoded. */
+ * followed by sRGB -> XYZ(D50) -> original primaries / white point otherwise (P3, Rec.2100, custom xy); for a grey
+ * (D65) original every row becomes luminances x matrix, so that R = G = B = the grey sample -- and the luminance
+ * weights of that space (jxlhip_output_format::luminances, the HLG OOTF).  JXLHIP_ERR_UNSUPPORTED: an ICC original, a
+ * transfer function outside the enumerated ones, an image that is not XYB encoded. */
 JXLHIP_EXPORT int jxlhip_output_opsin_matrix(const jxlhip_image_header* header, float inverse_matrix[9],
                                              float luminances[3]);
 

@@ -1941,7 +1941,22 @@ int jxlhip_output_opsin_matrix(const jxlhip_image_header* ih, float inverse_matr
   luminances[0] = 0.2126f, luminances[1] = 0.7152f, luminances[2] = 0.0722f;
   if (!ih->xyb_encoded || c.want_icc) return JXLHIP_ERR_UNSUPPORTED;  // (an ICC original: the reference needs a CMS)
   if (c.all_default) return kOk;
-  if (c.color_space != JXLHIP_CS_RGB) return JXLHIP_ERR_UNSUPPORTED;   // grey: a 1-channel pipeline in the reference
+  if (c.color_space == JXLHIP_CS_GRAY) {
+    // a grey original (D65: CanOutputToColorEncoding, dec_xyb.cc:137-140): every output channel is the luminance of
+    // the linear sRGB pixel -- the matrix' rows become luminances x matrix (:226-230)
+    if (c.white_point != JXLHIP_WP_D65) return JXLHIP_ERR_UNSUPPORTED;
+    const Mat3 luma = {{luminances[0], luminances[1], luminances[2]},
+                       {luminances[0], luminances[1], luminances[2]},
+                       {luminances[0], luminances[1], luminances[2]}};
+    Mat3 orig, out;
+    for (int j = 0; j < 3; j++)
+      for (int i = 0; i < 3; i++) orig[j][i] = ih->inverse_opsin_matrix[j * 3 + i];
+    MulMat(luma, orig, out);
+    for (int j = 0; j < 3; j++)
+      for (int i = 0; i < 3; i++) inverse_matrix[j * 3 + i] = out[j][i];
+    return kOk;
+  }
+  if (c.color_space != JXLHIP_CS_RGB) return JXLHIP_ERR_UNSUPPORTED;
   // CanOutputToColorEncoding: every enumerated transfer function the kernels have (the caller picks it)
   if (!c.have_gamma && c.transfer_function != 1 && c.transfer_function != 8 && c.transfer_function != 13 &&
       c.transfer_function != 16 && c.transfer_function != 17 && c.transfer_function != 18)

@@ -222,7 +222,13 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
       metadata.m.color_encoding = c;
     }
   }
-  const ColorEncoding c_pixels = ColorEncoding::LinearSRGB(/*is_gray=*/false);
+  // JXR_ORIGINAL=gray8: a grey original (8-bit, sRGB transfer function): the pixels handed over are grey as well
+  const bool gray = getenv("JXR_ORIGINAL") && !strcmp(getenv("JXR_ORIGINAL"), "gray8");
+  if (gray) {
+    metadata.m.SetUintSamples(8);
+    metadata.m.color_encoding = ColorEncoding::SRGB(/*is_gray=*/true);
+  }
+  const ColorEncoding c_pixels = ColorEncoding::LinearSRGB(/*is_gray=*/gray);
   JXL_RETURN_IF_ERROR(metadata.size.Set(xs, ys));
   // JXR_ALPHA=8 | 16: an alpha channel of that many bits (the encoder codes it losslessly in the frame's Modular
   // sub-bitstream, like cjxl does for an RGBA PNG): soft-edged disc, a ramp, a hard-edged box, a noisy band
@@ -242,11 +248,19 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   CodecMetadata metadata_enc = metadata;
   if (!(metadata.m.color_encoding.GetPrimariesType() == Primaries::kSRGB &&
         metadata.m.color_encoding.GetWhitePointType() == WhitePoint::kD65))
-    metadata_enc.m.color_encoding = ColorEncoding::LinearSRGB(/*is_gray=*/false);
+    metadata_enc.m.color_encoding = ColorEncoding::LinearSRGB(/*is_gray=*/gray);
   ImageBundle ib(&mm, &metadata_enc.m);
   {
     JXL_ASSIGN_OR_RETURN(Image3F img, Image3F::Create(&mm, xs, ys));
     FillImage(&img, seed);
+    if (gray) {
+      for (size_t y = 0; y < ys; y++) {
+        float* r = img.PlaneRow(0, y);
+        float* g = img.PlaneRow(1, y);
+        float* b = img.PlaneRow(2, y);
+        for (size_t x = 0; x < xs; x++) r[x] = g[x] = b[x] = 0.2126f * r[x] + 0.7152f * g[x] + 0.0722f * b[x];
+      }
+    }
     JXL_RETURN_IF_ERROR(ib.SetFromImage(std::move(img), c_pixels));
   }
   if (alpha_bits) {

@@ -196,7 +196,7 @@ def test_display_orientation_like_jxldecoder(L, ref, orientation, monkeypatch):
         dec.close()
 
 
-ORIGINALS = [None, "srgb8", "p3", "rec2100pq", "customxy"]
+ORIGINALS = [None, "srgb8", "p3", "rec2100pq", "customxy", "gray8"]
 
 
 @pytest.mark.parametrize("original", ORIGINALS)
@@ -219,17 +219,19 @@ def test_inverse_opsin_matrix_for_the_original_colour_space(L, ref, original):
     blob = cs.tobytes()
     assert L.jxlhip_codestream_basic_info(blob, len(blob), C.byref(info)) == 0
     want = {None: (8, 1, 1, 0.0), "srgb8": (13, 1, 1, 0.0), "p3": (13, 11, 1, 0.0), "rec2100pq": (16, 9, 1, 0.0),
-            "customxy": (None, 2, 2, 1 / 2.2)}[original]
-    assert (info.primaries, info.white_point) == want[1:3] and abs(info.gamma - want[3]) < 1e-6
+            "customxy": (None, 2, 2, 1 / 2.2), "gray8": (13, None, 1, 0.0)}[original]
+    assert info.white_point == want[2] and abs(info.gamma - want[3]) < 1e-6
+    if want[1] is not None:
+        assert info.primaries == want[1]
     if want[0] is not None:
         assert info.transfer_function == want[0]
     assert list(info.luminances) == list(lum)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("original", ["p3", "rec2100pq", "customxy"])
+@pytest.mark.parametrize("original", ["p3", "rec2100pq", "customxy", "gray8"])
 def test_pixels_in_the_original_colour_space(L, ref, original):
-    """Display P3, Rec.2100 PQ and custom-primaries originals: jxlhip_decode_codestream with the transfer function the
+    """Display P3, Rec.2100 PQ, custom-primaries and grey (R = G = B) originals: jxlhip_decode_codestream with the transfer function the
     info struct names -> the pixels the reference decoder wrote (its default: the original space)."""
     import torch
     from libjxl_amd import VarDctDecoder
@@ -237,7 +239,7 @@ def test_pixels_in_the_original_colour_space(L, ref, original):
     cs = rs.codestream.tobytes()
     info = abi.CodestreamInfo()
     assert L.jxlhip_codestream_basic_info(cs, len(cs), C.byref(info)) == 0
-    tf, par = {"p3": (1, 0.0), "rec2100pq": (2, info.intensity_target), "customxy": (4, info.gamma)}[original]
+    tf, par = {"p3": (1, 0.0), "rec2100pq": (2, info.intensity_target), "customxy": (4, info.gamma), "gray8": (1, 0.0)}[original]
     fmt = abi.OutputFormat(tf, 0, 3, 32, 0, par, info.luminances)
     dec = VarDctDecoder(0)
     try:
