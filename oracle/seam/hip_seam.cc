@@ -134,7 +134,7 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     extra_buffers = true;
   }
   if (alpha_ec >= 0 && ds->unpremul_alpha) return decline("un-premultiplied alpha");
-  const bool alpha_in_main = alpha_ec >= 0 && mo.format.num_channels == 4;
+  const bool alpha_in_main = alpha_ec >= 0 && (mo.format.num_channels == 4 || mo.format.num_channels == 2);
   const bool want_alpha = alpha_in_main || extra_buffers;  // = the frame's Modular image is needed
   if (!fh.is_last || fh.CanBeReferenced() || fh.frame_type != FrameType::kRegularFrame) return decline("not a single regular frame");
   if (fd->decoded_->IsJPEG()) return decline("JPEG reconstruction");
@@ -145,7 +145,14 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   // (lib/extras/enc/pnm.cc:118-132), float for PFM / NPY
   const bool to_callback = mo.callback.IsPresent();
   if (!to_callback && !mo.buffer) return decline("no image output set");
-  if (mo.format.num_channels != 3 && mo.format.num_channels != 4) return decline("grey output");
+  // grey outputs (1 or 2 channels, what djxl asks for from a grey image: .pgm / .npy): the back-end writes RGB(A) --
+  // for a grey original the rows of its opsin inverse are equal (luminances x matrix, dec_xyb.cc:226-230), R = G = B
+  // -- and the first (and alpha) sample of every pixel is handed out below
+  const uint32_t out_nc = mo.format.num_channels;
+  const bool grey_out = out_nc == 1 || out_nc == 2;
+  if (out_nc < 1 || out_nc > 4) return decline("output channel count");
+  if (grey_out && !oe.color_encoding.IsGray()) return decline("grey output of a colour image");
+  const uint32_t dev_nc = out_nc == 1 ? 3 : (out_nc == 2 ? 4 : out_nc);
   uint32_t sample_type, bits = 32;
   switch (mo.format.data_type) {
     case JXL_TYPE_FLOAT: sample_type = JXLHIP_SAMPLE_F32; break;
@@ -159,7 +166,8 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   // the stage list behind XYBStage must be FromLinearStage alone (dec_cache.cc:255-345): the output space is an
   // RGB one, no CMS stage (the encoding is the original one or no CMS was given), no tone mapping
   // (stage_tone_mapping.cc:33-60)
-  if (oe.color_encoding.Channels() != 3 || oe.color_encoding.GetColorSpace() == ColorSpace::kXYB) return decline("output colour space is not RGB");
+  if (oe.color_encoding.GetColorSpace() == ColorSpace::kXYB) return decline("XYB output");
+  if (oe.color_encoding.IsGray() && oe.color_encoding.GetWhitePointType() != WhitePoint::kD65) return decline("grey, not D65");
   if (!oe.color_encoding_is_original && oe.cms_set) return decline("a CMS stage is needed");
   {
     const auto& otf = oe.orig_color_encoding.Tf();
@@ -260,7 +268,7 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   for (int i = 0; i < 9; i++) p.inverse_opsin_matrix[i] = oe.opsin_params.inverse_opsin_matrix[i * 4];
   p.out_format.transfer = transfer;
   p.out_format.sample_type = sample_type;
-  p.out_format.num_channels = mo.format.num_channels;
+  p.out_format.num_channels = dev_nc;
   p.out_format.bits_per_sample = bits;
   // SwapEndianness (stage_write.cc:238-252): this host is little-endian
   p.out_format.swap_endianness = (mo.format.endianness == JXL_BIG_ENDIAN && sample_type != JXLHIP_SAMPLE_U8) ? 1 : 0;
@@ -430,7 +438,8 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     }
   }
   t_entropy = now();
-  if (!to_callback) {
+  const size_t sample_bytes = sample_type == JXLHIP_SAMPLE_F32 ? 4 : (sample_type == JXLHIP_SAMPLE_U8 ? 1 : 2);
+  if (!to_callback && !grey_out) {
     JXL_RETURN_IF_ERROR(check(jxlhip_decode_frame_host(ctx, mo.buffer, mo.stride, 0), "decode_frame"));
     t_decode = now();
   } else {
@@ -438,38 +447,61 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     // frame arrives in the context's pinned host frame, already in display orientation, and is handed out as
     // WriteToOutputStage does it (stage_write.cc:324-338,399-409,662-700): Init(num_threads, chunk) once, row
     // runs of at most kChunkSize = 1024 pixels from the pool's threads with their thread id, destroy at the end.
+    // Grey outputs: sample 0 (and the alpha sample) of every RGB(A) pixel, into the buffer or a chunk for the callback.
     const void* frame = nullptr;
     size_t pitch = 0;
     JXL_RETURN_IF_ERROR(check(jxlhip_decode_frame_pinned(ctx, &frame, &pitch), "decode_frame"));
     t_decode = now();
     const bool transposed = static_cast<uint32_t>(ds->undo_orientation) >= 5;
     const size_t ow = transposed ? dim.ysize : dim.xsize, oh = transposed ? dim.xsize : dim.ysize;
-    const size_t px_bytes =
-        mo.format.num_channels * (sample_type == JXLHIP_SAMPLE_F32 ? 4 : sample_type == JXLHIP_SAMPLE_U8 ? 1 : 2);
+    const size_t dev_px = dev_nc * sample_bytes, out_px = out_nc * sample_bytes;
     constexpr size_t kChunk = 1024;
-    void* run_opaque = nullptr;
-    const PixelCallback& cb = mo.callback;
-    const auto init = [&](size_t num_threads) -> Status {
-      run_opaque = cb.Init(num_threads, kChunk);
-      return run_opaque != nullptr;
-    };
-    const auto row = [&](uint32_t y, size_t thread) -> Status {
-      const uint8_t* src = static_cast<const uint8_t*>(frame) + static_cast<size_t>(y) * pitch;
-      for (size_t x = 0; x < ow; x += kChunk) {
-        const size_t n = std::min(kChunk, ow - x);
-        cb.run(run_opaque, thread, x, y, n, src + x * px_bytes);
+    auto to_grey = [&](const uint8_t* src, size_t n, uint8_t* dst) {
+      for (size_t i = 0; i < n; i++) {
+        memcpy(dst + i * out_px, src + i * dev_px, sample_bytes);
+        if (out_nc == 2) memcpy(dst + i * out_px + sample_bytes, src + i * dev_px + 3 * sample_bytes, sample_bytes);
       }
-      return true;
     };
-    const Status ok = RunOnPool(fd->pool_, 0, static_cast<uint32_t>(oh), init, row, "jxlhip rows");
-    if (run_opaque) cb.destroy(run_opaque);
-    JXL_RETURN_IF_ERROR(ok);
+    if (!to_callback) {
+      if (mo.stride < ow * out_px || mo.buffer_size < (oh - 1) * mo.stride + ow * out_px) return JXL_FAILURE("image out buffer too small");
+      const auto row = [&](uint32_t y, size_t /*thread*/) -> Status {
+        to_grey(static_cast<const uint8_t*>(frame) + static_cast<size_t>(y) * pitch, ow,
+                static_cast<uint8_t*>(mo.buffer) + static_cast<size_t>(y) * mo.stride);
+        return true;
+      };
+      JXL_RETURN_IF_ERROR(RunOnPool(fd->pool_, 0, static_cast<uint32_t>(oh), ThreadPool::NoInit, row, "jxlhip grey rows"));
+    } else {
+      void* run_opaque = nullptr;
+      const PixelCallback& cb = mo.callback;
+      std::vector<std::vector<uint8_t>> chunk;
+      const auto init = [&](size_t num_threads) -> Status {
+        run_opaque = cb.Init(num_threads, kChunk);
+        if (grey_out) chunk.assign(num_threads ? num_threads : 1, std::vector<uint8_t>(kChunk * out_px));
+        return run_opaque != nullptr;
+      };
+      const auto row = [&](uint32_t y, size_t thread) -> Status {
+        const uint8_t* src = static_cast<const uint8_t*>(frame) + static_cast<size_t>(y) * pitch;
+        for (size_t x = 0; x < ow; x += kChunk) {
+          const size_t n = std::min(kChunk, ow - x);
+          if (grey_out) {
+            to_grey(src + x * dev_px, n, chunk[thread].data());
+            cb.run(run_opaque, thread, x, y, n, chunk[thread].data());
+          } else {
+            cb.run(run_opaque, thread, x, y, n, src + x * dev_px);
+          }
+        }
+        return true;
+      };
+      const Status ok = RunOnPool(fd->pool_, 0, static_cast<uint32_t>(oh), init, row, "jxlhip rows");
+      if (run_opaque) cb.destroy(run_opaque);
+      JXL_RETURN_IF_ERROR(ok);
+    }
   }
   if (verbose)
     fprintf(stderr, "jxlhip seam: frame %zux%zu decoded on the HIP back-end (%s, %u-bit sample type %u, %u channels); ms: "
                     "side info %.2f, AC global + entropy decode + uploads %.2f, kernels + copy out %.2f, row callbacks %.2f\n",
             static_cast<size_t>(dim.xsize), static_cast<size_t>(dim.ysize), to_callback ? "callback" : "buffer", bits,
-            sample_type, mo.format.num_channels, t_side - t_begin, t_entropy - t_side, t_decode - t_entropy, now() - t_decode);
+            sample_type, out_nc, t_side - t_begin, t_entropy - t_side, t_decode - t_entropy, now() - t_decode);
   for (size_t g = 0; g < dim.num_groups; g++) {
     fd->decoded_passes_per_ac_group_[g] = static_cast<uint8_t>(np);
     for (size_t ps = 0; ps < np && !single; ps++) section_status[ac_group_sec[g][ps]] = FrameDecoder::SectionStatus::kDone;

@@ -76,12 +76,12 @@ def read_pnm(path):
     dims, rest = rest.split(b"\n", 1)
     mx, data = rest.split(b"\n", 1)
     w, h = (int(v) for v in dims.split())
-    if magic == b"PF":
-        a = np.frombuffer(data, "<f4" if float(mx) < 0 else ">f4").reshape(h, w, 3)
+    if magic in (b"PF", b"Pf"):
+        a = np.frombuffer(data, "<f4" if float(mx) < 0 else ">f4").reshape(h, w, 3 if magic == b"PF" else 1)
         return a[::-1]  # PFM rows run bottom to top
-    assert magic == b"P6"
+    assert magic in (b"P6", b"P5")  # P5: a grey image
     dt = np.uint8 if int(mx) < 256 else np.dtype(">u2")
-    return np.frombuffer(data, dt).reshape(h, w, 3), int(mx)
+    return np.frombuffer(data, dt).reshape(h, w, 3 if magic == b"P6" else 1), int(mx)
 
 
 def read_pam(path):
@@ -90,7 +90,7 @@ def read_pam(path):
     head, data = b.split(b"ENDHDR\n", 1)
     f = dict(l.split(b" ", 1) for l in head.split(b"\n")[1:] if l)
     w, h, d, mx = int(f[b"WIDTH"]), int(f[b"HEIGHT"]), int(f[b"DEPTH"]), int(f[b"MAXVAL"])
-    assert head.startswith(b"P7") and d == 4
+    assert head.startswith(b"P7") and d in (2, 4)  # RGB_ALPHA / GRAYSCALE_ALPHA
     return np.frombuffer(data, np.uint8 if mx < 256 else np.dtype(">u2")).reshape(h, w, d), mx
 
 
@@ -99,8 +99,8 @@ def compare(a_path, b_path, ext):
         (a, ma), (b, mb) = read_pam(a_path), read_pam(b_path)
         assert ma == mb and a.shape == b.shape
         # alpha is coded losslessly and leaves through the same arithmetic: identical
-        assert np.array_equal(a[..., 3], b[..., 3])
-        d = np.abs(a[..., :3].astype(np.int64) - b[..., :3].astype(np.int64))
+        assert np.array_equal(a[..., -1], b[..., -1])
+        d = np.abs(a[..., :-1].astype(np.int64) - b[..., :-1].astype(np.int64))
         assert int(d.max()) <= (1 if ma < 256 else 2), int(d.max())
         assert float((d != 0).mean()) < (1e-3 if ma < 256 else 0.5)
         return
@@ -187,6 +187,10 @@ CASES = [
     (dict(seed=10, xsize=520, ysize=300, distance=1.0, speed_tier=3, alpha_bits=8), "srgb8", None, ("pam", "npy")),
     (dict(seed=11, xsize=776, ysize=520, distance=2.0, speed_tier=4, alpha_bits=16), "srgb16", 5, ("pam", "npy")),
     (dict(seed=12, xsize=200, ysize=120, distance=1.0, speed_tier=3, alpha_bits=8), "srgb8", 8, ("npy", "pam")),
+    # grey originals: djxl asks for 1 (or, with alpha, 2) channels; the back-end writes RGB(A) with R = G = B and the
+    # seam hands out the first sample of every pixel
+    (dict(seed=13, xsize=520, ysize=300, distance=1.0, speed_tier=3), "gray8", None, ("pgm", "npy", "pfm")),
+    (dict(seed=14, xsize=456, ysize=280, distance=1.5, speed_tier=4, alpha_bits=8), "gray8", 6, ("pam", "npy")),
 ]
 
 
