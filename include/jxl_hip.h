@@ -260,7 +260,7 @@ JXLHIP_EXPORT int jxlhip_upload_side_info(
  * (stride_floats per row; 1.0 = opaque), copied into context-owned HBM.  It is written to the output like a
  * colour channel without the transfer function -- what WriteToOutputStage does with input channel alpha_c
  * (stage_write.cc:350-366); not un-premultiplied.  Without this call (jxlhip_frame_begin resets it) alpha is the
- * opaque 1.0 the reference substitutes (:355-360).  Single-device contexts. */
+ * opaque 1.0 the reference substitutes (:355-360).  On a multi-device context every stripe takes its own rows. */
 JXLHIP_EXPORT int jxlhip_set_alpha(jxlhip_ctx* ctx, const float* host_plane, size_t stride_floats);
 /* A pinned host plane of the current frame's size, owned by the context, for the caller to fill and hand to
  * jxlhip_set_alpha (the copy is then a true asynchronous DMA).  Valid until the next jxlhip_frame_begin of a larger

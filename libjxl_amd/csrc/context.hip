@@ -746,7 +746,6 @@ static int EnsureUploadBuffers(jxlhip_ctx* c) {
 
 int jxlhip_alpha_staging(jxlhip_ctx* c, float** plane, size_t* stride_floats) {
   if (!c || !plane || !stride_floats) return JXLHIP_ERR_INVALID_ARGUMENT;
-  if (!c->children.empty()) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "alpha on a multi-device context");
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "alpha_staging before frame_begin");
   const size_t need = (size_t)c->f.xsize * c->f.ysize;
   if (need > c->alpha_host_items) {
@@ -769,16 +768,23 @@ int jxlhip_alpha_staging(jxlhip_ctx* c, float** plane, size_t* stride_floats) {
 // input channel alpha_c, stage_write.cc:350-366); frame_begin resets to "opaque".
 int jxlhip_set_alpha(jxlhip_ctx* c, const float* host_plane, size_t stride_floats) {
   if (!c || !host_plane) return JXLHIP_ERR_INVALID_ARGUMENT;
-  if (!c->children.empty()) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "alpha on a multi-device context");
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "set_alpha before frame_begin");
-  const size_t w = c->f.xsize, h = c->f.ysize;
+  if (!c->children.empty()) {  // every stripe takes its own rows of the plane
+    for (jxlhip_ctx* k : c->children) {
+      const int rc = jxlhip_set_alpha(k, host_plane, stride_floats);
+      if (rc) return MultiCheck(c, k, rc);
+    }
+    return JXLHIP_OK;
+  }
+  const size_t w = c->f.xsize, y0 = c->f.y0, rows = c->f.y1 - c->f.y0;
   if (stride_floats < w) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "alpha stride %zu < xsize", stride_floats);
   HIPCHK(c, hipSetDevice(c->device));
-  const int rc = Grow(c, &c->alpha_dev, &c->alpha_items, w * h);
+  const int rc = Grow(c, &c->alpha_dev, &c->alpha_items, w * rows);
   if (rc) return rc;
-  HIPCHK(c, hipMemcpy2DAsync(c->alpha_dev, w * sizeof(float), host_plane, stride_floats * sizeof(float), w * sizeof(float), h,
-                             hipMemcpyHostToDevice, c->stream));
-  c->fp.alpha = c->alpha_dev;
+  // the rows of this context's stripe; the kernels index the plane by IMAGE row: the base pointer is that of row 0
+  HIPCHK(c, hipMemcpy2DAsync(c->alpha_dev, w * sizeof(float), host_plane + y0 * stride_floats, stride_floats * sizeof(float),
+                             w * sizeof(float), rows, hipMemcpyHostToDevice, c->stream));
+  c->fp.alpha = c->alpha_dev - y0 * w;
   c->fp.alpha_stride = (uint32_t)w;
   return JXLHIP_OK;
 }

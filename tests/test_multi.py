@@ -177,3 +177,63 @@ def test_multi_context_stripes_take_the_fused_kernel(oracle, monkeypatch, nstrip
     assert rel_err(got, ref) <= TIGHT
     assert rel_err(single, ref) <= TIGHT
     assert np.array_equal(got, single)
+
+
+@pytest.mark.parametrize("nstripes,host_out", [(2, False), (3, True)])
+@pytest.mark.parametrize("st,bits", [(1, 8), (0, 0)])
+def test_multi_context_alpha_plane(oracle, monkeypatch, nstripes, host_out, st, bits):
+    """jxlhip_set_alpha on a multi-device context: every stripe takes its own rows of the plane (through the
+    context's pinned staging plane, jxlhip_alpha_staging); RGBA out equals the single-context result bit for bit."""
+    L = abi.load_library()
+    xs, ys = 600, 1100
+    fmt = dict(transfer=1, sample_type=st, num_channels=4, bits_per_sample=bits)
+    params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=True, epf_iters=1, seed=93, output_kind=2, out_format=fmt,
+                                     intensity_target=80.0)
+    rng = np.random.default_rng(5)
+    alpha = rng.integers(0, 256, size=(ys, xs)).astype(np.float32) * np.float32(1 / 255)
+    d = VarDctDecoder(0)
+    d.begin_frame(params)
+    dq = d.default_dequant_tables()
+    d.set_inputs({k: ([x.cuda() for x in v] if isinstance(v, list) else v.cuda()) for k, v in t.items()}, dq)
+    d.set_alpha(alpha)
+    single = d.decode_frame().cpu().numpy()
+    d.sync()
+    table_host = dq.cpu().numpy()
+    d.close()
+    ndev = torch.cuda.device_count()
+    devices = [i % ndev for i in range(nstripes)]
+    ctx = C.c_void_p()
+    devs = (C.c_int * len(devices))(*devices)
+    assert L.jxlhip_create_multi(devs, len(devices), None, C.byref(ctx)) == 0
+    try:
+        p = abi.make_params(params)
+        assert L.jxlhip_frame_begin(ctx, C.byref(p)) == 0, L.jxlhip_last_error(ctx)
+        npy = {k: ([x.numpy() for x in v] if isinstance(v, list) else v.numpy()) for k, v in t.items()}
+        dc3 = (C.c_void_p * 3)(*[a.ctypes.data for a in npy["dc"]])
+        assert L.jxlhip_upload_side_info(ctx, npy["ac_strategy"].ctypes.data, npy["raw_quant"].ctypes.data,
+                                         npy["epf_sharpness"].ctypes.data, npy["ytox_map"].ctypes.data,
+                                         npy["ytob_map"].ctypes.data, dc3, table_host.ctypes.data) == 0
+        ng = ((xs + 255) // 256) * ((ys + 255) // 256)
+        for g in range(ng):
+            ptrs = (C.c_void_p * 3)(*[c[g * 65536:].ctypes.data for c in npy["coeffs"]])
+            assert L.jxlhip_submit_group(ctx, g, ptrs, 65536) == 0, L.jxlhip_last_error(ctx)
+        plane, stride = C.c_void_p(), C.c_size_t(0)
+        assert L.jxlhip_alpha_staging(ctx, C.byref(plane), C.byref(stride)) == 0, L.jxlhip_last_error(ctx)
+        assert stride.value == xs
+        C.memmove(plane, alpha.ctypes.data, alpha.nbytes)
+        assert L.jxlhip_set_alpha(ctx, plane, stride.value) == 0, L.jxlhip_last_error(ctx)
+        px = 4 * (1 if st == 1 else 4)
+        if host_out:
+            out = np.zeros((ys, xs, 4), np.uint8 if st == 1 else np.float32)
+            assert L.jxlhip_decode_frame_host(ctx, out.ctypes.data, xs * px, 0) == 0, L.jxlhip_last_error(ctx)
+            got = out
+        else:
+            dev_out = torch.empty((ys, xs, 4), dtype=torch.uint8 if st == 1 else torch.float32, device=f"cuda:{devices[0]}")
+            assert L.jxlhip_decode_frame(ctx, dev_out.data_ptr(), xs * px, 0) == 0, L.jxlhip_last_error(ctx)
+            assert L.jxlhip_sync(ctx) == 0, L.jxlhip_last_error(ctx)
+            got = dev_out.cpu().numpy()
+    finally:
+        L.jxlhip_destroy(ctx)
+    assert np.array_equal(got, single)
+    a = got[..., 3]
+    assert np.array_equal(a, np.rint(alpha * 255).astype(np.uint8)) if st == 1 else np.array_equal(a, alpha)
