@@ -12,9 +12,9 @@
 // JxlDecoderSetImageOutBuffer buffer or hands them row by row to the JxlDecoderSetImageOutCallback callback, in
 // whatever sample format the caller chose.  Extra channels are decoded from the frame's Modular bytes by the
 // product's host front-end (jxlhip_modular_*): an alpha channel going to an RGBA output is written by the back-end,
-// float extra-channel buffers (JxlDecoderSetExtraChannelBuffer) are filled here.  Frames it does not take (Modular,
-// integer extra-channel buffers, blending, grey outputs, a CMS stage, tone mapping ...) fall through to the
-// untouched CPU path.
+// extra-channel buffers (JxlDecoderSetExtraChannelBuffer: float, or integers of the channel's bit depth) are filled
+// here.  Frames it does not take (Modular, blending, a CMS stage, tone mapping ...) fall through to the untouched
+// CPU path.
 //
 // FrameDecoder's members are private; a maintainer would add this as a member function.  Here the class
 // definition is taken as is and its access checks are lifted for this translation unit only.
@@ -128,9 +128,14 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     const ImageOutput& eo = ds->extra_output[i];
     if (eo.callback.IsPresent()) return decline("extra-channel callback");
     if (!eo.buffer) continue;
-    if (i >= md.num_extra_channels || eo.format.data_type != JXL_TYPE_FLOAT || eo.format.num_channels != 1 ||
-        eo.format.endianness == JXL_BIG_ENDIAN)
-      return decline("extra-channel buffer that is not native float");
+    if (i >= md.num_extra_channels || eo.format.num_channels != 1) return decline("extra-channel buffer layout");
+    // float samples, or integers of the channel's own bit depth (then the sample IS the coded integer: x (2^bits - 1),
+    // the 8-bit dither of magnitude < 0.5 and the rounding of MakeUnsigned, stage_write.cc:263-284, land on it)
+    const uint32_t ec_bits = md.extra_channel_info[i].bit_depth.bits_per_sample;
+    const bool is_float = eo.format.data_type == JXL_TYPE_FLOAT && eo.format.endianness != JXL_BIG_ENDIAN;
+    const bool is_int = (eo.format.data_type == JXL_TYPE_UINT8 && ec_bits <= 8 && eo.bits_per_sample == ec_bits) ||
+                        (eo.format.data_type == JXL_TYPE_UINT16 && ec_bits <= 16 && eo.bits_per_sample == ec_bits);
+    if (!is_float && !is_int) return decline("extra-channel buffer: neither float nor integers of the channel's bit depth");
     extra_buffers = true;
   }
   if (alpha_ec >= 0 && ds->unpremul_alpha) return decline("un-premultiplied alpha");
@@ -414,15 +419,28 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
                                                                    md.bit_depth.bits_per_sample, alpha.data(), dim.xsize),
                                   "extra channel samples"));
         const size_t ow = tr ? dim.ysize : dim.xsize, oh = tr ? dim.xsize : dim.ysize;
-        if (eo.stride < ow * sizeof(float) || eo.buffer_size < (oh - 1) * eo.stride + ow * sizeof(float))
+        const size_t sb = eo.format.data_type == JXL_TYPE_FLOAT ? 4 : (eo.format.data_type == JXL_TYPE_UINT8 ? 1 : 2);
+        const float maxval = static_cast<float>((1u << md.extra_channel_info[i].bit_depth.bits_per_sample) - 1);
+        const bool swap = sb == 2 && eo.format.endianness == JXL_BIG_ENDIAN;
+        if (eo.stride < ow * sb || eo.buffer_size < (oh - 1) * eo.stride + ow * sb)
           return JXL_FAILURE("extra channel buffer too small");
         const auto row = [&](uint32_t y, size_t /*thread*/) -> Status {
           const float* src = alpha.data() + static_cast<size_t>(y) * dim.xsize;
           const size_t yo = fy ? dim.ysize - 1 - y : y;
           for (size_t x = 0; x < dim.xsize; x++) {
             const size_t xo = fx ? dim.xsize - 1 - x : x;
-            char* d = static_cast<char*>(eo.buffer) + (tr ? xo * eo.stride + yo * sizeof(float) : yo * eo.stride + xo * sizeof(float));
-            memcpy(d, &src[x], sizeof(float));
+            char* d = static_cast<char*>(eo.buffer) + (tr ? xo * eo.stride + yo * sb : yo * eo.stride + xo * sb);
+            if (sb == 4) {
+              memcpy(d, &src[x], 4);
+            } else {
+              const uint32_t k = static_cast<uint32_t>(lrintf(src[x] * maxval));
+              if (sb == 1) {
+                *reinterpret_cast<uint8_t*>(d) = static_cast<uint8_t>(k);
+              } else {
+                const uint16_t v = swap ? static_cast<uint16_t>((k >> 8) | (k << 8)) : static_cast<uint16_t>(k);
+                memcpy(d, &v, 2);
+              }
+            }
           }
           return true;
         };

@@ -181,16 +181,15 @@ CASES = [
     (dict(seed=8, xsize=2200, ysize=264, distance=1.5, speed_tier=4), "srgb8", 6, ("ppm", "pfm")),   # rotate 90
     (dict(seed=9, xsize=200, ysize=120, distance=1.0, speed_tier=3), "srgb8", 3, ("ppm", "npy")),     # one section
     # RGBA: the alpha channel comes out of the frame's Modular bytes through the product's host front-end
-    # (PAM is djxl's interleaved RGBA output; for NPY it asks for the alpha channel in a float buffer of its own,
-    # lib/extras/dec/jxl.cc:574-607, which the seam fills from the plane the host front-end decoded; for PPM in an
-    # integer buffer, which the seam leaves to the CPU path)
-    (dict(seed=10, xsize=520, ysize=300, distance=1.0, speed_tier=3, alpha_bits=8), "srgb8", None, ("pam", "npy")),
+    # (PAM is djxl's interleaved RGBA output; for NPY / PPM it asks for the alpha channel in a float / integer buffer of
+    # its own, lib/extras/dec/jxl.cc:574-607, which the seam fills from the plane the host front-end decoded)
+    (dict(seed=10, xsize=520, ysize=300, distance=1.0, speed_tier=3, alpha_bits=8), "srgb8", None, ("pam", "npy", "ppm")),
     (dict(seed=11, xsize=776, ysize=520, distance=2.0, speed_tier=4, alpha_bits=16), "srgb16", 5, ("pam", "npy")),
     (dict(seed=12, xsize=200, ysize=120, distance=1.0, speed_tier=3, alpha_bits=8), "srgb8", 8, ("npy", "pam")),
     # grey originals: djxl asks for 1 (or, with alpha, 2) channels; the back-end writes RGB(A) with R = G = B and the
     # seam hands out the first sample of every pixel
     (dict(seed=13, xsize=520, ysize=300, distance=1.0, speed_tier=3), "gray8", None, ("pgm", "npy", "pfm")),
-    (dict(seed=14, xsize=456, ysize=280, distance=1.5, speed_tier=4, alpha_bits=8), "gray8", 6, ("pam", "npy")),
+    (dict(seed=14, xsize=456, ysize=280, distance=1.5, speed_tier=4, alpha_bits=8), "gray8", 6, ("pam", "npy", "pgm")),
 ]
 
 

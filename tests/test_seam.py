@@ -66,7 +66,7 @@ def load(path):
     return L
 
 
-def jxl_decode(L, data, runner=None, runner_opaque=None, channels=3, extra_channel=None):
+def jxl_decode(L, data, runner=None, runner_opaque=None, channels=3, extra_channel=None, extra_type=0):
     """JxlDecoder event loop of lib/extras/dec/jxl.cc, float output.  Returns [H, W, channels] float32 -- and, with
     extra_channel = index, that extra channel in a buffer of its own (JxlDecoderSetExtraChannelBuffer): a tuple."""
     dec = L.JxlDecoderCreate(None)
@@ -91,9 +91,9 @@ def jxl_decode(L, data, runner=None, runner_opaque=None, channels=3, extra_chann
                 out = np.zeros((n.value // (int(w) * channels * 4), int(w), channels), np.float32)
                 assert L.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), out.ctypes.data, n.value) == JXL_DEC_SUCCESS
                 if extra_channel is not None:
-                    efmt, en = PixelFormat(1, 0, 0, 0), C.c_size_t(0)
+                    efmt, en = PixelFormat(1, extra_type, 0, 0), C.c_size_t(0)  # JXL_TYPE_FLOAT 0, UINT8 2, UINT16 3
                     assert L.JxlDecoderExtraChannelBufferSize(dec, C.byref(efmt), C.byref(en), extra_channel) == JXL_DEC_SUCCESS
-                    ec = np.full((out.shape[0], out.shape[1]), -3.0, np.float32)
+                    ec = np.full((out.shape[0], out.shape[1]), 77, {0: np.float32, 2: np.uint8, 3: np.uint16}[extra_type])
                     assert en.value == ec.nbytes
                     assert L.JxlDecoderSetExtraChannelBuffer(dec, C.byref(efmt), ec.ctypes.data, en.value,
                                                              extra_channel) == JXL_DEC_SUCCESS
@@ -187,7 +187,8 @@ def test_oriented_stream_through_the_patched_jxldecoder(libs, ref, orientation, 
 def test_rgba_stream_through_the_patched_jxldecoder(libs, ref, kw, orientation, monkeypatch):
     """An image with an alpha channel: RGBA in the main buffer (the back-end writes the alpha plane the host front-end
     decoded), RGB only (the Modular bytes are skipped; FinalizeFrame must not render the frame a second time), and RGB
-    plus the alpha channel in a float buffer of its own (JxlDecoderSetExtraChannelBuffer, display orientation)."""
+    plus the alpha channel in a buffer of its own (JxlDecoderSetExtraChannelBuffer: float, or integers of the channel's
+    bit depth; display orientation)."""
     Lr, Lh = load(libs[0]), load(libs[1])
     R, runner, pool = hip_runner()
     try:
@@ -196,15 +197,16 @@ def test_rgba_stream_through_the_patched_jxldecoder(libs, ref, kw, orientation, 
         rs = ref.RealStream(seed=43, distance=1.0, speed_tier=3, **kw)
         monkeypatch.delenv("JXR_ORIENTATION", raising=False)
         cs = rs.codestream.tobytes()
-        for channels, ec in ((4, None), (3, None), (3, 0), (4, 0)):
-            want = jxl_decode(Lr, cs, runner, pool, channels, ec)
+        itype = 2 if kw["alpha_bits"] == 8 else 3   # integers of the channel's own bit depth
+        for channels, ec, et in ((4, None, 0), (3, None, 0), (3, 0, 0), (4, 0, 0), (3, 0, itype)):
+            want = jxl_decode(Lr, cs, runner, pool, channels, ec, et)
             before = Lh.jxlhip_seam_frames_decoded()
-            got = jxl_decode(Lh, cs, runner, pool, channels, ec)
+            got = jxl_decode(Lh, cs, runner, pool, channels, ec, et)
             assert Lh.jxlhip_seam_frames_decoded() == before + 1, ("the frame did not go through the HIP back-end", channels, ec)
             if ec is not None:
                 (want, want_ec), (got, got_ec) = want, got
-                assert np.array_equal(got_ec, want_ec), float(np.abs(got_ec - want_ec).max())
-                assert want_ec.min() >= 0.0 and len(np.unique(want_ec)) > 1
+                assert got_ec.dtype == want_ec.dtype and np.array_equal(got_ec, want_ec)
+                assert len(np.unique(want_ec)) > 1
             assert got.shape == want.shape
             scale = max(1.0, float(np.abs(want[..., :3]).max()))
             assert float(np.abs(got[..., :3] - want[..., :3]).max()) / scale <= 1e-4   # (sRGB-encoded samples: slope 12.92)
