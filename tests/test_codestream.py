@@ -252,3 +252,32 @@ def test_pixels_in_the_original_colour_space(L, ref, original):
         assert float(np.abs(got - rs.rgb).mean()) <= 2e-5
     finally:
         dec.close()
+
+
+@pytest.mark.gpu
+def test_first_frame_of_a_context_behind_a_busy_stream(L, ref):
+    """The hand-over of a context's FIRST frame (fresh upload buffers, the sparse arena just allocated) while the stream
+    it shares with the caller still has ~50 ms of the caller's work queued: the uploads travel on other streams and
+    must not depend on anything that only runs once the shared stream drains.  (Round 3: the arena used to be cleared
+    by a NULL-stream hipMemset at allocation, which then ran AFTER the first batch of coefficients had landed; the
+    frame came out as its DC image.)"""
+    import torch
+    from libjxl_amd import VarDctDecoder
+    rs = ref.RealStream(seed=31, xsize=776, ysize=520, distance=2.0, speed_tier=3, epf=1)
+    cs = rs.codestream.tobytes()
+    a = torch.randn((4096, 4096), device="cuda")
+    torch.cuda.synchronize()
+    for workers_none in (True, False):
+        dec = VarDctDecoder(0)          # a fresh context per run: its first frame
+        try:
+            b = a
+            for _ in range(40):           # queued, not waited for
+                b = b @ a
+                b = b / b.abs().max()
+            out = torch.full((520, 776, 3), -7.0, dtype=torch.float32, device="cuda")
+            rc = L.jxlhip_decode_codestream(dec.ctx, None, None, cs, len(cs), 1, None, out.data_ptr(), 776 * 12, 0, None)
+            assert rc == 0, L.jxlhip_last_error(dec.ctx)
+            got = out.cpu().numpy()
+            assert float(np.abs(got - rs.rgb).max()) / max(1.0, float(np.abs(rs.rgb).max())) <= TIGHT
+        finally:
+            dec.close()
