@@ -255,7 +255,8 @@ def test_pixels_in_the_original_colour_space(L, ref, original):
 
 
 @pytest.mark.gpu
-def test_first_frame_of_a_context_behind_a_busy_stream(L, ref):
+@pytest.mark.parametrize("sparse", ["1", "0"])
+def test_first_frame_of_a_context_behind_a_busy_stream(L, ref, sparse, monkeypatch):
     """The hand-over of a context's FIRST frame (fresh upload buffers, the sparse arena just allocated) while the stream
     it shares with the caller still has ~50 ms of the caller's work queued: the uploads travel on other streams and
     must not depend on anything that only runs once the shared stream drains.  (Round 3: the arena used to be cleared
@@ -263,6 +264,7 @@ def test_first_frame_of_a_context_behind_a_busy_stream(L, ref):
     frame came out as its DC image.)"""
     import torch
     from libjxl_amd import VarDctDecoder
+    monkeypatch.setenv("JXLHIP_SPARSE_UPLOAD", sparse)   # both forms of the coefficient hand-over
     rs = ref.RealStream(seed=31, xsize=776, ysize=520, distance=2.0, speed_tier=3, epf=1)
     cs = rs.codestream.tobytes()
     a = torch.randn((4096, 4096), device="cuda")
