@@ -53,11 +53,22 @@ typedef struct jxlhip_codestream_info {
      exponent when its transfer function is a gamma curve (tf_param of JXLHIP_TF_GAMMA), else 0 */
   float luminances[3];
   float gamma;
+  /* headers: the original carried an ICC profile of this many bytes (0 = an enumerated colour encoding; fetch it with
+     jxlhip_codestream_icc_profile).  The pixels of such an image are LINEAR sRGB (transfer_function 8, primaries /
+     white_point 1), grey for a grey profile -- JxlDecoder's output when no CMS is set (dec_xyb.cc:160-164).
+     grey: the original is a grey image (R = G = B in every output) */
+  uint32_t icc_size, grey;
 } jxlhip_codestream_info;
 
 /* Headers only (no device needed): size and colour metadata of the first frame's image.  JXLHIP_ERR_BAD_STREAM /
  * JXLHIP_ERR_UNSUPPORTED as the decode call would return them for the header part. */
 JXLHIP_EXPORT int jxlhip_codestream_basic_info(const uint8_t* data, size_t size, jxlhip_codestream_info* info);
+
+/* The original's ICC profile (JxlDecoderGetColorAsICCProfile(JXL_COLOR_PROFILE_TARGET_ORIGINAL), decode.cc:2411-2430)
+ * of a .jxl file or bare codestream.  *icc_size = its size, 0 for an image with an enumerated colour encoding;
+ * icc_capacity 0 only asks for the size, a capacity below the size is JXLHIP_ERR_INVALID_ARGUMENT. */
+JXLHIP_EXPORT int jxlhip_codestream_icc_profile(const uint8_t* data, size_t size, uint8_t* icc, size_t icc_capacity,
+                                                size_t* icc_size);
 
 /* Decodes the (single, VarDCT) frame of a .jxl file or bare codestream into device memory.
  *   alpha                  : an alpha channel of the image is decoded (host, Modular) and written as the fourth

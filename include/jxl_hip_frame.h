@@ -116,13 +116,24 @@ JXLHIP_EXPORT int jxlhip_image_header_decode(const uint8_t* data, size_t size, s
                                              jxlhip_extra_channel* extra, size_t extra_capacity,
                                              jxlhip_image_header* out);
 
+/* The ICC profile of the original, coded behind the image header when color_encoding.want_icc (ICCReader::Init /
+ * Process + UnpredictICC, icc_codec.cc:135-334,340-421; read by JxlDecoderReadAllHeaders, decode.cc:1101-1133).
+ * *bit_pos: in = the position jxlhip_image_header_decode returned, out = the byte-aligned first bit of the first
+ * frame header.  icc may be NULL (the stream is still decoded and checked: that is the only way to find its end);
+ * *icc_size (may be NULL) = the profile's size; icc_capacity below it with a non-NULL icc is INVALID_ARGUMENT.
+ * JXLHIP_ERR_BAD_STREAM on everything the reference rejects. */
+JXLHIP_EXPORT int jxlhip_icc_decode(const uint8_t* data, size_t size, size_t* bit_pos, uint8_t* icc,
+                                    size_t icc_capacity, size_t* icc_size);
+
 /* The inverse opsin matrix (unscaled: multiply by 255 / intensity_target for jxlhip_frame_params) that makes the
  * back-end's pixels come out in the image's ORIGINAL colour space -- what OutputEncodingInfo::SetFromMetadata /
  * SetColorEncoding derive (dec_xyb.cc:144-165,180-249): the coded matrix for sRGB / D65 originals, the coded matrix
  * followed by sRGB -> XYZ(D50) -> original primaries / white point otherwise (P3, Rec.2100, custom xy); for a grey
  * (D65) original every row becomes luminances x matrix, so that R = G = B = the grey sample -- and the luminance
- * weights of that space (jxlhip_output_format::luminances, the HLG OOTF).  JXLHIP_ERR_UNSUPPORTED: an ICC original, a
- * transfer function outside the enumerated ones, an image that is not XYB encoded. */
+ * weights of that space (jxlhip_output_format::luminances, the HLG OOTF).  An ICC original (want_icc): the reference
+ * without a CMS falls back to LINEAR sRGB (grey for a grey profile, dec_xyb.cc:160-164), and so does this: the coded
+ * matrix, transfer function linear.  JXLHIP_ERR_UNSUPPORTED: a transfer function outside the enumerated ones, an
+ * image that is not XYB encoded. */
 JXLHIP_EXPORT int jxlhip_output_opsin_matrix(const jxlhip_image_header* header, float inverse_matrix[9],
                                              float luminances[3]);
 

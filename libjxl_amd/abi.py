@@ -144,7 +144,7 @@ class CodestreamInfo(C.Structure):
                 ("num_groups", C.c_uint32), ("num_dc_groups", C.c_uint32), ("epf_iters", C.c_uint32),
                 ("gab", C.c_uint32), ("used_acs", C.c_uint32), ("coeff_type", C.c_uint32), ("fused", C.c_uint32),
                 ("num_extra_channels", C.c_uint32), ("alpha_bits", C.c_uint32), ("alpha_premultiplied", C.c_uint32),
-                ("luminances", C.c_float * 3), ("gamma", C.c_float)]
+                ("luminances", C.c_float * 3), ("gamma", C.c_float), ("icc_size", C.c_uint32), ("grey", C.c_uint32)]
 
 
 class FrameParams(C.Structure):
@@ -238,11 +238,11 @@ EXPORTS = [
     "jxlhip_dequant_encodings_decode", "jxlhip_ac_global_decode", "jxlhip_ac_group_decode_submit_passes",
     "jxlhip_ac_groups_decode_submit", "jxlhip_ac_groups_decode_submit_ex", "jxlhip_num_toc_entries", "jxlhip_toc_decode", "jxlhip_ac_global_decode_at",
     # include/jxl_hip_frame.h
-    "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode", "jxlhip_output_opsin_matrix",
+    "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode", "jxlhip_icc_decode", "jxlhip_output_opsin_matrix",
     "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
     "jxlhip_modular_ac_group_decode", "jxlhip_modular_ac_group_decode_f32", "jxlhip_modular_extra_channel_f32",
     # include/jxl_hip_codestream.h
-    "jxlhip_codestream_basic_info", "jxlhip_decode_codestream",
+    "jxlhip_codestream_basic_info", "jxlhip_decode_codestream", "jxlhip_codestream_icc_profile",
 ]
 
 
@@ -329,6 +329,8 @@ def load_library():
     L.jxlhip_dequant_dc.argtypes = [vp, vp * 3, vp * 3, vp, C.c_float, C.c_float, i32]
     L.jxlhip_dequant_dc_groups.argtypes = [vp, vp * 3, vp * 3, vp, C.c_float, C.c_float, i32, vp]
     L.jxlhip_codestream_basic_info.argtypes = [vp, sz, C.POINTER(CodestreamInfo)]
+    L.jxlhip_codestream_icc_profile.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]
+    L.jxlhip_icc_decode.argtypes = [vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz)]
     L.jxlhip_decode_codestream.argtypes = [vp, vp, vp, vp, sz, u32, vp, vp, sz, sz, C.POINTER(CodestreamInfo)]
     L.jxlhip_ac_global_decode_at.argtypes = [vp, sz, C.POINTER(sz), u32, u32, u32, vp, vp, C.POINTER(u32), C.POINTER(vp)]
     _lib = L

@@ -1939,12 +1939,15 @@ int jxlhip_output_opsin_matrix(const jxlhip_image_header* ih, float inverse_matr
   const jxlhip_color_encoding& c = ih->color_encoding;
   memcpy(inverse_matrix, ih->inverse_opsin_matrix, 9 * sizeof(float));
   luminances[0] = 0.2126f, luminances[1] = 0.7152f, luminances[2] = 0.0722f;
-  if (!ih->xyb_encoded || c.want_icc) return JXLHIP_ERR_UNSUPPORTED;  // (an ICC original: the reference needs a CMS)
+  if (!ih->xyb_encoded) return JXLHIP_ERR_UNSUPPORTED;
   if (c.all_default) return kOk;
+  // An ICC original: without a CMS the reference cannot reach the profile's space and falls back to linear sRGB, grey
+  // for a grey profile (SetFromMetadata, dec_xyb.cc:160-164) -- the coded matrix, or its luminance rows
+  if (c.want_icc && c.color_space != JXLHIP_CS_GRAY) return kOk;
   if (c.color_space == JXLHIP_CS_GRAY) {
     // a grey original (D65: CanOutputToColorEncoding, dec_xyb.cc:137-140): every output channel is the luminance of
     // the linear sRGB pixel -- the matrix' rows become luminances x matrix (:226-230)
-    if (c.white_point != JXLHIP_WP_D65) return JXLHIP_ERR_UNSUPPORTED;
+    if (!c.want_icc && c.white_point != JXLHIP_WP_D65) return JXLHIP_ERR_UNSUPPORTED;
     const Mat3 luma = {{luminances[0], luminances[1], luminances[2]},
                        {luminances[0], luminances[1], luminances[2]},
                        {luminances[0], luminances[1], luminances[2]}};
@@ -2117,6 +2120,284 @@ int jxlhip_image_header_decode(const uint8_t* data, size_t size, size_t* bit_pos
     *bit_pos = br.BitsConsumed();
   }
   return kOk;
+}
+
+
+// ---- ICC profile of the original (icc_codec.cc, icc_codec_common.cc) ---------------------------
+// The profile travels as a byte stream `enc` = varint(profile size) varint(size of the command part) commands data,
+// entropy coded one byte per symbol with a context made of the two bytes before it.  The command part drives the
+// reconstruction: header bytes as differences from a predicted header, the tag table from one-byte tag codes, the
+// tag data as runs that are copied, de-interleaved or summed onto an order-0/1/2 linear prediction.
+namespace {
+
+inline uint32_t IccContext(size_t i, uint8_t b1, uint8_t b2) {  // ICCANSContext, icc_codec_common.cc:19-41,171-174
+  if (i <= 128) return 0;
+  auto wordlike = [](uint8_t b, uint32_t* kind) {
+    if ((uint8_t)((b | 0x20) - 'a') < 26) return *kind = 0, true;
+    if ((uint8_t)(b - '0') < 10 || b == '.' || b == ',') return *kind = 1, true;
+    return false;
+  };
+  uint32_t k1, k2;
+  if (!wordlike(b1, &k1)) k1 = b1 == 0 ? 2 : b1 == 1 ? 3 : b1 < 16 ? 4 : b1 == 255 ? 6 : b1 > 240 ? 5 : 7;
+  if (!wordlike(b2, &k2)) k2 = b2 < 16 ? 2 : b2 > 240 ? 3 : 4;
+  return 1 + k1 + 8 * k2;
+}
+
+struct IccCursor {  // one of the two read positions inside enc: [pos, end)
+  const uint8_t* p;
+  size_t pos, end;
+  bool ok = true;
+  size_t Left() const { return end - pos; }
+  uint8_t Byte() {
+    if (pos >= end) return ok = false, 0;
+    return p[pos++];
+  }
+  uint64_t Varint() {  // base 128, little endian groups, at most ten bytes (DecodeVarInt, icc_codec.cc:62-88)
+    uint64_t v = 0;
+    for (int i = 0; i < 10; i++) {
+      const uint8_t b = Byte();
+      if (!ok) return 0;
+      if (i == 9 && (b & 0xFE)) return ok = false, 0;
+      v |= (uint64_t)(b & 0x7F) << (7 * i);
+      if (!(b & 0x80)) return v;
+    }
+    return ok = false, 0;
+  }
+};
+
+// The encoder wrote the `width` interleaved byte planes of a run one after the other; back to sample order
+// (Shuffle, icc_codec.cc:36-56): output byte i comes from plane i % width, element i / width, where the first
+// n % width planes (all of them when n divides) hold ceil(n / width) bytes
+void IccInterleave(const uint8_t* planes, size_t n, size_t width, uint8_t* out) {
+  const size_t rows = (n + width - 1) / width;
+  size_t src = 0, plane = 0;
+  for (size_t i = 0; i < n; i++) {
+    out[i] = planes[src];
+    src += rows;
+    if (src >= n) src = ++plane;
+  }
+}
+
+constexpr char kIccTagNames[] = "cprtwtptbkptrXYZgXYZbXYZkXYZrTRCgTRCbTRCkTRCchaddescchrmdmnddmddlumi";  // tag codes 4..20
+constexpr char kIccTypeNames[] = "XYZ desctextmlucparacurvsf32gbd ";                                     // commands 16..23
+
+int UnpredictIcc(const std::vector<uint8_t>& enc, std::vector<uint8_t>* out) {
+  IccCursor cmd{enc.data(), 0, enc.size()};
+  const uint64_t osize = cmd.Varint();
+  const uint64_t csize = cmd.Varint();
+  if (!cmd.ok || (osize >> 32) || (csize >> 32) || csize > cmd.Left()) return kBad;
+  if (osize + 65536 < enc.size() || osize > (1u << 28)) return kBad;  // CheckPreamble (:93-113)
+  IccCursor dat{enc.data(), cmd.pos + (size_t)csize, enc.size()};
+  cmd.end = dat.pos;
+  std::vector<uint8_t>& icc = *out;
+  icc.clear();
+  icc.reserve((size_t)osize);
+  auto put32 = [&](uint64_t v) {
+    if (v >> 32) return false;
+    for (int s = 24; s >= 0; s -= 8) icc.push_back((uint8_t)(v >> s));
+    return true;
+  };
+  auto put_name = [&](const char* four) { icc.insert(icc.end(), four, four + 4); };
+  auto finished = [&]() { return icc.size() == osize && cmd.Left() == 0 && dat.Left() == 0 ? kOk : kBad; };
+
+  // 128 header bytes: differences from a predicted header that learns from the bytes already there
+  // (kIccInitialHeaderPrediction + ICCPredictHeader, icc_codec_common.cc:87-138)
+  uint8_t guess[128] = {};
+  for (int s = 0; s < 4; s++) guess[s] = (uint8_t)(osize >> (24 - 8 * s));
+  guess[8] = 4;
+  memcpy(guess + 12, "mntrRGB XYZ ", 12);
+  memcpy(guess + 36, "acsp", 4);
+  guess[70] = 246, guess[71] = 214, guess[73] = 1, guess[78] = 211, guess[79] = 45;
+  for (size_t i = 0; i < 128; i++) {
+    if (icc.size() == osize) return finished();
+    if (i == 8) memcpy(guess + 80, icc.data() + 4, 4);  // the creator field repeats the preferred CMM
+    if (i == 41) {
+      if (icc[40] == 'A') memcpy(guess + 41, "PPL", 3);
+      if (icc[40] == 'M') memcpy(guess + 41, "SFT", 3);
+    }
+    if (i == 42) {
+      if (icc[40] == 'S' && icc[41] == 'G') memcpy(guess + 42, "I ", 2);
+      if (icc[40] == 'S' && icc[41] == 'U') memcpy(guess + 42, "NW", 2);
+    }
+    const uint8_t d = dat.Byte();
+    if (!dat.ok) return kBad;
+    icc.push_back((uint8_t)(d + guess[i]));
+  }
+  if (icc.size() == osize) return finished();
+  if (cmd.Left() == 0) return kBad;
+
+  // tag table: count + 1, then one command per entry (or per rTRC/gTRC/bTRC, rXYZ/gXYZ/bXYZ triple)
+  uint64_t ntags = cmd.Varint();
+  if (!cmd.ok) return kBad;
+  if (ntags != 0) {
+    ntags--;
+    if (!put32(ntags)) return kBad;
+    uint64_t prev_start = 128 + ntags * 12, prev_size = 0;
+    while (cmd.Left() != 0) {
+      if (icc.size() > osize) return kBad;
+      const uint8_t command = cmd.Byte();
+      const uint32_t code = command & 63;
+      if (code == 0) break;
+      char name[4];
+      if (code == 1) {  // spelled out in the data part
+        for (char& ch : name) ch = (char)dat.Byte();
+        if (!dat.ok) return kBad;
+      } else if (code == 2) {
+        memcpy(name, "rTRC", 4);
+      } else if (code == 3) {
+        memcpy(name, "rXYZ", 4);
+      } else if (code - 4 < 17) {
+        memcpy(name, kIccTagNames + 4 * (code - 4), 4);
+      } else {
+        return kBad;
+      }
+      put_name(name);
+      uint64_t size = prev_size;
+      if ((!memcmp(name + 1, "XYZ", 3) && name[0] && strchr("rgbk", name[0])) || !memcmp(name, "wtpt", 4) ||
+          !memcmp(name, "bkpt", 4) || !memcmp(name, "lumi", 4))
+        size = 20;
+      uint64_t start;
+      if (command & 64) {
+        start = cmd.Varint();
+      } else {
+        if (prev_start >> 32) return kBad;
+        start = prev_start + prev_size;
+      }
+      if (!cmd.ok || !put32(start)) return kBad;
+      if (command & 128) size = cmd.Varint();
+      if (!cmd.ok || !put32(size)) return kBad;
+      prev_start = start, prev_size = size;
+      if (code == 2) {  // three curves sharing one tag body
+        put_name("gTRC"), put32(start), put32(size);
+        put_name("bTRC"), put32(start), put32(size);
+      } else if (code == 3) {  // three colorants one behind the other
+        if ((start + size * 2) >> 32) return kBad;
+        put_name("gXYZ"), put32(start + size), put32(size);
+        put_name("bXYZ"), put32(start + size * 2), put32(size);
+      }
+    }
+  }
+
+  // tag data
+  std::vector<uint8_t> run;
+  while (cmd.Left() != 0) {
+    if (icc.size() > osize) return kBad;
+    const uint8_t command = cmd.Byte();
+    if (command == 1 || command == 2 || command == 3) {  // verbatim / 2 planes / 4 planes
+      const uint64_t n = cmd.Varint();
+      if (!cmd.ok || n > dat.Left()) return kBad;
+      const size_t at = icc.size();
+      icc.resize(at + (size_t)n);
+      if (command == 1) {
+        if (n) memcpy(icc.data() + at, dat.p + dat.pos, (size_t)n);
+      } else {
+        IccInterleave(dat.p + dat.pos, (size_t)n, command == 2 ? 2 : 4, icc.data() + at);
+      }
+      dat.pos += (size_t)n;
+    } else if (command == 4) {  // residuals of a linear prediction over samples `width` bytes wide, `stride` apart
+      if (cmd.Left() < 2) return kBad;
+      const uint8_t flags = cmd.Byte();
+      const size_t width = (flags & 3) + 1;
+      const int order = (flags >> 2) & 3;
+      if (width == 3 || order == 3) return kBad;
+      uint64_t stride = width;
+      if (flags & 16) {
+        stride = cmd.Varint();
+        if (!cmd.ok || stride < width) return kBad;
+      }
+      if (icc.empty() || ((icc.size() - 1) >> 2) < stride) return kBad;  // three samples back must exist
+      const uint64_t n = cmd.Varint();
+      if (!cmd.ok || n > dat.Left()) return kBad;
+      run.resize((size_t)n);
+      if (width > 1) IccInterleave(dat.p + dat.pos, (size_t)n, width, run.data());
+      else if (n) memcpy(run.data(), dat.p + dat.pos, (size_t)n);
+      dat.pos += (size_t)n;
+      const size_t start = icc.size(), st = (size_t)stride;
+      icc.resize(start + (size_t)n);
+      uint8_t* d = icc.data();
+      // big-endian sample ending before `limit` (a sample cut short by the bytes written so far reads as 0,
+      // DecodeUint32's bound in LinearPredictICCValue, icc_codec_common.cc:145-169)
+      for (size_t i = 0; i < (size_t)n; i++) {
+        const size_t at = start + i, base = start + (i & ~(width - 1));
+        auto sample = [&](size_t back) -> uint32_t {
+          const size_t q = base - back * st;
+          if (width == 1) return d[at - back * st];
+          if (width == 2) return ((uint32_t)d[q] << 8) | d[q + 1];
+          if (q + 4 > at) return 0;
+          return ((uint32_t)d[q] << 24) | ((uint32_t)d[q + 1] << 16) | ((uint32_t)d[q + 2] << 8) | d[q + 3];
+        };
+        uint32_t pred;
+        if (order == 0) pred = sample(1);
+        else if (order == 1) pred = 2 * sample(1) - sample(2);
+        else pred = 3 * sample(1) - 3 * sample(2) + sample(3);
+        const uint32_t byte_in_sample = (uint32_t)(i & (width - 1));
+        const uint8_t pb = (uint8_t)(pred >> (8 * (width - 1 - byte_in_sample)));
+        d[at] = (uint8_t)(pb + run[i]);
+      }
+    } else if (command == 10) {  // an 'XYZ ' tag body: signature, reserved, 12 data bytes
+      if (dat.Left() < 12) return kBad;
+      put_name("XYZ ");
+      icc.insert(icc.end(), 4, 0);
+      icc.insert(icc.end(), dat.p + dat.pos, dat.p + dat.pos + 12);
+      dat.pos += 12;
+    } else if (command >= 16 && command < 24) {  // a type signature + reserved
+      put_name(kIccTypeNames + 4 * (command - 16));
+      icc.insert(icc.end(), 4, 0);
+    } else {
+      return kBad;
+    }
+  }
+  return finished();
+}
+
+}  // namespace
+
+int jxlhip_icc_decode(const uint8_t* data, size_t size, size_t* bit_pos, uint8_t* icc, size_t icc_capacity,
+                      size_t* icc_size) {
+  if (!data || !bit_pos || (icc_capacity && !icc)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (icc_size) *icc_size = 0;
+  try {
+    BitReader br(data, size, *bit_pos);
+    const size_t first_bit = *bit_pos;
+    FieldReader r(&br);
+    const uint64_t enc_size = r.U64();
+    if (!br.Healthy() || enc_size > (1u << 28)) return kBad;  // ICCReader::Init, icc_codec.cc:343-349
+    EntropyCode code;
+    int rc = DecodeEntropyCode(&br, 41, &code, /*disallow_lz77=*/false, 0);
+    if (rc) return rc;
+    SymbolReader reader(&code, &br);
+    if (!reader.Ok()) return JXLHIP_ERR_OUT_OF_MEMORY;
+    std::vector<uint8_t> enc;
+    enc.reserve((size_t)std::min<uint64_t>(enc_size, 1u << 16));
+    uint8_t b1 = 0, b2 = 0;
+    for (size_t i = 0; i < enc_size; i++) {
+      if ((i & 0xFFF) == 0 && i) {
+        // a stream that ends early, or one that claims more than 256 profile bytes per coded byte, is damaged (:403-408)
+        if (!br.Healthy() || reader.Corrupt()) return kBad;
+        if ((i & 0xFFFF) == 0 && (double)i > (double)(br.BitsConsumed() - first_bit) / 8.0 * 256.0) return kBad;
+      }
+      const uint8_t b = (uint8_t)reader.ReadHybridUint(code.context_map[IccContext(i, b1, b2)], &br);
+      enc.push_back(b);
+      b2 = b1, b1 = b;
+    }
+    if (!br.Healthy() || reader.Corrupt() || !reader.FinalStateOk()) return kBad;
+    std::vector<uint8_t> profile;
+    if ((rc = UnpredictIcc(enc, &profile))) return rc;
+    if (profile.empty()) return kBad;  // decode.cc:1124
+    // the first frame starts on a byte (decode.cc:1133)
+    const uint32_t rem = (uint32_t)(br.BitsConsumed() % 8);
+    if (rem != 0 && br.Read(8 - rem) != 0) return kBad;
+    if (!br.Healthy()) return kBad;
+    *bit_pos = br.BitsConsumed();
+    if (icc_size) *icc_size = profile.size();
+    if (icc) {
+      if (icc_capacity < profile.size()) return JXLHIP_ERR_INVALID_ARGUMENT;
+      memcpy(icc, profile.data(), profile.size());
+    }
+    return kOk;
+  } catch (const std::bad_alloc&) {
+    return JXLHIP_ERR_OUT_OF_MEMORY;
+  }
 }
 
 #include "modular.inc"

@@ -479,7 +479,7 @@ class RealStream:
                  alpha=(16, np.float32))
 
     def __init__(self, xsize, ysize, seed=1, distance=1.0, speed_tier=3, epf=-1, progressive=0, alpha_bits=0,
-                 alpha_levels=0, original=None):
+                 alpha_levels=0, original=None, icc=None):
         L = ref_lib()
         L.jxr_real_case_create.restype = C.c_void_p
         L.jxr_real_case_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int, C.c_int]
@@ -489,7 +489,15 @@ class RealStream:
         L.jxr_real_case_info.restype = C.c_uint64
         L.jxr_real_case_info.argtypes = [C.c_void_p, C.c_int]
         # original = "srgb8" | "srgb16": the stream describes an integer sRGB original, like a file cjxl made from a PNG
-        knobs = {"JXR_ALPHA": alpha_bits, "JXR_ALPHA_LEVELS": alpha_levels, "JXR_ORIGINAL": original}
+        # icc = bytes: the original carries this ICC profile (coded behind the image header; pixels: linear sRGB)
+        icc_file = None
+        if icc:
+            import tempfile
+            icc_file = tempfile.NamedTemporaryFile(suffix=".icc", delete=False)
+            icc_file.write(bytes(icc))
+            icc_file.close()
+        knobs = {"JXR_ALPHA": alpha_bits, "JXR_ALPHA_LEVELS": alpha_levels, "JXR_ORIGINAL": original,
+                 "JXR_ICC_FILE": icc_file.name if icc_file else None}
         old = {k: os.environ.get(k) for k in knobs}
         for k, v in knobs.items():
             if v:
@@ -503,6 +511,8 @@ class RealStream:
                         del os.environ[k]
                     else:
                         os.environ[k] = old[k]
+            if icc_file:
+                os.unlink(icc_file.name)
         if not h:
             raise ValueError("reference encode/decode failed")
         try:

@@ -27,8 +27,9 @@ FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fno-lto", "-ffunction-sections", "-fdat
          "-I" + SHIM, "-I" + REF, "-I" + os.path.join(REF, "lib", "include"),
          "-DJPEGXL_ENABLE_SKCMS=0", "-DJXL_DEBUG_ON_ERROR=0"]  # (defining JXL_CRASH_ON_ERROR at all turns it on)
 # reference translation units that are not needed by (or not linkable into) the
-# VarDCT back-end harness: public API front-end, JPEG reconstruction, ICC codec
-SKIP = re.compile(r"(decode\.cc|decode_to_jpeg\.cc|jpeg/|icc_codec\.cc|_test\.cc|_gbench\.cc|test_)")
+# VarDCT back-end harness: public API front-end, JPEG reconstruction (the ICC codec is in: ref_real_stream.cc
+# writes streams of ICC originals and runs ICCReader beside the product's jxlhip_icc_decode)
+SKIP = re.compile(r"(decode\.cc|decode_to_jpeg\.cc|jpeg/|_test\.cc|_gbench\.cc|test_)")
 
 
 def source_list():

@@ -27,7 +27,7 @@ import build_ref as B  # noqa: E402
 SEAM = os.path.join(HERE, "_build", "seam")
 ROOT = os.path.dirname(HERE)
 HIPLIB_DIR = os.path.join(ROOT, "libjxl_amd", "csrc")
-EXTRA_TUS = ["jxl/decode.cc", "jxl/icc_codec.cc", "jxl/decode_to_jpeg.cc"]  # what build_ref.py leaves out
+EXTRA_TUS = ["jxl/decode.cc", "jxl/decode_to_jpeg.cc"]  # what build_ref.py leaves out
 FLAGS = B.FLAGS + ["-DJPEGXL_ENABLE_BOXES=0", "-DJPEGXL_ENABLE_TRANSCODE_JPEG=0"]
 
 # (anchor line of lib/jxl/dec_frame.cc, text inserted BEFORE its FIRST occurrence); every anchor must exist

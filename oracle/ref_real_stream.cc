@@ -28,7 +28,10 @@
 #include "lib/jxl/enc_fields.h"
 #include "lib/jxl/enc_frame.h"
 #include "lib/jxl/enc_params.h"
+#include "lib/jxl/enc_ans.h"
 #include "lib/jxl/frame_header.h"
+#include "lib/jxl/icc_codec.h"
+#include "lib/jxl/icc_codec_common.h"
 #include "lib/jxl/image.h"
 #include "lib/jxl/image_bundle.h"
 #include "lib/jxl/image_metadata.h"
@@ -61,9 +64,6 @@ size_t BrotliEncoderMaxCompressedSize(size_t n) { return n + 1024; }
 }
 extern "C" const JxlCmsInterface* JxlGetDefaultCms() { return nullptr; }
 namespace jxl {
-Status WriteICC(Span<const uint8_t>, BitWriter* JXL_RESTRICT, LayerType, AuxOut* JXL_RESTRICT) {
-  return JXL_FAILURE("ICC profiles are not part of the oracle build");
-}
 namespace jpeg {
 Status EncodeJPEGData(JxlMemoryManager*, JPEGData&, std::vector<uint8_t>*, const CompressParams&) {
   return JXL_FAILURE("JPEG transcoding is not part of the oracle build");
@@ -228,6 +228,25 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
     metadata.m.SetUintSamples(8);
     metadata.m.color_encoding = ColorEncoding::SRGB(/*is_gray=*/true);
   }
+  // JXR_ICC_FILE=path: the original carries that ICC profile (bytes taken as they are, no CMS to parse them): the
+  // stream gets want_icc + the coded profile, and the decoder below -- like JxlDecoder without a CMS -- produces linear
+  // sRGB (grey with JXR_ORIGINAL=gray8), SetFromMetadata dec_xyb.cc:160-164
+  bool have_icc = false;
+  if (const char* path = getenv("JXR_ICC_FILE")) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return JXL_FAILURE("JXR_ICC_FILE");
+    IccBytes icc;
+    uint8_t buf[4096];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof(buf), f)) > 0) icc.insert(icc.end(), buf, buf + got);
+    fclose(f);
+    if (icc.empty()) return JXL_FAILURE("JXR_ICC_FILE is empty");
+    ColorEncoding c;
+    c.SetColorSpace(gray ? ColorSpace::kGray : ColorSpace::kRGB);
+    c.SetICCRaw(std::move(icc));
+    metadata.m.color_encoding = c;
+    have_icc = true;
+  }
   const ColorEncoding c_pixels = ColorEncoding::LinearSRGB(/*is_gray=*/gray);
   JXL_RETURN_IF_ERROR(metadata.size.Set(xs, ys));
   // JXR_ALPHA=8 | 16: an alpha channel of that many bits (the encoder codes it losslessly in the frame's Modular
@@ -246,8 +265,8 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   // through xyb_encoded / the intensity target / the extra channels, which the copy shares; the headers written to
   // the stream and the decoder below carry the original's colour encoding.
   CodecMetadata metadata_enc = metadata;
-  if (!(metadata.m.color_encoding.GetPrimariesType() == Primaries::kSRGB &&
-        metadata.m.color_encoding.GetWhitePointType() == WhitePoint::kD65))
+  if (have_icc || !(metadata.m.color_encoding.GetPrimariesType() == Primaries::kSRGB &&
+                    metadata.m.color_encoding.GetWhitePointType() == WhitePoint::kD65))
     metadata_enc.m.color_encoding = ColorEncoding::LinearSRGB(/*is_gray=*/gray);
   ImageBundle ib(&mm, &metadata_enc.m);
   {
@@ -303,6 +322,8 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   JXL_RETURN_IF_ERROR(ParamsPostInit(&cparams));
   BitWriter writer{&mm};
   JXL_RETURN_IF_ERROR(WriteCodestreamHeaders(&metadata, &writer, nullptr));
+  if (have_icc)  // encode.cc:817-821
+    JXL_RETURN_IF_ERROR(WriteICC(Bytes(metadata.m.color_encoding.ICC()), &writer, LayerType::Header, nullptr));
   JXL_RETURN_IF_ERROR(writer.WithMaxBits(8, LayerType::Header, nullptr, [&] {
     writer.ZeroPadToByte();
     return true;
@@ -535,4 +556,54 @@ JXR_EXPORT uint64_t jxr_real_case_info(void* h, int what) {
       return c->shift[what - 16];
     default: return 0;
   }
+}
+
+// ---- ICC differential harness (tests/test_icc.py): an ARBITRARY "predicted profile" byte string entropy-coded the way
+// WriteICC codes PredictICC's output (enc_icc_codec.cc:455-481; prefix codes like libjxl, or ANS; LZ77 or not), then
+// the reference's ICCReader over the result.  Returns -1 = the harness itself failed, 0 = ICCReader rejects the stream,
+// 1 = accepted (*icc_size bytes in icc).  *bits = where ICCReader stopped reading.
+JXR_EXPORT int jxr_icc_stream(const uint8_t* enc, size_t n, int use_ans, int lz77, uint8_t* stream, size_t stream_cap,
+                              size_t* stream_size, uint8_t* icc, size_t icc_cap, size_t* icc_size, size_t* bits) {
+  using namespace jxl;
+  JxlMemoryManager mm;
+  if (!MemoryManagerInit(&mm, nullptr)) return -1;
+  BitWriter writer{&mm};
+  auto write = [&]() -> Status {
+    std::vector<std::vector<Token>> tokens(1);
+    JXL_RETURN_IF_ERROR(writer.WithMaxBits(128, LayerType::Header, nullptr, [&] { return U64Coder::Write(n, &writer); }));
+    for (size_t i = 0; i < n; i++)
+      tokens[0].emplace_back(static_cast<uint32_t>(ICCANSContext(i, i > 0 ? enc[i - 1] : 0, i > 1 ? enc[i - 2] : 0)), enc[i]);
+    HistogramParams params;
+    params.lz77_method = lz77 == 0   ? HistogramParams::LZ77Method::kNone
+                         : lz77 == 1 ? HistogramParams::LZ77Method::kOptc256
+                                     : HistogramParams::LZ77Method::kLZ77b3w3f;
+    params.force_huffman = !use_ans;
+    EntropyEncodingData code;
+    JXL_ASSIGN_OR_RETURN(size_t cost, BuildAndEncodeHistograms(&mm, params, kNumICCContexts, tokens, &code, &writer,
+                                                               LayerType::Header, nullptr));
+    (void)cost;
+    JXL_RETURN_IF_ERROR(WriteTokens(tokens[0], code, 0, &writer, LayerType::Header, nullptr));
+    return writer.WithMaxBits(8, LayerType::Header, nullptr, [&] {
+      writer.ZeroPadToByte();
+      return true;
+    });
+  };
+  if (!write()) return -1;
+  PaddedBytes bytes = std::move(writer).TakeBytes();
+  *stream_size = bytes.size();
+  if (bytes.size() > stream_cap) return -1;
+  memcpy(stream, bytes.data(), bytes.size());
+  BitReader reader(Bytes(bytes.data(), bytes.size()));
+  ICCReader icc_reader(&mm);
+  PaddedBytes profile{&mm};
+  Status ok = icc_reader.Init(&reader);
+  if (ok) ok = icc_reader.Process(&reader, &profile);
+  *bits = reader.TotalBitsConsumed();
+  (void)reader.Close();
+  *icc_size = 0;
+  if (!ok || profile.empty()) return 0;  // (an empty profile: decode.cc:1124)
+  *icc_size = profile.size();
+  if (profile.size() > icc_cap) return -1;
+  memcpy(icc, profile.data(), profile.size());
+  return 1;
 }

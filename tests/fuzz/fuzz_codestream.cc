@@ -1,6 +1,6 @@
 // fuzz_codestream.cc -- sanitizer harness for the host front-end as a chain (libjxl_amd/csrc/
 // entropy.cc + modular.inc compiled INTO this binary with -fsanitize=address,undefined): damaged
-// copies of genuine codestreams go through jxlhip_image_header_decode -> jxlhip_frame_header_decode
+// copies of genuine codestreams go through jxlhip_image_header_decode (-> jxlhip_icc_decode) -> jxlhip_frame_header_decode
 // -> jxlhip_toc_decode -> jxlhip_dc_global_decode -> jxlhip_modular_global_decode ->
 // jxlhip_dc_group_decode, every buffer an exact-size heap block.  Prints "<ok> <rejected>".
 #include <stdint.h>
@@ -41,7 +41,14 @@ bool Chain(const Bytes& cs) {
   jxlhip_extra_channel ec[4];
   size_t pos = 0;
   if (jxlhip_image_header_decode(all.p, all.n, &pos, ec, 4, &ih) != JXLHIP_OK) return false;
-  if (ih.color_encoding.want_icc) return false;
+  if (ih.color_encoding.want_icc) {  // the coded ICC profile: once for its size, once into an exact-size block
+    size_t icc_size = 0, p2 = pos;
+    if (jxlhip_icc_decode(all.p, all.n, &pos, nullptr, 0, &icc_size) != JXLHIP_OK) return false;
+    uint8_t* profile = (uint8_t*)malloc(icc_size);
+    const int rc = jxlhip_icc_decode(all.p, all.n, &p2, profile, icc_size, &icc_size);
+    free(profile);
+    if (rc != JXLHIP_OK || p2 != pos) abort();
+  }
   uint8_t shifts[4] = {0, 0, 0, 0};
   for (uint32_t i = 0; i < ih.num_extra_channels && i < 4; i++) shifts[i] = (uint8_t)ec[i].dim_shift;
   if (ih.num_extra_channels > 4) return false;

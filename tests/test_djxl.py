@@ -190,6 +190,9 @@ CASES = [
     # seam hands out the first sample of every pixel
     (dict(seed=13, xsize=520, ysize=300, distance=1.0, speed_tier=3), "gray8", None, ("pgm", "npy", "pfm")),
     (dict(seed=14, xsize=456, ysize=280, distance=1.5, speed_tier=4, alpha_bits=8), "gray8", 6, ("pam", "npy", "pgm")),
+    # ICC originals (8-bit samples): no CMS in either build, so both write linear sRGB (dec_xyb.cc:160-164)
+    (dict(seed=15, xsize=520, ysize=300, distance=1.0, speed_tier=3, icc="rgb"), "srgb8", None, ("ppm", "npy", "pfm")),
+    (dict(seed=16, xsize=456, ysize=280, distance=1.5, speed_tier=4, icc="grey", alpha_bits=8), "gray8", None, ("pam", "npy")),
 ]
 
 
@@ -198,6 +201,9 @@ CASES = [
 def test_djxl_on_the_hip_backend_writes_what_djxl_writes(tools, ref, tmp_path, kw, original, orientation, outputs):
     djxl_ref, djxl_hip = tools
     jxl = tmp_path / "a.jxl"
+    if kw.get("icc"):
+        from test_icc import make_profile
+        kw = dict(kw, icc=make_profile(kw["icc"] == "grey", 1024))
     jxl.write_bytes(stream(ref, original=original, orientation=orientation, **kw))
     for ext in outputs:
         for threads in (("--num_threads", "0"), ()) if ext == outputs[0] else ((),):

@@ -7,8 +7,9 @@ extensions (tools/djxl_main.cc, lib/extras/enc/pnm.cc):
   .pfm  linear-light float RGB, bottom-up rows, little endian (scale -1.0)
   .npy  float32 [H, W, 3] linear RGB (what tools/conformance/conformance.py reads, conformance.py:34-66)
   .ppm  8-bit RGB               .pam  8-bit RGBA (the image's alpha channel, opaque without one)
-        -- both in the image's original colour encoding (its transfer function over its primaries)
-Streams outside the back-end (Modular frames, squeezed extra channels, ICC, animation ...) exit with status 3 and the error text so that a
+        -- both in the image's original colour encoding (its transfer function over its primaries; an ICC
+           original: linear sRGB, like djxl without a CMS)
+Streams outside the back-end (Modular frames, squeezed extra channels, animation ...) exit with status 3 and the error text so that a
 wrapper can fall back to libjxl's djxl.  Prints Mpx/s of the decode call like djxl's SpeedStats."""
 import argparse
 import ctypes as C
