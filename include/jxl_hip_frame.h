@@ -223,7 +223,9 @@ JXLHIP_EXPORT int jxlhip_dc_global_decode(const uint8_t* data, size_t size, size
  * (modular/encoding/encoding.cc:553-680) and the property / predictor definitions of
  * modular/encoding/context_predict.h, the self-correcting predictor included.
  * JXLHIP_ERR_UNSUPPORTED for what libjxl's encoder does not write into these streams: transforms
- * (RCT, palette, squeeze), LZ77 with 2-D distances; also for chroma subsampling and DC frames. */
+ * (RCT, multi-channel / delta palettes; single-channel palettes and the squeeze of the extra channels' global image
+ * are taken, see jxlhip_modular_groups_are_final), LZ77 with 2-D distances; also for chroma subsampling and DC
+ * frames. */
 typedef struct jxlhip_modular_tree jxlhip_modular_tree;
 
 /* The rest of the DC-global section behind jxlhip_dc_global_decode: *tree receives the global MA
@@ -245,12 +247,19 @@ JXLHIP_EXPORT int jxlhip_modular_ac_group_decode(jxlhip_modular_tree* tree, cons
  * planes[e] for extra channel e (NULL = not wanted), rows of stride_floats, ec_bits[e] / image_bits as for
  * jxlhip_modular_extra_channel_f32 -- so that the frame's int32 image is never allocated and nothing is left to
  * convert afterwards.  Channels that fit one group are coded in the global section and do not pass here: they are
- * read with jxlhip_modular_extra_channel_f32.  JXLHIP_ERR_UNSUPPORTED: the global image carries a palette of a
- * palette (use the collecting form above). */
+ * read with jxlhip_modular_extra_channel_f32.  JXLHIP_ERR_UNSUPPORTED: the global image carries a squeeze or a
+ * palette of a palette -- jxlhip_modular_groups_are_final says so beforehand (use the collecting form above). */
 JXLHIP_EXPORT int jxlhip_modular_ac_group_decode_f32(jxlhip_modular_tree* tree, const jxlhip_frame_header* frame,
                                                      uint32_t group, uint32_t pass, const uint8_t* data, size_t size,
                                                      size_t* bit_pos, const uint32_t* ec_bits, uint32_t image_bits,
                                                      float* const* planes, size_t stride_floats);
+/* 1: the groups' samples of the extra channels are final as they arrive (jxlhip_modular_ac_group_decode_f32 may write
+ * them out); 0: the global image carries transforms that need every group first -- a squeeze (Haar-like pyramid with
+ * a smoothness term, modular/transform/squeeze.cc; what `cjxl -p` applies to extra channels: their 1:8 and smaller
+ * levels then sit in the DC groups, which jxlhip_dc_group_decode reads into the handle, the finer ones in the AC
+ * groups pass by pass) or a palette of a palette: collect with jxlhip_modular_ac_group_decode, then
+ * jxlhip_modular_extra_channel_f32 undoes them.  A NULL tree (no extra channels) is 1. */
+JXLHIP_EXPORT int jxlhip_modular_groups_are_final(const jxlhip_modular_tree* tree);
 /* Once every group is in: extra channel `ec` as float samples, out[y * stride_floats + x] = v / (2^ec_bits - 1)
  * (FinalizeDecoding + ModularImageToDecodedRect, dec_modular.cc:686-737,739-760; image_bits = the IMAGE's
  * bits_per_sample, which picks the float or the double multiply, :726-731).  The first call undoes the global

@@ -241,8 +241,11 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     size_t mpos = 0;
     int rc = jxlhip_dc_global_decode(dbr->FirstByte(), dbr->TotalBytes(), &mpos, fh.flags, &dcg);
     if (rc == JXLHIP_OK) rc = jxlhip_modular_global_decode(dbr->FirstByte(), dbr->TotalBytes(), &mpos, &mfh, &mtree.t);
-    if (rc == JXLHIP_ERR_UNSUPPORTED) return decline("extra channels coded with transforms (e.g. squeezed, progressive)");
+    if (rc == JXLHIP_ERR_UNSUPPORTED) return decline("extra channels coded with transforms outside the front-end");
     JXL_RETURN_IF_ERROR(check(rc, "modular global"));
+    // squeezed (progressive) extra channels: their coarse levels came with the DC groups, which libjxl has already
+    // taken in -- the product's front-end reads them in jxlhip_dc_group_decode (jxlhip_decode_codestream), not here
+    if (!jxlhip_modular_groups_are_final(mtree.t)) return decline("squeezed extra channels (levels in the DC groups)");
   }
   // ---- per-frame parameters
   jxlhip_frame_params p = {};

@@ -98,6 +98,20 @@ bool Chain(const Bytes& cs) {
     ok = jxlhip_dc_group_decode(tree, sg.p, sg.n, &gp, &fh, g, q, &prec, acs.data(), rq.data(), sharp.data(),
                                 ytox.data(), ytob.data(), &used) == JXLHIP_OK;
   }
+  // extra channels: what follows the coefficients is out of reach here (the AC groups are not entropy-decoded), but the
+  // collecting form on the groups' sections from bit 0 and the final undo (squeeze, palettes) must hold up on whatever
+  // state the damaged stream left
+  if (ok && fh.num_extra_channels && tree) {
+    const uint32_t first_ac = 2 + (uint32_t)fh.num_dc_groups;
+    for (uint32_t g = 0; g < fh.num_groups && g < 4; g++) {
+      if (!section(first_ac + g, &d, &n)) break;
+      Exact sg(d, n);
+      size_t gp = 0;
+      (void)jxlhip_modular_ac_group_decode(tree, &fh, g, 0, sg.p, sg.n, &gp);
+    }
+    std::vector<float> plane((size_t)fh.xsize * fh.ysize);
+    (void)jxlhip_modular_extra_channel_f32(tree, 0, 8, 8, plane.data(), fh.xsize);
+  }
   jxlhip_modular_tree_destroy(tree);
   return ok;
 }

@@ -154,11 +154,29 @@ def test_alpha_plane_from_the_codestream_bytes(L, ref, kw, direct):
     assert np.array_equal(alpha, rs.alpha), float(np.abs(alpha - rs.alpha).max())
 
 
-@pytest.mark.parametrize("progressive", [1, 2])
-def test_squeezed_alpha_of_progressive_streams_is_refused(L, ref, progressive):
-    """cjxl -p codes the extra channels through the Squeeze transform (responsive Modular): outside this front-end,
-    and said so before anything is decoded (the caller falls back to the reference decoder)."""
-    rs = ref.RealStream(seed=29, xsize=520, ysize=300, alpha_bits=8, progressive=progressive, distance=2.0)
+SQUEEZED = [
+    dict(xsize=520, ysize=300, alpha_bits=8, progressive=1, distance=2.0),
+    dict(xsize=520, ysize=300, alpha_bits=8, progressive=2, distance=2.0),
+    dict(xsize=200, ysize=120, alpha_bits=8, progressive=1),                      # one group: undone in the global section
+    dict(xsize=2200, ysize=264, alpha_bits=16, progressive=1, speed_tier=4),      # a 275 x 33 level: in the DC groups
+    dict(xsize=777, ysize=1033, alpha_bits=8, progressive=2, original="srgb8"),   # tall: vertical split first
+    dict(xsize=520, ysize=300, alpha_bits=8, alpha_levels=2, progressive=1, original="srgb8"),  # palette, then squeeze
+]
+
+
+@pytest.mark.parametrize("kw", SQUEEZED)
+def test_squeezed_alpha_of_progressive_streams(L, ref, kw):
+    """cjxl -p codes the extra channels through the Squeeze transform (responsive Modular): a pyramid of averages and
+    residuals whose levels arrive with the global section (what fits a group), the DC groups (1:8 and below) and the
+    AC groups pass by pass; undone once every group is in.  Bit-exact against the reference decoder's plane."""
+    rs = ref.RealStream(seed=29, **kw)
+    alpha, ih, fh = decode_alpha_on_host(L, rs, direct=False)
+    assert np.array_equal(alpha, rs.alpha), float(np.abs(alpha - rs.alpha).max())
+
+
+def test_squeezed_channels_are_not_final_group_by_group(L, ref):
+    """jxlhip_modular_groups_are_final tells the caller beforehand; the float-on-the-spot form refuses."""
+    rs = ref.RealStream(seed=29, xsize=520, ysize=300, alpha_bits=8, progressive=1, distance=2.0)
     cs = np.ascontiguousarray(rs.codestream)
     ih, pos = abi.ImageHeader(), C.c_size_t(0)
     assert L.jxlhip_image_header_decode(cs.ctypes.data, len(cs), C.byref(pos), None, 0, C.byref(ih)) == 0
@@ -171,8 +189,21 @@ def test_squeezed_alpha_of_progressive_streams_is_refused(L, ref, progressive):
     s0 = cs[pos.value // 8 + int(off[0]):][:int(sz[0])]
     dcg, spos, tree = abi.DcGlobal(), C.c_size_t(0), C.c_void_p()
     assert L.jxlhip_dc_global_decode(s0.ctypes.data, len(s0), C.byref(spos), fh.flags, C.byref(dcg)) == 0
-    assert L.jxlhip_modular_global_decode(s0.ctypes.data, len(s0), C.byref(spos), C.byref(fh), C.byref(tree)) == -7
-    assert not tree.value
+    assert L.jxlhip_modular_global_decode(s0.ctypes.data, len(s0), C.byref(spos), C.byref(fh), C.byref(tree)) == 0
+    try:
+        assert L.jxlhip_modular_groups_are_final(tree) == 0 and L.jxlhip_modular_groups_are_final(None) == 1
+        plane = np.zeros((300, 520), np.float32)
+        g0 = cs[pos.value // 8 + int(off[3]):][:int(sz[3])]
+        gp = C.c_size_t(0)
+        assert L.jxlhip_modular_ac_group_decode_f32(tree, C.byref(fh), 0, 0, g0.ctypes.data, len(g0), C.byref(gp),
+                                                    (C.c_uint32 * 4)(8, 8, 8, 8), 32, (C.c_void_p * 4)(plane.ctypes.data, None, None, None),
+                                                    520) == -7
+    finally:
+        L.jxlhip_modular_tree_destroy(tree)
+    plain = ref.RealStream(seed=29, xsize=520, ysize=300, alpha_bits=8)
+    # (an unsqueezed stream: final)
+    alpha, _, _ = decode_alpha_on_host(L, plain, direct=True)
+    assert np.array_equal(alpha, plain.alpha)
 
 
 GPU_CASES = [
@@ -181,6 +212,8 @@ GPU_CASES = [
     dict(xsize=776, ysize=520, alpha_bits=16, distance=2.0, epf=1),
     dict(xsize=2200, ysize=520, alpha_bits=8, speed_tier=4),       # two DC groups, 27 AC groups
     dict(xsize=520, ysize=300, alpha_bits=8, alpha_levels=2, original="srgb8"),   # a mask: global palette
+    dict(xsize=2200, ysize=520, alpha_bits=8, progressive=1, speed_tier=4),      # squeezed alpha (levels in DC + AC groups)
+    dict(xsize=200, ysize=120, alpha_bits=8, progressive=2),                      # squeezed, one section
 ]
 
 

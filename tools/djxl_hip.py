@@ -9,7 +9,7 @@ extensions (tools/djxl_main.cc, lib/extras/enc/pnm.cc):
   .ppm  8-bit RGB               .pam  8-bit RGBA (the image's alpha channel, opaque without one)
         -- both in the image's original colour encoding (its transfer function over its primaries; an ICC
            original: linear sRGB, like djxl without a CMS)
-Streams outside the back-end (Modular frames, squeezed extra channels, animation ...) exit with status 3 and the error text so that a
+Streams outside the back-end (Modular frames, patches / noise, animation ...) exit with status 3 and the error text so that a
 wrapper can fall back to libjxl's djxl.  Prints Mpx/s of the decode call like djxl's SpeedStats."""
 import argparse
 import ctypes as C
