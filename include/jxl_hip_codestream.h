@@ -91,6 +91,19 @@ JXLHIP_EXPORT int jxlhip_decode_codestream(jxlhip_ctx* ctx, jxlhip_parallel_runn
                                            const jxlhip_output_format* out_format, void* out, size_t out_stride,
                                            size_t out_plane_stride, jxlhip_codestream_info* info);
 
+/* jxlhip_decode_codestream, and the image's extra channels (alpha, depth, spot colours ...) as float planes in HOST
+ * memory -- what JxlDecoderSetExtraChannelBuffer with JXL_TYPE_FLOAT gives (decode.cc:2627; samples v / (2^bits - 1),
+ * ModularImageToDecodedRect dec_modular.cc:686-737): extra_planes[e] for extra channel e < num_extra_planes (NULL = not
+ * wanted; entries beyond the image's channels are ignored), rows of extra_stride floats (>= xsize), in CODED
+ * orientation (JXLHIP_OUT_UNDO_ORIENTATION turns `out` only).  The planes are complete when the call returns.  An
+ * alpha channel may be asked for here and ride in a 4-channel `out` at the same time. */
+JXLHIP_EXPORT int jxlhip_decode_codestream_extra(jxlhip_ctx* ctx, jxlhip_parallel_runner runner, void* runner_opaque,
+                                                 const uint8_t* data, size_t size, uint32_t output_kind,
+                                                 const jxlhip_output_format* out_format, void* out, size_t out_stride,
+                                                 size_t out_plane_stride, float* const* extra_planes,
+                                                 uint32_t num_extra_planes, size_t extra_stride,
+                                                 jxlhip_codestream_info* info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -253,6 +253,12 @@ JXLHIP_EXPORT int jxlhip_modular_ac_group_decode_f32(jxlhip_modular_tree* tree, 
                                                      uint32_t group, uint32_t pass, const uint8_t* data, size_t size,
                                                      size_t* bit_pos, const uint32_t* ec_bits, uint32_t image_bits,
                                                      float* const* planes, size_t stride_floats);
+/* (the same with a row stride per plane: strides_floats[e] for planes[e], e < 4) */
+JXLHIP_EXPORT int jxlhip_modular_ac_group_decode_f32_strided(jxlhip_modular_tree* tree, const jxlhip_frame_header* frame,
+                                                             uint32_t group, uint32_t pass, const uint8_t* data,
+                                                             size_t size, size_t* bit_pos, const uint32_t* ec_bits,
+                                                             uint32_t image_bits, float* const* planes,
+                                                             const size_t* strides_floats);
 /* 1: the groups' samples of the extra channels are final as they arrive (jxlhip_modular_ac_group_decode_f32 may write
  * them out); 0: the global image carries transforms that need every group first -- a squeeze (Haar-like pyramid with
  * a smoothness term, modular/transform/squeeze.cc; what `cjxl -p` applies to extra channels: their 1:8 and smaller

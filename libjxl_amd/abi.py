@@ -241,9 +241,10 @@ EXPORTS = [
     "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode", "jxlhip_icc_decode", "jxlhip_output_opsin_matrix",
     "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
     "jxlhip_modular_ac_group_decode", "jxlhip_modular_ac_group_decode_f32", "jxlhip_modular_extra_channel_f32",
-    "jxlhip_modular_groups_are_final",
+    "jxlhip_modular_groups_are_final", "jxlhip_modular_ac_group_decode_f32_strided",
     # include/jxl_hip_codestream.h
-    "jxlhip_codestream_basic_info", "jxlhip_decode_codestream", "jxlhip_codestream_icc_profile",
+    "jxlhip_codestream_basic_info", "jxlhip_decode_codestream", "jxlhip_decode_codestream_extra",
+    "jxlhip_codestream_icc_profile",
 ]
 
 
@@ -334,6 +335,9 @@ def load_library():
     L.jxlhip_codestream_icc_profile.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]
     L.jxlhip_icc_decode.argtypes = [vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz)]
     L.jxlhip_decode_codestream.argtypes = [vp, vp, vp, vp, sz, u32, vp, vp, sz, sz, C.POINTER(CodestreamInfo)]
+    L.jxlhip_decode_codestream_extra.argtypes = [vp, vp, vp, vp, sz, u32, vp, vp, sz, sz, C.POINTER(vp), u32, sz,
+                                                 C.POINTER(CodestreamInfo)]
+    L.jxlhip_modular_ac_group_decode_f32_strided.argtypes = [vp, vp, u32, u32, vp, sz, C.POINTER(sz), vp, u32, vp, vp]
     L.jxlhip_ac_global_decode_at.argtypes = [vp, sz, C.POINTER(sz), u32, u32, u32, vp, vp, C.POINTER(u32), C.POINTER(vp)]
     _lib = L
     return L

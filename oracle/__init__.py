@@ -476,10 +476,10 @@ class RealStream:
                  dc_x=(6, np.float32), dc_y=(7, np.float32), dc_b=(8, np.float32), quant_dc=(9, np.uint8),
                  block_ctx_bytes=(10, np.uint8), rgb=(11, np.float32), section_offset=(12, np.uint64),
                  section_size=(13, np.uint64), params=(14, np.uint8), dequant_table=(15, np.float32),
-                 alpha=(16, np.float32))
+                 alpha=(16, np.float32), extra=(17, np.float32))
 
     def __init__(self, xsize, ysize, seed=1, distance=1.0, speed_tier=3, epf=-1, progressive=0, alpha_bits=0,
-                 alpha_levels=0, original=None, icc=None):
+                 alpha_levels=0, original=None, icc=None, extra=0):
         L = ref_lib()
         L.jxr_real_case_create.restype = C.c_void_p
         L.jxr_real_case_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int, C.c_int]
@@ -496,7 +496,8 @@ class RealStream:
             icc_file = tempfile.NamedTemporaryFile(suffix=".icc", delete=False)
             icc_file.write(bytes(icc))
             icc_file.close()
-        knobs = {"JXR_ALPHA": alpha_bits, "JXR_ALPHA_LEVELS": alpha_levels, "JXR_ORIGINAL": original,
+        # extra = n: n more extra channels (depth 16 bit, thermal 8 bit, optional 12 bit) behind the alpha channel
+        knobs = {"JXR_ALPHA": alpha_bits, "JXR_ALPHA_LEVELS": alpha_levels, "JXR_ORIGINAL": original, "JXR_EXTRA": extra,
                  "JXR_ICC_FILE": icc_file.name if icc_file else None}
         old = {k: os.environ.get(k) for k in knobs}
         for k, v in knobs.items():

@@ -105,6 +105,7 @@ struct RealCase {
   std::vector<float> dc[3];
   std::vector<float> rgb;     // reference decoder output, interleaved linear RGB
   std::vector<float> alpha;   // ... and its alpha channel (JXR_ALPHA streams)
+  std::vector<float> extra;   // JXR_EXTRA streams: the other extra channels' planes, one behind the other
   std::vector<float> dequant; // the frame's DequantMatrices table (JXLHIP_DEQUANT_TABLE_FLOATS)
 };
 
@@ -254,6 +255,22 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   uint32_t alpha_bits = 0;
   if (const char* e = getenv("JXR_ALPHA")) alpha_bits = static_cast<uint32_t>(atoi(e));
   if (alpha_bits) metadata.m.SetAlphaBits(alpha_bits);
+  // JXR_EXTRA=n (1..3): n more extra channels behind the alpha channel (depth 16 bit, thermal 8 bit, optional 12 bit),
+  // coded losslessly like it; the decoder below hands them out through extra-channel buffers
+  uint32_t num_more = 0;
+  if (const char* e = getenv("JXR_EXTRA")) num_more = std::min(3, std::max(0, atoi(e)));
+  static const ExtraChannel kMoreType[3] = {ExtraChannel::kDepth, ExtraChannel::kThermal, ExtraChannel::kOptional};
+  static const uint32_t kMoreBits[3] = {16, 8, 12};
+  for (uint32_t i = 0; i < num_more; i++) {
+    ExtraChannelInfo eci;
+    eci.type = kMoreType[i];
+    eci.bit_depth.bits_per_sample = kMoreBits[i];
+    eci.bit_depth.exponent_bits_per_sample = 0;
+    eci.bit_depth.floating_point_sample = false;
+    eci.dim_shift = 0;
+    metadata.m.extra_channel_info.push_back(eci);
+  }
+  metadata.m.num_extra_channels = static_cast<uint32_t>(metadata.m.extra_channel_info.size());
   // JXR_ORIENTATION=2..8: ImageMetadata::orientation of the written stream (tests of undo_orientation); the
   // FrameDecoder run below keeps the coded orientation, JxlDecoder (tests/test_seam.py) undoes it
   if (const char* e = getenv("JXR_ORIENTATION")) {
@@ -308,6 +325,36 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
     }
     JXL_RETURN_IF_ERROR(ib.SetAlpha(std::move(alpha)));
   }
+  if (num_more) {
+    std::vector<ImageF> all;
+    if (alpha_bits) {
+      JXL_ASSIGN_OR_RETURN(ImageF a, ImageF::Create(&mm, xs, ys));
+      JXL_RETURN_IF_ERROR(CopyImageTo(*ib.alpha(), &a));
+      all.emplace_back(std::move(a));
+    }
+    for (uint32_t i = 0; i < num_more; i++) {
+      JXL_ASSIGN_OR_RETURN(ImageF pl, ImageF::Create(&mm, xs, ys));
+      const float levels = static_cast<float>((1u << kMoreBits[i]) - 1);
+      uint32_t s2 = seed * 2654435761u + i * 977u + 1u;
+      for (size_t y = 0; y < ys; y++) {
+        float* row = pl.Row(y);
+        for (size_t x = 0; x < xs; x++) {
+          float v;
+          if (i == 0) {  // depth: a tilted plane with a step
+            v = 0.15f + 0.6f * (static_cast<float>(x) / xs) * (static_cast<float>(y) / ys) + (x > xs / 2 ? 0.2f : 0.0f);
+          } else if (i == 1) {  // blobs
+            v = 0.5f + 0.5f * std::sin(x * 0.031f) * std::cos(y * 0.047f);
+          } else {  // stripes + a little noise
+            s2 = s2 * 1664525u + 1013904223u;
+            v = ((x / 16 + y / 24) & 1 ? 0.75f : 0.25f) + ((s2 >> 24) / 255.0f - 0.5f) * 0.02f;
+          }
+          row[x] = std::floor(std::min(1.0f, std::max(0.0f, v)) * levels + 0.5f) / levels;
+        }
+      }
+      all.emplace_back(std::move(pl));
+    }
+    JXL_RETURN_IF_ERROR(ib.SetExtraChannels(std::move(all)));
+  }
   CompressParams cparams;
   cparams.butteraugli_distance = distance;
   cparams.speed_tier = static_cast<SpeedTier>(speed_tier);
@@ -357,6 +404,14 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   JXL_RETURN_IF_ERROR(fd.SetImageOutput(PixelCallback(), out->rgb.data(), out->rgb.size() * sizeof(float), xs, ys,
                                         JxlPixelFormat{nch, JXL_TYPE_FLOAT, JXL_NATIVE_ENDIAN, 0}, 32,
                                         /*unpremul_alpha=*/false, /*undo_orientation=*/false));
+  if (num_more) {  // one entry per extra channel, in order (decode.cc:1477-1490); the alpha channel rides in the main output
+    out->extra.assign(static_cast<size_t>(xs) * ys * num_more, 0.0f);
+    const JxlPixelFormat one{1, JXL_TYPE_FLOAT, JXL_NATIVE_ENDIAN, 0};
+    if (alpha_bits) JXL_RETURN_IF_ERROR(fd.AddExtraChannelOutput(nullptr, 0, xs, one, 32));
+    for (uint32_t i = 0; i < num_more; i++)
+      JXL_RETURN_IF_ERROR(fd.AddExtraChannelOutput(out->extra.data() + static_cast<size_t>(xs) * ys * i,
+                                                   static_cast<size_t>(xs) * ys * sizeof(float), xs, one, 32));
+  }
   const size_t header_bytes = reader.TotalBitsConsumed() / kBitsPerByte;
   JXL_RETURN_IF_ERROR(reader.Close());
   out->sections_offset = out->frame_offset + header_bytes;
@@ -513,7 +568,7 @@ JXR_EXPORT void jxr_real_case_destroy(void* h) { delete static_cast<RealCase*>(h
 
 // what = 0 codestream, 1 acs, 2 raw_quant, 3 sharpness, 4 ytox, 5 ytob, 6..8 dc x/y/b, 9 quant_dc,
 // 10 block-ctx-map bytes, 11 rgb, 12 section offsets (u64), 13 section sizes (u64), 14 frame params,
-// 15 dequant table, 16 alpha (JXR_ALPHA)
+// 15 dequant table, 16 alpha (JXR_ALPHA), 17 the other extra channels (JXR_EXTRA)
 JXR_EXPORT const void* jxr_real_case_data(void* h, int what, size_t* bytes) {
   RealCase* c = static_cast<RealCase*>(h);
   auto ret = [&](const void* p, size_t n) {
@@ -536,6 +591,7 @@ JXR_EXPORT const void* jxr_real_case_data(void* h, int what, size_t* bytes) {
     case 14: return ret(&c->params, sizeof(c->params));
     case 15: return ret(c->dequant.data(), c->dequant.size() * 4);
     case 16: return ret(c->alpha.data(), c->alpha.size() * 4);
+    case 17: return ret(c->extra.data(), c->extra.size() * 4);
     default: *bytes = 0; return static_cast<const void*>(nullptr);
   }
 }

@@ -45,6 +45,9 @@ def ref(oracle):
 def stream(ref, original=None, orientation=None, **kw):
     """A genuine VarDCT codestream from the reference encoder; `original` = what the stream says its original was."""
     old = {k: os.environ.get(k) for k in ("JXR_ORIGINAL", "JXR_ORIENTATION")}
+    if isinstance(kw.get("icc"), str):  # "rgb" | "grey": a display profile made on the spot (tests/test_icc.py)
+        from test_icc import make_profile
+        kw = dict(kw, icc=make_profile(kw["icc"] == "grey", 1024))
     try:
         for k, v in (("JXR_ORIGINAL", original), ("JXR_ORIENTATION", orientation)):
             if v is None:
@@ -201,9 +204,6 @@ CASES = [
 def test_djxl_on_the_hip_backend_writes_what_djxl_writes(tools, ref, tmp_path, kw, original, orientation, outputs):
     djxl_ref, djxl_hip = tools
     jxl = tmp_path / "a.jxl"
-    if kw.get("icc"):
-        from test_icc import make_profile
-        kw = dict(kw, icc=make_profile(kw["icc"] == "grey", 1024))
     jxl.write_bytes(stream(ref, original=original, orientation=orientation, **kw))
     for ext in outputs:
         for threads in (("--num_threads", "0"), ()) if ext == outputs[0] else ((),):

@@ -32,19 +32,26 @@ def L():
 
 
 def decode_alpha_on_host(L, rs, direct=False):
-    """The product's host parsers only; returns (alpha plane, image header, frame header).  direct: the groups write
-    their float samples straight into the plane (jxlhip_modular_ac_group_decode_f32) instead of being collected in
-    the frame's int32 image and converted at the end."""
+    planes, ih, fh = decode_extra_on_host(L, rs, direct)
+    assert len(planes) == 1
+    return planes[0], ih, fh
+
+
+def decode_extra_on_host(L, rs, direct=False):
+    """The product's host parsers only; returns (the extra channels' planes, image header, frame header).  direct: the
+    groups write their float samples straight into the planes (jxlhip_modular_ac_group_decode_f32) instead of being
+    collected in the frame's int32 image and converted at the end."""
     cs = np.ascontiguousarray(rs.codestream)
     base, n = cs.ctypes.data, len(cs)
     ih, pos = abi.ImageHeader(), C.c_size_t(0)
     extra = (abi.ExtraChannel * 4)()
     assert L.jxlhip_image_header_decode(base, n, C.byref(pos), extra, 4, C.byref(ih)) == 0
-    assert ih.num_extra_channels == 1 and extra[0].type == 0  # JXLHIP_EC_ALPHA
+    nec = ih.num_extra_channels
+    assert 1 <= nec <= 4
     info = abi.ImageInfo(ih.xsize, ih.ysize, ih.xyb_encoded, ih.num_extra_channels, None, 0, 0, 0)
     fh = abi.FrameHeader()
     assert L.jxlhip_frame_header_decode(base, n, C.byref(pos), C.byref(info), C.byref(fh)) == 0
-    assert fh.num_extra_channels == 1 and fh.ec_upsampling[0] == 1
+    assert fh.num_extra_channels == nec and all(fh.ec_upsampling[i] == 1 for i in range(nec))
     nt = int(fh.num_toc_entries)
     off, sz, total = np.zeros(nt, np.uint64), np.zeros(nt, np.uint32), C.c_uint64(0)
     assert L.jxlhip_toc_decode(base, n, C.byref(pos), nt, off.ctypes.data, sz.ctypes.data, C.byref(total)) == 0
@@ -93,10 +100,10 @@ def decode_alpha_on_host(L, rs, direct=False):
                                              C.byref(bits)) == 0
         scratch = [np.zeros(65536, np.int32) for _ in range(3)]
         ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in scratch])
-        alpha = np.full((fh.ysize, fh.xsize), -1.0, np.float32)
+        alpha = np.full((nec, fh.ysize, fh.xsize), -1.0, np.float32)
         in_groups = fh.xsize > fh.group_dim or fh.ysize > fh.group_dim
-        ec_bits = (C.c_uint32 * 4)(extra[0].bit_depth.bits_per_sample, 8, 8, 8)
-        planes = (C.c_void_p * 4)(alpha.ctypes.data, None, None, None)
+        ec_bits = (C.c_uint32 * 4)(*[extra[i].bit_depth.bits_per_sample if i < nec else 8 for i in range(4)])
+        planes = (C.c_void_p * 4)(*[alpha[i].ctypes.data if i < nec else None for i in range(4)])
         for g in range(ng):
             for ps in range(npass):
                 d = s0 if single else sections[2 + ndc + ps * ng + g]
@@ -111,9 +118,10 @@ def decode_alpha_on_host(L, rs, direct=False):
                 else:
                     assert L.jxlhip_modular_ac_group_decode(tree, C.byref(fh), g, ps, d.ctypes.data, len(d), C.byref(gp)) == 0
                 assert (gp.value + 7) // 8 == len(d), (g, ps, gp.value, len(d))  # the section is consumed exactly
-        rc = L.jxlhip_modular_extra_channel_f32(tree, 0, extra[0].bit_depth.bits_per_sample, ih.bit_depth.bits_per_sample,
-                                                alpha.ctypes.data, fh.xsize) if not (direct and in_groups) else 0
-        assert rc == 0
+        if not (direct and in_groups):
+            for i in range(nec):
+                assert L.jxlhip_modular_extra_channel_f32(tree, i, extra[i].bit_depth.bits_per_sample,
+                                                          ih.bit_depth.bits_per_sample, alpha[i].ctypes.data, fh.xsize) == 0
         if direct and in_groups:  # the int32 image was never allocated: the collecting reader says so
             tmp = np.zeros((fh.ysize, fh.xsize), np.float32)
             assert L.jxlhip_modular_extra_channel_f32(tree, 0, 8, 8, tmp.ctypes.data, fh.xsize) == -6  # JXLHIP_ERR_STATE
@@ -152,6 +160,39 @@ def test_alpha_plane_from_the_codestream_bytes(L, ref, kw, direct):
     rs = ref.RealStream(seed=29, **dict(dict(distance=1.0, speed_tier=3), **kw))
     alpha, ih, fh = decode_alpha_on_host(L, rs, direct)
     assert np.array_equal(alpha, rs.alpha), float(np.abs(alpha - rs.alpha).max())
+
+
+MULTI = [
+    # (stream, direct): alpha + depth (16 bit) / thermal (8 bit) / optional (12 bit) channels, or no alpha at all
+    (dict(xsize=520, ysize=300, alpha_bits=8, extra=1), False),
+    (dict(xsize=520, ysize=300, alpha_bits=8, extra=3), True),
+    (dict(xsize=520, ysize=300, extra=2), True),
+    (dict(xsize=200, ysize=120, alpha_bits=16, extra=3), False),
+    (dict(xsize=520, ysize=300, alpha_bits=8, extra=3, original="srgb8"), True),
+    # squeezed: with three or more channels the default sequence halves the 2nd and 3rd both ways first, residuals at
+    # the END of the channel list (the 4:2:0-preview branch of DefaultSqueezeParameters)
+    (dict(xsize=520, ysize=300, alpha_bits=8, extra=2, progressive=1, distance=2.0), False),
+    (dict(xsize=520, ysize=300, alpha_bits=8, extra=3, progressive=1, distance=2.0), False),
+    (dict(xsize=2200, ysize=264, extra=3, progressive=2, speed_tier=4), False),
+]
+
+
+def reference_planes(rs, kw):
+    want = [rs.alpha.reshape(kw["ysize"], kw["xsize"])] if kw.get("alpha_bits") else []
+    more = rs.extra.reshape(-1, kw["ysize"], kw["xsize"])
+    return want + [more[i] for i in range(more.shape[0])]
+
+
+@pytest.mark.parametrize("kw,direct", MULTI)
+def test_several_extra_channels(L, ref, kw, direct):
+    """Every extra channel of the image, bit-exact against the planes the reference decoder hands out through
+    extra-channel buffers (JxlDecoderSetExtraChannelBuffer's path, stage_write.cc)."""
+    rs = ref.RealStream(seed=29, **kw)
+    planes, ih, fh = decode_extra_on_host(L, rs, direct)
+    want = reference_planes(rs, kw)
+    assert len(planes) == len(want)
+    for i, w in enumerate(want):
+        assert np.array_equal(planes[i], w), (i, float(np.abs(planes[i] - w).max()))
 
 
 SQUEEZED = [
@@ -319,3 +360,61 @@ def test_damaged_modular_bytes_never_crash(L, ref):
         except AssertionError:
             outcomes["refused"] += 1
     assert outcomes["refused"] > 20, outcomes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(xsize=520, ysize=300, alpha_bits=8, extra=3),
+                                dict(xsize=2200, ysize=520, extra=2, speed_tier=4),
+                                dict(xsize=200, ysize=120, alpha_bits=16, extra=1),
+                                dict(xsize=776, ysize=520, alpha_bits=8, extra=3, progressive=1, distance=2.0)])
+@pytest.mark.parametrize("workers", [0, 5])
+def test_extra_channel_planes_of_the_codestream_decoder(L, ref, kw, workers):
+    """jxlhip_decode_codestream_extra: the image's extra channels as float planes in host memory next to the pixels on
+    the device -- exactly the reference decoder's planes; an alpha channel asked for as a plane AND in an RGBA output."""
+    import torch
+    from libjxl_amd import VarDctDecoder
+    rs = ref.RealStream(seed=37, **kw)
+    cs = rs.codestream.tobytes()
+    want = reference_planes(rs, kw)
+    W, H = kw["xsize"], kw["ysize"]
+    R = C.CDLL(abi.runner_library_path())
+    R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    pool = R.JxlThreadParallelRunnerCreate(None, workers) if workers else None
+    runner = C.cast(R.JxlThreadParallelRunner, C.c_void_p) if workers else None
+    dec = VarDctDecoder(0)
+    try:
+        stride = W + 24
+        for rgba in (True, False):
+            planes = np.full((len(want), H, stride), -3.0, np.float32)
+            ptrs = (C.c_void_p * 4)(*[planes[i].ctypes.data if i < len(want) else None for i in range(4)])
+            if len(want) > 2:
+                ptrs[1] = None  # one channel not wanted
+            nc = 4 if rgba else 3
+            fmt = abi.OutputFormat(0, 0, nc, 32, 0, 0.0, (C.c_float * 3)(0.2126, 0.7152, 0.0722))
+            out = torch.full((H, W, nc), -7.0, dtype=torch.float32, device="cuda")
+            info = abi.CodestreamInfo()
+            rc = L.jxlhip_decode_codestream_extra(dec.ctx, runner, pool, cs, len(cs), 2, C.byref(fmt), out.data_ptr(), W * nc * 4, 0,
+                                                  ptrs, 4, stride, C.byref(info))
+            assert rc == 0, L.jxlhip_last_error(dec.ctx)
+            assert info.num_extra_channels == len(want)
+            for i, w in enumerate(want):
+                if len(want) > 2 and i == 1:
+                    assert np.all(planes[i] == -3.0)
+                    continue
+                assert np.array_equal(planes[i][:, :W], w), (rgba, i)
+                assert np.all(planes[i][:, W:] == -3.0)
+            got = out.cpu().numpy()
+            assert float(np.abs(got[..., :3] - rs.rgb).max()) <= 2e-5 * max(1.0, float(np.abs(rs.rgb).max()))
+            if rgba:
+                a = want[0] if kw.get("alpha_bits") else np.ones((H, W), np.float32)
+                assert np.array_equal(got[..., 3], a)
+        # a stride below the width
+        bad = L.jxlhip_decode_codestream_extra(dec.ctx, runner, pool, cs, len(cs), 2, C.byref(fmt), out.data_ptr(), W * nc * 4, 0,
+                                               ptrs, 4, W - 1, None)
+        assert bad == -1
+    finally:
+        dec.close()
+        if pool:
+            R.JxlThreadParallelRunnerDestroy(pool)
