@@ -146,6 +146,7 @@ typedef struct jxlhip_image_info {
   uint32_t have_animation;        /* ImageMetadata::have_animation */
   uint32_t have_timecodes;        /* AnimationHeader::have_timecodes */
   uint32_t is_preview;            /* FrameHeader::nonserialized_is_preview */
+  uint32_t bits_per_sample;       /* ImageMetadata::bit_depth.bits_per_sample: lands in jxlhip_frame_header::image_bits */
 } jxlhip_image_info;
 
 enum { JXLHIP_FRAME_REGULAR = 0, JXLHIP_FRAME_DC = 1, JXLHIP_FRAME_REFERENCE_ONLY = 2, JXLHIP_FRAME_SKIP_PROGRESSIVE = 3 };
@@ -190,6 +191,9 @@ typedef struct jxlhip_frame_header {
      each at the frame's own resolution (ec_upsampling == upsampling == 1); JXLHIP_ERR_UNSUPPORTED otherwise */
   uint32_t num_extra_channels;
   uint32_t ec_upsampling[4];   /* FrameHeader::extra_channel_upsampling of the first four (dim_shift applied) */
+  uint32_t image_bits;         /* jxlhip_image_info::bits_per_sample (the Modular Image's bitdepth: the implicit entries
+                                  of multi-channel palettes scale with it, palette.h:53-122); 0 = not given: such a
+                                  palette is then JXLHIP_ERR_UNSUPPORTED */
 } jxlhip_frame_header;
 
 /* ReadFrameHeader (frame_header.cc:212-215): reads the header at bit *bit_pos of data (advanced to
@@ -223,9 +227,9 @@ JXLHIP_EXPORT int jxlhip_dc_global_decode(const uint8_t* data, size_t size, size
  * (modular/encoding/encoding.cc:553-680) and the property / predictor definitions of
  * modular/encoding/context_predict.h, the self-correcting predictor included.
  * JXLHIP_ERR_UNSUPPORTED for what libjxl's encoder does not write into these streams: transforms
- * (RCT, multi-channel / delta palettes; single-channel palettes and the squeeze of the extra channels' global image
- * are taken, see jxlhip_modular_groups_are_final), LZ77 with 2-D distances; also for chroma subsampling and DC
- * frames. */
+ * (RCT, delta palettes; palettes without deltas -- over one channel or several -- and the squeeze of the extra
+ * channels' global image are taken, see jxlhip_modular_groups_are_final), LZ77 with 2-D distances; also for chroma
+ * subsampling and DC frames. */
 typedef struct jxlhip_modular_tree jxlhip_modular_tree;
 
 /* The rest of the DC-global section behind jxlhip_dc_global_decode: *tree receives the global MA
@@ -263,7 +267,7 @@ JXLHIP_EXPORT int jxlhip_modular_ac_group_decode_f32_strided(jxlhip_modular_tree
  * them out); 0: the global image carries transforms that need every group first -- a squeeze (Haar-like pyramid with
  * a smoothness term, modular/transform/squeeze.cc; what `cjxl -p` applies to extra channels: their 1:8 and smaller
  * levels then sit in the DC groups, which jxlhip_dc_group_decode reads into the handle, the finer ones in the AC
- * groups pass by pass) or a palette of a palette: collect with jxlhip_modular_ac_group_decode, then
+ * groups pass by pass), one palette over several channels, or a palette of a palette: collect with jxlhip_modular_ac_group_decode, then
  * jxlhip_modular_extra_channel_f32 undoes them.  A NULL tree (no extra channels) is 1. */
 JXLHIP_EXPORT int jxlhip_modular_groups_are_final(const jxlhip_modular_tree* tree);
 /* Once every group is in: extra channel `ec` as float samples, out[y * stride_floats + x] = v / (2^ec_bits - 1)

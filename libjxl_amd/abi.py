@@ -71,7 +71,7 @@ class ImageInfo(C.Structure):
     """jxlhip_image_info (include/jxl_hip_frame.h)."""
     _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32), ("xyb_encoded", C.c_uint32),
                 ("num_extra_channels", C.c_uint32), ("ec_dim_shift", C.c_void_p), ("have_animation", C.c_uint32),
-                ("have_timecodes", C.c_uint32), ("is_preview", C.c_uint32)]
+                ("have_timecodes", C.c_uint32), ("is_preview", C.c_uint32), ("bits_per_sample", C.c_uint32)]
 
 
 class BitDepth(C.Structure):
@@ -133,7 +133,7 @@ class FrameHeader(C.Structure):
                 ("group_dim", C.c_uint32), ("xsize_groups", C.c_uint32), ("ysize_groups", C.c_uint32),
                 ("num_groups", C.c_uint64), ("num_dc_groups", C.c_uint64), ("num_toc_entries", C.c_uint64),
                 ("x_dm_multiplier", C.c_float), ("b_dm_multiplier", C.c_float),
-                ("num_extra_channels", C.c_uint32), ("ec_upsampling", C.c_uint32 * 4)]
+                ("num_extra_channels", C.c_uint32), ("ec_upsampling", C.c_uint32 * 4), ("image_bits", C.c_uint32)]
 
 
 class CodestreamInfo(C.Structure):

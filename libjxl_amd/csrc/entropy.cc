@@ -1482,6 +1482,7 @@ int jxlhip_frame_header_decode(const uint8_t* data, size_t size, size_t* bit_pos
   h->b_qm_scale = 2;
   h->num_passes = 1;
   for (uint32_t& u : h->ec_upsampling) u = 1;
+  h->image_bits = im->bits_per_sample;
   h->is_last = 1;
   h->color_transform = JXLHIP_CT_XYB;
   const bool xyb = im->xyb_encoded != 0;

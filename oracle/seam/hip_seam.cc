@@ -236,6 +236,7 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     mfh.num_groups = dim.num_groups;
     mfh.num_dc_groups = dim.num_dc_groups;
     mfh.num_extra_channels = md.num_extra_channels;
+    mfh.image_bits = md.bit_depth.bits_per_sample;
     for (size_t i = 0; i < md.num_extra_channels; i++) mfh.ec_upsampling[i] = fh.extra_channel_upsampling[i];
     jxlhip_dc_global dcg;
     size_t mpos = 0;

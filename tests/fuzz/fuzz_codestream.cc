@@ -53,7 +53,7 @@ bool Chain(const Bytes& cs) {
   for (uint32_t i = 0; i < ih.num_extra_channels && i < 4; i++) shifts[i] = (uint8_t)ec[i].dim_shift;
   if (ih.num_extra_channels > 4) return false;
   jxlhip_image_info info = {ih.xsize, ih.ysize, ih.xyb_encoded, ih.num_extra_channels, shifts,
-                            ih.have_animation, ih.have_timecodes, 0};
+                            ih.have_animation, ih.have_timecodes, 0, ih.bit_depth.bits_per_sample};
   jxlhip_frame_header fh;
   if (jxlhip_frame_header_decode(all.p, all.n, &pos, &info, &fh) != JXLHIP_OK) return false;
   if (fh.num_toc_entries == 0 || fh.num_toc_entries > 4096) return false;
@@ -110,7 +110,8 @@ bool Chain(const Bytes& cs) {
       (void)jxlhip_modular_ac_group_decode(tree, &fh, g, 0, sg.p, sg.n, &gp);
     }
     std::vector<float> plane((size_t)fh.xsize * fh.ysize);
-    (void)jxlhip_modular_extra_channel_f32(tree, 0, 8, 8, plane.data(), fh.xsize);
+    for (uint32_t e = 0; e < fh.num_extra_channels; e++)
+      (void)jxlhip_modular_extra_channel_f32(tree, e, 8, ih.bit_depth.bits_per_sample, plane.data(), fh.xsize);
   }
   jxlhip_modular_tree_destroy(tree);
   return ok;

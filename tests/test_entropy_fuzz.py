@@ -90,7 +90,9 @@ def test_damaged_codestreams_through_the_front_end_chain_under_asan_ubsan(oracle
                             dict(xsize=520, ysize=136, seed=5, distance=0.5, speed_tier=2, progressive=1),
                             dict(xsize=264, ysize=200, seed=6, distance=2.0, icc="profile"),  # an ICC original
                             dict(xsize=520, ysize=300, seed=7, distance=2.0, alpha_bits=8),
-                            dict(xsize=2200, ysize=264, seed=8, distance=2.0, alpha_bits=8, progressive=1, speed_tier=4)]):  # squeezed alpha
+                            dict(xsize=2200, ysize=264, seed=8, distance=2.0, alpha_bits=8, progressive=1, speed_tier=4),  # squeezed alpha
+                            dict(xsize=520, ysize=513, seed=480, speed_tier=4, alpha_bits=8, alpha_levels=5, extra=3,
+                                 original="srgb16")]):  # one palette over four extra channels
         if kw.get("icc"):
             from test_icc import extra_tags, make_profile
             kw["icc"] = make_profile(False, 300, extra_tags(np.random.default_rng(1)))

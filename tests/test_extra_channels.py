@@ -48,7 +48,7 @@ def decode_extra_on_host(L, rs, direct=False):
     assert L.jxlhip_image_header_decode(base, n, C.byref(pos), extra, 4, C.byref(ih)) == 0
     nec = ih.num_extra_channels
     assert 1 <= nec <= 4
-    info = abi.ImageInfo(ih.xsize, ih.ysize, ih.xyb_encoded, ih.num_extra_channels, None, 0, 0, 0)
+    info = abi.ImageInfo(ih.xsize, ih.ysize, ih.xyb_encoded, ih.num_extra_channels, None, 0, 0, 0, ih.bit_depth.bits_per_sample)
     fh = abi.FrameHeader()
     assert L.jxlhip_frame_header_decode(base, n, C.byref(pos), C.byref(info), C.byref(fh)) == 0
     assert fh.num_extra_channels == nec and all(fh.ec_upsampling[i] == 1 for i in range(nec))
@@ -174,6 +174,10 @@ MULTI = [
     (dict(xsize=520, ysize=300, alpha_bits=8, extra=2, progressive=1, distance=2.0), False),
     (dict(xsize=520, ysize=300, alpha_bits=8, extra=3, progressive=1, distance=2.0), False),
     (dict(xsize=2200, ysize=264, extra=3, progressive=2, speed_tier=4), False),
+    # four channels with few value combinations: the encoder writes ONE palette over all of them (num_c = 4, implicit
+    # colour-cube entries included) and leaves a single index channel to the groups
+    (dict(xsize=520, ysize=513, seed=480, speed_tier=4, alpha_bits=8, alpha_levels=5, extra=3, original="srgb16"), False),
+    (dict(xsize=257, ysize=776, seed=847, distance=4.0, speed_tier=4, extra=3, original="srgb16"), False),
 ]
 
 
@@ -187,7 +191,7 @@ def reference_planes(rs, kw):
 def test_several_extra_channels(L, ref, kw, direct):
     """Every extra channel of the image, bit-exact against the planes the reference decoder hands out through
     extra-channel buffers (JxlDecoderSetExtraChannelBuffer's path, stage_write.cc)."""
-    rs = ref.RealStream(seed=29, **kw)
+    rs = ref.RealStream(**dict(dict(seed=29), **kw))
     planes, ih, fh = decode_extra_on_host(L, rs, direct)
     want = reference_planes(rs, kw)
     assert len(planes) == len(want)
@@ -202,6 +206,10 @@ SQUEEZED = [
     dict(xsize=2200, ysize=264, alpha_bits=16, progressive=1, speed_tier=4),      # a 275 x 33 level: in the DC groups
     dict(xsize=777, ysize=1033, alpha_bits=8, progressive=2, original="srgb8"),   # tall: vertical split first
     dict(xsize=520, ysize=300, alpha_bits=8, alpha_levels=2, progressive=1, original="srgb8"),  # palette, then squeeze
+    # wider than a group, yet every level fits one: all of it sits in the global section, STAYS squeezed until the end,
+    # and the groups find nothing of theirs in the list
+    dict(xsize=257, ysize=64, alpha_bits=16, alpha_levels=2, progressive=1, distance=0.5),
+    dict(xsize=97, ysize=300, alpha_bits=8, alpha_levels=5, progressive=2, distance=4.0, speed_tier=4),
 ]
 
 

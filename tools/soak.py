@@ -1,6 +1,7 @@
 """GPU box: a randomized soak of the whole-file path.  N genuine streams from the reference encoder (random size,
-distance, effort, EPF setting, progressive mode, alpha on / off, sRGB or float original) through
-jxlhip_decode_codestream -- ONE context for all of them, random worker counts, RGB float and RGBA8 outputs --
+distance, effort, EPF setting, progressive mode -- extra channels then squeezed --, alpha on / off, up to three more
+extra channels, sRGB / float / ICC original) through jxlhip_decode_codestream_extra -- ONE context for all of them,
+random worker counts, RGB float and RGBA8 outputs, every extra channel as a host plane --
 against the pixels the reference decoder produced for the same bytes.  usage: python tools/soak.py [N] [seed]"""
 import ctypes as C
 import random
@@ -31,11 +32,19 @@ for i in range(N):
               seed=rng.randrange(1000), distance=rng.choice((0.5, 1.0, 1.0, 2.0, 4.0)), speed_tier=rng.choice((3, 4, 5, 7)),
               epf=rng.choice((-1, -1, 0, 1, 2, 3)), progressive=rng.choice((0, 0, 0, 1, 2)))
     alpha = rng.random() < 0.5
-    if alpha:
-        kw.update(alpha_bits=rng.choice((8, 16)), alpha_levels=rng.choice((0, 0, 2, 5)), progressive=0)
+    if alpha:  # (with a progressive mode the extra channels are squeezed)
+        kw.update(alpha_bits=rng.choice((8, 16)), alpha_levels=rng.choice((0, 0, 2, 5)))
+    more = rng.choice((0, 0, 0, 1, 3))  # extra channels behind the alpha channel: depth / thermal / optional
+    if more:
+        kw["extra"] = more
     original = rng.choice((None, "srgb8", "srgb16"))
     if original:
         kw["original"] = original
+    icc = rng.random() < 0.15  # an ICC original: both decoders (no CMS) write linear sRGB
+    if icc:
+        sys.path.insert(0, "tests")
+        from test_icc import make_profile
+        kw["icc"] = make_profile(False, rng.choice((1, 256, 1024)))
     try:
         rs = oracle.RealStream(**kw)
     except ValueError:
@@ -45,14 +54,22 @@ for i in range(N):
     W, H = kw["xsize"], kw["ysize"]
     w = rng.choice((0, 3, 8, 24))
     args = (runner, pools[w]) if w else (None, None)
-    encoded = original is not None
+    encoded = original is not None and not icc
     scale = max(1.0, float(np.abs(rs.rgb).max()))
     msgs = []
     # float RGB(A) in the space the reference wrote
     nch = 4 if alpha else rng.choice((3, 4))
     fmt = abi.OutputFormat(1 if encoded else 0, 0, nch, 32, 0, 0.0, lum)
     out = torch.full((H, W, nch), -7.0, dtype=torch.float32, device="cuda")
-    rc = L.jxlhip_decode_codestream(dec.ctx, *args, cs, len(cs), 2, C.byref(fmt), out.data_ptr(), W * 4 * nch, 0, None)
+    planes = np.full((4, H, W), -3.0, np.float32)
+    ptrs = (C.c_void_p * 4)(*[planes[k].ctypes.data for k in range(4)])
+    rc = L.jxlhip_decode_codestream_extra(dec.ctx, *args, cs, len(cs), 2, C.byref(fmt), out.data_ptr(), W * 4 * nch, 0,
+                                          ptrs, 4, W, None)
+    if not rc:
+        want_planes = ([rs.alpha.reshape(H, W)] if alpha else []) + list(rs.extra.reshape(-1, H, W))
+        for k, wp in enumerate(want_planes):
+            if not np.array_equal(planes[k], wp):
+                msgs.append("extra channel %d differs" % k)
     if rc:
         msgs.append("rc %d %s" % (rc, L.jxlhip_last_error(dec.ctx).decode()))
     else:
@@ -79,6 +96,8 @@ for i in range(N):
             msgs.append("u8 alpha differs")
     if msgs:
         bad += 1
+    if "icc" in kw:
+        kw["icc"] = "%d bytes" % len(kw["icc"])
     print(i, "FAIL" if msgs else "ok", kw, "workers", w, msgs, flush=True)
 dec.close()
 print("soak: %d streams, %d failed" % (N, bad))
