@@ -270,6 +270,9 @@ JXLHIP_EXPORT int jxlhip_modular_ac_group_decode_f32_strided(jxlhip_modular_tree
  * groups pass by pass), one palette over several channels, or a palette of a palette: collect with jxlhip_modular_ac_group_decode, then
  * jxlhip_modular_extra_channel_f32 undoes them.  A NULL tree (no extra channels) is 1. */
 JXLHIP_EXPORT int jxlhip_modular_groups_are_final(const jxlhip_modular_tree* tree);
+/* 1: part of the extra channels is coded in the DC groups (a squeezed image): a caller that does not run
+ * jxlhip_dc_group_decode with this handle cannot complete them. */
+JXLHIP_EXPORT int jxlhip_modular_uses_dc_groups(const jxlhip_modular_tree* tree);
 /* Once every group is in: extra channel `ec` as float samples, out[y * stride_floats + x] = v / (2^ec_bits - 1)
  * (FinalizeDecoding + ModularImageToDecodedRect, dec_modular.cc:686-737,739-760; image_bits = the IMAGE's
  * bits_per_sample, which picks the float or the double multiply, :726-731).  The first call undoes the global

@@ -246,7 +246,7 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     JXL_RETURN_IF_ERROR(check(rc, "modular global"));
     // squeezed (progressive) extra channels: their coarse levels came with the DC groups, which libjxl has already
     // taken in -- the product's front-end reads them in jxlhip_dc_group_decode (jxlhip_decode_codestream), not here
-    if (!jxlhip_modular_groups_are_final(mtree.t)) return decline("squeezed extra channels (levels in the DC groups)");
+    if (jxlhip_modular_uses_dc_groups(mtree.t)) return decline("squeezed extra channels (levels in the DC groups)");
   }
   // ---- per-frame parameters
   jxlhip_frame_params p = {};
@@ -380,7 +380,8 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
     std::atomic<int> status{JXLHIP_OK};
     // Alpha for the main output only, in a channel larger than a group: the groups' threads write the float samples
     // straight into the context's pinned plane.  Otherwise the samples are collected and converted below.
-    const bool direct = alpha_in_main && !extra_buffers && (dim.xsize > dim.group_dim || dim.ysize > dim.group_dim);
+    const bool direct = alpha_in_main && !extra_buffers && (dim.xsize > dim.group_dim || dim.ysize > dim.group_dim) &&
+                        jxlhip_modular_groups_are_final(mtree.t);
     float* staging = nullptr;
     size_t staging_stride = 0;
     uint32_t ec_bits[4] = {8, 8, 8, 8};

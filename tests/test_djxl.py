@@ -193,6 +193,8 @@ CASES = [
     # seam hands out the first sample of every pixel
     (dict(seed=13, xsize=520, ysize=300, distance=1.0, speed_tier=3), "gray8", None, ("pgm", "npy", "pfm")),
     (dict(seed=14, xsize=456, ysize=280, distance=1.5, speed_tier=4, alpha_bits=8), "gray8", 6, ("pam", "npy", "pgm")),
+    # alpha + three more extra channels under ONE palette: .npy carries all seven channels (extra-channel buffers)
+    (dict(seed=480, xsize=520, ysize=513, speed_tier=4, alpha_bits=8, alpha_levels=5, extra=3), "srgb16", None, ("npy", "ppm")),
     # ICC originals (8-bit samples): no CMS in either build, so both write linear sRGB (dec_xyb.cc:160-164)
     (dict(seed=15, xsize=520, ysize=300, distance=1.0, speed_tier=3, icc="rgb"), "srgb8", None, ("ppm", "npy", "pfm")),
     (dict(seed=16, xsize=456, ysize=280, distance=1.5, speed_tier=4, icc="grey", alpha_bits=8), "gray8", None, ("pam", "npy")),

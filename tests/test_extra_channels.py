@@ -241,6 +241,7 @@ def test_squeezed_channels_are_not_final_group_by_group(L, ref):
     assert L.jxlhip_modular_global_decode(s0.ctypes.data, len(s0), C.byref(spos), C.byref(fh), C.byref(tree)) == 0
     try:
         assert L.jxlhip_modular_groups_are_final(tree) == 0 and L.jxlhip_modular_groups_are_final(None) == 1
+        assert L.jxlhip_modular_uses_dc_groups(tree) == 1 and L.jxlhip_modular_uses_dc_groups(None) == 0
         plane = np.zeros((300, 520), np.float32)
         g0 = cs[pos.value // 8 + int(off[3]):][:int(sz[3])]
         gp = C.c_size_t(0)
