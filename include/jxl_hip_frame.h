@@ -270,6 +270,18 @@ JXLHIP_EXPORT int jxlhip_modular_ac_group_decode_f32_strided(jxlhip_modular_tree
  * groups pass by pass), one palette over several channels, or a palette of a palette: collect with jxlhip_modular_ac_group_decode, then
  * jxlhip_modular_extra_channel_f32 undoes them.  A NULL tree (no extra channels) is 1. */
 JXLHIP_EXPORT int jxlhip_modular_groups_are_final(const jxlhip_modular_tree* tree);
+/* Once every group is in (collecting form): undoes the global image's transforms with the caller's threads -- every
+ * level of a squeeze pyramid spread over `runner` (a JxlParallelRunner, NULL = calling thread; 8-row / 64-column tasks
+ * like InvHSqueeze / InvVSqueeze, squeeze.cc:171-228,262-303), then the palettes.  jxlhip_modular_extra_channel_f32
+ * does the same serially on its first call; after this call it -- and the thread-safe row-range form below -- only
+ * convert.  (the runner type: include/jxl_hip_entropy.h) */
+JXLHIP_EXPORT int jxlhip_modular_finalize(jxlhip_modular_tree* tree,
+                                          int (*runner)(void*, void*, int (*)(void*, size_t), void (*)(void*, uint32_t, size_t),
+                                                        uint32_t, uint32_t),
+                                          void* runner_opaque);
+JXLHIP_EXPORT int jxlhip_modular_extra_channel_rows_f32(const jxlhip_modular_tree* tree, uint32_t ec, uint32_t ec_bits,
+                                                        uint32_t image_bits, uint32_t y0, uint32_t y1, float* out,
+                                                        size_t stride_floats);
 /* 1: part of the extra channels is coded in the DC groups (a squeezed image): a caller that does not run
  * jxlhip_dc_group_decode with this handle cannot complete them. */
 JXLHIP_EXPORT int jxlhip_modular_uses_dc_groups(const jxlhip_modular_tree* tree);

@@ -241,7 +241,8 @@ EXPORTS = [
     "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode", "jxlhip_icc_decode", "jxlhip_output_opsin_matrix",
     "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
     "jxlhip_modular_ac_group_decode", "jxlhip_modular_ac_group_decode_f32", "jxlhip_modular_extra_channel_f32",
-    "jxlhip_modular_groups_are_final", "jxlhip_modular_uses_dc_groups", "jxlhip_modular_ac_group_decode_f32_strided",
+    "jxlhip_modular_groups_are_final", "jxlhip_modular_uses_dc_groups", "jxlhip_modular_finalize",
+    "jxlhip_modular_extra_channel_rows_f32", "jxlhip_modular_ac_group_decode_f32_strided",
     # include/jxl_hip_codestream.h
     "jxlhip_codestream_basic_info", "jxlhip_decode_codestream", "jxlhip_decode_codestream_extra",
     "jxlhip_codestream_icc_profile",
@@ -299,6 +300,8 @@ def load_library():
     L.jxlhip_modular_extra_channel_f32.argtypes = [vp, u32, u32, u32, vp, sz]
     L.jxlhip_modular_groups_are_final.argtypes = [vp]
     L.jxlhip_modular_uses_dc_groups.argtypes = [vp]
+    L.jxlhip_modular_finalize.argtypes = [vp, vp, vp]
+    L.jxlhip_modular_extra_channel_rows_f32.argtypes = [vp, u32, u32, u32, u32, u32, vp, sz]
     L.jxlhip_modular_ac_group_decode_f32.argtypes = [vp, C.POINTER(FrameHeader), u32, u32, vp, sz, C.POINTER(sz), vp, u32, vp, sz]
     L.jxlhip_dc_group_decode.argtypes = [vp, vp, sz, C.POINTER(sz), C.POINTER(FrameHeader), C.c_uint32,
                                          C.POINTER(vp), C.POINTER(C.c_uint32), vp, vp, vp, vp, vp,

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>

@@ -37,7 +37,7 @@ def decode_alpha_on_host(L, rs, direct=False):
     return planes[0], ih, fh
 
 
-def decode_extra_on_host(L, rs, direct=False):
+def decode_extra_on_host(L, rs, direct=False, finalize_threads=None):
     """The product's host parsers only; returns (the extra channels' planes, image header, frame header).  direct: the
     groups write their float samples straight into the planes (jxlhip_modular_ac_group_decode_f32) instead of being
     collected in the frame's int32 image and converted at the end."""
@@ -118,7 +118,24 @@ def decode_extra_on_host(L, rs, direct=False):
                 else:
                     assert L.jxlhip_modular_ac_group_decode(tree, C.byref(fh), g, ps, d.ctypes.data, len(d), C.byref(gp)) == 0
                 assert (gp.value + 7) // 8 == len(d), (g, ps, gp.value, len(d))  # the section is consumed exactly
-        if not (direct and in_groups):
+        if finalize_threads is not None:  # the transforms undone on a thread pool, the planes in row ranges
+            R = C.CDLL(abi.runner_library_path())
+            R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+            R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+            R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+            pool = R.JxlThreadParallelRunnerCreate(None, finalize_threads) if finalize_threads else None
+            try:
+                assert L.jxlhip_modular_extra_channel_rows_f32(tree, 0, 8, 8, 0, 1, alpha[0].ctypes.data, fh.xsize) in (0, -6)
+                assert L.jxlhip_modular_finalize(tree, C.cast(R.JxlThreadParallelRunner, C.c_void_p) if pool else None, pool) == 0
+            finally:
+                if pool:
+                    R.JxlThreadParallelRunnerDestroy(pool)
+            for i in range(nec):
+                for y0 in range(0, fh.ysize, 97):
+                    assert L.jxlhip_modular_extra_channel_rows_f32(tree, i, extra[i].bit_depth.bits_per_sample,
+                                                                   ih.bit_depth.bits_per_sample, y0, min(fh.ysize, y0 + 97),
+                                                                   alpha[i].ctypes.data, fh.xsize) == 0
+        elif not (direct and in_groups):
             for i in range(nec):
                 assert L.jxlhip_modular_extra_channel_f32(tree, i, extra[i].bit_depth.bits_per_sample,
                                                           ih.bit_depth.bits_per_sample, alpha[i].ctypes.data, fh.xsize) == 0
@@ -221,6 +238,19 @@ def test_squeezed_alpha_of_progressive_streams(L, ref, kw):
     rs = ref.RealStream(seed=29, **kw)
     alpha, ih, fh = decode_alpha_on_host(L, rs, direct=False)
     assert np.array_equal(alpha, rs.alpha), float(np.abs(alpha - rs.alpha).max())
+
+
+@pytest.mark.parametrize("threads", [0, 5])
+@pytest.mark.parametrize("kw", [dict(xsize=2200, ysize=264, alpha_bits=16, progressive=1, speed_tier=4),
+                                dict(xsize=777, ysize=1033, alpha_bits=8, extra=3, progressive=2, original="srgb8"),
+                                dict(xsize=520, ysize=513, seed=480, speed_tier=4, alpha_bits=8, alpha_levels=5, extra=3, original="srgb16")])
+def test_transforms_undone_on_the_callers_threads(L, ref, kw, threads):
+    """jxlhip_modular_finalize: the squeeze pyramid (and palettes) undone with a JxlParallelRunner, every level spread
+    over its threads; then jxlhip_modular_extra_channel_rows_f32 in row ranges.  Same planes as the serial form."""
+    rs = ref.RealStream(**dict(dict(seed=29), **kw))
+    planes, ih, fh = decode_extra_on_host(L, rs, direct=False, finalize_threads=threads)
+    for i, w in enumerate(reference_planes(rs, kw)):
+        assert np.array_equal(planes[i], w), i
 
 
 def test_squeezed_channels_are_not_final_group_by_group(L, ref):
