@@ -1391,17 +1391,32 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? JXLHIP_R_WAVES : 2) void k_t
   // workgroups of the other classes in the dispatch order, so that the two kinds run side by side from the first
   // wave on -- as two launches the second waits for the first's tail, which on frames of a few Mpx is most of it
   // (1080p: blocks 39 -> ? us; the two-stream form pays ~40 us of fork / join events instead).
+  // The launch is sized for a frame of nothing but DCT8 (dct8_wgs); k_prepare's count says how many of those
+  // workgroups have work (need8).  On genuine content -- a few per cent DCT8 -- thousands of empty workgroups between
+  // the persistent ones cost more than the DCT8 blocks themselves: then only the ones with work alternate and the
+  // surplus sits at the end of the grid, leaving at once (two-phase, real-content shares: 8K 257 -> 200 us, 4K 61 ->
+  // 51 us).  With a quarter or more of the bound in use (the d1 mix: 45 %) the old placement stays: there the empty
+  // workgroups between the later persistent ones HELP (4K 39 vs 45 us; profiles/r03_dct8_workgroup_roles.txt).
   const uint32_t np = big_wgs + r_wgs;
   const uint32_t i = blockIdx.x - special_wgs;
-  const uint32_t pairs = np < dct8_wgs ? np : dct8_wgs;
+  const uint32_t need8 = (wl.count[kClsDct8 * kCounterPad] + Dct8Geom<CT>::kPerWg - 1) / Dct8Geom<CT>::kPerWg;
+#if defined(JXLHIP_DCT8_STATIC)  // (experiment builds: every workgroup of the bound alternates / only those with work)
+  const uint32_t d8 = dct8_wgs;
+#elif defined(JXLHIP_DCT8_DYNAMIC)
+  const uint32_t d8 = need8 < dct8_wgs ? need8 : dct8_wgs;
+#else
+  const uint32_t d8 = need8 * 4 < dct8_wgs ? need8 : dct8_wgs;
+#endif
+  const uint32_t pairs = np < d8 ? np : d8;
   bool is_dct8;
   uint32_t idx;
   if (i < 2 * pairs) {
     is_dct8 = (i & 1u) != 0;
     idx = i >> 1;
   } else {
-    is_dct8 = dct8_wgs > np;
+    is_dct8 = d8 > np;
     idx = i - pairs;
+    if (idx >= (is_dct8 ? d8 : np)) return;
   }
   if (is_dct8) {
     Dct8Rows<CT>(f, wl.list[kClsDct8], wl.count[kClsDct8 * kCounterPad], idx);
