@@ -9,6 +9,7 @@ bytes (oracle.RealStream(alpha_bits=...): the reference's own encoder writes the
               global with the indices in the groups: a mask); the squeezed alpha of a progressive stream is refused.
   GPU suite : jxlhip_decode_codestream with a 4-channel packed output -- RGB as before, alpha = that plane."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -37,7 +38,7 @@ def decode_alpha_on_host(L, rs, direct=False):
     return planes[0], ih, fh
 
 
-def decode_extra_on_host(L, rs, direct=False, finalize_threads=None):
+def decode_extra_on_host(L, rs, direct=False, finalize_threads=None, strict=True):
     """The product's host parsers only; returns (the extra channels' planes, image header, frame header).  direct: the
     groups write their float samples straight into the planes (jxlhip_modular_ac_group_decode_f32) instead of being
     collected in the frame's int32 image and converted at the end."""
@@ -70,7 +71,7 @@ def decode_extra_on_host(L, rs, direct=False, finalize_threads=None):
     try:
         # (libjxl's encoder ends the global stream with the ANS state of an EMPTY token list when every channel is
         # left to the groups, which no decoder reads: the section may be 4 bytes longer than what is consumed)
-        assert (spos.value + 7) // 8 <= len(s0)
+        assert not strict or (spos.value + 7) // 8 <= len(s0)
         qdc = [np.zeros(xsb * ysb, np.int32) for _ in range(3)]
         acs, rq, sharp = np.zeros(xsb * ysb, np.uint8), np.zeros(xsb * ysb, np.int32), np.zeros(xsb * ysb, np.uint8)
         cw, chh = (xsb + 7) // 8, (ysb + 7) // 8
@@ -83,9 +84,9 @@ def decode_extra_on_host(L, rs, direct=False, finalize_threads=None):
             assert L.jxlhip_dc_group_decode(tree, d.ctypes.data, len(d), C.byref(gp), C.byref(fh), g, ptrs, C.byref(ep),
                                             acs.ctypes.data, rq.ctypes.data, sharp.ctypes.data, ytox.ctypes.data,
                                             ytob.ctypes.data, C.byref(used)) == 0
-            if not single:
+            if not single and strict:
                 assert (gp.value + 7) // 8 == len(d)
-        assert np.array_equal(acs, rs.ac_strategy.ravel())
+        assert not strict or np.array_equal(acs, rs.ac_strategy.ravel())
         qctx = np.zeros(xsb * ysb, np.uint8)
         qp = (C.c_void_p * 3)(*[q.ctypes.data for q in qdc])
         assert L.jxlhip_quant_dc_contexts(C.byref(dcg.block_ctx_map), xsb * ysb, qp, qctx.ctypes.data) == 0
@@ -117,7 +118,7 @@ def decode_extra_on_host(L, rs, direct=False, finalize_threads=None):
                                                                 ec_bits, ih.bit_depth.bits_per_sample, planes, fh.xsize) == 0
                 else:
                     assert L.jxlhip_modular_ac_group_decode(tree, C.byref(fh), g, ps, d.ctypes.data, len(d), C.byref(gp)) == 0
-                assert (gp.value + 7) // 8 == len(d), (g, ps, gp.value, len(d))  # the section is consumed exactly
+                assert not strict or (gp.value + 7) // 8 == len(d), (g, ps, gp.value, len(d))  # the section is consumed exactly
         if finalize_threads is not None:  # the transforms undone on a thread pool, the planes in row ranges
             R = C.CDLL(abi.runner_library_path())
             R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
@@ -457,3 +458,62 @@ def test_extra_channel_planes_of_the_codestream_decoder(L, ref, kw, workers):
         dec.close()
         if pool:
             R.JxlThreadParallelRunnerDestroy(pool)
+
+
+def test_damaged_streams_same_verdict_as_the_reference_decoder(L, ref):
+    """Differential: genuine RGBA streams (plain, palette, squeezed, one-section) with a flipped bit or a changed byte
+    anywhere in the frame go through the reference's public JxlDecoder (oracle/_ref/libjxl_dec_ref.so) and through the
+    product's host front-end: both refuse, or both accept and hand out the same alpha plane.  (2 000 such streams were
+    run once with identical verdicts throughout; the suite keeps 80.)"""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import build_seam
+    import test_seam as S
+    try:
+        ref_so, _ = build_seam.build()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    Lr = S.load(ref_so)
+    kws = [dict(xsize=520, ysize=300, seed=29, alpha_bits=8),
+           dict(xsize=520, ysize=300, seed=29, alpha_bits=8, alpha_levels=2, original="srgb8"),
+           dict(xsize=300, ysize=280, seed=3, alpha_bits=16, progressive=1, distance=2.0),
+           dict(xsize=200, ysize=120, seed=4, alpha_bits=8)]
+    streams = [ref.RealStream(**kw) for kw in kws]
+    rng = random.Random(2026)
+
+    class Damaged:
+        pass
+    both_ok = both_bad = 0
+    for it in range(80):
+        k = it % len(streams)
+        rs = streams[k]
+        b = bytearray(rs.codestream.tobytes())
+        lo = rs.frame_offset
+        how = rng.randrange(3)
+        if how == 0:
+            for _ in range(rng.randrange(1, 3)):
+                b[rng.randrange(lo, len(b))] ^= 1 << rng.randrange(8)
+        elif how == 1:  # the first sections: DC global with the Modular global image
+            b[rng.randrange(lo, min(len(b), lo + 400))] ^= 1 << rng.randrange(8)
+        else:
+            b[rng.randrange(lo, len(b))] = rng.randrange(256)
+        data = bytes(b)
+        try:
+            want = S.jxl_decode(Lr, data, channels=4)
+        except AssertionError:
+            want = None
+        d = Damaged()
+        d.codestream = np.frombuffer(data, np.uint8).copy()
+        d.ac_strategy = rs.ac_strategy
+        try:
+            planes, _, _ = decode_extra_on_host(L, d, direct=bool(it & 1) and not kws[k].get("progressive"), strict=False)
+        except AssertionError:
+            planes = None
+        assert (want is None) == (planes is None), (it, kws[k], how)
+        if want is not None:
+            assert np.array_equal(planes[0], want[..., 3]), (it, kws[k])
+            both_ok += 1
+        else:
+            both_bad += 1
+    assert both_ok >= 3 and both_bad >= 40, (both_ok, both_bad)
