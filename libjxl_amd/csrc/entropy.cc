@@ -2193,7 +2193,7 @@ int UnpredictIcc(const std::vector<uint8_t>& enc, std::vector<uint8_t>* out) {
   cmd.end = dat.pos;
   std::vector<uint8_t>& icc = *out;
   icc.clear();
-  icc.reserve((size_t)osize);
+  icc.reserve((size_t)std::min<uint64_t>(osize, 1u << 20));  // (the claimed size is not trusted with an allocation)
   auto put32 = [&](uint64_t v) {
     if (v >> 32) return false;
     for (int s = 24; s >= 0; s -= 8) icc.push_back((uint8_t)(v >> s));
