@@ -302,6 +302,9 @@ JXLHIP_EXPORT int jxlhip_modular_extra_channel_f32(jxlhip_modular_tree* tree, ui
  *   epf_sharpness   0..7 per block
  *   ytox_map, ytob_map   int8 per 8x8 blocks, ceil(xsize_blocks/8) per row
  *   *used_acs       |= bit per strategy type seen (jxlhip_frame_params::used_acs)
+ * Between the DC image and the metadata sits the ModularDC stream (dec_frame.cc:330-337): the group's rectangle of
+ * the extra channels' sub-channels at 1:8 and below, present when their image is squeezed
+ * (jxlhip_modular_uses_dc_groups); it is read INTO the handle's image (the handle is const for everything else).
  * Safe to call from several threads for different groups. */
 JXLHIP_EXPORT int jxlhip_dc_group_decode(const jxlhip_modular_tree* global_tree, const uint8_t* data, size_t size,
                                          size_t* bit_pos, const jxlhip_frame_header* frame, uint32_t dc_group,
