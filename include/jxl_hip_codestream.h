@@ -4,17 +4,23 @@
  * What FrameDecoder does for a plain VarDCT still image, with the same order of operations (libjxl tree, lib/jxl/):
  *   container boxes (jxlc / jxlp)                       decode.cc:1639-1672 (ParseBoxHeader), 1674-2020 (HandleBoxes)
  *   signature, SizeHeader, ImageMetadata, transform data decode.cc:1049-1133  -> jxlhip_image_header_decode
+ *   the original's ICC profile                          decode.cc:1101-1130, icc_codec.cc -> jxlhip_icc_decode
  *   FrameHeader, TOC                                    dec_frame.cc:96-189  -> jxlhip_frame_header_decode, jxlhip_toc_decode
  *   ProcessDCGlobal                                     dec_frame.cc:268-302 -> jxlhip_dc_global_decode, jxlhip_modular_global_decode
  *   ProcessDCGroup on the pool                          dec_frame.cc:318-342, 660-680 -> jxlhip_dc_group_decode on the runner
  *   FinalizeDC (DequantDC + AdaptiveDCSmoothing)        dec_frame.cc:344-360, compressed_dc.cc:128-250 -> jxlhip_dequant_dc_groups (device)
  *   ProcessACGlobal                                     dec_frame.cc:372-416 -> jxlhip_ac_global_decode, jxlhip_dequant_tables (device)
  *   ProcessACGroup on the pool                          dec_frame.cc:455-560, 700-760 -> jxlhip_ac_groups_decode_submit
+ *   ... its Modular half (extra channels) + FinalizeDecoding  dec_frame.cc:497-530, dec_modular.cc:739-760
+ *                                                       -> jxlhip_modular_ac_group_decode[_f32], jxlhip_modular_finalize
  *   the render pipeline                                 dec_cache.cc:117-371 -> jxlhip_decode_frame (device)
+ * Taken: any enumerated colour encoding and ICC originals (pixels then linear sRGB, like JxlDecoder without a CMS),
+ * grey images, up to four full-resolution integer extra channels (alpha into a 4-channel output, all of them as host
+ * planes) incl. the squeeze `cjxl -p` puts on them and palettes without deltas, progressive passes, orientation.
  * Everything this front-end does not decode is refused with JXLHIP_ERR_UNSUPPORTED so that the caller can hand the
- * file to libjxl's CPU decoder: Modular-mode frames, extra channels (alpha ...), ICC profiles, animation / multiple
- * frames, previews, patches / splines / noise, chroma subsampling and YCbCr (JPEG recompression), upsampling,
- * cropped frames, DC frames, RAW dequant tables, Modular transforms inside the DC groups.
+ * file to libjxl's CPU decoder: Modular-mode frames, animation / multiple frames, previews, patches / splines / noise,
+ * chroma subsampling and YCbCr (JPEG recompression), upsampling, cropped frames, DC frames, RAW dequant tables, RCT /
+ * delta palettes in the extra channels' Modular streams.
  */
 #ifndef JXL_HIP_CODESTREAM_H_
 #define JXL_HIP_CODESTREAM_H_
