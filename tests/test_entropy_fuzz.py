@@ -63,7 +63,7 @@ def cases(oracle, tmp_path_factory):
 
 def test_damaged_streams_under_asan_ubsan(fuzzer, cases):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    iters = int(os.environ.get("JXLHIP_FUZZ_ITERS", "6000"))
+    iters = int(os.environ.get("JXLHIP_FUZZ_ITERS", "3000"))
     r = subprocess.run([fuzzer, str(iters), "20260923"] + cases, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-4000:])
     ok, rejected = map(int, r.stdout.split())
@@ -102,7 +102,7 @@ def test_damaged_codestreams_through_the_front_end_chain_under_asan_ubsan(oracle
             f.write(rs.codestream.tobytes())
         paths.append(p)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    iters = int(os.environ.get("JXLHIP_FUZZ_ITERS", "6000"))
+    iters = int(os.environ.get("JXLHIP_FUZZ_ITERS", "3000"))
     r = subprocess.run([out, str(iters), "20260924"] + paths, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-4000:])
     ok, rejected = map(int, r.stdout.split())
