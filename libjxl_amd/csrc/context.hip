@@ -55,6 +55,7 @@ struct jxlhip_ctx {
   bool have_frame = false;
   bool have_inputs = false;
   bool blocks_done = false;
+  bool tiles_on = false;     // the last LaunchBlocksBand ran k_prepare in tile mode (DevFrame::fused_tiles)
   bool blocks_fused = false;  // jxlhip_decode_blocks ran in fused-stripe mode: the planes lack the inner DCT8 blocks
   jxlhip_frame_params p{};
   DevFrame f{};
@@ -365,7 +366,7 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
     return fail(JXLHIP_ERR_HIP);
   if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kCountStride * kMaxBands) != hipSuccess ||
       hipMalloc((void**)&c->error_flag, sizeof(int32_t) * 2) != hipSuccess ||
-      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024 + 2048 + 256)) != hipSuccess ||
+      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024 + 2048 + 512)) != hipSuccess ||
       hipMalloc((void**)&c->quant_enc, sizeof(jxlhip_quant_encoding) * JXLHIP_NUM_QUANT_TABLES) != hipSuccess)
     return fail(JXLHIP_ERR_OUT_OF_MEMORY);
   if (hipMemset(c->error_flag, 0, sizeof(int32_t) * 2) != hipSuccess ||
@@ -376,9 +377,9 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
           hipSuccess)
     return fail(JXLHIP_ERR_HIP);
   {
-    float mfma_tab[2048 + 256];
+    float mfma_tab[2048 + 512];  // the 16-point table is the first half of the tile producer's pair
     MfmaDct32Constants(mfma_tab);
-    MfmaDct16Constants(mfma_tab + 2048);
+    TileProducerConstants(mfma_tab + 2048);
     if (hipMemcpy(c->tables + 1600, mfma_tab, sizeof(mfma_tab), hipMemcpyHostToDevice) != hipSuccess)
       return fail(JXLHIP_ERR_HIP);
   }
@@ -1245,6 +1246,10 @@ int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, int fuse
   f.band_g1 = g1;
   f.fused = (uint32_t)fused;
   f.cell_info = c->cell_info;
+  // whole frames through k_fused_pc: DCT8 and the 16-point classes on the producing wave's matrix cores
+  c->tiles_on = fused == 1 && FusedTilesWanted(f, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind);
+  f.fused_tiles = c->tiles_on ? 1u : 0u;
+  f.tile_tabs = c->tables + 1600 + 2048;
   {
     constexpr uint32_t kOthers32 = (1u << 8) | (1u << 9) | (1u << 10) | (1u << 11);  // 32x8 .. 16x32
     const bool lone32 = (f.used_acs & (1u << 5)) && !(f.used_acs & kOthers32);
@@ -1258,7 +1263,7 @@ int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, int fuse
                         (!(f.used_acs & (1u << 5)) || f.mfma32) && (uint64_t)f.xsize * f.ysize >= (16u << 20);
     f.mfma16 = (c->mfma > 0 || (c->mfma < 0 && lone16)) ? c->tables + 1600 + 2048 : nullptr;
   }
-  if (fused)  // every cell "from the planes" until k_prepare says otherwise
+  if (fused && !f.fused_tiles)  // every cell "from the planes" until k_prepare says otherwise (tile mode: k_prepare writes every cell)
     HIPCHK(c, hipMemsetAsync(c->cell_info, 0xFF, sizeof(uint2) * (size_t)f.xsb * f.ysb, st));
   WorkLists wl = c->wl;
   wl.count = c->counts + (size_t)band * kCountStride;
@@ -1293,6 +1298,8 @@ int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint3
   f.fy1 = fy1;
   f.fused = fused ? 1u : 0u;
   f.cell_info = c->cell_info;
+  f.fused_tiles = (fused && c->tiles_on) ? 1u : 0u;
+  f.tile_tabs = c->tables + 1600 + 2048;
   ProfBegin(c);
   if (fused) {
     if (!LaunchFused(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind, c->stream))

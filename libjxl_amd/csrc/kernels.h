@@ -79,6 +79,7 @@ bool LaunchOrient(const void* src, size_t src_stride, uint32_t xsize, uint32_t y
 // Matrix-core 32x32 IDCT (kernels_mfma.hip), opt-in through DevFrame::mfma32
 void MfmaDct32Constants(float* host /* 2048 floats */);
 void MfmaDct16Constants(float* host /* 256 floats */);
+void TileProducerConstants(float* host /* 512 floats */);
 // emit != nullptr: the frame is DCT32X32 only and has no loop filter -- the kernel writes linear float RGB to
 // emit->out itself (rows f.y0 .. f.y1) instead of XYB planes
 void LaunchMfma32(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st, const FilterParams* emit = nullptr);
@@ -89,6 +90,8 @@ void LaunchMfma16(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStr
 // filter wave itself, other classes copied from the planes).  FusedSupported: frames it takes --
 // decided before k_prepare, which routes the DCT8 blocks (DevFrame::fused).
 bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind);
+// ... with the 8- and 16-point classes decoded by its producing wave on the matrix cores (DevFrame::fused_tiles)
+bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind);
 bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,
                  hipStream_t st);
 

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   __shared__ uint16_t wave_cls[16][kNumClasses];  // per-wave class counts -> bases
   __shared__ uint32_t wg_base[kNumClasses];
   __shared__ float cell_sq[1024];                 // sigma_quant of the covering varblock
+  __shared__ uint2 cell_ci[1024];                 // tile mode: cell_info of the group's cells
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t gx = blockIdx.x % f.xsg;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   bool first = raw & 1;
   uint32_t s = raw >> 1;
   bool bad = false;
+  if (f.fused_tiles) cell_ci[tid] = make_uint2(kCellFromPlanes, 0u);
   if (s >= JXLHIP_NUM_STRATEGIES) {
     bad = valid;
     s = 0;
@@ -83,7 +85,9 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   const int cls_frame = first ? (int)kClassLut.v[s] : -1;
   const bool edge_row = f.fused == 2 && ((aby == (f.y0 >> 3) && f.group_y0 > 0) ||
                                          (aby == ((f.y1 - 1) >> 3) && f.group_y0 + f.group_rows < f.ysg));
-  const int cls = (f.fused && cls_frame == kClsDct8 && !edge_row) ? -1 : cls_frame;
+  // Tile mode (whole frames only): DCT8, DCT8X16, DCT16X8 and DCT16X16 are decoded by the fused kernel's producer
+  const int tile_kind = (f.fused_tiles && first) ? TileKindOfStrategy(s) : -1;
+  const int cls = ((f.fused && cls_frame == kClsDct8 && !edge_row) || tile_kind >= 0) ? -1 : cls_frame;
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t rank_in_wave = 0;
 #pragma unroll
@@ -124,14 +128,22 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     for (uint32_t iy = 0; iy < cy; iy++)
       for (uint32_t ix = 0; ix < cx; ix++) cell_sq[(by + iy) * gw + bx + ix] = sigma_quant;
   }
+  if (tile_kind >= 0 && in_stripe && group_ok) {  // every cell of the varblock: offset, quant / CfL word, kind and position
+    const uint32_t qc = ((uint32_t)cell_q & 0xffffu) | cell_cfl;
+    for (uint32_t iy = 0; iy < cy; iy++)
+      for (uint32_t ix = 0; ix < cx; ix++)
+        cell_ci[(by + iy) * gw + bx + ix] =
+            make_uint2(g * f.coef_stride64 + off64, qc | (((uint32_t)tile_kind | (ix << 2) | (iy << 3)) << kTileTagShift));
+  }
   __syncthreads();
+  if (f.fused_tiles && valid) f.cell_info[cell] = cell_ci[tid];
   if (in_stripe && group_ok && cls_frame >= 0) {
     WorkItem it;
     it.pos = (aby << 16) | abx;
     it.off = g * f.coef_stride64 + off64;
     it.qc = ((uint32_t)cell_q & 0xffffu) | cell_cfl;
     it.pad = 0;
-    if (f.fused && cls_frame == kClsDct8) f.cell_info[cell] = make_uint2(it.off, it.qc);
+    if (f.fused && !f.fused_tiles && cls_frame == kClsDct8) f.cell_info[cell] = make_uint2(it.off, it.qc);
     if (cls >= 0) {
       uint32_t pos = wg_base[cls] + rank_in_wave;
       for (uint32_t w = 0; w < wave; w++) pos += wave_cls[w][cls];
@@ -1472,9 +1484,10 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
       if (f.used_acs & (1u << st)) return true;
     return false;
   };
-  const bool need_r16 = any({6, 7}) || (!f.mfma16 && any({4}));
+  // tile mode: the 16-point classes are decoded inside the fused kernel (their lists stay empty)
+  const bool need_r16 = !f.fused_tiles && (any({6, 7}) || (!f.mfma16 && any({4})));
   const bool need_r32 = any({8, 9, 10, 11}) || (!f.mfma32 && any({5}));
-  const bool merged_r = need_r16 && need_r32;
+  const bool merged_r = f.fused_tiles ? need_r32 : (need_r16 && need_r32);
   const bool have_big = any({18, 19, 20});
   bool specials_in_r = false, dct8_in_r = false;
   uint32_t grid_specials = 0, grid_dct8 = 0;
@@ -1507,7 +1520,7 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     if (need_r32) hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
   }
   if (f.mfma32 && any({5})) LaunchMfma32(f, wl, cells, s1, emit);
-  if (f.mfma16 && any({4})) LaunchMfma16(f, wl, cells, s1);
+  if (f.mfma16 && any({4}) && !f.fused_tiles) LaunchMfma16(f, wl, cells, s1);
   if (cells >= 256 && any({21, 22, 23, 24, 25, 26}))
     hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, s1, f, wl.list[kClsLarge],
                        wl.count + kClsLarge * kCounterPad, wc, resample);

@@ -27,6 +27,8 @@
 // loop_filter.h:26-29); the parity tests run both.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "blocks_common.h"
 #include "filters_march.h"
 
@@ -38,6 +40,9 @@
 #endif
 #ifndef JXLHIP_FUSED_PC_DEFAULT
 #define JXLHIP_FUSED_PC_DEFAULT 1
+#endif
+#ifndef JXLHIP_TILE_SLOTS  // units of the matrix-core producer whose loads are in flight together (16-bit coefficients)
+#define JXLHIP_TILE_SLOTS 6
 #endif
 
 namespace jxlhip {
@@ -670,6 +675,361 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The producer on the MATRIX CORES (round 4): DCT8, DCT8X16, DCT16X8 and DCT16X16 -- 77 % of a d1.0 frame -- are
+// decoded by the producing wave, whatever their mix inside the window; their pixels never exist in HBM.
+//
+// A row-per-lane step (ProducePC2 above, k_transform_r) wants 8 - 16 varblocks of ONE class, and a window's block row
+// holds one or two of each 16-point class: as butterflies every class would cost a nearly empty step per block row.
+// As two dense products on v_mfma_f32_16x16x4_f32 the decode costs the same whatever the class: the wave works on
+// UNITS of one 16 x 16 coefficient tile M,
+//     pixels = L M R        (L, R: the 16-point IDCT matrix B16, or diag(B8, B8) = two 8-point IDCTs side by side)
+//   4 x DCT8      M = [[a, b], [c, d]]  (four independent blocks, any four DCT8 cells of the block row)   L = R = diag(B8, B8)
+//   2 x DCT16X8   M = [a; b]  (stored transposed, 8 x 16 each: rows = horizontal frequency)              L = diag(B8, B8), R = B16
+//   2 x DCT8X16   M = [a; b]  (8 x 16 each: rows = vertical frequency)                                     R = B16, then diag(B8, B8) from the right of the transpose
+//   1 x DCT16X16  M = the block (stored transposed)                                                        L = R = B16
+// with the lane layout of k_transform_mfma16 (kernels_mfma.hip): lane (m = lane % 16, h = lane / 16) holds M[m][4 h ..
+// 4 h + 3] -- one 8- or 16-byte load per lane and channel --, dequantises in place (dec_group.cc:115-181), product 1's
+// accumulator feeds product 2 as it stands, and the result is four consecutive pixels of one row per lane: one
+// ds_write_b128 into the slab.  The class only selects per-lane addresses, two of three preloaded dequant-table register
+// sets and which of the two constant operand tables each product takes -- data, not code.
+//
+// A varblock two block rows high is decoded once per block row it crosses and only the eight rows of the block row
+// being filled are written (stateless: the slab stays one block row x two buffers, six windows per CU as before); a
+// varblock two cells wide that straddles the window's edge is decoded whole and only its cells inside the window are
+// written.  k_prepare (DevFrame::fused_tiles) leaves in every cell such a varblock covers the varblock's coefficient
+// offset, quant / CfL word, kind and the cell's position inside it; every other cell comes from the planes by LDS-DMA
+// as before (the 32- and 64-point classes and the nine special 8x8 kinds, decoded by k_transform_r).
+// Reference: DequantBlock + LowestFrequenciesFromDC + TransformToPixels (dec_group.cc:115-181,431-450,
+// dec_transforms-inl.h:456-818, dct-inl.h:376-397).
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <typename CT>
+struct TileSlot {  // what one unit needs from memory
+  typedef typename std::conditional<sizeof(CT) == 2, uint2, uint4>::type Raw;
+  Raw raw[3];  // M[m][4 h .. 4 h + 3] of the lane's block, per channel
+  float dcv;   // lane 16 r + 4 c + 2 dy + dx: DC (channel c, row dy, column dx) of the patch of the unit's r-th varblock
+};
+
+struct TileRow {  // wave-uniform: the block row being filled
+  int nb;         // block row
+  int n[4];       // varblocks of each kind that the window sees in this block row (its representatives' count)
+  int base[4];    // their first entry in the LDS list
+};
+struct TileUnit {  // wave-uniform
+  int kind, r0, nr;
+};
+__device__ __forceinline__ int TileUnits(const TileRow& R) { return ((R.n[0] + 3) >> 2) + ((R.n[1] + 1) >> 1) + ((R.n[2] + 1) >> 1) + R.n[3]; }
+__device__ __forceinline__ TileUnit TileUnitOf(const TileRow& R, int u) {
+  const int u0 = (R.n[0] + 3) >> 2, u1 = (R.n[1] + 1) >> 1, u2 = (R.n[2] + 1) >> 1;
+  TileUnit t;
+  if (u < u0) {
+    t.kind = 0, t.r0 = R.base[0] + 4 * u, t.nr = min(4, R.n[0] - 4 * u);
+  } else if (u < u0 + u1) {
+    u -= u0;
+    t.kind = 1, t.r0 = R.base[1] + 2 * u, t.nr = min(2, R.n[1] - 2 * u);
+  } else if (u < u0 + u1 + u2) {
+    u -= u0 + u1;
+    t.kind = 2, t.r0 = R.base[2] + 2 * u, t.nr = min(2, R.n[2] - 2 * u);
+  } else {
+    u -= u0 + u1 + u2;
+    t.kind = 3, t.r0 = R.base[3] + u, t.nr = 1;
+  }
+  return t;
+}
+// the lane's input varblock of a unit (which of its nr) and its first coefficient inside that varblock
+__device__ __forceinline__ int TileRepIn(int kind, int l15, int h) { return kind == 0 ? 2 * (l15 >> 3) + (h >> 1) : (kind == 3 ? 0 : l15 >> 3); }
+__device__ __forceinline__ int TileIntra(int kind, int l15, int h) {
+  return kind == 0 ? (l15 & 7) * 8 + (h & 1) * 4 : (kind == 3 ? l15 * 16 + 4 * h : (l15 & 7) * 16 + 4 * h);
+}
+
+template <typename CT>
+__device__ __forceinline__ void TileLoad(FrameArgs fa, const LdsU* list, const TileRow& R, const TileUnit U, int bc0, TileSlot<CT>& S) {
+  const FrameArgs f = Fresh(fa);
+  typedef typename TileSlot<CT>::Raw Raw;
+  const int lane = threadIdx.x & 63;
+  const int l15 = lane & 15, h = lane >> 4;
+  {
+    const int rep = min(TileRepIn(U.kind, l15, h), U.nr - 1);
+    const uint32_t off = list[(U.r0 + rep) * 4 + 1];
+    const size_t elem = (size_t)off * 64u + (size_t)TileIntra(U.kind, l15, h);
+#pragma unroll
+    for (int c = 0; c < 3; c++) S.raw[c] = *(const Raw*)((const CT*)f->coeffs[c] + elem);
+  }
+  {
+    // DC patch of varblock r = lane / 16 (CY x CX = (1 + kind / 2) x (1 + kind % 2) values per channel)
+    const int rep = min(h, U.nr - 1);
+    const int cell = (int)list[(U.r0 + rep) * 4 + 0];
+    const uint32_t tag = list[(U.r0 + rep) * 4 + 2] >> kTileTagShift;
+    const int aby = R.nb - (int)((tag >> 3) & 1u), abx = bc0 + cell - (int)((tag >> 2) & 1u);
+    const int k = min(l15, 11);
+    const int dy = min((k >> 1) & 1, U.kind >> 1), dx = min(k & 1, U.kind & 1);
+    S.dcv = f->dc[k >> 2][(size_t)(aby + dy) * f->xsb + (size_t)(abx + dx)];
+  }
+}
+
+// DequantLane + chroma from luma (dec_group.cc:115-181) of the lane's four coefficients of the three channels
+template <typename CT>
+__device__ __forceinline__ void TileDequant(const TileSlot<CT>& S, const float (&tab)[3][4], float sx, float sy, float sb, float x_cc,
+                                            float b_cc, float bias0, float bias1, float bias2, float bias3, float (&v)[3][4]) {
+  auto unpack = [](const typename TileSlot<CT>::Raw& r, int32_t* q) {
+    if constexpr (sizeof(CT) == 2) {
+      q[0] = (int32_t)(int16_t)(r.x & 0xffffu);
+      q[1] = (int32_t)r.x >> 16;
+      q[2] = (int32_t)(int16_t)(r.y & 0xffffu);
+      q[3] = (int32_t)r.y >> 16;
+    } else {
+      q[0] = (int32_t)r.x;
+      q[1] = (int32_t)r.y;
+      q[2] = (int32_t)r.z;
+      q[3] = (int32_t)r.w;
+    }
+  };
+  {
+    int32_t q[4];
+    unpack(S.raw[1], q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[1][k] = AdjustQuantBias(q[k], bias1, bias3) * (tab[1][k] * sy);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c += 2) {
+    const float sc = c == 0 ? sx : sb;
+    const float cc = c == 0 ? x_cc : b_cc;
+    int32_t q[4];
+    unpack(S.raw[c], q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float d = AdjustQuantBias(q[k], c == 0 ? bias0 : bias2, bias3) * (tab[c][k] * sc);
+      v[c][k] = __builtin_fmaf(cc, v[1][k], d);
+    }
+  }
+}
+
+// tabs: the lane's entries of the dequant matrices of DCT8 [0], DCT16X8 = DCT8X16 [1] and DCT16X16 [2] (per channel,
+// the four entries matching the lane's coefficients); t16 / t8: the two operand tables
+template <typename CT>
+__device__ __forceinline__ void TileCompute(FrameArgs fa, LdsF* slab, const LdsU* list, const TileUnit U, const TileSlot<CT>& S,
+                                            const float (&tabs)[3][3][4], const float (&t16)[4], const float (&t8)[4]) {
+  const FrameArgs f = Fresh(fa);
+  const int lane = threadIdx.x & 63;
+  const int l15 = lane & 15, h = lane >> 4;
+  const int kind = U.kind;
+  const int rep_in = min(TileRepIn(kind, l15, h), U.nr - 1);
+  const uint32_t qc = list[(U.r0 + rep_in) * 4 + 2];
+  float sx, sy, sb, x_cc, b_cc;
+  {
+    const int quant = (int)(qc & kTileQuantMask);
+    const float sq = f->inv_global_scale / (float)quant;  // dec_group.cc:164
+    sx = sq * f->x_dm;
+    sy = sq;
+    sb = sq * f->b_dm;
+    x_cc = f->cfl_base_x + (float)(int8_t)((qc >> 16) & 0xffu) * f->color_scale;
+    b_cc = f->cfl_base_b + (float)(int8_t)(qc >> 24) * f->color_scale;
+  }
+  const float bias0 = f->biases[0], bias1 = f->biases[1], bias2 = f->biases[2], bias3 = f->biases[3];
+  // (one copy of the dequantisation per table set, picked by a wave-uniform branch: selecting the table values
+  // per coefficient made the compiler keep the 36 values in scratch and index them)
+  float v[3][4];
+  if (kind == 0) TileDequant<CT>(S, tabs[0], sx, sy, sb, x_cc, b_cc, bias0, bias1, bias2, bias3, v);
+  else if (kind == 3) TileDequant<CT>(S, tabs[2], sx, sy, sb, x_cc, b_cc, bias0, bias1, bias2, bias3, v);
+  else TileDequant<CT>(S, tabs[1], sx, sy, sb, x_cc, b_cc, bias0, bias1, bias2, bias3, v);
+  // lowest frequencies from the DC patch (LowestFrequenciesFromDC, dec_transforms-inl.h:691-818; the operation order of
+  // RowLaneUnit, kernels_blocks.hip): the lane holding the corner M[0][0 .. 1] of its varblock (DCT16X16: the lanes of rows
+  // 0 and 1) fetches the patch from the lanes that loaded it
+  {
+    constexpr float r1 = kResampleUpHost[1], r2 = kResampleUpHost[2], r3 = kResampleUpHost[3];
+    const int src = 16 * rep_in;
+    if (kind == 0) {
+      const bool corner = (l15 & 7) == 0 && (h & 1) == 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float d = __shfl(S.dcv, src + 4 * c, 64);
+        if (corner) v[c][0] = d;
+      }
+    } else if (kind == 3) {
+      const bool corner = h == 0 && l15 < 2;
+      const float rx = l15 == 0 ? r2 : r3;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float d[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[i >> 1][i & 1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S.dcv), 4 * c + i));
+        float dp[2][2];
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+          dp[0][x] = 0.5f * (d[0][x] + d[1][x]);
+          dp[1][x] = 0.5f * (d[0][x] - d[1][x]);
+        }
+#pragma unroll
+        for (int y = 0; y < 2; y++) {
+          const float val = 0.5f * (l15 == 0 ? dp[y][0] + dp[y][1] : dp[y][0] - dp[y][1]);
+          const float llf = val * rx * (y == 0 ? r2 : r3);
+          if (corner) v[c][y] = llf;
+        }
+      }
+    } else {
+      const bool corner = (l15 & 7) == 0 && h == 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        // kind 1 (DCT8X16, 1 x 2 patch): the two values of row 0; kind 2 (DCT16X8, 2 x 1): those of column 0
+        const float d0 = __shfl(S.dcv, src + 4 * c, 64);
+        const float d1 = __shfl(S.dcv, src + 4 * c + (kind == 1 ? 1 : 2), 64);
+        const float a = 0.5f * (d0 + d1), b = 0.5f * (d0 - d1);
+        // DCT8X16: val * ry * R[CX + x] with ry = R[1]; DCT16X8: val * R[CX + 0] * R[CY + y] with R[1] in front
+        const float l0 = a * r1 * r2;
+        const float l1 = b * r1 * r3;
+        if (corner) {
+          v[c][0] = l0;
+          v[c][1] = l1;
+        }
+      }
+    }
+  }
+  // the two products.  Product 1: A = the coefficients, B = B16 (diag(B8, B8) for DCT8).  Product 2: A = the constant
+  // table, B = product 1's accumulator (DCT8X16: A = the accumulator read as its transpose, B = diag(B8, B8))
+  v4f p[3];
+  {
+    v4f q[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) q[c] = v4f{0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 3; kk >= 0; kk--) {
+      const float b1 = kind == 0 ? t8[kk] : t16[kk];
+#pragma unroll
+      for (int c = 0; c < 3; c++) q[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c][kk], b1, q[c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) p[c] = v4f{0, 0, 0, 0};
+    if (kind == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) p[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c][i], t8[i], p[c], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float a2 = kind == 3 ? t16[i] : t8[i];
+#pragma unroll
+        for (int c = 0; c < 3; c++) p[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, q[c][i], p[c], 0, 0, 0);
+      }
+    }
+  }
+  // the lane holds four consecutive pixels of row (lane % 8) of a cell: which varblock of the unit, which of its cells
+  {
+    const int rep_out = kind == 0 ? 2 * (h >> 1) + (l15 >> 3) : (kind == 1 ? l15 >> 3 : (kind == 2 ? h >> 1 : 0));
+    const int ro = min(rep_out, U.nr - 1);
+    const int cell = (int)list[(U.r0 + ro) * 4 + 0];
+    const uint32_t tag = list[(U.r0 + ro) * 4 + 2] >> kTileTagShift;
+    const int cell_out = cell - (int)((tag >> 2) & 1u) + ((kind & 1) ? (h >> 1) : 0);
+    const bool half_ok = kind < 2 || (uint32_t)(l15 >> 3) == ((tag >> 3) & 1u);
+    if (rep_out < U.nr && cell_out >= 0 && cell_out < 16 && half_ok) {
+      typedef v4f __attribute__((address_space(3))) * P4;
+      LdsF* dst = slab + (l15 & 7) * kSlabCols + cell_out * 8 + 4 * (h & 1);
+#pragma unroll
+      for (int c = 0; c < 3; c++) *(P4)(dst + c * kSlabPlaneFloats) = p[c];
+    }
+  }
+}
+
+template <int HX, typename CT>
+__device__ __forceinline__ void ProduceTiles(FrameArgs fa, StripLds* w, int bc0, int y_begin, int y_end, int nb_last) {
+  constexpr int kSlots = sizeof(CT) == 2 ? JXLHIP_TILE_SLOTS : 3;
+  const int lane = threadIdx.x & 63;
+  const int l15 = lane & 15, h = lane >> 4;
+  const int r_first = HX ? y_begin - 8 : y_begin;
+  const int G = PcGroups<HX>(y_begin, y_end);
+  // per lane, once per wave: its entries of the three dequant-matrix sets (DequantLane, dec_group.cc:115-153) and of the
+  // two operand tables
+  float tabs[3][3][4], t16[4], t8[4];
+  {
+    const FrameArgs f = Fresh(fa);
+#pragma unroll
+    for (int ts = 0; ts < 3; ts++) {
+      const int kind = ts == 0 ? 0 : (ts == 1 ? 1 : 3);
+      const uint32_t base = ts == 0 ? DequantOffset(0) : (ts == 1 ? DequantOffset(6) : DequantOffset(4));
+      const uint32_t size = ts == 0 ? 64u : (ts == 1 ? 128u : 256u);
+      const int intra = TileIntra(kind, l15, h);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float4 t = *(const float4*)(f->dequant + base + c * size + intra);
+        tabs[ts][c][0] = t.x, tabs[ts][c][1] = t.y, tabs[ts][c][2] = t.z, tabs[ts][c][3] = t.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      t16[i] = f->tile_tabs[i * 64 + lane];
+      t8[i] = f->tile_tabs[256 + i * 64 + lane];
+    }
+  }
+  LdsU* list = (LdsU*)w->list[0];
+  auto request = [&](int nb, uint2& ci, float& sg) {
+    const FrameArgs f = Fresh(fa);
+    const int xsb = (int)f->xsb;
+    int col = bc0 + (lane & 15);
+    col = col < 0 ? 0 : (col >= xsb ? xsb - 1 : col);
+    ci = f->cell_info[(size_t)nb * xsb + col];
+    sg = f->inv_sigma[(size_t)nb * xsb + col];
+  };
+  uint2 ci;
+  float sg;
+  int nb = GroupBlockRow(r_first, nb_last);
+  request(nb, ci, sg);
+  for (int g = 0; g < G; g++) {
+    LdsF* slab = (LdsF*)w->slab[JXLHIP_PC_SLAB(g & 1)];  // free: the march left it before the previous barrier
+    // the block row's cells: from the planes / decoded here; of each varblock decoded here the leftmost of its cells
+    // inside the window represents it
+    TileRow R;
+    R.nb = nb;
+    NextRow cur;
+    {
+      const FrameArgs f = Fresh(fa);
+      const int c16 = bc0 + lane;
+      const bool valid_cell = lane < 16 && c16 >= 0 && c16 < (int)f->xsb;
+      const bool inker = valid_cell && ci.x != kCellFromPlanes;
+      const uint32_t tag = ci.y >> kTileTagShift;
+      const int kind = (int)(tag & 3u);
+      const bool rep = inker && ((kind & 1) == 0 || ((tag >> 2) & 1u) == 0 || lane == 0);
+      cur.nb = nb;
+      cur.mp = (uint32_t)__ballot(valid_cell && !inker) & 0xffffu;
+      cur.m8 = 0;
+      cur.ci = make_uint2(0u, 0u);
+      int base = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t m = (uint32_t)__ballot(rep && kind == k) & 0xffffu;
+        R.n[k] = __builtin_popcount(m);
+        R.base[k] = base;
+        if (kind == k && rep) {
+          const int rank = base + __builtin_popcount(m & ((1u << lane) - 1u));
+          list[rank * 4 + 0] = (uint32_t)lane;
+          list[rank * 4 + 1] = ci.x;
+          list[rank * 4 + 2] = ci.y;
+        }
+        base += R.n[k];
+      }
+    }
+    const float sg_cur = sg;
+    if (g + 1 < G) {  // the next block row's cell info / sigma travel while this one is decoded
+      nb = GroupBlockRow(r_first + 8 * (g + 1), nb_last);
+      request(nb, ci, sg);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) DmaPlaneRows(fa, slab, cur, bc0, k);
+    const int units = TileUnits(R);
+    for (int ub = 0; ub < units; ub += kSlots) {  // all loads of up to kSlots units first, then their arithmetic
+      TileSlot<CT> S[kSlots];
+#pragma unroll
+      for (int s = 0; s < kSlots; s++)
+        if (ub + s < units) TileLoad<CT>(fa, list, R, TileUnitOf(R, ub + s), bc0, S[s]);
+#pragma unroll
+      for (int s = 0; s < kSlots; s++)
+        if (ub + s < units) TileCompute<CT>(fa, slab, list, TileUnitOf(R, ub + s), S[s], tabs, t16, t8);
+    }
+    if (lane < 16) ((LdsF*)w->sigma[g & 1])[lane] = sg_cur;
+    PcBarrierProducer();
+  }
+}
+
 template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, int NB = 2>
 __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P, Lane& L, StripLdsT<NB>* w, int bc0,
                                         int y_begin, int y_end) {
@@ -817,6 +1177,10 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
   const int bc0 = x0 >> 3;
   const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
   if (wave == 1) {
+    if (f.fused_tiles) {  // uniform
+      ProduceTiles<MarchGeom<GAB, EPF>::HX, CT>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
+      return;
+    }
 #ifndef JXLHIP_PC_PRODUCER_V1
     if constexpr (sizeof(CT) == 2) ProducePC2<MarchGeom<GAB, EPF>::HX>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
     else
@@ -1006,6 +1370,14 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) 
   if ((f.fy0 & 7u) != 0) return false;
   if ((uint64_t)f.plane_tile_rows * f.tile_stride * 256u >= (1ull << 32)) return false;
   return true;
+}
+
+// Does the frame's fused launch run the matrix-core producer (ProduceTiles)?  Decided with FusedSupported, before
+// k_prepare (DevFrame::fused_tiles routes the 8- and 16-point classes): whole frames whose fused kernel is k_fused_pc.
+bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind) {
+  const char* e = getenv("JXLHIP_FUSED_TILES");  // read per frame: the tests switch it
+  if (e && atoi(e) == 0) return false;
+  return FusedPcEnabled() && output_kind != JXLHIP_OUT_PACKED && FusedSupported(f, gab, epf_iters, output_kind);
 }
 
 #endif  // JXLHIP_FUSED_PART == 0

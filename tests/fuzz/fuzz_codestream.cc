@@ -101,7 +101,27 @@ bool Chain(const Bytes& cs) {
   // extra channels: what follows the coefficients is out of reach here (the AC groups are not entropy-decoded), but the
   // collecting form on the groups' sections from bit 0 and the final undo (squeeze, palettes) must hold up on whatever
   // state the damaged stream left
-  if (ok && fh.num_extra_channels && tree) {
+  if (ok && fh.num_extra_channels && tree && jxlhip_modular_groups_are_final(tree)) {
+    // the form jxlhip_decode_codestream takes by default: every group converts its samples on the spot (pending
+    // single-channel palettes through their table) and writes them into exact-size planes -- ASAN sees an overrun
+    const uint32_t first_ac = 2 + (uint32_t)fh.num_dc_groups;
+    const uint32_t ne = fh.num_extra_channels < 4 ? fh.num_extra_channels : 4;
+    std::vector<std::vector<float>> store(ne, std::vector<float>((size_t)fh.xsize * fh.ysize));
+    float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t strides[4] = {fh.xsize, fh.xsize, fh.xsize, fh.xsize};
+    uint32_t bits[4] = {8, 8, 8, 8};
+    for (uint32_t e = 0; e < ne; e++) planes[e] = store[e].data();
+    for (uint32_t g = 0; g < fh.num_groups && g < 4; g++) {
+      if (!section(first_ac + g, &d, &n)) break;
+      Exact sg(d, n);
+      size_t gp = 0;
+      (void)jxlhip_modular_ac_group_decode_f32_strided(tree, &fh, g, 0, sg.p, sg.n, &gp, bits, ih.bit_depth.bits_per_sample,
+                                                       planes, strides);
+    }
+    (void)jxlhip_modular_finalize(tree, nullptr, nullptr);
+    for (uint32_t e = 0; e < ne; e++)
+      (void)jxlhip_modular_extra_channel_rows_f32(tree, e, 8, ih.bit_depth.bits_per_sample, 0, fh.ysize, store[e].data(), fh.xsize);
+  } else if (ok && fh.num_extra_channels && tree) {
     const uint32_t first_ac = 2 + (uint32_t)fh.num_dc_groups;
     for (uint32_t g = 0; g < fh.num_groups && g < 4; g++) {
       if (!section(first_ac + g, &d, &n)) break;

@@ -287,6 +287,42 @@ def test_squeezed_channels_are_not_final_group_by_group(L, ref):
     assert np.array_equal(alpha, plain.alpha)
 
 
+def test_empty_global_palette_is_the_zero_entry(L, ref):
+    """A pending global palette with nb_colors = 0 (legal: kColors is BitsOffset(8, 0)) leaves an EMPTY table: the
+    float-on-the-spot form must take every index to the implicit zero entry like UndoPalettes / the reference's
+    InvPalette do (palette.cc:29-100), not index the table.  (Round 3's advisor: a 4-byte global section and a 3-byte
+    group section crashed jxlhip_modular_ac_group_decode_f32_strided.)  Whatever the verdict on these hand-made bytes,
+    the call returns."""
+    rs = ref.RealStream(seed=3, xsize=512, ysize=256, alpha_bits=8)
+    cs = np.ascontiguousarray(rs.codestream)
+    ih, pos = abi.ImageHeader(), C.c_size_t(0)
+    assert L.jxlhip_image_header_decode(cs.ctypes.data, len(cs), C.byref(pos), None, 0, C.byref(ih)) == 0
+    info = abi.ImageInfo(ih.xsize, ih.ysize, ih.xyb_encoded, ih.num_extra_channels, None, 0, 0, 0)
+    fh = abi.FrameHeader()
+    assert L.jxlhip_frame_header_decode(cs.ctypes.data, len(cs), C.byref(pos), C.byref(info), C.byref(fh)) == 0
+    assert fh.num_extra_channels == 1 and fh.num_groups == 2
+    for glob, grp in ((bytes([0x2C, 0, 0, 0]), bytes([0x22, 0x81, 0])), (bytes([0x2C, 0, 0, 0]), bytes([0x22, 0x01, 0, 0]))):
+        g = np.frombuffer(glob, np.uint8).copy()
+        tree, spos = C.c_void_p(), C.c_size_t(0)
+        rc = L.jxlhip_modular_global_decode(g.ctypes.data, len(g), C.byref(spos), C.byref(fh), C.byref(tree))
+        if rc != 0:
+            continue
+        try:
+            plane = np.full((256, 512), 7.0, np.float32)
+            d = np.frombuffer(grp, np.uint8).copy()
+            for group in range(2):
+                gp = C.c_size_t(0)
+                rc = L.jxlhip_modular_ac_group_decode_f32(tree, C.byref(fh), group, 0, d.ctypes.data, len(d), C.byref(gp),
+                                                          (C.c_uint32 * 4)(8, 8, 8, 8), 8,
+                                                          (C.c_void_p * 4)(plane.ctypes.data, None, None, None), 512)
+                assert rc <= 0
+                if rc == 0:  # accepted: every sample is the zero entry
+                    x0 = 256 * group
+                    assert not plane[:, x0:x0 + 256].any()
+        finally:
+            L.jxlhip_modular_tree_destroy(tree)
+
+
 GPU_CASES = [
     dict(xsize=520, ysize=300, alpha_bits=8),
     dict(xsize=200, ysize=120, alpha_bits=8),                      # one section, bit-chained

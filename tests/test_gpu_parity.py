@@ -398,6 +398,7 @@ def test_fused_producer_consumer_form_is_bit_identical(dq, oracle, gab, epf, siz
     ref = fr.decode(threads=4)
     outs = {}
     monkeypatch.setenv("JXLHIP_FUSE", "1")
+    monkeypatch.setenv("JXLHIP_FUSED_TILES", "0")  # the row-per-lane producer: the arithmetic of the single-wave kernel
     for pc in ("1", "0"):
         monkeypatch.setenv("JXLHIP_FUSED_PC", pc)
         for rh in ("0", "64") if pc != "0" else ("0",):
@@ -411,6 +412,44 @@ def test_fused_producer_consumer_form_is_bit_identical(dq, oracle, gab, epf, siz
     assert rel_err(outs["00"], ref) <= TIGHT
     assert np.array_equal(outs["10"], outs["00"]), np.argwhere(outs["10"] != outs["00"])[:5]
     assert np.array_equal(outs["164"], outs["00"]), np.argwhere(outs["164"] != outs["00"])[:5]
+
+
+TILE_MIX = {0: 30, 4: 25, 6: 20, 7: 20, 5: 3, 13: 2}   # the four classes the producer decodes + two that stay on the planes
+
+
+@pytest.mark.parametrize("gab,epf,out", [(1, 1, 1), (0, 0, 0), (1, 2, 1), (0, 1, 0)])
+@pytest.mark.parametrize("size,coeff_type,mix", [((1000, 520), 0, None), ((333, 268), 1, "tile"), ((117, 67), 0, "tile"),
+                                                  ((2048, 1029 - 5), 0, "all"), ((1500, 2100), 0, "tile"), ((1500, 700), 1, None)])
+def test_fused_tile_producer_matches_oracle(dq, oracle, gab, epf, out, size, coeff_type, mix, monkeypatch):
+    """k_fused_pc's matrix-core producer (kernels_fused.hip ProduceTiles, DevFrame::fused_tiles; the default for whole
+    frames through the fused kernel): DCT8, DCT8X16, DCT16X8 and DCT16X16 are decoded by the producing wave as two
+    v_mfma_f32_16x16x4_f32 products per channel, the other classes come from the planes.  Against the oracle at the
+    bar of every other path; JXLHIP_FUSED_TILES=0 (the row-per-lane DCT8 producer) must be as close and must differ in
+    the last bits -- a dense product rounds differently from the butterflies -- which shows that the producer engaged.
+    Sizes: varblocks cut by window edges (windows are 14 cells apart), several row chunks per window (JXLHIP_FUSED_PC_RH),
+    ragged right / bottom edges, int32 coefficients; RGB and planar XYB outputs."""
+    xs, ys = size
+    kw = dict(coeff_type=1, amp=200000.0, decay=3.0) if coeff_type else {}
+    m = {None: synth.MIX_D1, "tile": TILE_MIX, "all": synth.MIX_ALL}[mix]
+    params, t, fr = frames.make_case(xs, ys, mix=m, gab=bool(gab), epf_iters=epf, seed=91 + xs, output_kind=out, **kw)
+    ref = fr.decode(threads=4)
+    outs = {}
+    monkeypatch.setenv("JXLHIP_FUSE", "1")
+    for tiles, rh in (("1", "0"), ("1", "64"), ("0", "0")):
+        monkeypatch.setenv("JXLHIP_FUSED_TILES", tiles)
+        monkeypatch.setenv("JXLHIP_FUSED_PC_RH", rh)
+        d = VarDctDecoder(0)
+        d.begin_frame(params)
+        d.set_inputs(to_dev(t), dq)
+        o = d.decode_frame()
+        outs[tiles + rh] = o.cpu().numpy()
+        d.sync()
+        d.close()
+    refa = ref
+    for k, v in outs.items():
+        assert rel_err(v, refa) <= TIGHT, (k, np.argwhere(np.abs(v - refa) > 1e-3)[:5])
+    assert np.array_equal(outs["10"], outs["164"])          # the chunking does not change a pixel
+    assert not np.array_equal(outs["10"], outs["00"])       # ... and the matrix cores did the work
 
 
 @pytest.mark.parametrize("coeff_type", [0, 1])
