@@ -55,6 +55,10 @@ struct jxlhip_ctx {
   bool have_frame = false;
   bool have_inputs = false;
   bool blocks_done = false;
+  // One-band decodes of whole frames alternate between counter blocks 0 and 1: k_prepare of frame N zeroes the block
+  // frame N + 1 will use (DevFrame::zero_counts) -- no memset launch per frame.  clean[b]: block b is all zero.
+  int counts_slot = 0;
+  bool counts_clean[2] = {false, false};
   bool tiles_on = false;     // the last LaunchBlocksBand ran k_prepare in tile mode (DevFrame::fused_tiles)
   bool blocks_fused = false;  // jxlhip_decode_blocks ran in fused-stripe mode: the planes lack the inner DCT8 blocks
   jxlhip_frame_params p{};
@@ -1239,7 +1243,7 @@ namespace {
 // fused: 0 = two-phase, 1 = the whole frame through the fused kernel, 2 = a STRIPE through it (the DCT8 cells of
 // the stripe's first / last block row are decoded into the planes as well: they are the halo rows its neighbours pull)
 int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, int fused = 0,
-                     const FilterParams* emit = nullptr) {
+                     const FilterParams* emit = nullptr, int zero_band = -1) {
   hipStream_t st = c->stream;
   DevFrame f = c->f;
   f.band_g0 = g0;
@@ -1263,7 +1267,8 @@ int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, int fuse
                         (!(f.used_acs & (1u << 5)) || f.mfma32) && (uint64_t)f.xsize * f.ysize >= (16u << 20);
     f.mfma16 = (c->mfma > 0 || (c->mfma < 0 && lone16)) ? c->tables + 1600 + 2048 : nullptr;
   }
-  if (fused && !f.fused_tiles)  // every cell "from the planes" until k_prepare says otherwise (tile mode: k_prepare writes every cell)
+  f.zero_counts = zero_band >= 0 ? c->counts + (size_t)zero_band * kCountStride : nullptr;
+  if (fused == 2)  // a stripe: every cell "from the planes" until k_prepare says otherwise (whole frames: k_prepare writes every cell)
     HIPCHK(c, hipMemsetAsync(c->cell_info, 0xFF, sizeof(uint2) * (size_t)f.xsb * f.ysb, st));
   WorkLists wl = c->wl;
   wl.count = c->counts + (size_t)band * kCountStride;
@@ -1382,7 +1387,10 @@ int BeginDecode(jxlhip_ctx* c, uint32_t nbands) {
     LaunchExpandSparse(c->sp_dev, c->sp_off_dev, (int16_t*)c->up_coeffs[0], c->f.group_y0 * c->f.xsg, c->f.group_rows * c->f.xsg, st);
   }
   if (nbands > (uint32_t)kMaxBands) nbands = kMaxBands;
-  HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kCountStride * nbands, st));
+  if (nbands) {
+    HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kCountStride * nbands, st));
+    c->counts_clean[0] = c->counts_clean[1] = false;  // used by the bands that follow
+  }
   return JXLHIP_OK;
 }
 
@@ -1519,8 +1527,19 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   c->blocks_fused = false;
   uint32_t br = c->band_rows ? (uint32_t)c->band_rows : f.group_rows;
   while ((f.group_rows + br - 1) / br > (uint32_t)kMaxBands) br++;
-  int rc = BeginDecode(c, (f.group_rows + br - 1) / br);
+  // one band (the default): the counter blocks 0 / 1 alternate and k_prepare zeroes the next frame's -- no memset launch
+  const uint32_t nbands = (f.group_rows + br - 1) / br;
+  const bool one_band = nbands == 1;
+  const int slot = one_band ? c->counts_slot : 0;
+  int rc = BeginDecode(c, one_band ? 0 : nbands);
   if (rc) return rc;
+  if (one_band && !c->counts_clean[slot])
+    HIPCHK(c, hipMemsetAsync(c->counts + (size_t)slot * kCountStride, 0, sizeof(uint32_t) * kCountStride, c->stream));
+  auto rotate = [&]() {  // after a successful LaunchBlocksBand(.., slot, .., slot ^ 1)
+    c->counts_clean[slot] = false;
+    c->counts_clean[slot ^ 1] = true;
+    c->counts_slot = slot ^ 1;
+  };
   rc = CheckOutArgs(c, out, out_stride, out_plane_stride);
   if (rc) return rc;
   FilterParams fp = c->fp;
@@ -1532,7 +1551,8 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   // no second kernel.  used_acs is the caller's promise; k_prepare reports any other strategy it meets.
   if (c->mfma != 0 && f.used_acs == (1u << 5) && c->p.lf.gab == 0 && c->p.lf.epf_iters == 0 &&
       c->p.output_kind == JXLHIP_OUT_LINEAR_RGB_F32 && !c->generic_filters && c->band_rows == 0) {
-    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, 0, 0, &fp);
+    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, slot, 0, &fp, one_band ? slot ^ 1 : -1);
+    if (!rc && one_band) rotate();
     c->blocks_done = false;  // nothing in the planes
     return rc;
   }
@@ -1544,8 +1564,9 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   // frame has no DCT8 block -- then the slab is only a detour (configs[4]: 76.1 vs 79.6 Gpx/s)
   if (WantFused(c) && f.group_y0 == 0 && f.group_rows == f.ysg) {
     if ((rc = Grow(c, &c->cell_info, &c->cell_info_items, (size_t)f.xsb * f.ysb))) return rc;
-    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, 0, 1);
+    rc = LaunchBlocksBand(c, f.group_y0, f.group_y0 + f.group_rows, slot, 1, nullptr, one_band ? slot ^ 1 : -1);
     if (rc) return rc;
+    if (one_band) rotate();
     c->blocks_done = false;  // the planes do not hold the whole frame
     return LaunchFiltersRows(c, fp, f.y0, f.y1, true);
   }
@@ -1554,8 +1575,9 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   int band = 0;
   for (uint32_t g0 = f.group_y0; g0 < g_end; g0 += br, band++) {
     const uint32_t g1 = g0 + br < g_end ? g0 + br : g_end;
-    rc = LaunchBlocksBand(c, g0, g1, band);
+    rc = one_band ? LaunchBlocksBand(c, g0, g1, slot, 0, nullptr, slot ^ 1) : LaunchBlocksBand(c, g0, g1, band);
     if (rc) return rc;
+    if (one_band) rotate();
     if (g0 > f.group_y0) {  // rows of the previous band: its lower halo now exists
       rc = LaunchFiltersRows(c, fp, prev_y0, g0 * 256);
       if (rc) return rc;

@@ -157,6 +157,9 @@ struct DevFrame {
   // quant / CfL word with a tag in bits 12..15 (cell_info.y: kTile* below); every other cell says kCellFromPlanes
   uint32_t fused_tiles;
   const float* tile_tabs;  // TileProducerConstants (kernels_mfma.hip): 2 x 256 floats
+  // != nullptr: k_prepare's first workgroup zeroes these kCountStride counters -- the counter block the NEXT frame's
+  // k_prepare will use (two blocks alternate), which saves a memset launch per frame
+  uint32_t* zero_counts;
 };
 // cell_info.y of a tile-mode cell: raw_quant in bits 0..8 (1..256, dec_modular.cc:551-552), tag in bits 12..15,
 // ytox / ytob in bits 16..31

@@ -58,6 +58,8 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   uint32_t s = raw >> 1;
   bool bad = false;
   if (f.fused_tiles) cell_ci[tid] = make_uint2(kCellFromPlanes, 0u);
+  static_assert(kCountStride == 1024, "one counter per thread");
+  if (f.zero_counts && blockIdx.x == 0) f.zero_counts[tid] = 0;
   if (s >= JXLHIP_NUM_STRATEGIES) {
     bad = valid;
     s = 0;
@@ -137,13 +139,18 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   }
   __syncthreads();
   if (f.fused_tiles && valid) f.cell_info[cell] = cell_ci[tid];
+  // whole frame through the fused kernel: EVERY cell says what it is (no memset of the table in front of this kernel)
+  if (f.fused == 1 && !f.fused_tiles && valid) {
+    const bool own = in_stripe && group_ok && cls_frame == kClsDct8;
+    f.cell_info[cell] = own ? make_uint2(g * f.coef_stride64 + off64, ((uint32_t)cell_q & 0xffffu) | cell_cfl) : make_uint2(kCellFromPlanes, 0u);
+  }
   if (in_stripe && group_ok && cls_frame >= 0) {
     WorkItem it;
     it.pos = (aby << 16) | abx;
     it.off = g * f.coef_stride64 + off64;
     it.qc = ((uint32_t)cell_q & 0xffffu) | cell_cfl;
     it.pad = 0;
-    if (f.fused && !f.fused_tiles && cls_frame == kClsDct8) f.cell_info[cell] = make_uint2(it.off, it.qc);
+    if (f.fused == 2 && cls_frame == kClsDct8) f.cell_info[cell] = make_uint2(it.off, it.qc);  // (a stripe: the rest keeps its 0xFF fill)
     if (cls >= 0) {
       uint32_t pos = wg_base[cls] + rank_in_wave;
       for (uint32_t w = 0; w < wave; w++) pos += wave_cls[w][cls];

@@ -1375,8 +1375,14 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) 
 // Does the frame's fused launch run the matrix-core producer (ProduceTiles)?  Decided with FusedSupported, before
 // k_prepare (DevFrame::fused_tiles routes the 8- and 16-point classes): whole frames whose fused kernel is k_fused_pc.
 bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind) {
-  const char* e = getenv("JXLHIP_FUSED_TILES");  // read per frame: the tests switch it
-  if (e && atoi(e) == 0) return false;
+  // OPT-IN (JXLHIP_FUSED_TILES=1; read per frame: the tests switch it).  Measured on MI355X, 8K d1.0 Gaborish + EPF1
+  // (profiles/r04_tile_producer.txt): phase 1 93 -> 55 us, the fused kernel 187 -> 353 us, the step 109 -> 78 Gpx/s.
+  // The fused kernel is bound by VALU issue (59 % busy in both forms): the march is 56 M wave-instructions per frame,
+  // the row-per-lane DCT8 producer 12 M; this producer is 72 M -- 300 per unit of four cells, of which the transform
+  // itself (24 MFMAs) is none: dequantisation is 9 instructions per coefficient whatever decodes it, and a 16 x 16 unit
+  // amortises its addressing / quantiser / LLF / emit overhead over 12 coefficients per lane only.
+  const char* e = getenv("JXLHIP_FUSED_TILES");
+  if (!e || atoi(e) == 0) return false;
   return FusedPcEnabled() && output_kind != JXLHIP_OUT_PACKED && FusedSupported(f, gab, epf_iters, output_kind);
 }
 
