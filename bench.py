@@ -200,6 +200,92 @@ def pcie_inclusive(torch, dec, params, t, dq, out, xs, ys, n):
     return res
 
 
+def e2e_block(torch, local):
+    """Whole-file rates at the boundary north_star names ("drops in behind djxl"), never `value`: one genuine 8K d1.0 RGB
+    codestream written by the reference encoder (oracle/make_e2e_stream.py; effort 7, libjxl's default) --
+      codestream_8k_rgb : jxlhip_decode_codestream, bytes -> float RGB in HBM, DC groups and every header included, at
+                          the best of a few worker counts, with the per-phase milliseconds of that call;
+      djxl_hip / djxl_ref: the reference's own tool, unmodified, on the HIP back-end (libjxl_dec_hip.so +
+                          libjxl_threads_hip.so) and on libjxl's CPU decoder (the single-lane Highway build of
+                          oracle/_ref), `--num_reps 10 --disable_output`, MP/s as SpeedStats prints it
+                          (tools/djxl_main.cc:392-426, tools/speed_stats.cc:102-121)."""
+    import ctypes as C
+    import re
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_e2e_stream
+    from libjxl_amd import VarDctDecoder, abi
+    path = make_e2e_stream.ensure()
+    if path is None:
+        return {"error": "oracle/_ref (reference encoder) not available: no stream"}
+    blob = open(path, "rb").read()
+    L = abi.load_library()
+    info = abi.CodestreamInfo()
+    if L.jxlhip_codestream_basic_info(blob, len(blob), C.byref(info)):
+        return {"error": "e2e stream rejected"}
+    w, h = info.xsize, info.ysize
+    res = {"stream": f"{os.path.relpath(path, ROOT)}: {w}x{h} RGB VarDCT d1.0 effort 7, {len(blob)} bytes, written by the "
+                     "reference encoder from a procedural image", "unit": "Mpixels/s"}
+    R = C.CDLL(abi.runner_library_path())
+    R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    runner = C.cast(R.JxlThreadParallelRunner, C.c_void_p)
+    ncpu = os.cpu_count() or 1
+    names = ["headers", "dc_groups", "ac_global", "side_info", "ac_groups", "extra_channels", "kernels_sync"]
+    dec = VarDctDecoder(local)
+    out = torch.empty((h, w, 3), dtype=torch.float32, device=f"cuda:{local}")
+    best = None
+    for threads in sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu}):
+        pool = R.JxlThreadParallelRunnerCreate(None, threads)
+        ts, phases = [], []
+        for rep in range(6):
+            t0 = time.perf_counter()
+            rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, blob, len(blob), 1, None, out.data_ptr(), w * 12, 0,
+                                            C.byref(info))
+            dt = time.perf_counter() - t0
+            if rc:
+                R.JxlThreadParallelRunnerDestroy(pool)
+                return {"error": f"jxlhip_decode_codestream: {L.jxlhip_last_error(dec.ctx).decode()}"}
+            ms = (C.c_double * 7)()
+            L.jxlhip_codestream_phase_ms(dec.ctx, ms)
+            if rep:  # the first repetition allocates
+                ts.append(dt)
+                phases.append(list(ms))
+        R.JxlThreadParallelRunnerDestroy(pool)
+        i = min(range(len(ts)), key=ts.__getitem__)
+        geo = float(torch.tensor(ts).log().mean().exp())
+        if best is None or geo < best["geo"]:
+            best = {"geo": geo, "threads": threads, "min": ts[i], "phases": phases[i]}
+    dec.close()
+    res["codestream_8k_rgb"] = {
+        "value": round(w * h / best["geo"] / 1e6, 1), "best_rep": round(w * h / best["min"] / 1e6, 1), "threads": best["threads"],
+        "ms_per_file": round(best["geo"] * 1e3, 2), "reps": 5,
+        "phase_ms_of_best_rep": {n: round(v, 2) for n, v in zip(names, best["phases"])},
+        "what": "jxlhip_decode_codestream: bytes -> linear f32 RGB in HBM, whole file (geomean of 5 reps after a warm-up)"}
+    for tool in ("djxl_hip", "djxl_ref"):
+        exe = os.path.join(ROOT, "oracle", "_ref", tool)
+        if not os.path.exists(exe):
+            res[tool] = {"error": "not built"}
+            continue
+        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref") + ":" + os.path.join(ROOT, "libjxl_amd", "csrc") +
+                   ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        got = None
+        for threads in sorted({t for t in (16, 64) if t <= ncpu}):
+            try:
+                r = subprocess.run([exe, path, "--disable_output", "--num_reps", "10", "--num_threads", str(threads)],
+                                   capture_output=True, text=True, env=env, timeout=600)
+            except subprocess.TimeoutExpired:
+                continue
+            m = re.search(r"([0-9.]+) MP/s", r.stderr)
+            if r.returncode == 0 and m and (got is None or float(m.group(1)) > got["value"]):
+                got = {"value": float(m.group(1)), "threads": threads, "line": r.stderr.strip().splitlines()[-1][:200]}
+        res[tool] = got or {"error": "djxl failed"}
+    if "value" in res.get("djxl_hip", {}) and "value" in res.get("djxl_ref", {}):
+        res["djxl_hip_over_ref"] = round(res["djxl_hip"]["value"] / res["djxl_ref"]["value"], 2)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +304,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the output stripes sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (N=1)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-file block (N=1, default workload)")
     ap.add_argument("--calib-copy", action="store_true",
                     help="run one known-size (1 GiB) device copy so PMC passes can be calibrated")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=None)
@@ -383,6 +470,11 @@ def main():
                                "what": "the same frame, output stripes left in each GPU's HBM (no gather)"}
         if pcie:
             line["pcie_inclusive"] = pcie
+        if world == 1 and name == "c3" and not custom and not args.no_e2e and not args.no_cpu_baseline:  # (profiling runs skip every side measurement)
+            try:
+                line["e2e"] = e2e_block(torch, local)
+            except Exception as ex:  # the bench line must come out whatever happens to the side measurements
+                line["e2e"] = {"error": repr(ex)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             if name == "c1":
                 line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample or (1024, 1024), 1)

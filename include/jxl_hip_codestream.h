@@ -110,6 +110,21 @@ JXLHIP_EXPORT int jxlhip_decode_codestream_extra(jxlhip_ctx* ctx, jxlhip_paralle
                                                  uint32_t num_extra_planes, size_t extra_stride,
                                                  jxlhip_codestream_info* info);
 
+/* Wall-clock milliseconds of the phases of the LAST jxlhip_decode_codestream[_extra] call on this context, ms[0 ..
+ * JXLHIP_CODESTREAM_PHASES): what bench.py's `e2e` block prints beside the whole-file rate (the project's own measure is
+ * the whole call: tools/djxl_main.cc:392-426, tools/speed_stats.cc:102-121). */
+enum {
+  JXLHIP_PHASE_HEADERS = 0,        /* container, image / frame header, TOC, DC global, the global Modular tree */
+  JXLHIP_PHASE_DC_GROUPS = 1,      /* DecodeVarDCTDC + DecodeAcMetadata of every DC group, on the runner */
+  JXLHIP_PHASE_AC_GLOBAL = 2,      /* block contexts, dequant encodings, histograms and coefficient orders of every pass */
+  JXLHIP_PHASE_SIDE_INFO = 3,      /* frame_begin, side-info uploads, DC dequant + smoothing and dequant tables queued */
+  JXLHIP_PHASE_AC_GROUPS = 4,      /* entropy decode of every AC group on the runner + the coefficient uploads queued */
+  JXLHIP_PHASE_EXTRA_CHANNELS = 5, /* alpha / extra channels (Modular), 0 when none is asked for */
+  JXLHIP_PHASE_KERNELS = 6,        /* jxlhip_decode_frame + jxlhip_sync: what is left of uploads and kernels */
+  JXLHIP_CODESTREAM_PHASES = 7
+};
+JXLHIP_EXPORT int jxlhip_codestream_phase_ms(const jxlhip_ctx* ctx, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

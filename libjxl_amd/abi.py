@@ -245,7 +245,7 @@ EXPORTS = [
     "jxlhip_modular_extra_channel_rows_f32", "jxlhip_modular_ac_group_decode_f32_strided",
     # include/jxl_hip_codestream.h
     "jxlhip_codestream_basic_info", "jxlhip_decode_codestream", "jxlhip_decode_codestream_extra",
-    "jxlhip_codestream_icc_profile",
+    "jxlhip_codestream_icc_profile", "jxlhip_codestream_phase_ms",
 ]
 
 
@@ -339,6 +339,7 @@ def load_library():
     L.jxlhip_codestream_icc_profile.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]
     L.jxlhip_icc_decode.argtypes = [vp, sz, C.POINTER(sz), vp, sz, C.POINTER(sz)]
     L.jxlhip_decode_codestream.argtypes = [vp, vp, vp, vp, sz, u32, vp, vp, sz, sz, C.POINTER(CodestreamInfo)]
+    L.jxlhip_codestream_phase_ms.argtypes = [vp, C.POINTER(C.c_double)]
     L.jxlhip_decode_codestream_extra.argtypes = [vp, vp, vp, vp, sz, u32, vp, vp, sz, sz, C.POINTER(vp), u32, sz,
                                                  C.POINTER(CodestreamInfo)]
     L.jxlhip_modular_ac_group_decode_f32_strided.argtypes = [vp, vp, u32, u32, vp, sz, C.POINTER(sz), vp, u32, vp, vp]

@@ -57,6 +57,59 @@ def _link(target, objs, extra=()):
     return target
 
 
+def _uint(b, i):
+    t = b[i]
+    if t <= 0x7F:
+        return t
+    if t == 0xCC:
+        return b[i + 1]
+    if t == 0xCD:
+        return int.from_bytes(b[i + 1:i + 3], "big")
+    if t == 0xCE:
+        return int.from_bytes(b[i + 1:i + 5], "big")
+    raise ValueError(hex(t))
+
+
+def kernel_resources(so):
+    """{mangled kernel name: {scratch, vgprs, spills}} from the code-object metadata inside a built library (the AMDGPU
+    msgpack notes: .private_segment_fixed_size, .symbol, .vgpr_count, .vgpr_spill_count; the keys of a kernel record are
+    sorted)."""
+    import re
+    b = open(so, "rb").read()
+    out = {}
+    for m in re.finditer(rb"\xbb\.private_segment_fixed_size", b):
+        scratch = _uint(b, m.end())
+        s = b.find(b"\xa7.symbol", m.end(), m.end() + 400)
+        if s < 0:
+            continue
+        t = b[s + 8]
+        if t == 0xD9:
+            n, at = b[s + 9], s + 10
+        elif t == 0xDA:
+            n, at = int.from_bytes(b[s + 9:s + 11], "big"), s + 11
+        else:
+            n, at = t & 0x1F, s + 9
+        name = b[at:at + n].decode()
+        v = b.find(b"\xab.vgpr_count", at, at + 600)
+        sp = b.find(b"\xb1.vgpr_spill_count", at, at + 700)
+        out[name] = dict(scratch=scratch, vgprs=_uint(b, v + 12), spills=_uint(b, sp + 18))
+    return out
+
+
+def check_no_scratch(so, pattern="k_fused_pc"):
+    """A build whose producer / consumer fused kernels touch scratch must not ship: k_fused_pc's producing wave
+    prefetches through inline-asm loads whose only wait is the barrier's vmcnt(0) (kernels_fused.hip) -- the compiler
+    believes those registers hold their values from the asm statement on, so a spill or a scratch copy of one of them
+    in between stores a value that has not arrived (a 128-VGPR ablation build did exactly that and faulted).  A ROCm
+    point release that changes the register allocation must fail HERE, not corrupt memory on the GPU."""
+    bad = {k: v for k, v in kernel_resources(so).items() if pattern in k and (v["scratch"] or v["spills"])}
+    if bad:
+        os.remove(so)
+        raise RuntimeError("refusing to ship %s: %d %s kernels use scratch (inline-asm prefetch registers may be "
+                           "spilled before their loads land): %s" % (os.path.basename(so), len(bad), pattern,
+                                                                      sorted(bad.items())[:2]))
+
+
 def build(verbose=False):
     os.makedirs(BUILD, exist_ok=True)
     srcs = list(LIB_SOURCES)
@@ -66,6 +119,7 @@ def build(verbose=False):
     with ThreadPoolExecutor(max_workers=6) as ex:
         objs = dict(zip(srcs, ex.map(_compile, srcs)))
     lib = _link(os.path.join(CSRC, "libjxl_hip.so"), [objs[s] for s in LIB_SOURCES])
+    check_no_scratch(lib)
     out = [lib]
     if have_runner:
         out.append(_link(os.path.join(CSRC, "libjxl_threads_hip.so"),

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <atomic>
 #include <mutex>
@@ -59,6 +60,7 @@ struct jxlhip_ctx {
   // frame N + 1 will use (DevFrame::zero_counts) -- no memset launch per frame.  clean[b]: block b is all zero.
   int counts_slot = 0;
   bool counts_clean[2] = {false, false};
+  double cs_phase_ms[8] = {};  // jxlhip_codestream_phase_ms
   bool tiles_on = false;     // the last LaunchBlocksBand ran k_prepare in tile mode (DevFrame::fused_tiles)
   bool blocks_fused = false;  // jxlhip_decode_blocks ran in fused-stripe mode: the planes lack the inner DCT8 blocks
   jxlhip_frame_params p{};

@@ -418,7 +418,7 @@ TILE_MIX = {0: 30, 4: 25, 6: 20, 7: 20, 5: 3, 13: 2}   # the four classes the pr
 
 
 @pytest.mark.parametrize("gab,epf,out", [(1, 1, 1), (0, 0, 0), (1, 2, 1), (0, 1, 0)])
-@pytest.mark.parametrize("size,coeff_type,mix", [((1000, 520), 0, None), ((333, 268), 1, "tile"), ((117, 67), 0, "tile"),
+@pytest.mark.parametrize("size,coeff_type,mix", [((1000, 520), 0, None), ((333, 268), 1, "tile"), ((117, 68), 0, "tile"),
                                                   ((2048, 1029 - 5), 0, "all"), ((1500, 2100), 0, "tile"), ((1500, 700), 1, None)])
 def test_fused_tile_producer_matches_oracle(dq, oracle, gab, epf, out, size, coeff_type, mix, monkeypatch):
     """k_fused_pc's matrix-core producer (kernels_fused.hip ProduceTiles, DevFrame::fused_tiles; the default for whole

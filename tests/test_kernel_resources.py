@@ -16,41 +16,9 @@ from libjxl_amd import abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _uint(b, i):
-    t = b[i]
-    if t <= 0x7F:
-        return t
-    if t == 0xCC:
-        return b[i + 1]
-    if t == 0xCD:
-        return int.from_bytes(b[i + 1:i + 3], "big")
-    if t == 0xCE:
-        return int.from_bytes(b[i + 1:i + 5], "big")
-    raise ValueError(hex(t))
-
-
 def kernels():
-    so = os.path.join(ROOT, "libjxl_amd", "csrc", "libjxl_hip.so")
-    b = open(so, "rb").read()
-    out = {}
-    # the keys of a kernel record are sorted: .private_segment_fixed_size ... .symbol ... .vgpr_count .vgpr_spill_count
-    for m in re.finditer(rb"\xbb\.private_segment_fixed_size", b):
-        scratch = _uint(b, m.end())
-        s = b.find(b"\xa7.symbol", m.end(), m.end() + 400)
-        if s < 0:
-            continue
-        t = b[s + 8]
-        if t == 0xD9:
-            n, at = b[s + 9], s + 10
-        elif t == 0xDA:
-            n, at = int.from_bytes(b[s + 9:s + 11], "big"), s + 11
-        else:
-            n, at = t & 0x1F, s + 9
-        name = b[at:at + n].decode()
-        v = b.find(b"\xab.vgpr_count", at, at + 600)
-        sp = b.find(b"\xb1.vgpr_spill_count", at, at + 700)
-        out[name] = dict(scratch=scratch, vgprs=_uint(b, v + 12), spills=_uint(b, sp + 18))
-    return out
+    from libjxl_amd import build
+    return build.kernel_resources(os.path.join(ROOT, "libjxl_amd", "csrc", "libjxl_hip.so"))
 
 
 def test_fused_pc_kernels_have_no_scratch():
@@ -61,6 +29,23 @@ def test_fused_pc_kernels_have_no_scratch():
     bad = {k: v for k, v in pc.items() if v["scratch"] or v["spills"]}
     assert not bad, bad
     assert max(v["vgprs"] for v in pc.values()) <= 168  # three waves per SIMD
+
+
+def test_a_build_with_scratch_in_the_fused_kernels_is_refused(tmp_path):
+    """libjxl_amd/build.py checks the same metadata at build time (check_no_scratch) and deletes a library that fails:
+    here against a copy of the shipped library and a pattern that does have scratch (k_transform_r<short> keeps its
+    cold-path spills on purpose)."""
+    import shutil
+    from libjxl_amd import build
+    so = str(tmp_path / "copy.so")
+    shutil.copy(os.path.join(ROOT, "libjxl_amd", "csrc", "libjxl_hip.so"), so)
+    build.check_no_scratch(so)  # the shipped fused kernels: clean
+    assert os.path.exists(so)
+    if any(v["scratch"] for v in build.kernel_resources(so).values()):
+        spilling = next(k for k, v in build.kernel_resources(so).items() if v["scratch"])
+        with pytest.raises(RuntimeError, match="refusing to ship"):
+            build.check_no_scratch(so, pattern=spilling)
+        assert not os.path.exists(so)
 
 
 def test_metadata_reader_sees_the_known_kernels():

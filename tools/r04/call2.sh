@@ -10,5 +10,5 @@ for rep in 1 2; do q ""; done
 q "" --config c2; q "" --config c1; q "" --mix real4k; q "" --config c4; q "" --width 3840 --height 2160
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tl
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $R/bench.py --no-cpu-baseline --no-pcie --steps 60 --warmup 5 > /tmp/tl.log 2>&1
-f=$(find /tmp/tl -name "*kernel_trace.csv" | head -1); python $R/tools/timeline.py $f
+f=$(find /tmp/tl -name "*kernel_trace.csv" | head -1); echo "trace: $f"; tail -3 /tmp/tl.log; python $R/tools/timeline.py $f
 } 2>&1 | tee $O/r04_call2_bench.txt

@@ -7,8 +7,14 @@ import sys
 from collections import defaultdict
 
 rows = []
-for r in csv.DictReader(open(sys.argv[1])):
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rd = csv.DictReader(open(sys.argv[1]))
+cols = {c.lower(): c for c in rd.fieldnames}
+ks, ke, kn = cols.get("start_timestamp"), cols.get("end_timestamp"), cols.get("kernel_name")
+if not (ks and ke and kn):
+    sys.exit("unexpected columns: %s" % rd.fieldnames)
+for r in rd:
+    rows.append((int(r[ks]), int(r[ke]), r[kn]))
+print("%d launches in %s" % (len(rows), sys.argv[1]))
 rows.sort()
 first = sys.argv[2] if len(sys.argv) > 2 else "k_prepare"
 steps, cur = [], None
@@ -21,7 +27,11 @@ for s, e, n in rows:
         cur.append((s, e, n))
 if cur:
     steps.append(cur)
-steps = [st for st in steps if len(st) == max(len(x) for x in steps)][5:-1]  # steady state, complete steps
+if not steps:
+    sys.exit("no launch named *%s*; first names: %s" % (first, [n[:50] for _, _, n in rows[:5]]))
+from collections import Counter
+common = Counter(len(x) for x in steps).most_common(1)[0][0]
+steps = [st for st in steps if len(st) == common][5:-1]  # steady state, steps of the usual shape
 acc = defaultdict(lambda: [0.0, 0.0, 0])
 period = []
 for i, st in enumerate(steps):
