@@ -268,7 +268,8 @@ def e2e_block(torch, local):
         if not os.path.exists(exe):
             res[tool] = {"error": "not built"}
             continue
-        env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref") + ":" + os.path.join(ROOT, "libjxl_amd", "csrc") +
+        env = dict(os.environ, JXLHIP_SEAM_VERBOSE="1",
+                   LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref") + ":" + os.path.join(ROOT, "libjxl_amd", "csrc") +
                    ":" + os.environ.get("LD_LIBRARY_PATH", ""))
         got = None
         for threads in sorted({t for t in (16, 64) if t <= ncpu}):
@@ -280,6 +281,12 @@ def e2e_block(torch, local):
             m = re.search(r"([0-9.]+) MP/s", r.stderr)
             if r.returncode == 0 and m and (got is None or float(m.group(1)) > got["value"]):
                 got = {"value": float(m.group(1)), "threads": threads, "line": r.stderr.strip().splitlines()[-1][:200]}
+                # the binding's own clock (JXLHIP_SEAM_VERBOSE): what of a repetition is the back-end, what is libjxl's
+                # front end (headers, Modular DC groups) and djxl itself (a fresh float frame per repetition)
+                seam = [l for l in r.stderr.splitlines() if l.startswith("jxlhip seam: frame")]
+                if seam:
+                    got["seam_ms_last_rep"] = seam[-1].split("; ms: ")[-1][:200]
+                    got["ms_per_rep"] = round(w * h / got["value"] / 1e3, 1)
         res[tool] = got or {"error": "djxl failed"}
     if "value" in res.get("djxl_hip", {}) and "value" in res.get("djxl_ref", {}):
         res["djxl_hip_over_ref"] = round(res["djxl_hip"]["value"] / res["djxl_ref"]["value"], 2)
@@ -305,6 +312,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (N=1)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-file block (N=1, default workload)")
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="N=1: decoder contexts (each on a HIP stream of its own) the steps rotate over, default 3: launch "
+                         "gaps, k_prepare and kernel tails of one frame overlap the next frame's kernels.  1 = one frame "
+                         "at a time (also measured and reported as `one_frame_in_flight`)")
     ap.add_argument("--calib-copy", action="store_true",
                     help="run one known-size (1 GiB) device copy so PMC passes can be calibrated")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=None)
@@ -348,10 +359,34 @@ def main():
     gather = world > 1 and not args.no_gather
     full = sd.alloc_gather(out) if gather else None
 
+    # N = 1: a pool of decoder contexts, one HIP stream each, over the same (read-only) inputs: step k runs on
+    # context k % F.  Every step is a whole frame -- k_prepare, transforms, fused filter kernel -- nothing is shared
+    # between steps but the inputs; what overlaps is one frame's launch gaps / tail with the next frame's kernels.
+    inflight = max(1, args.frames_in_flight if args.frames_in_flight is not None else (3 if world == 1 else 1))
+    if world > 1:
+        inflight = 1
+    slots = [(dec, out)]
+    for _ in range(inflight - 1):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            d2 = VarDctDecoder(local)  # its launches go to st
+        d2.begin_frame(params)
+        d2.set_inputs(t, dq)
+        slots.append((d2, d2.alloc_output()))
+    counter = [0]
+
     def step():
+        if world == 1:
+            d, o = slots[counter[0] % inflight]
+            counter[0] += 1
+            d.decode_frame(o)
+            return
         sd.decode(out)
         if gather:
             sd.gather(out, full)
+
+    def step_one():
+        dec.decode_frame(out)
 
     def fence():
         if world > 1:
@@ -381,10 +416,40 @@ def main():
         return t
 
     dt = timed(step)
+    dt_one = timed(step_one) if (world == 1 and inflight > 1) else None
+    for d2, o2 in slots[1:]:
+        assert torch.equal(o2, out), "a pooled context decoded a different frame"
     # N > 1: the same frame with the output stripes left sharded in each GPU's HBM (a consumer on the device, or
     # every GPU writing its own stripe to the host): the form in which the split scales -- the gather of a 1.59 GB
     # float frame into ONE GPU is per-link bound
     dt_sharded = timed(lambda: sd.decode(out)) if gather else None
+
+    # N > 1: where a step's time goes on each rank (HIP events on the compute stream around the phases of
+    # StripeDecoder.decode and the gather; average over the steps, then the MAX over ranks): blocks = phase 1,
+    # interior = halo export + posting the sends + the rows that need no halo, halo_wait = what is left of the exchange
+    # after that, boundary = halo import + the two boundary block rows, gather = the stripes into rank 0's frame
+    phase_ms = None
+    if world > 1:
+        T = {}
+        n_prof = max(4, min(args.steps, 20))
+        for _ in range(n_prof):
+            sd.decode(out, timing=T)
+            if gather:
+                sd.gather(out, full)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            T.setdefault("gather", []).append(ev)
+        fence()
+        order = ["t0", "blocks", "interior", "halo_wait", "boundary", "gather"]
+        vals = []
+        for a, b in zip(order, order[1:]):
+            if a in T and b in T and len(T[a]) == len(T[b]):
+                vals.append(sum(x.elapsed_time(y) for x, y in zip(T[a], T[b])) / len(T[a]))
+            else:
+                vals.append(0.0)
+        tt = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        phase_ms = {k: round(float(v), 4) for k, v in zip(order[1:], tt.tolist())}
 
     # per-kernel device time with HIP events on the launch stream (own pass)
     dec.profile(True)
@@ -447,8 +512,11 @@ def main():
                                    f"epf_iters={cfg['epf']}, {'int32' if cfg['coeff32'] else 'int16'} "
                                    f"coefficients, strategy mix {cfg['mix']}, intensity_target {cfg['intensity']:g}, "
                                    f"linear RGB f32 out",
+                       "frames_in_flight": inflight,
                        "stripes": world, "halo_rows": dec.halo_rows(),
                        "gather_in_step": bool(gather),
+                       "phase_ms_max_over_ranks": phase_ms,
+                       "interior_first": os.environ.get("JXLHIP_STRIPES_INTERIOR_FIRST", "1") != "0" if world > 1 else None,
                        "kernel_ms": kern},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -464,6 +532,12 @@ def main():
                          "algorithmic_bytes_frame": b_alg_frame,
                          "kernel_own_bytes_per_launch": b_own},
         }
+        if dt_one is not None:
+            line["one_frame_in_flight"] = {"value": round(px / (dt_one / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                                           "ms_per_step": round(dt_one / args.steps * 1e3, 4),
+                                           "what": "the same steps on ONE context / stream, a frame at a time (the figure of rounds 1-3); "
+                                                   "`value` rotates the steps over `frames_in_flight` contexts"}
+            line["roofline"]["frac_one_frame_in_flight"] = round(b_alg_frame / (dt_one / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
         if dt_sharded is not None:
             line["sharded"] = {"value": round(px / (dt_sharded / args.steps) / 1e6, 1), "unit": "Mpixels/s",
                                "ms_per_step": round(dt_sharded / args.steps * 1e3, 4),

@@ -307,6 +307,14 @@ JXLHIP_EXPORT int jxlhip_halo_import(jxlhip_ctx* ctx, int which,
 JXLHIP_EXPORT int jxlhip_decode_filters(jxlhip_ctx* ctx, void* out,
                                         size_t out_stride,
                                         size_t out_plane_stride);
+/* Phase 2 for the frame rows [y_begin, y_end) of the stripe only (`out` still names the stripe's first row).  What a
+ * stripe with neighbours does while its halo rows travel: the rows whose filter support stays inside the stripe -- all
+ * but the first / last block row -- need no halo (the reference hands a group's border rows to its neighbours without
+ * waiting for them either, dec_group_border.cc:68-187; stage borders: loop_filter.h:26-29), the two boundary block
+ * rows follow once jxlhip_halo_import has run.  y_begin and y_end must be multiples of 8 or the stripe's own first /
+ * last row; the pixels do not depend on how the rows are cut. */
+JXLHIP_EXPORT int jxlhip_decode_filters_rows(jxlhip_ctx* ctx, void* out, size_t out_stride, size_t out_plane_stride,
+                                             uint32_t y_begin, uint32_t y_end);
 
 /* Both phases (single GPU).  When the context holds the whole frame (no stripe)
  * and the stage list has at most two EPF passes this runs FUSED

@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE ONLY.  Builds the reference's own command-line decoder, `djxl`, UNMODIFIED, twice:
+"""Builds the reference's own command-line decoder, `djxl`, UNMODIFIED, twice:
 
   oracle/_ref/djxl_ref   tools/djxl_main.cc + lib/extras (PNM / PFM / PGX / NPY writers; the PNG / JPEG / EXR / GIF
                          codecs compile to their "not available" stubs) on oracle/_ref/libjxl_dec_ref.so (the
                          reference decoder, unpatched) and oracle/_ref/libjxl_threads_ref.so (lib/threads)
   oracle/_ref/djxl_hip   the same objects on oracle/_ref/libjxl_dec_hip.so (the reference decoder with the
-                         three-statement seam of oracle/build_seam.py -> libjxl_hip.so) and the product's runner
+                         three-statement seam of integration/build_seam.py -> libjxl_hip.so) and the product's runner
                          libjxl_amd/csrc/libjxl_threads_hip.so
 
 Every translation unit is compiled in place from /root/reference (g++, the Highway shim of oracle/hwy_shim);
-nothing of the reference is stored in the repository.  The only source added is oracle/djxl_support.cc (one
+nothing of the reference is stored in the repository.  The only source added is integration/djxl_support.cc (one
 encoder-API helper lib/extras needs from the full libjxl, and the default CMS when lcms2 is not installed).
 tests/test_djxl.py runs both tools on the same .jxl files (GPU suite) and tools/conformance_hip.py runs a
 conformance corpus through them.
@@ -20,13 +20,15 @@ import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))      # integration/: the binding and its build recipes
+ROOT = os.path.dirname(HERE)
+ORACLE = os.path.join(ROOT, "oracle")                   # build_ref.py, the Highway shim, _ref/ (outputs), _build/ (scratch)
 sys.path.insert(0, HERE)
+sys.path.insert(0, ORACLE)
 import build_ref as B  # noqa: E402
 import build_seam as S  # noqa: E402
 
-OBJ = os.path.join(HERE, "_build", "djxl")
-ROOT = os.path.dirname(HERE)
+OBJ = os.path.join(ORACLE, "_build", "djxl")
 HIPLIB_DIR = os.path.join(ROOT, "libjxl_amd", "csrc")
 TOOL_TUS = ["tools/djxl_main.cc", "tools/cmdline.cc", "tools/codec_config.cc", "tools/speed_stats.cc",
             "tools/tool_version.cc"]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE ONLY.  Compiles the drop-in boundary of INTEGRATION.md for real.
+"""The drop-in boundary of INTEGRATION.md compiled for real (the maintainer's patch + the recipe that builds libjxl with it).
 
 Two shared libraries with the reference's PUBLIC decoder API (lib/include/jxl/decode.h: JxlDecoderCreate,
 JxlDecoderProcessInput, JxlDecoderSetImageOutBuffer ...; lib/jxl/decode.cc compiled in place) over the same
@@ -8,7 +8,7 @@ reference translation units oracle/build_ref.py builds (objects reused from orac
   oracle/_ref/libjxl_dec_ref.so   the reference decoder, unmodified
   oracle/_ref/libjxl_dec_hip.so   the same with FrameDecoder::ProcessSections handing the AC groups of eligible
                                   frames to the HIP back-end: a patched COPY of lib/jxl/dec_frame.cc (written to
-                                  oracle/_build/seam/, git-ignored, never committed) + oracle/seam/hip_seam.cc,
+                                  oracle/_build/seam/, git-ignored, never committed) + integration/hip_seam.cc,
                                   linked against libjxl_amd/csrc/libjxl_hip.so
 
 The patch is three inserted statements, applied by anchor (PATCH below) -- the reference file is read where it
@@ -20,12 +20,14 @@ import os
 import subprocess
 import sys
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.abspath(__file__))      # integration/: the binding and its build recipes
+ROOT = os.path.dirname(HERE)
+ORACLE = os.path.join(ROOT, "oracle")                   # build_ref.py, the Highway shim, _ref/ (outputs), _build/ (scratch)
 sys.path.insert(0, HERE)
+sys.path.insert(0, ORACLE)
 import build_ref as B  # noqa: E402
 
-SEAM = os.path.join(HERE, "_build", "seam")
-ROOT = os.path.dirname(HERE)
+SEAM = os.path.join(ORACLE, "_build", "seam")
 HIPLIB_DIR = os.path.join(ROOT, "libjxl_amd", "csrc")
 EXTRA_TUS = ["jxl/decode.cc", "jxl/decode_to_jpeg.cc"]  # what build_ref.py leaves out
 FLAGS = B.FLAGS + ["-DJPEGXL_ENABLE_BOXES=0", "-DJPEGXL_ENABLE_TRANSCODE_JPEG=0"]
@@ -45,7 +47,7 @@ PATCH = [
      "  // jxlhip seam: where AC global starts in its reader (a one-section frame shares the reader)\n"
      "  const size_t jxlhip_ac_global_bit = ac_global_sec != num ? sections[ac_global_sec].br->TotalBitsConsumed() : 0;\n"),
     ("    // Mark all the AC groups that we received as not complete yet.",
-     "    {  // jxlhip seam (oracle/seam/hip_seam.cc): the whole frame's AC groups on the HIP back-end when eligible\n"
+     "    {  // jxlhip seam (integration/hip_seam.cc): the whole frame's AC groups on the HIP back-end when eligible\n"
      "      bool jxlhip_done = false;\n"
      "      JXL_RETURN_IF_ERROR(JxlHipTryAcGroups(this, sections, num, ac_group_sec, desired_num_ac_passes,\n"
      "                                            ac_global_sec, jxlhip_ac_global_bit, section_status, &jxlhip_done));\n"
@@ -122,7 +124,7 @@ def build(verbose=False):
     o_patched = os.path.join(SEAM, "dec_frame_hip.o")
     _cc(patched, o_patched, inc)
     o_seam = os.path.join(SEAM, "hip_seam.o")
-    _cc(os.path.join(HERE, "seam", "hip_seam.cc"), o_seam, inc)
+    _cc(os.path.join(HERE, "hip_seam.cc"), o_seam, inc)
     # the encoder's public API (JxlEncoder*) wants the JPEG-transcoding translation units: not part of a decoder library
     objs = [o for o in objs if not o.endswith("jxl__encode.o")]
     dec_frame_obj = [o for o in objs if o.endswith("jxl__dec_frame.o")]

@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE ONLY (linked into oracle/_ref/djxl_ref and djxl_hip by oracle/build_djxl.py; never part of
+// TEST INFRASTRUCTURE ONLY (linked into oracle/_ref/djxl_ref and djxl_hip by integration/build_djxl.py; never part of
 // the product).  The two symbols tools/djxl_main.cc + lib/extras need from the FULL libjxl that a decoder-only
 // library (lib/jxl/decode.cc over the decoder translation units) does not carry:
 //

@@ -1,7 +1,8 @@
-// TEST INFRASTRUCTURE (compiled into oracle/_ref/libjxl_dec_hip.so by oracle/build_seam.py; never part of the
-// product): the reference-side binding of INTEGRATION.md, compiled for real.
+// The reference-side binding of INTEGRATION.md, compiled for real: what a libjxl maintainer adds to the tree to put the
+// HIP back-end behind JxlDecoder (built into oracle/_ref/libjxl_dec_hip.so by integration/build_seam.py, on the reference
+// sources where they lie; libjxl_hip.so itself never links or loads it).
 //
-// oracle/build_seam.py makes a patched COPY of the reference's lib/jxl/dec_frame.cc (two inserted statements,
+// integration/build_seam.py makes a patched COPY of the reference's lib/jxl/dec_frame.cc (two inserted statements,
 // see there) in which FrameDecoder::ProcessSections, once DC global / DC groups / AC global are decoded by the
 // reference's own code and every AC section of the frame is present, calls JxlHipTryAcGroups() below instead of
 // running DecodeGroup + the CPU render pipeline per group (lib/jxl/dec_frame.cc:694-731).  This function is the

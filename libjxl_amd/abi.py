@@ -225,7 +225,7 @@ EXPORTS = [
     "jxlhip_destroy", "jxlhip_last_error", "jxlhip_set_stream",
     "jxlhip_frame_begin", "jxlhip_frame_set_inputs", "jxlhip_upload_side_info",
     "jxlhip_submit_group", "jxlhip_set_alpha", "jxlhip_alpha_staging", "jxlhip_decode_blocks", "jxlhip_halo_rows",
-    "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_frame",
+    "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_filters_rows", "jxlhip_decode_frame",
     "jxlhip_decode_frame_host", "jxlhip_decode_frame_pinned",
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
     "jxlhip_profile_enable", "jxlhip_profile_read",
@@ -320,6 +320,7 @@ def load_library():
     L.jxlhip_halo_export.argtypes = [vp, i32, vp]
     L.jxlhip_halo_import.argtypes = [vp, i32, vp]
     L.jxlhip_decode_filters.argtypes = [vp, vp, sz, sz]
+    L.jxlhip_decode_filters_rows.argtypes = [vp, vp, sz, sz, u32, u32]
     L.jxlhip_decode_frame.argtypes = [vp, vp, sz, sz]
     L.jxlhip_decode_frame_host.argtypes = [vp, vp, sz, sz]
     L.jxlhip_decode_frame_pinned.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]

@@ -1473,6 +1473,12 @@ int jxlhip_halo_import(jxlhip_ctx* c, int which, const float* dev) {
 
 int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  return jxlhip_decode_filters_rows(c, out, out_stride, out_plane_stride, c->f.y0, c->f.y1);
+}
+
+int jxlhip_decode_filters_rows(jxlhip_ctx* c, void* out, size_t out_stride, size_t out_plane_stride, uint32_t y_begin,
+                               uint32_t y_end) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   JXLHIP_NO_MULTI(c);
   if (!c->blocks_done) return Fail(c, JXLHIP_ERR_STATE, "decode_filters before decode_blocks");
   if (c->p.undo_orientation > 1) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "undo_orientation with the split calls");
@@ -1483,7 +1489,16 @@ int jxlhip_decode_filters(jxlhip_ctx* c, void* out, size_t out_stride, size_t ou
   fp.out = out;
   fp.out_stride = out_stride;
   fp.out_plane_stride = out_plane_stride;
-  return LaunchFiltersRows(c, fp, c->f.y0, c->f.y1, c->blocks_fused);
+  const bool whole = y_begin == c->f.y0 && y_end == c->f.y1;
+  if (!whole) {
+    if (y_begin < c->f.y0 || y_end > c->f.y1 || y_begin > y_end ||
+        ((y_begin & 7u) && y_begin != c->f.y0) || ((y_end & 7u) && y_end != c->f.y1))
+      return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "rows [%u, %u) of a stripe [%u, %u): block-row multiples inside it only", y_begin,
+                  y_end, c->f.y0, c->f.y1);
+    if (c->p.lf.epf_iters == 3) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "row ranges with epf_iters = 3 (two marches over a second plane set)");
+    if (y_begin == y_end) return JXLHIP_OK;
+  }
+  return LaunchFiltersRows(c, fp, y_begin, y_end, c->blocks_fused);
 }
 
 // Both phases.  With JXLHIP_BAND_ROWS = n > 0 the stripe is walked in bands of n

@@ -130,9 +130,14 @@ class VarDctDecoder:
     def decode_blocks(self):
         _check(self.L, self.ctx, self.L.jxlhip_decode_blocks(self.ctx), "decode_blocks")
 
-    def decode_filters(self, out):
+    def decode_filters(self, out, rows=None):
+        """Phase 2 into `out` (the stripe's rows).  rows = (y_begin, y_end): only those frame rows (block-row multiples
+        inside the stripe, jxlhip_decode_filters_rows) -- the interior first while the halo rows travel."""
         a = self._out_args(out)
-        _check(self.L, self.ctx, self.L.jxlhip_decode_filters(self.ctx, *a), "decode_filters")
+        if rows is None:
+            _check(self.L, self.ctx, self.L.jxlhip_decode_filters(self.ctx, *a), "decode_filters")
+        else:
+            _check(self.L, self.ctx, self.L.jxlhip_decode_filters_rows(self.ctx, *a, int(rows[0]), int(rows[1])), "decode_filters_rows")
 
     def decode_frame(self, out=None):
         if out is None:

@@ -89,6 +89,8 @@ class StripeDecoder:
         self.rows = [stripe_pixel_rows(params["ysize"], a, b) for a, b in self.parts]
         decoder.begin_frame(self.params)
         self._halo = None  # persistent send / receive buffers of the halo exchange
+        import os
+        self.interior_first = os.environ.get("JXLHIP_STRIPES_INTERIOR_FIRST", "1") != "0"
 
     def _halo_buffers(self):
         if self._halo is None:
@@ -123,34 +125,64 @@ class StripeDecoder:
             req.wait()
         return full
 
-    def decode(self, out):
+    def decode(self, out, timing=None):
+        """Both phases of this rank's stripe.  timing: an optional dict that receives torch.cuda.Event pairs around the
+        phases ("blocks", "interior", "halo_wait", "boundary"), for bench.py's per-phase report."""
         d = self.dec
         if self.world == 1:
             # no neighbours: both phases in one call, walked in bands so that the
             # XYB planes of a band are filtered while still cache resident
             return d.decode_frame(out)
+
+        def mark(name):
+            if timing is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                timing.setdefault(name, []).append(ev)
+
+        mark("t0")
         d.decode_blocks()
+        mark("blocks")
         h = d.halo_rows()
-        if h > 0:
-            # the boundary rows leave phase 1's planes for dense buffers that live as long as the decoder, travel
-            # to the two neighbours point to point (RCCL over the direct xGMI link) and are installed above / below
-            # this stripe's planes; every step is ordered on streams (an RCCL request's wait() makes the compute
-            # stream wait, not the host)
-            b = self._halo_buffers()
-            ops = []
-            if self.rank > 0:
-                d.halo_export(0, b["up_send"])
-                ops += [dist.P2POp(dist.isend, b["up_send"], self.rank - 1, self.group),
-                        dist.P2POp(dist.irecv, b["up_recv"], self.rank - 1, self.group)]
-            if self.rank + 1 < self.world:
-                d.halo_export(1, b["dn_send"])
-                ops += [dist.P2POp(dist.isend, b["dn_send"], self.rank + 1, self.group),
-                        dist.P2POp(dist.irecv, b["dn_recv"], self.rank + 1, self.group)]
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            if self.rank > 0:
-                d.halo_import(0, b["up_recv"])
-            if self.rank + 1 < self.world:
-                d.halo_import(1, b["dn_recv"])
-        d.decode_filters(out)
+        if h == 0:
+            d.decode_filters(out)
+            mark("interior")
+            return out
+        # the boundary rows leave phase 1's planes for dense buffers that live as long as the decoder and travel to
+        # the two neighbours point to point (RCCL over the direct xGMI link; requests are ordered on streams: wait()
+        # makes the compute stream wait, not the host)
+        b = self._halo_buffers()
+        ops = []
+        if self.rank > 0:
+            d.halo_export(0, b["up_send"])
+            ops += [dist.P2POp(dist.isend, b["up_send"], self.rank - 1, self.group),
+                    dist.P2POp(dist.irecv, b["up_recv"], self.rank - 1, self.group)]
+        if self.rank + 1 < self.world:
+            d.halo_export(1, b["dn_send"])
+            ops += [dist.P2POp(dist.isend, b["dn_send"], self.rank + 1, self.group),
+                    dist.P2POp(dist.irecv, b["dn_recv"], self.rank + 1, self.group)]
+        reqs = dist.batch_isend_irecv(ops)
+        # INTERIOR FIRST: while the halo messages fly, filter the rows whose support stays inside the stripe -- all
+        # but the first / last block row next to a neighbour (8 rows >= LoopFilter::Padding(), loop_filter.h:26-29;
+        # the reference overlaps its neighbour hand-off as well, dec_group_border.cc:68-187)
+        y0, y1 = self.rows[self.rank]
+        ya = y0 + 8 if self.rank > 0 else y0
+        yb = y1 - 8 if self.rank + 1 < self.world else y1
+        split = self.interior_first and yb - ya >= 8 and d.params.lf.epf_iters < 3
+        if split:
+            d.decode_filters(out, rows=(ya, yb))
+        mark("interior")
+        for req in reqs:
+            req.wait()
+        mark("halo_wait")
+        if self.rank > 0:
+            d.halo_import(0, b["up_recv"])
+        if self.rank + 1 < self.world:
+            d.halo_import(1, b["dn_recv"])
+        if split:
+            d.decode_filters(out, rows=(y0, ya))
+            d.decode_filters(out, rows=(yb, y1))
+        else:
+            d.decode_filters(out)
+        mark("boundary")
         return out

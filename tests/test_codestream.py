@@ -165,7 +165,7 @@ def test_display_orientation_like_jxldecoder(L, ref, orientation, monkeypatch):
     import torch
     from libjxl_amd import VarDctDecoder
     import test_seam
-    sys.path.insert(0, os.path.join(test_seam.ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(test_seam.ROOT, "integration"))
     import build_seam
     try:
         ref_so, _ = build_seam.build()

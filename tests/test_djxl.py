@@ -1,4 +1,4 @@
-"""djxl, unmodified, on the HIP back-end (oracle/build_djxl.py).
+"""djxl, unmodified, on the HIP back-end (integration/build_djxl.py).
 
   oracle/_ref/djxl_ref : tools/djxl_main.cc + lib/extras on the reference decoder + lib/threads
   oracle/_ref/djxl_hip : the SAME objects on libjxl_dec_hip.so (reference JxlDecoder + the three-statement seam ->
@@ -25,7 +25,7 @@ TIGHT = 2e-5
 
 @pytest.fixture(scope="module")
 def tools(oracle):
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
     import build_djxl
     try:
         ref, hip = build_djxl.build()
@@ -103,9 +103,11 @@ def compare(a_path, b_path, ext):
         assert ma == mb and a.shape == b.shape
         # alpha is coded losslessly and leaves through the same arithmetic: identical
         assert np.array_equal(a[..., -1], b[..., -1])
-        d = np.abs(a[..., :-1].astype(np.int64) - b[..., :-1].astype(np.int64))
+        sd = a[..., :-1].astype(np.int64) - b[..., :-1].astype(np.int64)
+        d = np.abs(sd)
         assert int(d.max()) <= (1 if ma < 256 else 2), int(d.max())
         assert float((d != 0).mean()) < (1e-3 if ma < 256 else 0.5)
+        assert abs(float(sd.mean())) < (1e-3 if ma < 256 else 0.02), float(sd.mean())  # no systematic bias (in LSB)
         return
     if ext == "npy":
         a, b = np.load(a_path), np.load(b_path)
@@ -114,10 +116,15 @@ def compare(a_path, b_path, ext):
     else:
         (a, ma), (b, mb) = read_pnm(a_path), read_pnm(b_path)
         assert ma == mb and a.shape == b.shape
-        d = np.abs(a.astype(np.int64) - b.astype(np.int64))
+        sd = a.astype(np.int64) - b.astype(np.int64)
+        d = np.abs(sd)
         # the float pipeline in front differs by <= 2e-5: a sample may land on the other side of a rounding step
+        # (16-bit: 2e-5 x 65535 = 1.3 LSB, so up to half of the samples may differ by one) -- but not to ONE side: the
+        # mean SIGNED difference stays a small fraction of an LSB (a systematic half-LSB bias would pass the two
+        # bounds above and fail here)
         assert int(d.max()) <= (1 if ma < 256 else 2), int(d.max())
         assert float((d != 0).mean()) < (1e-3 if ma < 256 else 0.5)
+        assert abs(float(sd.mean())) < (1e-3 if ma < 256 else 0.02), float(sd.mean())
         return
     assert a.shape == b.shape and a.dtype == b.dtype
     scale = max(1.0, float(np.abs(a).max()))
@@ -230,6 +237,31 @@ def test_djxl_on_a_genuine_4k_stream(tools, tmp_path):
         compare(str(tmp_path / f"r.{ext}"), str(tmp_path / f"h.{ext}"), ext)
 
 
+def e2e_stream_path():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_e2e_stream
+    p = make_e2e_stream.DEFAULT
+    return p if os.path.exists(p) else None
+
+
+@pytest.mark.gpu
+def test_djxl_on_a_genuine_8k_stream(tools, tmp_path):
+    """BASELINE's frame size through the drop-in path: oracle/_ref/e2e_8k_d1.jxl (7680x4320, d1.0, effort 7, written by
+    the reference encoder: oracle/make_e2e_stream.py; the stream bench.py's e2e block times) through the unmodified
+    djxl on the HIP back-end against the same tool on libjxl's CPU decoder: float pixels (.npy, .pfm) within 2e-5."""
+    djxl_ref, djxl_hip = tools
+    jxl = e2e_stream_path()
+    if jxl is None:
+        pytest.skip("oracle/_ref/e2e_8k_d1.jxl not made (python oracle/make_e2e_stream.py)")
+    for ext, extra in (("npy", []), ("pfm", ["--num_threads", "8"])):
+        run(djxl_ref, [jxl, str(tmp_path / f"r.{ext}")] + extra)
+        err = run(djxl_hip, [jxl, str(tmp_path / f"h.{ext}")] + extra, verbose=True)
+        assert "jxlhip seam: frame 7680x4320" in err, err[-1500:]
+        compare(str(tmp_path / f"r.{ext}"), str(tmp_path / f"h.{ext}"), ext)
+        os.remove(str(tmp_path / f"r.{ext}"))
+        os.remove(str(tmp_path / f"h.{ext}"))
+
+
 @pytest.mark.gpu
 def test_conformance_mini_corpus_through_djxl_hip(tools, ref, tmp_path):
     """Expectations = the reference decoder's float pixels (djxl_ref -> reference_image.npy, reference.icc,
@@ -245,6 +277,10 @@ def test_conformance_mini_corpus_through_djxl_hip(tools, ref, tmp_path):
     p = tmp_path / "real4k.jxl"
     p.write_bytes(np.load(os.path.join(ROOT, "tests", "data", "real_4k_d1.npz"))["codestream"].tobytes())
     inputs.append(str(p))
+    if e2e_stream_path():  # BASELINE's 8K frame size as a corpus entry
+        p8 = tmp_path / "real8k.jxl"
+        os.symlink(e2e_stream_path(), p8)
+        inputs.append(str(p8))
     corpus = str(tmp_path / "corpus")
     ch.generate(djxl_ref, corpus, inputs, peak_error=1e-4, rmse=2e-5)
     log = []

@@ -503,7 +503,7 @@ def test_damaged_streams_same_verdict_as_the_reference_decoder(L, ref):
     run once with identical verdicts throughout; the suite keeps 80.)"""
     import random
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "integration"))
     import build_seam
     import test_seam as S
     try:

@@ -271,6 +271,55 @@ def test_stripes_through_the_fused_kernel_equal_whole_frame(dq, oracle, gab, epf
         d.close()
 
 
+@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("gab,epf", [(1, 1), (1, 2), (0, 1)])
+def test_stripe_interior_rows_before_the_halo_arrives(dq, oracle, gab, epf, fuse, monkeypatch):
+    """jxlhip_decode_filters_rows: a stripe filters the rows whose support stays inside it BEFORE its neighbours' halo
+    rows are installed (what libjxl_amd.stripes and jxlhip_create_multi do while the halo messages travel), then the
+    first / last block row.  Three stripes, fused kernel and two-phase: bit-equal to the whole frame; and the interior
+    rows really do not read the halo (they are computed with the halo rows still unset)."""
+    monkeypatch.setenv("JXLHIP_FUSE", fuse)
+    params, t, fr = frames.make_case(600, 1100, mix=synth.MIX_D1, gab=bool(gab), epf_iters=epf, seed=23)
+    devt = to_dev(t)
+    d0 = VarDctDecoder(0)
+    d0.begin_frame(params)
+    d0.set_inputs(devt, dq)
+    whole = d0.decode_frame().clone()
+    d0.sync()
+    d0.close()
+    parts, decs = [], []
+    bounds = []
+    for (g0, gr) in [(0, 2), (2, 1), (3, 2)]:
+        d = VarDctDecoder(0)
+        d.begin_frame(dict(params, stripe_group_y0=g0, stripe_group_rows=gr))
+        d.set_inputs(devt, dq)
+        d.decode_blocks()
+        y0, y1 = d.stripe_rows()
+        ya = y0 + 8 if g0 > 0 else y0
+        yb = y1 - 8 if g0 + gr < 5 else y1
+        out = d.alloc_output()
+        out.fill_(float("nan"))
+        d.decode_filters(out, rows=(ya, yb))  # no halo rows installed yet
+        d.sync()
+        assert not torch.isnan(out[ya - y0:yb - y0]).any() and torch.isnan(out[:ya - y0]).all() and torch.isnan(out[yb - y0:]).all()
+        decs.append(d)
+        parts.append(out)
+        bounds.append((y0, ya, yb, y1))
+    for i in range(2):
+        decs[i + 1].halo_import(0, decs[i].halo_export(1))
+        decs[i].halo_import(1, decs[i + 1].halo_export(0))
+    for d, out, (y0, ya, yb, y1) in zip(decs, parts, bounds):
+        d.decode_filters(out, rows=(y0, ya))
+        d.decode_filters(out, rows=(yb, y1))
+        d.sync()
+        with pytest.raises(Exception):
+            d.decode_filters(out, rows=(y0 + 4, y1))  # not a block-row multiple
+    got = torch.cat(parts, dim=0)
+    assert torch.equal(got, whole), (got - whole).abs().max()
+    for d in decs:
+        d.close()
+
+
 def test_upload_path_equals_device_path(dec, dq, oracle):
     """Host-pointer hand-off (upload_side_info + submit_group per group, as a
     FrameDecoder would call it) gives the same pixels as device-resident inputs."""

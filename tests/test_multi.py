@@ -72,6 +72,10 @@ def test_multi_context_matches_single_context(oracle, monkeypatch, nstripes, gat
     got = run_multi(L, devices, params, t, table_host, host_out)
     assert rel_err(got, ref) <= TIGHT
     assert np.array_equal(got, single)  # stripes + halo exchange reproduce the whole-frame two-phase result bit for bit
+    # interior rows first (the default: they are filtered while the halo rows travel) or everything behind the exchange
+    # (round 3's order): the same pixels
+    monkeypatch.setenv("JXLHIP_MULTI_INTERIOR_FIRST", "0")
+    assert np.array_equal(run_multi(L, devices, params, t, table_host, host_out), single)
 
 
 def test_multi_context_refuses_what_it_does_not_do():

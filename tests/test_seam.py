@@ -1,9 +1,9 @@
-"""The drop-in boundary compiled for real (oracle/build_seam.py): the reference's PUBLIC decoder API
+"""The drop-in boundary compiled for real (integration/build_seam.py): the reference's PUBLIC decoder API
 (JxlDecoderCreate / JxlDecoderProcessInput / JxlDecoderSetImageOutBuffer, lib/include/jxl/decode.h) over
 
   libjxl_dec_ref.so : the reference decoder, unmodified
   libjxl_dec_hip.so : the same with FrameDecoder::ProcessSections patched so that the AC
-                      groups of eligible frames go through libjxl_hip.so (oracle/seam/hip_seam.cc)
+                      groups of eligible frames go through libjxl_hip.so (integration/hip_seam.cc)
 
 driven like djxl drives libjxl (tools/djxl_main.cc:377,525-533; lib/extras/dec/jxl.cc), with the
 JxlParallelRunner of libjxl_threads_hip.so.  CPU suite: both libraries build, export the API, and the patched one
@@ -31,7 +31,7 @@ class PixelFormat(C.Structure):  # JxlPixelFormat, lib/include/jxl/types.h:80-10
 @pytest.fixture(scope="module")
 def libs(oracle):
     import sys
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
     import build_seam
     try:
         ref_so, hip_so = build_seam.build()
