@@ -1491,12 +1491,12 @@ int jxlhip_decode_filters_rows(jxlhip_ctx* c, void* out, size_t out_stride, size
   fp.out_plane_stride = out_plane_stride;
   const bool whole = y_begin == c->f.y0 && y_end == c->f.y1;
   if (!whole) {
+    if (y_begin == y_end && y_begin >= c->f.y0 && y_end <= c->f.y1) return JXLHIP_OK;  // (an edge stripe has no boundary rows on its outer side)
     if (y_begin < c->f.y0 || y_end > c->f.y1 || y_begin > y_end ||
         ((y_begin & 7u) && y_begin != c->f.y0) || ((y_end & 7u) && y_end != c->f.y1))
       return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "rows [%u, %u) of a stripe [%u, %u): block-row multiples inside it only", y_begin,
                   y_end, c->f.y0, c->f.y1);
     if (c->p.lf.epf_iters == 3) return Fail(c, JXLHIP_ERR_UNSUPPORTED, "row ranges with epf_iters = 3 (two marches over a second plane set)");
-    if (y_begin == y_end) return JXLHIP_OK;
   }
   return LaunchFiltersRows(c, fp, y_begin, y_end, c->blocks_fused);
 }
