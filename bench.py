@@ -80,38 +80,45 @@ def cpu_baseline(cfg, sample, threads):
                                 coeff_type=int(cfg["coeff32"]), intensity_target=cfg["intensity"],
                                 quant_mul=cfg["quant_mul"])
     use_ref = oracle.ref_available()
-    fma = use_ref and oracle.ref_lib_fma() is not None
-    run = (lambda: fr.decode_ref(threads=cores, fma_build=True)) if use_ref else (lambda: fr.decode(threads=cores))
+    v8 = use_ref and oracle.ref_lib_v8() is not None    # the hot path on 8 float lanes (oracle/hwy_shim_v)
+    fma = use_ref and not v8 and oracle.ref_lib_fma() is not None
+    kw = dict(v8_build=True) if v8 else dict(fma_build=True)
+    run = (lambda: fr.decode_ref(threads=cores, **kw)) if use_ref else (lambda: fr.decode(threads=cores))
     run()  # warm
     if threads == 0 and use_ref and cores > 16:
-        # the reference's group-parallel decode does not scale to every hardware thread of a 256-thread host
-        # (measured on the GPU box's EPYC 9575F: 146 Mpx/s at 16 threads, 316 at 128, 160-317 at 256): time the
-        # thread count that is fastest on THIS host and say which
+        # the reference's group-parallel decode does not scale to every hardware thread of a 256-thread host: time
+        # the thread count that is fastest on THIS host and say which
         best = (0.0, cores)
         for thr in sorted({cores, max(16, cores // 2), max(16, cores // 4)}):
-            fr.decode_ref(threads=thr, fma_build=True)
+            fr.decode_ref(threads=thr, **kw)
             t0 = time.perf_counter()
             for _ in range(3):
-                fr.decode_ref(threads=thr, fma_build=True)
+                fr.decode_ref(threads=thr, **kw)
             rate = 3.0 / (time.perf_counter() - t0)
             if rate > best[0]:
                 best = (rate, thr)
         cores = best[1]
-        run = lambda: fr.decode_ref(threads=cores, fma_build=True)
+        run = lambda: fr.decode_ref(threads=cores, **kw)
     reps, t = 0, 0.0
     while reps < 2 or (t < 10.0 and reps < 40):
         t0 = time.perf_counter()
         run()
         t += time.perf_counter() - t0
         reps += 1
-    what = ("libjxl reference sources (lib/jxl, DecodeGroupForRoundtrip + LowMemoryRenderPipeline) built with "
-            "the single-lane Highway shim" + (", -O3 -mavx2 -mfma (hardware FMA, compiler auto-vectorisation of the "
-                                              "one-lane loops; bit-identical to the -O2 checker build)" if fma else " (-O2)") +
-            ".  NOT libjxl's AVX2 / AVX-512 Highway build: Highway is not vendored in the reference tree, that "
-            "figure is unknown here") if use_ref else \
-        "oracle/ C restatement (libjxl reference library not available)"
+    if v8:
+        what = ("libjxl reference sources (lib/jxl, DecodeGroupForRoundtrip + LowMemoryRenderPipeline); the decode hot path "
+                "(dec_group.cc with the inverse transforms, the Gaborish / EPF / XYB / write stages) compiled against an 8-lane "
+                "(256-bit, HWY_TARGET = HWY_AVX2) stand-in for Highway, oracle/hwy_shim_v, -O3 -mavx2 -mfma: libjxl's SIMD "
+                "code paths, bit-identical to the single-lane checker build here; everything else single-lane.  Not "
+                "Google Highway itself (un-vendored in the reference tree): reference, 8-lane shim")
+    elif use_ref:
+        what = ("libjxl reference sources (lib/jxl, DecodeGroupForRoundtrip + LowMemoryRenderPipeline) built with "
+                "the single-lane Highway shim" + (", -O3 -mavx2 -mfma" if fma else " (-O2)") +
+                " (the 8-lane build needs AVX2 + FMA on the host)")
+    else:
+        what = "oracle/ C restatement (libjxl reference library not available)"
     return {"value": round(w * h * reps / t / 1e6, 2), "unit": "Mpixels/s", "cores": cores,
-            "kind": "reference" if use_ref else "port",
+            "kind": "reference" if use_ref else "port", "simd_lanes": 8 if v8 else 1,
             "sample": f"{w}x{h} frame of this workload, {reps} reps, {cores} thread(s) over groups; {what}"}
 
 

@@ -299,6 +299,28 @@ def ref_lib_fma():
     return _ref_fma or None
 
 
+_ref_v8 = None
+
+
+def ref_lib_v8():
+    """The reference's decode hot path on 8 float lanes (build_ref.py variant "v8": dec_group.cc and the Gaborish / EPF /
+    XYB / write stages compiled against oracle/hwy_shim_v, 256-bit vectors; everything else = the "fma" objects):
+    bench.py's cpu_baseline -- libjxl's SIMD code path, not its code on one lane.  None without AVX2 / FMA."""
+    global _ref_v8
+    if _ref_v8 is None:
+        from . import build_ref
+        try:
+            flags = open("/proc/cpuinfo").read()
+            if " avx2" not in flags or " fma" not in flags:
+                raise RuntimeError("host CPU without AVX2 / FMA")
+            L = C.CDLL(build_ref.build(variant="v8"))
+            L.jxr_decode_frame.argtypes = [C.POINTER(OracleFrame), C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+            _ref_v8 = L
+        except (RuntimeError, OSError):
+            _ref_v8 = False
+    return _ref_v8 or None
+
+
 def ref_default_dequant_tables():
     t = np.zeros(DEQUANT_TABLE_FLOATS, np.float32)
     assert ref_lib().jxr_default_dequant_tables(_p(t)) == 0
@@ -376,7 +398,7 @@ def ref_threads(xsize, ysize, max_threads):
     return 1 if (narrow or small) else max_threads
 
 
-def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None, fma_build=False):
+def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None, fma_build=False, v8_build=False):
     """The same frame through the REFERENCE's DecodeGroupForRoundtrip + render
     pipeline (LowMemory executor by default, as djxl; simple_pipeline=True for
     SimpleRenderPipeline).  The reference computes its own dequant tables: the
@@ -392,7 +414,7 @@ def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None, fm
     p = self.params
     threads = ref_threads(p.xsize, p.ysize, threads)
     ref_lib()
-    R = (ref_lib_fma() if fma_build else None) or ref_lib()
+    R = (ref_lib_v8() if v8_build else None) or (ref_lib_fma() if fma_build else None) or ref_lib()
     # undo_orientation 5..8: the reference writes an xsize-high, ysize-wide frame (stage_write.cc:664-680)
     oh, ow = (p.xsize, p.ysize) if p.undo_orientation >= 5 else (p.ysize, p.xsize)
     if p.output_kind == 2:

@@ -56,10 +56,14 @@ def _compile(job):
     if src.startswith(HERE):  # the drivers also see the C ABI and the oracle's POD mirror
         inc = os.path.join(HERE, "..", "include")
         deps += [os.path.join(inc, h) for h in os.listdir(inc)] + [os.path.join(HERE, "jxl_oracle.h")]
+    vec = os.sep + "obj_v8" + os.sep in obj and any(src.endswith(u) for u in V8_UNITS)
+    if vec:
+        deps.append(os.path.join(SHIM_V, "hwy", "highway.h"))
     if os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in deps):
         return obj, ""
     extra = ["-I" + HERE] if src.startswith(HERE) else []
-    r = subprocess.run([CXX] + FLAGS + extra + ["-c", src, "-o", obj], capture_output=True, text=True)
+    flags = ["-I" + SHIM_V] + FLAGS if vec else FLAGS  # (the vector highway.h in front of the single-lane one)
+    r = subprocess.run([CXX] + flags + extra + ["-c", src, "-o", obj], capture_output=True, text=True)
     return (obj if r.returncode == 0 else None), r.stderr
 
 
@@ -67,7 +71,16 @@ def _compile(job):
 # one instruction instead of a libm call and the compiler may vectorise the one-lane loops.  Only bench.py's
 # cpu_baseline uses it (libjxl_ref_fma.so); the checker stays the portable -O2 build.  Same results bit for bit
 # (IEEE arithmetic either way, -ffp-contract=off; tests/test_reference_parity.py holds the two to equality).
-VARIANT_FLAGS = {"": [], "fma": ["-O3", "-mavx2", "-mfma"]}
+VARIANT_FLAGS = {"": [], "fma": ["-O3", "-mavx2", "-mfma"], "v8": ["-O3", "-mavx2", "-mfma"]}
+# variant "v8" (libjxl_ref_v8.so; bench.py's cpu_baseline): the translation units of the decode hot path compiled against
+# oracle/hwy_shim_v -- 256-bit vectors, 8 float lanes, HWY_TARGET = HWY_AVX2: libjxl's SIMD code paths (vector DCTs and
+# transposes, 8-pixel filter steps) instead of its one-lane ones -- and every other unit taken from the "fma" build.
+# Target-specific code lives in per-TU namespaces (HWY_NAMESPACE) behind plain-C++ entry points, so the two kinds of
+# object link together.  NOT bit-identical to the checker (other summation orders inside the vector DCTs): held to it
+# within the reference's own executor tolerance by tests/test_reference_parity.py.
+SHIM_V = os.path.join(HERE, "hwy_shim_v")
+V8_UNITS = ("jxl/dec_group.cc", "jxl/render_pipeline/stage_gaborish.cc", "jxl/render_pipeline/stage_epf.cc",
+            "jxl/render_pipeline/stage_xyb.cc", "jxl/render_pipeline/stage_write.cc", "jxl/dec_xyb.cc")
 
 
 def build(verbose=False, only_compile=False, variant=""):
@@ -90,11 +103,16 @@ def build(verbose=False, only_compile=False, variant=""):
 
 def _build(lib, OBJ, verbose, only_compile):
     jobs = []
+    v8 = OBJ.endswith("obj_v8")
+    shared = OBJ[:-len("obj_v8")] + "obj_fma" if v8 else OBJ  # v8: only the hot units have objects of their own
+    if v8:
+        os.makedirs(shared, exist_ok=True)
     for f in source_list():
-        jobs.append((os.path.join(REF, "lib", f), os.path.join(OBJ, f.replace("/", "__")[:-3] + ".o")))
+        d = OBJ if (not v8 or f in V8_UNITS) else shared
+        jobs.append((os.path.join(REF, "lib", f), os.path.join(d, f.replace("/", "__")[:-3] + ".o")))
     if not only_compile:
         for drv in ("ref_driver", "ref_real_stream"):
-            jobs.append((os.path.join(HERE, drv + ".cc"), os.path.join(OBJ, drv + ".o")))
+            jobs.append((os.path.join(HERE, drv + ".cc"), os.path.join(shared, drv + ".o")))
     objs, failed = [], []
     with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
         for (src, _), (obj, err) in zip(jobs, ex.map(_compile, jobs)):
@@ -119,5 +137,6 @@ def _build(lib, OBJ, verbose, only_compile):
 
 
 if __name__ == "__main__":
-    build(verbose=True, only_compile="--compile-only" in sys.argv, variant="fma" if "--fma" in sys.argv else "")
+    build(verbose=True, only_compile="--compile-only" in sys.argv,
+          variant="fma" if "--fma" in sys.argv else ("v8" if "--v8" in sys.argv else ""))
     sys.exit(0)
