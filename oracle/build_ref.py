@@ -80,7 +80,10 @@ VARIANT_FLAGS = {"": [], "fma": ["-O3", "-mavx2", "-mfma"], "v8": ["-O3", "-mavx
 # within the reference's own executor tolerance by tests/test_reference_parity.py.
 SHIM_V = os.path.join(HERE, "hwy_shim_v")
 V8_UNITS = ("jxl/dec_group.cc", "jxl/render_pipeline/stage_gaborish.cc", "jxl/render_pipeline/stage_epf.cc",
-            "jxl/render_pipeline/stage_xyb.cc", "jxl/render_pipeline/stage_write.cc", "jxl/dec_xyb.cc")
+            "jxl/render_pipeline/stage_xyb.cc", "jxl/render_pipeline/stage_write.cc", "jxl/dec_xyb.cc",
+            # MaxVectorSize(): what image rows (image.cc) and scratch buffers are padded for -- must say 32 bytes when
+            # any unit stores whole 8-lane vectors at row ends
+            "jxl/simd_util.cc")
 
 
 def build(verbose=False, only_compile=False, variant=""):
