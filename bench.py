@@ -551,6 +551,22 @@ def main():
                                "what": "the same frame, output stripes left in each GPU's HBM (no gather)"}
         if pcie:
             line["pcie_inclusive"] = pcie
+        if world == 1 and name == "c3" and not custom and not args.no_cpu_baseline:
+            # the same step on the strategy shares of a GENUINE libjxl d1.0 stream (42 % 64x64, 32 % 32x32, 7 % DCT8:
+            # what the reference encoder actually emits) -- the bench workload's mix is the contract's
+            try:
+                rp, rt = synth.synth_frame(xs, ys, mix=resolve_mix("real4k"), gab=True, epf_iters=1, device=f"cuda:{local}")
+                for d, _ in slots:
+                    d.begin_frame(rp)
+                    d.set_inputs(rt, dq)
+                counter[0] = 0
+                rdt = timed(step)
+                line["real_content_mix"] = {"value": round(px / (rdt / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                                            "ms_per_step": round(rdt / args.steps * 1e3, 4), "frames_in_flight": inflight,
+                                            "what": f"{xs}x{ys}, Gaborish + EPF1, strategy shares of tests/data/real_4k_d1.npz"}
+                del rt
+            except Exception as ex:
+                line["real_content_mix"] = {"error": repr(ex)[:200]}
         if world == 1 and name == "c3" and not custom and not args.no_e2e and not args.no_cpu_baseline:  # (profiling runs skip every side measurement)
             try:
                 line["e2e"] = e2e_block(torch, local)
