@@ -36,7 +36,7 @@ acc = defaultdict(lambda: [0.0, 0.0, 0])
 period = []
 for i, st in enumerate(steps):
     for j, (s, e, n) in enumerate(st):
-        short = n.split("(")[0].replace("void jxlhip::", "").replace("(anonymous namespace)::", "")[:60]
+        short = n.replace("(anonymous namespace)::", "").split("(")[0].replace("void jxlhip::", "").replace("jxlhip::", "")[:60]
         prev_end = st[j - 1][1] if j else (steps[i - 1][-1][1] if i else s)
         a = acc[(j, short)]
         a[0] += (e - s) / 1e3
