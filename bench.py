@@ -89,22 +89,31 @@ def cpu_baseline(cfg, sample, threads):
         # the reference's group-parallel decode does not scale to every hardware thread of a 256-thread host: time
         # the thread count that is fastest on THIS host and say which
         best = (0.0, cores)
-        for thr in sorted({cores, max(16, cores // 2), max(16, cores // 4)}):
+        for thr in sorted({cores, max(16, cores // 2), max(16, cores // 4), max(16, cores // 8)}):
             fr.decode_ref(threads=thr, **kw)
-            t0 = time.perf_counter()
+            sec = 0.0
             for _ in range(3):
                 fr.decode_ref(threads=thr, **kw)
-            rate = 3.0 / (time.perf_counter() - t0)
+                sec += fr.last_decode_seconds()
+            rate = 3.0 / sec
             if rate > best[0]:
                 best = (rate, thr)
         cores = best[1]
         run = lambda: fr.decode_ref(threads=cores, **kw)
-    reps, t = 0, 0.0
-    while reps < 2 or (t < 10.0 and reps < 40):
+    # timed: the section libjxl's decoder runs per frame on its thread pool -- every AC group through
+    # DecodeGroupForRoundtrip and the render pipeline (oracle/ref_driver.cc reports it: jxr_last_decode_seconds).  The
+    # driver's own serial set-up in front of it (widening the coefficient buffers into an ACImage, filling
+    # PassesSharedState from dense arrays) is not libjxl's decode and is left out, like the GPU side is timed with its
+    # inputs resident; `wall` below includes it.
+    reps, t, wall = 0, 0.0, 0.0
+    while reps < 2 or (wall < 10.0 and reps < 40):
         t0 = time.perf_counter()
         run()
-        t += time.perf_counter() - t0
+        wall += time.perf_counter() - t0
+        t += fr.last_decode_seconds() if use_ref else 0.0
         reps += 1
+    if not use_ref:
+        t = wall
     if v8:
         what = ("libjxl reference sources (lib/jxl, DecodeGroupForRoundtrip + LowMemoryRenderPipeline); the decode hot path "
                 "(dec_group.cc with the inverse transforms, the Gaborish / EPF / XYB / write stages) compiled against an 8-lane "
@@ -119,6 +128,7 @@ def cpu_baseline(cfg, sample, threads):
         what = "oracle/ C restatement (libjxl reference library not available)"
     return {"value": round(w * h * reps / t / 1e6, 2), "unit": "Mpixels/s", "cores": cores,
             "kind": "reference" if use_ref else "port", "simd_lanes": 8 if v8 else 1,
+            "value_with_driver_setup": round(w * h * reps / wall / 1e6, 2),
             "sample": f"{w}x{h} frame of this workload, {reps} reps, {cores} thread(s) over groups; {what}"}
 
 

@@ -61,6 +61,7 @@ struct jxlhip_ctx {
   int counts_slot = 0;
   bool counts_clean[2] = {false, false};
   double cs_phase_ms[8] = {};  // jxlhip_codestream_phase_ms
+  bool handover_fresh = false;  // frame_begin started the hand-over and upload_side_info has not been called since
   bool tiles_on = false;     // the last LaunchBlocksBand ran k_prepare in tile mode (DevFrame::fused_tiles)
   bool blocks_fused = false;  // jxlhip_decode_blocks ran in fused-stripe mode: the planes lack the inner DCT8 blocks
   jxlhip_frame_params p{};
@@ -638,6 +639,7 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   {
     const int rc = BeginHandover(c);
     if (rc) return rc;
+    c->handover_fresh = true;
   }
   c->have_frame = true;
   c->have_inputs = false;
@@ -815,7 +817,12 @@ int jxlhip_upload_side_info(jxlhip_ctx* c, const uint8_t* ac_strategy, const int
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = EnsureUploadBuffers(c))) return rc;
-  if ((rc = BeginHandover(c))) return rc;  // (again when the frame is handed over a second time)
+  // frame_begin has just started this frame's hand-over (serial, sparse table parity, arena): starting another one
+  // here would advance the serial twice per frame -- the double-buffered offset table would then sit on ONE parity
+  // and wait for the previous frame's copy every time -- and would drop groups submitted before the side info.  Only
+  // a frame handed over AGAIN (a second upload_side_info without a frame_begin) starts over.
+  if (c->handover_fresh) c->handover_fresh = false;
+  else if ((rc = BeginHandover(c))) return rc;
   const DevFrame& f = c->f;
   const size_t nb = (size_t)f.xsb * f.ysb;
   const size_t nt = (size_t)f.xtiles * ((f.ysb + 7) / 8);

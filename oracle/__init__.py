@@ -415,6 +415,7 @@ def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None, fm
     threads = ref_threads(p.xsize, p.ysize, threads)
     ref_lib()
     R = (ref_lib_v8() if v8_build else None) or (ref_lib_fma() if fma_build else None) or ref_lib()
+    self.last_ref_lib = R  # (last_decode_seconds reads this library's clock)
     # undo_orientation 5..8: the reference writes an xsize-high, ysize-wide frame (stage_write.cc:664-680)
     oh, ow = (p.xsize, p.ysize) if p.undo_orientation >= 5 else (p.ysize, p.xsize)
     if p.output_kind == 2:
@@ -438,6 +439,17 @@ def _decode_ref(self, threads=1, simple_pipeline=False, quant_encodings=None, fm
 
 
 Frame.decode_ref = _decode_ref
+
+
+def _last_decode_seconds(self):
+    """Seconds the last decode_ref spent in the reference's threaded group decode + render pipeline (jxr_decode_frame
+    without the driver's own serial set-up: oracle/ref_driver.cc)."""
+    R = getattr(self, "last_ref_lib", None) or ref_lib()
+    R.jxr_last_decode_seconds.restype = C.c_double
+    return float(R.jxr_last_decode_seconds())
+
+
+Frame.last_decode_seconds = _last_decode_seconds
 
 
 def _encode_ac_ref(self, force_huffman=False, lz77_method=0, custom_orders=True, histo_sets=1,

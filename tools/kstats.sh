@@ -5,7 +5,7 @@ envs="$1"; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p
-env $envs timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -- python $R/bench.py --no-cpu-baseline "$@" > /tmp/log 2>&1
+env $envs timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -- python $R/bench.py --no-cpu-baseline --frames-in-flight 1 "$@" > /tmp/log 2>&1
 echo "== env=[$envs] args=[$@]"
 grep -o "\"value\": [0-9.]*\|kernel_ms.: {[^}]*}" /tmp/log || tail -5 /tmp/log
 f=$(find /tmp/p -name "*kernel_stats.csv" | head -1)

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$ctr -- \
-    python $R/bench.py --no-cpu-baseline --calib-copy "$@" > $O/pmc_${ctr}_$tag.log 2>&1
+    python $R/bench.py --no-cpu-baseline --frames-in-flight 1 --calib-copy "$@" > $O/pmc_${ctr}_$tag.log 2>&1
   f=$(find /tmp/pmc_$ctr -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $O/pmc_${ctr}_$tag.csv
 done
