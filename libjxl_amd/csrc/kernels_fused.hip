@@ -41,6 +41,14 @@
 #ifndef JXLHIP_FUSED_PC_DEFAULT
 #define JXLHIP_FUSED_PC_DEFAULT 1
 #endif
+// The producing wave runs at a raised wave priority (s_setprio): the marching wave waits for it at every block row's
+// barrier, and at equal priority the SIMD's arbiter lets the (longer, never-waiting) marches of OTHER windows take the
+// issue slots a producer needs to finish its block row.  Measured, 8K d1.0, two repetitions on one box
+// (profiles/r04_setprio.txt): producer at 3: k_fused_pc 203.5 -> 196 us, 105.1 -> 107.6 Gpx/s one frame at a time,
+// 119.8 -> 122.7 with three in flight; the MARCH at 3: no change (203).
+#ifndef JXLHIP_PC_PRODUCER_PRIO
+#define JXLHIP_PC_PRODUCER_PRIO 3
+#endif
 #ifndef JXLHIP_TILE_SLOTS  // units of the matrix-core producer whose loads are in flight together (16-bit coefficients)
 #define JXLHIP_TILE_SLOTS 6
 #endif
@@ -1177,6 +1185,9 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
   const int bc0 = x0 >> 3;
   const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
   if (wave == 1) {
+#if JXLHIP_PC_PRODUCER_PRIO > 0
+    __builtin_amdgcn_s_setprio(JXLHIP_PC_PRODUCER_PRIO);
+#endif
     if (f.fused_tiles) {  // uniform
       ProduceTiles<MarchGeom<GAB, EPF>::HX, CT>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
       return;
@@ -1211,6 +1222,9 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
   L.fix_left = L.gx == -2;
   L.fix_right_even = L.gx == W;
   L.fix_right_odd = L.gx == W - 1;
+#ifdef JXLHIP_PC_MARCH_PRIO  // experiment builds: the marching wave ahead of the producing waves at the SIMD's issue arbiter
+  __builtin_amdgcn_s_setprio(JXLHIP_PC_MARCH_PRIO);
+#endif
   if (edge) MarchPC<GAB, EPF, OUTK, FMT, true>(f, P, L, &lds, bc0, y_begin, y_end);
   else MarchPC<GAB, EPF, OUTK, FMT, false>(f, P, L, &lds, bc0, y_begin, y_end);
 }
