@@ -1,6 +1,7 @@
 """Writes the whole-file workload of bench.py's `e2e` block and of the 8K tests: a genuine 7680x4320 RGB VarDCT
 codestream (d1.0, effort 7 = libjxl's default) made by the REFERENCE ENCODER (oracle/_ref/libjxl_ref.so =
-/root/reference/lib/jxl compiled in place, oracle/build_ref.py) from a procedural image -> oracle/_ref/e2e_8k_d1.jxl.
+/root/reference/lib/jxl compiled in place, oracle/build_ref.py) from a procedural image -> tests/data/e2e_8k_d1.jxl
+(the file is committed: a fixture like tests/data/real_4k_d1.npz, with this script as the record of how it was made).
 
 Test / measurement infrastructure, not product code.  Runs wherever oracle/_ref/libjxl_ref.so exists (the build
 container; the GPU box gets the prebuilt library AND the finished file with the snapshot, and can re-make the file with
@@ -11,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-DEFAULT = os.path.join(ROOT, "oracle", "_ref", "e2e_8k_d1.jxl")
+DEFAULT = os.path.join(ROOT, "tests", "data", "e2e_8k_d1.jxl")  # committed (3.1 MB): the GPU box needs no encoder run
 
 
 def make(out=DEFAULT, xsize=7680, ysize=4320, distance=1.0, speed_tier=3, seed=7):
@@ -25,12 +26,13 @@ def make(out=DEFAULT, xsize=7680, ysize=4320, distance=1.0, speed_tier=3, seed=7
     return out, rs
 
 
-def ensure(out=DEFAULT):
-    """The file's path, made on first use; None when the reference encoder is not available."""
+def ensure(out=DEFAULT, generate=True):
+    """The file's path, made on first use (about three minutes of one core: only with generate=True); None when it is
+    absent and cannot / may not be made."""
     if os.path.exists(out):
         return out
     import oracle
-    if not oracle.ref_available():
+    if not generate or not oracle.ref_available():
         return None
     return make(out)[0]
 

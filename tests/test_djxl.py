@@ -246,13 +246,13 @@ def e2e_stream_path():
 
 @pytest.mark.gpu
 def test_djxl_on_a_genuine_8k_stream(tools, tmp_path):
-    """BASELINE's frame size through the drop-in path: oracle/_ref/e2e_8k_d1.jxl (7680x4320, d1.0, effort 7, written by
+    """BASELINE's frame size through the drop-in path: tests/data/e2e_8k_d1.jxl (7680x4320, d1.0, effort 7, written by
     the reference encoder: oracle/make_e2e_stream.py; the stream bench.py's e2e block times) through the unmodified
     djxl on the HIP back-end against the same tool on libjxl's CPU decoder: float pixels (.npy, .pfm) within 2e-5."""
     djxl_ref, djxl_hip = tools
     jxl = e2e_stream_path()
     if jxl is None:
-        pytest.skip("oracle/_ref/e2e_8k_d1.jxl not made (python oracle/make_e2e_stream.py)")
+        pytest.skip("tests/data/e2e_8k_d1.jxl not made (python oracle/make_e2e_stream.py)")
     for ext, extra in (("npy", []), ("pfm", ["--num_threads", "8"])):
         run(djxl_ref, [jxl, str(tmp_path / f"r.{ext}")] + extra)
         err = run(djxl_hip, [jxl, str(tmp_path / f"h.{ext}")] + extra, verbose=True)
