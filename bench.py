@@ -392,6 +392,9 @@ def main():
         d2.begin_frame(params)
         d2.set_inputs(t, dq)
         slots.append((d2, d2.alloc_output()))
+    if inflight > 1:
+        for d, _ in slots:
+            d.set_concurrency_hint(inflight)  # (only moves the frame size from which the fused kernel is taken)
     counter = [0]
 
     def step():
@@ -435,6 +438,8 @@ def main():
         return t
 
     dt = timed(step)
+    if inflight > 1:
+        dec.set_concurrency_hint(1)  # from here on `dec` runs alone: one frame at a time, the per-kernel pass
     dt_one = timed(step_one) if (world == 1 and inflight > 1) else None
     for d2, o2 in slots[1:]:
         assert torch.equal(o2, out), "a pooled context decoded a different frame"

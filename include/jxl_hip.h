@@ -372,6 +372,14 @@ enum {
                                  EPF2 + output march that follows is the FILTERS span */
   JXLHIP_KERNEL_COUNT = 8
 };
+/* A hint, not a contract: `frames_in_flight` = how many contexts the caller keeps busy on this device at the same time
+ * (a pool of decoders over a queue of images; 1 = this context runs alone, the default).  It only moves the frame size
+ * from which jxlhip_decode_frame takes the fused kernel: alone, fusing pays from 12 Mpx (a fused wave's head / tail rows
+ * against the plane traffic it saves); with several frames in flight the device is bound by HBM
+ * traffic, which the fused path has less of, and it pays from 6 Mpx (4K d1.0, three in flight: 83 -> 105 Gpx/s; 1080p
+ * stays two-phase: 77 vs 67).  The pixels do not depend on it beyond the rounding difference between the two paths
+ * (both within the parity bar).  Nothing like it in libjxl. */
+JXLHIP_EXPORT int jxlhip_set_concurrency_hint(jxlhip_ctx* ctx, int frames_in_flight);
 JXLHIP_EXPORT int jxlhip_profile_enable(jxlhip_ctx* ctx, int enable);
 JXLHIP_EXPORT int jxlhip_profile_read(jxlhip_ctx* ctx,
                                       float ms[JXLHIP_KERNEL_COUNT],

@@ -228,7 +228,7 @@ EXPORTS = [
     "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_filters_rows", "jxlhip_decode_frame",
     "jxlhip_decode_frame_host", "jxlhip_decode_frame_pinned",
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
-    "jxlhip_profile_enable", "jxlhip_profile_read",
+    "jxlhip_set_concurrency_hint", "jxlhip_profile_enable", "jxlhip_profile_read",
     "jxlhip_dequant_tables", "jxlhip_default_dequant_tables", "jxlhip_dequant_dc",
     "jxlhip_dequant_dc_groups",
     # include/jxl_hip_entropy.h
@@ -328,6 +328,7 @@ def load_library():
     L.jxlhip_export_xyb.argtypes = [vp, vp * 3, sz]
     L.jxlhip_get_sigma.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.jxlhip_profile_enable.argtypes = [vp, i32]
+    L.jxlhip_set_concurrency_hint.argtypes = [vp, i32]
     L.jxlhip_profile_read.argtypes = [vp, C.c_float * KERNEL_COUNT, u32 * KERNEL_COUNT]
     L.jxlhip_default_dequant_tables.argtypes = [vp, vp]
     L.jxlhip_dequant_tables.argtypes = [vp, vp, vp]

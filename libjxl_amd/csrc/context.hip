@@ -61,6 +61,7 @@ struct jxlhip_ctx {
   int counts_slot = 0;
   bool counts_clean[2] = {false, false};
   double cs_phase_ms[8] = {};  // jxlhip_codestream_phase_ms
+  int concurrency = 1;  // jxlhip_set_concurrency_hint: contexts the caller keeps busy on this device at a time
   bool handover_fresh = false;  // frame_begin started the hand-over and upload_side_info has not been called since
   bool tiles_on = false;     // the last LaunchBlocksBand ran k_prepare in tile mode (DevFrame::fused_tiles)
   bool blocks_fused = false;  // jxlhip_decode_blocks ran in fused-stripe mode: the planes lack the inner DCT8 blocks
@@ -1358,7 +1359,10 @@ int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint3
 // (profiles/r03_packed_paths.txt).
 bool WantFused(const jxlhip_ctx* c) {
   const DevFrame& f = c->f;
-  const bool big = (uint64_t)f.xsize * f.ysize >= (12ull << 20) || (c->p.lf.gab == 0 && c->p.lf.epf_iters == 0);
+  // alone a context fuses from 12 Mpx; with several frames in flight on the device (jxlhip_set_concurrency_hint) the
+  // step is bound by HBM traffic and the fused path, which moves less, pays from 6 Mpx (profiles/r04_path_choice.txt)
+  const uint64_t min_px = c->concurrency > 1 ? (6ull << 20) : (12ull << 20);
+  const bool big = (uint64_t)f.xsize * f.ysize >= min_px || (c->p.lf.gab == 0 && c->p.lf.epf_iters == 0);
   const bool has_dct8 = f.used_acs == 0 || (f.used_acs & 1u);
   bool packed_fixed = false;
   if (c->p.output_kind == JXLHIP_OUT_PACKED) {
@@ -1719,6 +1723,13 @@ int jxlhip_get_sigma(jxlhip_ctx* c, float** inv_sigma, size_t* row_stride) {
   if (!c->have_frame) return Fail(c, JXLHIP_ERR_STATE, "no frame");
   *inv_sigma = c->f.inv_sigma;
   *row_stride = c->f.xsb;
+  return JXLHIP_OK;
+}
+
+int jxlhip_set_concurrency_hint(jxlhip_ctx* c, int frames_in_flight) {
+  if (!c || frames_in_flight < 1) return JXLHIP_ERR_INVALID_ARGUMENT;
+  c->concurrency = frames_in_flight;
+  for (jxlhip_ctx* k : c->children) k->concurrency = frames_in_flight;
   return JXLHIP_OK;
 }
 

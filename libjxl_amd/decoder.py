@@ -190,6 +190,11 @@ class VarDctDecoder:
         assert tuple(buf.shape) == (3, self.halo_rows(), self.params.xsize)
         _check(self.L, self.ctx, self.L.jxlhip_halo_import(self.ctx, which, C.c_void_p(buf.data_ptr())), "halo_import")
 
+    def set_concurrency_hint(self, frames_in_flight):
+        """How many contexts the caller keeps busy on this device at a time (a pool of decoders): moves the frame size
+        from which decode_frame takes the fused kernel (12 Mpx alone, 6 Mpx with several frames in flight)."""
+        _check(self.L, self.ctx, self.L.jxlhip_set_concurrency_hint(self.ctx, int(frames_in_flight)), "set_concurrency_hint")
+
     def profile(self, enable=True):
         _check(self.L, self.ctx, self.L.jxlhip_profile_enable(self.ctx, int(enable)), "profile_enable")
 

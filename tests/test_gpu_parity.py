@@ -320,6 +320,29 @@ def test_stripe_interior_rows_before_the_halo_arrives(dq, oracle, gab, epf, fuse
         d.close()
 
 
+def test_concurrency_hint_moves_the_fused_threshold(dq, oracle):
+    """jxlhip_set_concurrency_hint: a context that runs ALONE fuses from 12 Mpx, one of several in flight from 6 Mpx (the
+    device is then bound by HBM traffic, which the fused path has less of).  A 3328x2048 frame (6.8 Mpx): two-phase
+    without the hint, fused with it (the profile slots say which), both within the bar of the oracle."""
+    params, t, fr = frames.make_case(3328, 2048, mix=synth.MIX_D1, gab=True, epf_iters=1, seed=3)
+    ref = fr.decode(threads=8)
+    outs = {}
+    for hint in (1, 3):
+        d = VarDctDecoder(0)
+        d.set_concurrency_hint(hint)
+        d.begin_frame(params)
+        d.set_inputs(to_dev(t), dq)
+        d.profile(True)
+        outs[hint] = d.decode_frame().cpu().numpy()
+        d.sync()
+        slots = d.profile_read()
+        assert ("fused" in slots) == (hint == 3) and ("filters" in slots) == (hint == 1), slots
+        d.close()
+    assert rel_err(outs[1], ref) <= TIGHT and rel_err(outs[3], ref) <= TIGHT
+    with pytest.raises(Exception):
+        VarDctDecoder(0).set_concurrency_hint(0)
+
+
 def test_upload_path_equals_device_path(dec, dq, oracle):
     """Host-pointer hand-off (upload_side_info + submit_group per group, as a
     FrameDecoder would call it) gives the same pixels as device-resident inputs."""
