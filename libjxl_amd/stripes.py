@@ -96,7 +96,8 @@ class StripeDecoder:
         if self._halo is None:
             d, h = self.dec, self.dec.halo_rows()
             shape = (3, h, self.params["xsize"])
-            mk = lambda: torch.empty(shape, dtype=torch.float32, device=f"cuda:{d.device}")  # noqa: E731
+            dev = getattr(d, "tensor_device", None) or f"cuda:{d.device}"  # (a CPU stand-in decoder in the gloo tests)
+            mk = lambda: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
             self._halo = dict(up_send=mk(), dn_send=mk(), up_recv=mk(), dn_recv=mk())
         return self._halo
 

@@ -94,3 +94,79 @@ def test_two_rank_stripes_halo_exchange_and_gather(tmp_path, oracle):
     result = tmp_path / "result.txt"
     mp.spawn(_worker, args=(2, port, 300, 600, str(result)), nprocs=2, join=True)
     assert result.read_text() == "ok"
+
+
+class _RecordingDecoder:
+    """Stands in for VarDctDecoder on the CPU: records the call sequence of StripeDecoder.decode and moves recognisable
+    rows through the halo buffers."""
+    tensor_device = "cpu"
+    device = 0
+
+    def __init__(self, rank, xs, epf=1):
+        import types
+        self.rank, self.xs, self.calls = rank, xs, []
+        self.params = types.SimpleNamespace(lf=types.SimpleNamespace(epf_iters=epf), xsize=xs)
+        self.imported = {}
+
+    def begin_frame(self, params):
+        self.frame = params
+
+    def halo_rows(self):
+        return 3
+
+    def decode_blocks(self):
+        self.calls.append(("blocks",))
+
+    def halo_export(self, which, buf):
+        self.calls.append(("export", which))
+        buf.fill_(float(10 * self.rank + which))
+        return buf
+
+    def halo_import(self, which, buf):
+        self.calls.append(("import", which))
+        self.imported[which] = float(buf[0, 0, 0])
+
+    def decode_filters(self, out, rows=None):
+        self.calls.append(("filters", rows))
+
+
+def _flow_worker(rank, world, port, result_dir, interior_first):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["JXLHIP_STRIPES_INTERIOR_FIRST"] = "1" if interior_first else "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libjxl_amd import stripes
+    xs, ys = 300, 256 * 7
+    d = _RecordingDecoder(rank, xs)
+    sd = stripes.StripeDecoder(d, dict(xsize=xs, ysize=ys), rank, world)
+    sd.decode(torch.zeros(1))
+    y0, y1 = sd.rows[rank]
+    up, dn = rank > 0, rank + 1 < world
+    filt = [c[1] for c in d.calls if c[0] == "filters"]
+    ok = d.calls[0] == ("blocks",)
+    first_import = min([i for i, c in enumerate(d.calls) if c[0] == "import"], default=len(d.calls))
+    first_filter = min(i for i, c in enumerate(d.calls) if c[0] == "filters")
+    if interior_first:
+        ya, yb = (y0 + 8 if up else y0), (y1 - 8 if dn else y1)
+        ok &= filt == [(ya, yb), (y0, ya), (yb, y1)] and first_filter < first_import  # the interior rows go first
+    else:
+        ok &= filt == [None] and first_import < first_filter
+    # the rows that arrived are the neighbours': from above its "down" export (which = 1), from below its "up" export
+    ok &= d.imported.get(0, None) == (10.0 * (rank - 1) + 1 if up else None)
+    ok &= d.imported.get(1, None) == (10.0 * (rank + 1) + 0 if dn else None)
+    open(os.path.join(result_dir, "r%d" % rank), "w").write("ok" if ok else "bad: %r" % (d.calls,))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("interior_first", [True, False])
+def test_stripe_decoder_call_sequence_over_gloo(tmp_path, interior_first):
+    """libjxl_amd.stripes.StripeDecoder.decode -- what `bench.py --gpus N` runs on every rank -- with a recording stand-in
+    for the decoder, three ranks over gloo: phase 1, both exports, the interior rows BEFORE the halo rows are imported,
+    then the two boundary block rows (JXLHIP_STRIPES_INTERIOR_FIRST=0: round 3's order), and each rank receives its
+    neighbours' rows."""
+    port = 29500 + (os.getpid() + 7 + int(interior_first)) % 2000
+    mp.spawn(_flow_worker, args=(3, port, str(tmp_path), interior_first), nprocs=3, join=True)
+    for r in range(3):
+        assert (tmp_path / ("r%d" % r)).read_text() == "ok", (tmp_path / ("r%d" % r)).read_text()
