@@ -565,6 +565,9 @@ class SymbolReader {  // ANSSymbolReader
   }
   bool Ok() const { return !code_->lz77.enabled || window_; }
   bool FinalStateOk() const { return state_ == (kAnsSignature << 16); }
+  // (loops that keep the ANS state in a register of their own: modular.inc's self-correcting-predictor track)
+  uint32_t State() const { return state_; }
+  void SetState(uint32_t s) { state_ = s; }
 
   inline uint32_t ReadToken(uint32_t histo, BitReader* br) {
     if (code_->use_prefix) return code_->prefix[histo].ReadSymbol(br);

@@ -106,6 +106,98 @@ def test_dc_groups_of_genuine_codestreams(L, ref, kw):
         assert np.array_equal(got[c].ravel(), want.ravel()), c
 
 
+def _dc_groups_both_ways(L, fh, sections, monkeypatch, damage=None):
+    """Every DC group through the channel loops of their own (modular.inc: DecodeWpPureChannel, DecodeSimpleChannel) and
+    through the general loop (JXLHIP_WP_GENERAL=1): status, bits consumed and every output array."""
+    import os
+    s0 = sections[0]
+    dcg, dpos = abi.DcGlobal(), C.c_size_t(0)
+    assert L.jxlhip_dc_global_decode(s0.ctypes.data, len(s0), C.byref(dpos), fh.flags, C.byref(dcg)) == 0
+    tree = C.c_void_p()
+    assert L.jxlhip_modular_global_decode(s0.ctypes.data, len(s0), C.byref(dpos), C.byref(fh), C.byref(tree)) == 0
+    xsb, ysb = fh.xsize_blocks, fh.ysize_blocks
+    cw, chh = (xsb + 7) // 8, (ysb + 7) // 8
+    results = []
+    try:
+        for general in (False, True):
+            if general:
+                monkeypatch.setenv("JXLHIP_WP_GENERAL", "1")
+            else:
+                monkeypatch.delenv("JXLHIP_WP_GENERAL", raising=False)
+            qdc = [np.zeros(xsb * ysb, np.int32) for _ in range(3)]
+            acs, rq, sharp = np.zeros(xsb * ysb, np.uint8), np.zeros(xsb * ysb, np.int32), np.zeros(xsb * ysb, np.uint8)
+            ytox, ytob = np.zeros(cw * chh, np.int8), np.zeros(cw * chh, np.int8)
+            used, status = C.c_uint32(0), []
+            for g in range(int(fh.num_dc_groups)):
+                d = sections[1 + g] if damage is None else damage(g, sections[1 + g])
+                gp, ep = C.c_size_t(0), C.c_uint32(0)
+                ptrs = (C.c_void_p * 3)(*[q.ctypes.data for q in qdc])
+                rc = L.jxlhip_dc_group_decode(tree, d.ctypes.data, len(d), C.byref(gp), C.byref(fh), g, ptrs, C.byref(ep),
+                                              acs.ctypes.data, rq.ctypes.data, sharp.ctypes.data, ytox.ctypes.data,
+                                              ytob.ctypes.data, C.byref(used))
+                status.append((rc, gp.value if rc == 0 else -1, ep.value if rc == 0 else -1))
+            results.append((status, [q.copy() for q in qdc], acs, rq, sharp, ytox, ytob, used.value))
+    finally:
+        L.jxlhip_modular_tree_destroy(tree)
+        monkeypatch.delenv("JXLHIP_WP_GENERAL", raising=False)
+    return results
+
+
+def _same(a, b):
+    assert a[0] == b[0], (a[0], b[0])
+    ok = [g for g, st in enumerate(a[0]) if st[0] == 0]
+    if len(ok) == len(a[0]):  # (a failed group leaves its rectangle half written: compare the frames only when all went through)
+        for x, y in zip(a[1], b[1]):
+            assert np.array_equal(x, y)
+        for x, y in zip(a[2:7], b[2:7]):
+            assert np.array_equal(x, y)
+        assert a[7] == b[7]
+    return len(ok)
+
+
+def test_channel_loops_of_their_own_equal_the_general_loop(L, ref, monkeypatch):
+    """The self-correcting predictor's loop and the no-predictor-state loop are special cases of the general channel loop:
+    same samples, same bits consumed -- on genuine streams (the 8K d1.0 stream of tests/data included) and on damaged DC
+    group sections, where both must stop (or not) at the same place."""
+    import os
+    streams = []
+    for kw in (dict(xsize=520, ysize=300, distance=1.0, speed_tier=3), dict(xsize=2200, ysize=264, distance=1.5, speed_tier=4),
+               dict(xsize=300, ysize=300, distance=1.0, speed_tier=7)):
+        streams.append(ref.RealStream(seed=13, **kw))
+    path = os.path.join(os.path.dirname(__file__), "data", "e2e_8k_d1.jxl")
+    if os.path.exists(path):
+        class _File:
+            codestream = np.fromfile(path, np.uint8)
+        streams.append(_File())
+    rng = np.random.default_rng(5)
+    went_through = stopped = 0
+    for rs in streams:
+        cs, ih, fh, sections = parse_to_sections(L, rs)
+        a, b = _dc_groups_both_ways(L, fh, sections, monkeypatch)
+        assert _same(a, b) == int(fh.num_dc_groups)
+        if len(cs) > (1 << 20):
+            continue  # (the 8K stream: intact only -- a damaged copy of each of its groups costs seconds)
+        for trial in range(40):
+            flips = {}
+
+            def damage(g, d, flips=flips):
+                if g not in flips:
+                    e = np.array(d)
+                    for _ in range(int(rng.integers(1, 4))):
+                        k = int(rng.integers(0, len(e) * 8))
+                        e[k // 8] ^= np.uint8(1 << (k % 8))
+                    if trial % 5 == 0:
+                        e = e[: int(rng.integers(1, len(e) + 1))].copy()
+                    flips[g] = e
+                return flips[g]
+
+            a, b = _dc_groups_both_ways(L, fh, sections, monkeypatch, damage)
+            n = _same(a, b)
+            went_through += n
+            stopped += int(fh.num_dc_groups) - n
+    assert stopped > 50, (went_through, stopped)  # (nearly every flip derails the ANS stream: both loops must say so)
+
+
 def test_damaged_global_trees_fail_like_the_reference(L, ref):
     """DecodeTree + ValidateTree + DecodeHistograms (modular/encoding/dec_ma.cc) on damaged DC-global
     sections: same verdict and, when accepted, the same number of bits as the reference."""
