@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <condition_variable>
 #include <atomic>
 #include <mutex>
@@ -1004,7 +1005,8 @@ static bool SparseEligible(const jxlhip_ctx* c, uint32_t num_passes) {
 
 static int SubmitPassesImpl(jxlhip_ctx* c, uint32_t num_passes, const jxlhip_ac_pass* const* passes, const uint32_t* shifts,
                             uint32_t group_idx, const uint8_t* ac_strategy, const int32_t* raw_quant, const uint8_t* quant_dc,
-                            const uint8_t* const* data, const size_t* sizes, size_t* bit_pos, bool allow_sparse);
+                            const uint8_t* const* data, const size_t* sizes, size_t* bit_pos, bool allow_sparse,
+                            std::vector<uint8_t>* dense_scratch = nullptr);
 
 // f1: entropy-decode all passes of one AC group into a pinned staging slot and
 // queue its upload.  The slot is reused only after its copies completed.
@@ -1090,7 +1092,8 @@ static void ReleaseSlot(jxlhip_ctx* c, int slot, bool uploaded) {
 
 static int SubmitPassesImpl(jxlhip_ctx* c, uint32_t num_passes, const jxlhip_ac_pass* const* passes, const uint32_t* shifts,
                             uint32_t group_idx, const uint8_t* ac_strategy, const int32_t* raw_quant, const uint8_t* quant_dc,
-                            const uint8_t* const* data, const size_t* sizes, size_t* bit_pos, bool allow_sparse) {
+                            const uint8_t* const* data, const size_t* sizes, size_t* bit_pos, bool allow_sparse,
+                            std::vector<uint8_t>* dense_scratch) {
   const DevFrame& f = c->f;
   if (group_idx >= f.xsg * f.ysg) return Fail(c, JXLHIP_ERR_INVALID_ARGUMENT, "bad group %u", group_idx);
   const size_t esz = f.coeff_type == JXLHIP_COEFF_I16 ? 2 : 4;
@@ -1104,22 +1107,32 @@ static int SubmitPassesImpl(jxlhip_ctx* c, uint32_t num_passes, const jxlhip_ac_
     const int rf = SparseFlush(c, &b);
     if (rc == JXLHIP_OK) rc = rf;
   }
-  if (rc == JXLHIP_ERR_RANGE) {  // the dense form
-    int slot = -1;
-    if ((rc = AcquireSlot(c, slot_bytes, &slot))) return rc;
-    char* base = (char*)c->stage[slot];
+  if (rc == JXLHIP_ERR_RANGE) {
+    // the dense form: decoded into the caller's (or a local) heap buffer; a pinned staging slot is held only for the
+    // copy into it and the submit -- a textured group decodes for milliseconds, and with the slots held that long the
+    // 33rd such group of a frame waited for the first to finish
+    std::vector<uint8_t> local;
+    std::vector<uint8_t>& buf = dense_scratch ? *dense_scratch : local;
+    if (buf.size() < slot_bytes) buf.resize(slot_bytes);
+    char* base = (char*)buf.data();
     void* const ch[3] = {base, base + (size_t)JXLHIP_GROUP_COEFFS * esz, base + 2 * (size_t)JXLHIP_GROUP_COEFFS * esz};
     size_t ncoeffs = 0;
     memset(base, 0, slot_bytes);  // coefficients are accumulated (dec_group.cc:527-531)
+    rc = JXLHIP_OK;
     for (uint32_t p = 0; p < num_passes && rc == JXLHIP_OK; p++)
       rc = jxlhip_ac_group_decode(passes[p], f.xsb, f.ysb, group_idx % f.xsg, group_idx / f.xsg, ac_strategy,
                                   raw_quant, quant_dc, data[p], sizes[p], &bit_pos[p], shifts ? shifts[p] : 0,
                                   f.coeff_type, ch, &ncoeffs);
     if (rc == JXLHIP_OK) {
-      const void* const src[3] = {ch[0], ch[1], ch[2]};
+      int slot = -1;
+      if ((rc = AcquireSlot(c, slot_bytes, &slot))) return rc;
+      char* pinned = (char*)c->stage[slot];
+      const size_t chan = (size_t)JXLHIP_GROUP_COEFFS * esz;
+      memcpy(pinned, base, 2 * chan + ncoeffs * esz);  // (what jxlhip_submit_group_ev sends up in one copy)
+      const void* const src[3] = {pinned, pinned + chan, pinned + 2 * chan};
       rc = jxlhip_submit_group_ev(c, group_idx, src, ncoeffs, c->stage_ev[slot]);
+      ReleaseSlot(c, slot, rc == JXLHIP_OK);
     }
-    ReleaseSlot(c, slot, rc == JXLHIP_OK);
   }
   if (rc == JXLHIP_ERR_BAD_STREAM) return Fail(c, rc, "AC group %u: invalid entropy-coded data", group_idx);
   return rc;
@@ -1138,10 +1151,18 @@ struct GroupsJob {
   const size_t* sizes;
   size_t* end_bits = nullptr;
   std::atomic<int> status{JXLHIP_OK};
+  // the runner's task t is group order[t]: the sections with the most bytes first.  A group's decode time follows its
+  // bytes (r = 0.98 on the 8K d1.0 stream of tests/data) and a textured patch takes five times the mean: handed out
+  // last, one such group is the tail the whole frame waits for
+  std::vector<uint32_t> order;
+  // JXLHIP_CODESTREAM_VERBOSE=1: per task {start ms, end ms, thread}
+  std::vector<float> timeline;
+  std::chrono::steady_clock::time_point t0;
   // sparse hand-off: one open staging slot + one decode scratch per runner thread
   bool sparse = false;
   std::vector<SparseBatch> batch;
   std::vector<std::vector<uint8_t>> scratch;
+  std::vector<std::vector<uint8_t>> dense;  // per runner thread: where a group that goes up densely is decoded
 };
 int GroupsInit(void* opaque, size_t num_threads) {
   GroupsJob* j = static_cast<GroupsJob*>(opaque);
@@ -1149,11 +1170,25 @@ int GroupsInit(void* opaque, size_t num_threads) {
     j->batch.assign(num_threads ? num_threads : 1, SparseBatch());
     j->scratch.assign(num_threads ? num_threads : 1, std::vector<uint8_t>());
   }
+  j->dense.assign(num_threads ? num_threads : 1, std::vector<uint8_t>());
   return 0;
 }
-void GroupsFunc(void* opaque, uint32_t g, size_t thread) {
+// A section this large carries more non-zeros than a chroma list of the sparse form takes (kSparseCap; the stream above:
+// every group that overflowed had 32 000 bytes or more, none below 34 300 fitted with much to spare): decoded densely
+// straight away instead of finding that out three quarters of the way through the sparse attempt.
+static constexpr size_t kDenseFirstBytes = 30000;
+void GroupsFuncBody(GroupsJob* j, uint32_t task, size_t thread);
+void GroupsFunc(void* opaque, uint32_t task, size_t thread) {
   GroupsJob* j = static_cast<GroupsJob*>(opaque);
+  if (j->timeline.empty()) return GroupsFuncBody(j, task, thread);
+  const double a = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - j->t0).count();
+  GroupsFuncBody(j, task, thread);
+  const double b = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - j->t0).count();
+  j->timeline[3 * (size_t)task] = (float)a, j->timeline[3 * (size_t)task + 1] = (float)b, j->timeline[3 * (size_t)task + 2] = (float)thread;
+}
+void GroupsFuncBody(GroupsJob* j, uint32_t task, size_t thread) {
   if (j->status.load(std::memory_order_relaxed) != JXLHIP_OK) return;
+  const uint32_t g = j->order.empty() ? task : j->order[task];
   const DevFrame& f = j->c->f;
   const uint32_t gy = g / f.xsg;
   if (gy < f.group_y0 || gy >= f.group_y0 + f.group_rows) return;  // another rank's stripe
@@ -1165,14 +1200,15 @@ void GroupsFunc(void* opaque, uint32_t g, size_t thread) {
     pos[p] = 0;
   }
   int rc = JXLHIP_ERR_RANGE;
-  if (j->sparse && thread < j->batch.size()) {
+  if (j->sparse && thread < j->batch.size() && sizes[0] < kDenseFirstBytes) {
     if (j->scratch[thread].empty()) j->scratch[thread].resize(kSparseStride);
     rc = SparseAppend(j->c, &j->batch[thread], j->scratch[thread].data(), j->passes[0], j->shifts ? j->shifts[0] : 0, g, j->acs,
                       j->raw_quant, j->quant_dc, data[0], sizes[0], &pos[0]);
     if (rc == JXLHIP_ERR_BAD_STREAM) Fail(j->c, rc, "AC group %u: invalid entropy-coded data", g);
   }
   if (rc == JXLHIP_ERR_RANGE)
-    rc = SubmitPassesImpl(j->c, j->num_passes, j->passes, j->shifts, g, j->acs, j->raw_quant, j->quant_dc, data, sizes, pos, false);
+    rc = SubmitPassesImpl(j->c, j->num_passes, j->passes, j->shifts, g, j->acs, j->raw_quant, j->quant_dc, data, sizes, pos, false,
+                          thread < j->dense.size() ? &j->dense[thread] : nullptr);
   if (rc != JXLHIP_OK) {
     int expected = JXLHIP_OK;
     j->status.compare_exchange_strong(expected, rc);
@@ -1220,9 +1256,46 @@ int jxlhip_ac_groups_decode_submit_ex(jxlhip_ctx* c, jxlhip_parallel_runner runn
   job.sizes = sizes;
   job.end_bits = end_bits;
   job.sparse = SparseEligible(c, num_passes);
+  if (runner && job.num_groups > 1) {
+    std::vector<uint64_t> key(job.num_groups);  // (bytes over all passes) << 32 | ~group: sorted descending = largest first, ties in group order
+    for (uint32_t g = 0; g < job.num_groups; g++) {
+      uint64_t bytes = 0;
+      for (uint32_t p = 0; p < num_passes; p++) bytes += sizes[(size_t)p * job.num_groups + g];
+      key[g] = (std::min<uint64_t>(bytes, 0xFFFFFFFFu) << 32) | (uint32_t)~g;
+    }
+    std::sort(key.begin(), key.end(), std::greater<uint64_t>());
+    job.order.resize(job.num_groups);
+    for (uint32_t t = 0; t < job.num_groups; t++) job.order[t] = ~(uint32_t)key[t];
+  }
+  const bool verbose = getenv("JXLHIP_CODESTREAM_VERBOSE") != nullptr;
+  if (verbose) {
+    job.timeline.assign(3 * (size_t)job.num_groups, 0.0f);
+    job.t0 = std::chrono::steady_clock::now();
+  }
   if (runner) {
     if (runner(runner_opaque, &job, GroupsInit, GroupsFunc, 0, job.num_groups) != 0)
       return Fail(c, JXLHIP_ERR_STATE, "parallel runner failed");
+    if (verbose) {  // per thread: first start, last end, busy time, tasks; and the longest tasks
+      const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.t0).count();
+      struct Th { float first = 1e9f, last = 0, busy = 0; int n = 0; };
+      std::vector<Th> th(1024);
+      int used = 0;
+      float longest = 0, first_max = 0, last_min = 1e9f, busy_min = 1e9f, busy_max = 0;
+      for (uint32_t t = 0; t < job.num_groups; t++) {
+        const float a = job.timeline[3 * (size_t)t], b = job.timeline[3 * (size_t)t + 1];
+        Th& h = th[std::min<size_t>((size_t)job.timeline[3 * (size_t)t + 2], 1023)];
+        h.first = std::min(h.first, a), h.last = std::max(h.last, b), h.busy += b - a, h.n++;
+        longest = std::max(longest, b - a);
+      }
+      for (const Th& h : th) {
+        if (!h.n) continue;
+        used++;
+        first_max = std::max(first_max, h.first), last_min = std::min(last_min, h.last);
+        busy_min = std::min(busy_min, h.busy), busy_max = std::max(busy_max, h.busy);
+      }
+      fprintf(stderr, "[codestream] AC runner call: %.2f ms on %d threads; last thread started at %.2f, first finished at %.2f; busy per thread "
+              "%.2f .. %.2f ms; longest task %.2f ms\n", total, used, first_max, last_min, busy_min, busy_max, longest);
+    }
   } else {
     GroupsInit(&job, 1);
     for (uint32_t g = 0; g < job.num_groups; g++) GroupsFunc(&job, g, 0);

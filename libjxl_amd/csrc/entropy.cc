@@ -1011,8 +1011,17 @@ struct SparseSink {
 
 template <typename Sink, bool kPlainAns>
 int DecodeGroupImpl(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint32_t gx, uint32_t gy,
-                    const uint8_t* acs_map, const int32_t* raw_quant, const uint8_t* quant_dc, BitReader* br,
+                    const uint8_t* acs_map, const int32_t* raw_quant, const uint8_t* quant_dc, BitReader* br_io,
                     uint32_t shift, Sink& sink, size_t* ncoeffs) {
+  // the bit reader in a local for the length of the group (through the caller's pointer its bit count is reloaded after
+  // every coefficient store -- same type -- which puts a store-to-load round trip into the chain between two symbols)
+  BitReader local_br = *br_io;
+  BitReader* const br = &local_br;
+  struct WriteBack {
+    BitReader* to;
+    const BitReader* from;
+    ~WriteBack() { *to = *from; }
+  } write_back{br_io, &local_br};
   const uint32_t bx0 = gx * 32, by0 = gy * 32;
   if (bx0 >= xsb || by0 >= ysb) return JXLHIP_ERR_INVALID_ARGUMENT;
   const uint32_t gw = std::min(32u, xsb - bx0), gh = std::min(32u, ysb - by0);
