@@ -1177,18 +1177,21 @@ int GroupsInit(void* opaque, size_t num_threads) {
 // every group that overflowed had 32 000 bytes or more, none below 34 300 fitted with much to spare): decoded densely
 // straight away instead of finding that out three quarters of the way through the sparse attempt.
 static constexpr size_t kDenseFirstBytes = 30000;
-void GroupsFuncBody(GroupsJob* j, uint32_t task, size_t thread);
+void GroupsFuncBody(GroupsJob* j, uint32_t g, size_t thread);
+// one group, with its entry in the timeline (keyed by group) when one is kept
+void GroupsOne(GroupsJob* j, uint32_t g, size_t thread) {
+  if (j->timeline.empty()) return GroupsFuncBody(j, g, thread);
+  const double a = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - j->t0).count();
+  GroupsFuncBody(j, g, thread);
+  const double b = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - j->t0).count();
+  j->timeline[3 * (size_t)g] = (float)a, j->timeline[3 * (size_t)g + 1] = (float)b, j->timeline[3 * (size_t)g + 2] = (float)thread;
+}
 void GroupsFunc(void* opaque, uint32_t task, size_t thread) {
   GroupsJob* j = static_cast<GroupsJob*>(opaque);
-  if (j->timeline.empty()) return GroupsFuncBody(j, task, thread);
-  const double a = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - j->t0).count();
-  GroupsFuncBody(j, task, thread);
-  const double b = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - j->t0).count();
-  j->timeline[3 * (size_t)task] = (float)a, j->timeline[3 * (size_t)task + 1] = (float)b, j->timeline[3 * (size_t)task + 2] = (float)thread;
+  GroupsOne(j, j->order.empty() ? task : j->order[task], thread);
 }
-void GroupsFuncBody(GroupsJob* j, uint32_t task, size_t thread) {
+void GroupsFuncBody(GroupsJob* j, uint32_t g, size_t thread) {
   if (j->status.load(std::memory_order_relaxed) != JXLHIP_OK) return;
-  const uint32_t g = j->order.empty() ? task : j->order[task];
   const DevFrame& f = j->c->f;
   const uint32_t gy = g / f.xsg;
   if (gy < f.group_y0 || gy >= f.group_y0 + f.group_rows) return;  // another rank's stripe
@@ -1217,6 +1220,31 @@ void GroupsFuncBody(GroupsJob* j, uint32_t task, size_t thread) {
   }
 }
 }  // namespace
+
+// (JXLHIP_CODESTREAM_VERBOSE) per thread: first start, last end, busy time; and the longest task
+static void GroupsTimelineReport(const GroupsJob& job) {
+  const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.t0).count();
+  struct Th { float first = 1e9f, last = 0, busy = 0; int n = 0; };
+  std::vector<Th> th(1024);
+  int used = 0;
+  float longest = 0, first_min = 1e9f, first_max = 0, last_min = 1e9f, busy_min = 1e9f, busy_max = 0;
+  for (uint32_t t = 0; t < job.num_groups; t++) {
+    const float a = job.timeline[3 * (size_t)t], b = job.timeline[3 * (size_t)t + 1];
+    if (b <= 0) continue;
+    Th& h = th[std::min<size_t>((size_t)job.timeline[3 * (size_t)t + 2], 1023)];
+    h.first = std::min(h.first, a), h.last = std::max(h.last, b), h.busy += b - a, h.n++;
+    longest = std::max(longest, b - a);
+  }
+  for (const Th& h : th) {
+    if (!h.n) continue;
+    used++;
+    first_min = std::min(first_min, h.first), first_max = std::max(first_max, h.first), last_min = std::min(last_min, h.last);
+    busy_min = std::min(busy_min, h.busy), busy_max = std::max(busy_max, h.busy);
+  }
+  fprintf(stderr, "[codestream] AC groups: %.2f ms after the runner call began, on %d threads; first group started at %.2f, last thread started at "
+          "%.2f, first finished at %.2f; busy per thread %.2f .. %.2f ms; longest group %.2f ms\n", total, used, first_min, first_max, last_min,
+          busy_min, busy_max, longest);
+}
 
 int jxlhip_ac_groups_decode_submit(jxlhip_ctx* c, jxlhip_parallel_runner runner, void* runner_opaque,
                                    uint32_t num_passes, const jxlhip_ac_pass* const* passes,
@@ -1275,27 +1303,7 @@ int jxlhip_ac_groups_decode_submit_ex(jxlhip_ctx* c, jxlhip_parallel_runner runn
   if (runner) {
     if (runner(runner_opaque, &job, GroupsInit, GroupsFunc, 0, job.num_groups) != 0)
       return Fail(c, JXLHIP_ERR_STATE, "parallel runner failed");
-    if (verbose) {  // per thread: first start, last end, busy time, tasks; and the longest tasks
-      const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - job.t0).count();
-      struct Th { float first = 1e9f, last = 0, busy = 0; int n = 0; };
-      std::vector<Th> th(1024);
-      int used = 0;
-      float longest = 0, first_max = 0, last_min = 1e9f, busy_min = 1e9f, busy_max = 0;
-      for (uint32_t t = 0; t < job.num_groups; t++) {
-        const float a = job.timeline[3 * (size_t)t], b = job.timeline[3 * (size_t)t + 1];
-        Th& h = th[std::min<size_t>((size_t)job.timeline[3 * (size_t)t + 2], 1023)];
-        h.first = std::min(h.first, a), h.last = std::max(h.last, b), h.busy += b - a, h.n++;
-        longest = std::max(longest, b - a);
-      }
-      for (const Th& h : th) {
-        if (!h.n) continue;
-        used++;
-        first_max = std::max(first_max, h.first), last_min = std::min(last_min, h.last);
-        busy_min = std::min(busy_min, h.busy), busy_max = std::max(busy_max, h.busy);
-      }
-      fprintf(stderr, "[codestream] AC runner call: %.2f ms on %d threads; last thread started at %.2f, first finished at %.2f; busy per thread "
-              "%.2f .. %.2f ms; longest task %.2f ms\n", total, used, first_max, last_min, busy_min, busy_max, longest);
-    }
+    if (verbose) GroupsTimelineReport(job);
   } else {
     GroupsInit(&job, 1);
     for (uint32_t g = 0; g < job.num_groups; g++) GroupsFunc(&job, g, 0);
