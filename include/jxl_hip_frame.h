@@ -311,6 +311,19 @@ JXLHIP_EXPORT int jxlhip_dc_group_decode(const jxlhip_modular_tree* global_tree,
                                          int32_t* const quant_dc[3], uint32_t* extra_precision,
                                          uint8_t* ac_strategy, int32_t* raw_quant, uint8_t* epf_sharpness,
                                          int8_t* ytox_map, int8_t* ytob_map, uint32_t* used_acs);
+/* The same, announcing the moment the AC groups under this DC group can start: block_info_ready(opaque) is called (on
+ * the calling thread, at most once, only when the call goes on to succeed that far) as soon as the group's rectangles
+ * of quant_dc, ac_strategy and raw_quant are complete and *used_acs has this group's bits -- before the EPF sharpness
+ * channel, which is the last and, at one sample per block, a tenth of the section's decode time.  The reference runs
+ * every ProcessDCGroup to its end before the first ProcessACGroup (dec_frame.cc:318-360,596-703); nothing an AC group
+ * reads (dec_group.cc:431-560: strategy, quant field, the DC-derived block contexts) comes from the sharpness map.
+ * A failure reported AFTER the callback (a damaged sharpness channel) fails the frame all the same. */
+JXLHIP_EXPORT int jxlhip_dc_group_decode_staged(const jxlhip_modular_tree* global_tree, const uint8_t* data, size_t size,
+                                                size_t* bit_pos, const jxlhip_frame_header* frame, uint32_t dc_group,
+                                                int32_t* const quant_dc[3], uint32_t* extra_precision,
+                                                uint8_t* ac_strategy, int32_t* raw_quant, uint8_t* epf_sharpness,
+                                                int8_t* ytox_map, int8_t* ytob_map, uint32_t* used_acs,
+                                                void (*block_info_ready)(void* opaque), void* opaque);
 
 #ifdef __cplusplus
 }

@@ -239,7 +239,7 @@ EXPORTS = [
     "jxlhip_ac_groups_decode_submit", "jxlhip_ac_groups_decode_submit_ex", "jxlhip_num_toc_entries", "jxlhip_toc_decode", "jxlhip_ac_global_decode_at",
     # include/jxl_hip_frame.h
     "jxlhip_frame_header_decode", "jxlhip_dc_global_decode", "jxlhip_image_header_decode", "jxlhip_icc_decode", "jxlhip_output_opsin_matrix",
-    "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode",
+    "jxlhip_modular_global_decode", "jxlhip_modular_tree_destroy", "jxlhip_dc_group_decode", "jxlhip_dc_group_decode_staged",
     "jxlhip_modular_ac_group_decode", "jxlhip_modular_ac_group_decode_f32", "jxlhip_modular_extra_channel_f32",
     "jxlhip_modular_groups_are_final", "jxlhip_modular_uses_dc_groups", "jxlhip_modular_finalize",
     "jxlhip_modular_extra_channel_rows_f32", "jxlhip_modular_ac_group_decode_f32_strided",
@@ -306,6 +306,9 @@ def load_library():
     L.jxlhip_dc_group_decode.argtypes = [vp, vp, sz, C.POINTER(sz), C.POINTER(FrameHeader), C.c_uint32,
                                          C.POINTER(vp), C.POINTER(C.c_uint32), vp, vp, vp, vp, vp,
                                          C.POINTER(C.c_uint32)]
+    L.jxlhip_dc_group_decode_staged.argtypes = [vp, vp, sz, C.POINTER(sz), C.POINTER(FrameHeader), C.c_uint32,
+                                                C.POINTER(vp), C.POINTER(C.c_uint32), vp, vp, vp, vp, vp,
+                                                C.POINTER(C.c_uint32), vp, vp]
     L.jxlhip_image_header_decode.argtypes = [vp, sz, C.POINTER(sz), C.POINTER(ExtraChannel), sz,
                                              C.POINTER(ImageHeader)]
     L.jxlhip_output_opsin_matrix.argtypes = [C.POINTER(ImageHeader), C.c_float * 9, C.c_float * 3]

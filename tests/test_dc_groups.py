@@ -198,6 +198,57 @@ def test_channel_loops_of_their_own_equal_the_general_loop(L, ref, monkeypatch):
     assert stopped > 50, (went_through, stopped)  # (nearly every flip derails the ANS stream: both loops must say so)
 
 
+def test_staged_dc_group_announces_the_block_info_before_the_sharpness_channel(L, ref):
+    """jxlhip_dc_group_decode_staged: the callback fires once per group, on the calling thread, when the group's rectangles
+    of quant_dc / ac_strategy / raw_quant (and its used_acs bits) already hold their final values -- what the AC groups
+    under it read -- and the call then ends with the same outputs as jxlhip_dc_group_decode."""
+    rs = ref.RealStream(seed=13, xsize=2200, ysize=264, distance=1.5, speed_tier=4)
+    cs, ih, fh, sections = parse_to_sections(L, rs)
+    want = decode_side_info(L, fh, sections)
+    s0 = sections[0]
+    dcg, dpos = abi.DcGlobal(), C.c_size_t(0)
+    assert L.jxlhip_dc_global_decode(s0.ctypes.data, len(s0), C.byref(dpos), fh.flags, C.byref(dcg)) == 0
+    tree = C.c_void_p()
+    assert L.jxlhip_modular_global_decode(s0.ctypes.data, len(s0), C.byref(dpos), C.byref(fh), C.byref(tree)) == 0
+    xsb, ysb = fh.xsize_blocks, fh.ysize_blocks
+    qdc = [np.zeros(xsb * ysb, np.int32) for _ in range(3)]
+    acs, rq, sharp = np.zeros(xsb * ysb, np.uint8), np.zeros(xsb * ysb, np.int32), np.full(xsb * ysb, 99, np.uint8)
+    cw, chh = (xsb + 7) // 8, (ysb + 7) // 8
+    ytox, ytob = np.zeros(cw * chh, np.int8), np.zeros(cw * chh, np.int8)
+    used = C.c_uint32(0)
+    seen = []
+    gd = fh.group_dim
+    xdg = (xsb + gd - 1) // gd
+
+    @C.CFUNCTYPE(None, C.c_void_p)
+    def ready(opaque):
+        g = C.cast(opaque, C.POINTER(C.c_uint32))[0]
+        x0, y0 = (g % xdg) * gd, (g // xdg) * gd
+        rect = np.zeros((ysb, xsb), bool)
+        rect[y0:y0 + gd, x0:x0 + gd] = True
+        rect = rect.ravel()
+        seen.append((g, np.array_equal(acs[rect], want[3][rect]), np.array_equal(rq[rect], want[4][rect]),
+                     all(np.array_equal(q[rect], w[rect]) for q, w in zip(qdc, want[1])),
+                     bool((sharp[rect] == 99).all())))
+
+    try:
+        for g in range(int(fh.num_dc_groups)):
+            d = sections[1 + g]
+            gp, ep, gid = C.c_size_t(0), C.c_uint32(0), C.c_uint32(g)
+            ptrs = (C.c_void_p * 3)(*[q.ctypes.data for q in qdc])
+            rc = L.jxlhip_dc_group_decode_staged(tree, d.ctypes.data, len(d), C.byref(gp), C.byref(fh), g, ptrs, C.byref(ep),
+                                                 acs.ctypes.data, rq.ctypes.data, sharp.ctypes.data, ytox.ctypes.data,
+                                                 ytob.ctypes.data, C.byref(used), C.cast(ready, C.c_void_p), C.addressof(gid))
+            assert rc == 0 and (gp.value + 7) // 8 == len(d)
+    finally:
+        L.jxlhip_modular_tree_destroy(tree)
+    assert [s[0] for s in seen] == list(range(int(fh.num_dc_groups)))
+    # at the callback: strategy map, quant field and quantized DC final; not one sharpness value of the rectangle written yet
+    assert all(s[1] and s[2] and s[3] and s[4] for s in seen), seen
+    assert np.array_equal(acs, want[3]) and np.array_equal(sharp, want[5]) and used.value == want[8]
+    assert np.array_equal(ytox, want[6]) and np.array_equal(ytob, want[7])
+
+
 def test_damaged_global_trees_fail_like_the_reference(L, ref):
     """DecodeTree + ValidateTree + DecodeHistograms (modular/encoding/dec_ma.cc) on damaged DC-global
     sections: same verdict and, when accepted, the same number of bits as the reference."""

@@ -21,6 +21,7 @@ if os.environ.get("JXLHIP_LIB"):
     abi._SO = os.environ["JXLHIP_LIB"]
 L = abi.load_library()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+lenient = "--dc-only-lenient" in sys.argv  # (timing experiments that decode garbage: DC groups only, any status)
 
 
 class _File:
@@ -51,13 +52,15 @@ for rep in range(reps):
         rc = L.jxlhip_dc_group_decode(tree, d.ctypes.data, len(d), C.byref(gp), C.byref(fh), g, ptrs, C.byref(ep), acs.ctypes.data,
                                       rq.ctypes.data, sharp.ctypes.data, ytox.ctypes.data, ytob.ctypes.data, C.byref(used))
         ts.append((time.perf_counter() - t0) * 1e3)
-        assert rc == 0
+        assert rc == 0 or lenient
     best = ts if best is None else [min(a, b) for a, b in zip(best, ts)]
 print("DC groups, best of %d, ms each: %s; sum %.1f" % (reps, " ".join("%.2f" % t for t in best), sum(best)))
 h = hashlib.sha1()
 for a in qdc + [acs, rq, sharp, ytox, ytob]:
     h.update(a.tobytes())
 print("digest of the side info", h.hexdigest())
+if lenient:
+    sys.exit(0)
 
 sg = sections[1 + ndc]
 enc = (abi.QuantEncoding * 17)()
