@@ -29,7 +29,11 @@ namespace {
 constexpr int kPoolStreams = 8;
 constexpr int kMaxBlockStreams = 8;
 constexpr int kMaxBands = 64;
-constexpr int kStageSlots = 32;  // pinned staging buffers of jxlhip_ac_group_decode_submit (0.4 / 0.8 MB each)
+// pinned staging buffers of jxlhip_ac_group_decode_submit (0.4 / 0.8 MB each): kStageSlotsFirst at first use, one more
+// whenever a thread would otherwise have to wait for an upload to finish, up to kStageSlots.  (An upload is microseconds
+// of PCIe, but the runtime now and then sits on a queued copy for 10-30 ms -- profiles/r04_e2e_waits.txt -- and with 32
+// slots for 64 decoding threads that stall became every thread's.)
+constexpr int kStageSlots = 128, kStageSlotsFirst = 32;
 
 struct ProfSpan {
   hipEvent_t a, b;
@@ -122,6 +126,7 @@ struct jxlhip_ctx {
   void* stage[kStageSlots] = {nullptr};
   hipEvent_t stage_ev[kStageSlots] = {nullptr};
   int stage_state[kStageSlots] = {0};  // 0 free, 1 owned by a decoding thread, 2 upload queued (stage_ev)
+  int stage_count = 0;                 // slots allocated so far (<= kStageSlots)
   size_t stage_bytes = 0;
   std::mutex stage_mu;
   std::condition_variable stage_cv;
@@ -846,6 +851,25 @@ int jxlhip_upload_side_info(jxlhip_ctx* c, const uint8_t* ac_strategy, const int
   return JXLHIP_OK;
 }
 
+// JXLHIP_CODESTREAM_VERBOSE: the longest single wait of the upload path during one AC phase, microseconds
+// [0] a pinned slot (AcquireSlot), [1] one hipMemcpyAsync call, [2] one hipEventRecord call
+static std::atomic<int64_t> g_upload_wait_us[3];
+static std::atomic<bool> g_upload_wait_on{false};
+struct UploadWaitClock {
+  int which;
+  std::chrono::steady_clock::time_point t0;
+  explicit UploadWaitClock(int w) : which(w) {
+    if (g_upload_wait_on.load(std::memory_order_relaxed)) t0 = std::chrono::steady_clock::now();
+  }
+  ~UploadWaitClock() {
+    if (!g_upload_wait_on.load(std::memory_order_relaxed)) return;
+    const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    int64_t seen = g_upload_wait_us[which].load(std::memory_order_relaxed);
+    while (seen < us && !g_upload_wait_us[which].compare_exchange_weak(seen, us, std::memory_order_relaxed)) {
+    }
+  }
+};
+
 static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void* const coeffs[3],
                                   size_t ncoeffs, hipEvent_t done);
 
@@ -893,7 +917,11 @@ static int jxlhip_submit_group_ev(jxlhip_ctx* c, uint32_t group_idx, const void*
   char* dst0 = (char*)c->up_coeffs[0] + (size_t)group_idx * 3 * chan;
   if ((const char*)coeffs[1] == (const char*)coeffs[0] + chan && (const char*)coeffs[2] == (const char*)coeffs[0] + 2 * chan) {
     // the three channels sit in one staging slot: one copy up to the last used coefficient
-    hipError_t e = hipMemcpyAsync(dst0, coeffs[0], 2 * chan + ncoeffs * esz, hipMemcpyHostToDevice, c->pool[slot]);
+    hipError_t e;
+    {
+      UploadWaitClock w(1);
+      e = hipMemcpyAsync(dst0, coeffs[0], 2 * chan + ncoeffs * esz, hipMemcpyHostToDevice, c->pool[slot]);
+    }
     if (e != hipSuccess) return Fail(c, JXLHIP_ERR_HIP, "submit_group: %s", hipGetErrorString(e));
   } else {
     for (int ch = 0; ch < 3; ch++) {
@@ -932,11 +960,16 @@ struct SparseBatch {  // what one runner thread has collected (in its own heap b
 static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out);
 static void ReleaseSlot(jxlhip_ctx* c, int slot, bool uploaded);
 
+
 // the batch goes up as one copy through a pinned staging slot; its groups' headers are entered into the offset table
 static int SparseFlush(jxlhip_ctx* c, SparseBatch* b) {
   if (b->n == 0) return JXLHIP_OK;
   int slot = -1;
-  int rc = AcquireSlot(c, kSparseStride, &slot);
+  int rc;
+  {
+    UploadWaitClock w(0);
+    rc = AcquireSlot(c, kSparseStride, &slot);
+  }
   if (rc) return rc;
   memcpy(c->stage[slot], b->buf.data(), b->used);
   const size_t bytes = (b->used + 255) & ~(size_t)255;
@@ -950,9 +983,17 @@ static int SparseFlush(jxlhip_ctx* c, SparseBatch* b) {
   if (off + bytes > c->sp_bytes) rc = Fail(c, JXLHIP_ERR_STATE, "sparse arena overflow");
   if (!rc && hipSetDevice(c->device) != hipSuccess) rc = JXLHIP_ERR_HIP;
   if (!rc) {
-    hipError_t e = hipMemcpyAsync(c->sp_dev + off, c->stage[slot], b->used, hipMemcpyHostToDevice, c->pool[stream]);
-    if (e != hipSuccess) rc = Fail(c, JXLHIP_ERR_HIP, "sparse submit: %s", hipGetErrorString(e));
-    else if (hipEventRecord(c->stage_ev[slot], c->pool[stream]) != hipSuccess) rc = Fail(c, JXLHIP_ERR_HIP, "sparse submit: event record failed");
+    hipError_t e;
+    {
+      UploadWaitClock w(1);
+      e = hipMemcpyAsync(c->sp_dev + off, c->stage[slot], b->used, hipMemcpyHostToDevice, c->pool[stream]);
+    }
+    if (e != hipSuccess) {
+      rc = Fail(c, JXLHIP_ERR_HIP, "sparse submit: %s", hipGetErrorString(e));
+    } else {
+      UploadWaitClock w(2);
+      if (hipEventRecord(c->stage_ev[slot], c->pool[stream]) != hipSuccess) rc = Fail(c, JXLHIP_ERR_HIP, "sparse submit: event record failed");
+    }
   }
   if (!rc) {
     uint32_t* table = c->sp_off_host[c->frame_serial & 1u];
@@ -1036,33 +1077,41 @@ static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out) {
   int slot = -1;
   std::unique_lock<std::mutex> lock(c->stage_mu);
   if (hipSetDevice(c->device) != hipSuccess) return JXLHIP_ERR_HIP;
+  auto new_slot = [&](int i) -> int {
+    if (StageAlloc(c, &c->stage[i], c->stage_bytes) != JXLHIP_OK) return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
+    if (!c->stage_ev[i] && hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess)
+      return Fail(c, JXLHIP_ERR_HIP, "event creation failed");
+    c->stage_state[i] = 0;
+    return JXLHIP_OK;
+  };
   if (c->stage_bytes < slot_bytes) {
     // (re)allocation: only when no thread owns a slot
     c->stage_cv.wait(lock, [&] {
-      for (int i = 0; i < kStageSlots; i++)
+      for (int i = 0; i < c->stage_count; i++)
         if (c->stage_state[i] == 1) return false;
       return true;
     });
     if (c->stage_bytes < slot_bytes) {
-      for (int i = 0; i < kStageSlots; i++) {
+      for (int i = 0; i < c->stage_count; i++) {
         if (c->stage[i]) {
           if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
           StageFree(c, c->stage[i]);
           c->stage[i] = nullptr;
         }
         c->stage_state[i] = 0;
-        if (StageAlloc(c, &c->stage[i], slot_bytes) != JXLHIP_OK)
-          return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
-        if (!c->stage_ev[i] &&
-            hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess)
-          return Fail(c, JXLHIP_ERR_HIP, "event creation failed");
       }
       c->stage_bytes = slot_bytes;
+      c->stage_count = 0;
+      for (int i = 0; i < kStageSlotsFirst; i++) {
+        const int rc = new_slot(i);
+        if (rc) return rc;
+        c->stage_count = i + 1;
+      }
     }
   }
   while (slot < 0) {
     int pending = -1;
-    for (int i = 0; i < kStageSlots && slot < 0; i++) {
+    for (int i = 0; i < c->stage_count && slot < 0; i++) {
       if (c->stage_state[i] == 0) slot = i;
       else if (c->stage_state[i] == 2) {
         if (hipEventQuery(c->stage_ev[i]) == hipSuccess) slot = i;
@@ -1070,9 +1119,16 @@ static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out) {
       }
     }
     if (slot >= 0) break;
-    if (pending >= 0) {  // every slot is in flight: wait for one upload
-      if (hipEventSynchronize(c->stage_ev[pending]) != hipSuccess) return JXLHIP_ERR_HIP;
-      if (c->stage_state[pending] == 2) slot = pending;
+    if (c->stage_count < kStageSlots) {  // nothing free: one more slot rather than a wait
+      const int rc = new_slot(c->stage_count);
+      if (rc) return rc;
+      slot = c->stage_count++;
+    } else if (pending >= 0) {  // every slot is in flight: wait for one upload, without keeping the others out
+      hipEvent_t ev = c->stage_ev[pending];
+      lock.unlock();
+      const hipError_t e = hipEventSynchronize(ev);
+      lock.lock();
+      if (e != hipSuccess) return JXLHIP_ERR_HIP;
     } else {  // every slot is owned by another decoding thread
       c->stage_cv.wait(lock);
     }
@@ -1125,7 +1181,11 @@ static int SubmitPassesImpl(jxlhip_ctx* c, uint32_t num_passes, const jxlhip_ac_
                                   f.coeff_type, ch, &ncoeffs);
     if (rc == JXLHIP_OK) {
       int slot = -1;
-      if ((rc = AcquireSlot(c, slot_bytes, &slot))) return rc;
+      {
+        UploadWaitClock w(0);
+        rc = AcquireSlot(c, slot_bytes, &slot);
+      }
+      if (rc) return rc;
       char* pinned = (char*)c->stage[slot];
       const size_t chan = (size_t)JXLHIP_GROUP_COEFFS * esz;
       memcpy(pinned, base, 2 * chan + ncoeffs * esz);  // (what jxlhip_submit_group_ev sends up in one copy)
@@ -1241,6 +1301,8 @@ static void GroupsTimelineReport(const GroupsJob& job) {
     first_min = std::min(first_min, h.first), first_max = std::max(first_max, h.first), last_min = std::min(last_min, h.last);
     busy_min = std::min(busy_min, h.busy), busy_max = std::max(busy_max, h.busy);
   }
+  fprintf(stderr, "[codestream] longest single wait in the upload path: pinned slot %.2f ms, hipMemcpyAsync %.2f ms, hipEventRecord %.2f ms\n",
+          g_upload_wait_us[0].exchange(0) * 1e-3, g_upload_wait_us[1].exchange(0) * 1e-3, g_upload_wait_us[2].exchange(0) * 1e-3);
   fprintf(stderr, "[codestream] AC groups: %.2f ms after the runner call began, on %d threads; first group started at %.2f, last thread started at "
           "%.2f, first finished at %.2f; busy per thread %.2f .. %.2f ms; longest group %.2f ms\n", total, used, first_min, first_max, last_min,
           busy_min, busy_max, longest);
