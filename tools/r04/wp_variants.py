@@ -30,7 +30,7 @@ NO_HEALTH = """  }
 }
 
 // ---- channels whose subtree"""
-CLONES = '__attribute__((target_clones("default", "arch=x86-64-v3")))'
+CLONES = '#define JXLHIP_X86_64_V3_CLONE __attribute__((target_clones("default", "arch=x86-64-v3")))'
 ANS_A = "      br.Refill();\n      const uint32_t res = state & (kAnsTab - 1);\n      const AliasEntry e = alias[((size_t)ctx << log_alpha) + (res >> log_entry)];"
 ANS_B = "      const int64_t N8 = N * 8, W8 = W * 8"
 
@@ -43,9 +43,13 @@ def cut_ans(s):
 
 VARIANTS = {
     "current": (lambda s: s, []),
-    "no_clones": (lambda s: s.replace(CLONES, ""), []),
-    "bmi2_clone": (lambda s: s.replace(CLONES, '__attribute__((target_clones("default", "bmi2")))'), []),
-    "native": (lambda s: s.replace(CLONES, ""), ["-march=native"]),
+    "no_clones": (lambda s: s.replace(CLONES, "#define JXLHIP_X86_64_V3_CLONE"), []),
+    "bmi2_clone": (lambda s: s.replace(CLONES, '#define JXLHIP_X86_64_V3_CLONE __attribute__((target_clones("default", "bmi2")))'), []),
+    "native": (lambda s: s.replace(CLONES, "#define JXLHIP_X86_64_V3_CLONE"), ["-march=native"]),
+    "no_slp": (lambda s: s, ["-fno-slp-vectorize"]),
+    "no_slp_no_cmovconv": (lambda s: s, ["-fno-slp-vectorize", "-mllvm", "-x86-cmov-converter=false"]),
+    "no_slp_O2": (lambda s: s, ["-fno-slp-vectorize", "-O2"]),
+    "no_slp_no_ans": (lambda s: cut_ans(s).replace(HEALTH, NO_HEALTH), ["-fno-slp-vectorize"]),
     "no_ans": (lambda s: cut_ans(s).replace(HEALTH, NO_HEALTH), []),
     "const_weights": (lambda s: s.replace("weight(t[0] + twice * e1_0, 0)", "weight(t[0], 0)").replace("weight(t[1] + twice * e1_1, 1)", "weight(t[1], 1)")
                       .replace("weight(t[2] + twice * e1_2, 2)", "weight(t[2], 2)").replace("weight(t[3] + twice * e1_3, 3)", "weight(t[3], 3)")
@@ -63,7 +67,7 @@ def build(name):
     os.makedirs(os.path.join(d, "..", "..", "include"), exist_ok=True)
     src = open(os.path.join(CSRC, "modular.inc")).read()
     out = patch(src)
-    if name != "current" and out == src:
+    if name != "current" and out == src and not flags:
         raise SystemExit("variant %s: nothing to patch" % name)
     open(os.path.join(d, "modular.inc"), "w").write(out)
     text = open(os.path.join(d, "entropy.cc")).read().replace('"../../include/', '"%s/include/' % ROOT)
