@@ -115,6 +115,10 @@ JXLHIP_EXPORT int jxlhip_decode_codestream_extra(jxlhip_ctx* ctx, jxlhip_paralle
  * the whole call: tools/djxl_main.cc:392-426, tools/speed_stats.cc:102-121). */
 enum {
   JXLHIP_PHASE_HEADERS = 0,        /* container, image / frame header, TOC, DC global, the global Modular tree */
+  /* With a runner, the DC groups, AC global and the AC groups are ONE runner call over num_dc_groups + 1 + num_groups
+   * work units (the AC groups under a DC group start when its strategy map / quant field are in: DESIGN.md section 4;
+   * JXLHIP_NO_PIPELINE=1 restores the three barriers, JXLHIP_CODESTREAM_VERBOSE=1 prints the call's timeline to stderr):
+   * DC_GROUPS is then the time until the LAST DC group ended, AC_GROUPS what of the call came after it, AC_GLOBAL ~0. */
   JXLHIP_PHASE_DC_GROUPS = 1,      /* DecodeVarDCTDC + DecodeAcMetadata of every DC group, on the runner */
   JXLHIP_PHASE_AC_GLOBAL = 2,      /* block contexts, dequant encodings, histograms and coefficient orders of every pass */
   JXLHIP_PHASE_SIDE_INFO = 3,      /* frame_begin, side-info uploads, DC dequant + smoothing and dequant tables queued */
