@@ -1223,6 +1223,10 @@ struct GroupsJob {
   std::vector<SparseBatch> batch;
   std::vector<std::vector<uint8_t>> scratch;
   std::vector<std::vector<uint8_t>> dense;  // per runner thread: where a group that goes up densely is decoded
+  // test hook (JXLHIP_TEST_RANGE_GROUP=g, read by GroupsInit): group g reports a coefficient beyond 16 bits on the
+  // 16-bit attempt -- no stream libjxl's encoder writes at ordinary settings does, and the redo with int32 buffers
+  // (through the single runner call and through the three barriers) has to be reachable by a test
+  int64_t test_range_group = -1;
 };
 int GroupsInit(void* opaque, size_t num_threads) {
   GroupsJob* j = static_cast<GroupsJob*>(opaque);
@@ -1231,6 +1235,7 @@ int GroupsInit(void* opaque, size_t num_threads) {
     j->scratch.assign(num_threads ? num_threads : 1, std::vector<uint8_t>());
   }
   j->dense.assign(num_threads ? num_threads : 1, std::vector<uint8_t>());
+  if (const char* e = getenv("JXLHIP_TEST_RANGE_GROUP")) j->test_range_group = atoll(e);
   return 0;
 }
 // A section this large carries more non-zeros than a chroma list of the sparse form takes (kSparseCap; the stream above:
@@ -1263,6 +1268,11 @@ void GroupsFuncBody(GroupsJob* j, uint32_t g, size_t thread) {
     pos[p] = 0;
   }
   int rc = JXLHIP_ERR_RANGE;
+  if ((int64_t)g == j->test_range_group && f.coeff_type == JXLHIP_COEFF_I16) {
+    int expected = JXLHIP_OK;
+    j->status.compare_exchange_strong(expected, JXLHIP_ERR_RANGE);
+    return;
+  }
   if (j->sparse && thread < j->batch.size() && sizes[0] < kDenseFirstBytes) {
     if (j->scratch[thread].empty()) j->scratch[thread].resize(kSparseStride);
     rc = SparseAppend(j->c, &j->batch[thread], j->scratch[thread].data(), j->passes[0], j->shifts ? j->shifts[0] : 0, g, j->acs,

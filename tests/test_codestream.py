@@ -135,6 +135,101 @@ def test_decode_codestream_matches_the_reference_decoder(L, ref, kw, workers):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(xsize=2200, ysize=520, distance=1.5, speed_tier=4),                  # two DC groups, 27 AC groups
+    dict(xsize=776, ysize=520, distance=3.0, speed_tier=3, progressive=1),   # 3 AC passes
+    dict(xsize=2300, ysize=2100, distance=0.6, speed_tier=4),                 # four DC groups of four sizes
+    dict(xsize=640, ysize=520, distance=0.05, speed_tier=4),                  # coefficients beyond 16 bits, if any are
+])
+def test_one_runner_call_equals_three_barriers(L, ref, kw, monkeypatch):
+    """With a runner the DC groups, AC global and the AC groups are ONE pool of work units in one runner call, the AC
+    groups under a DC group starting when its block info is in (codestream.inc: PipelineJob); JXLHIP_NO_PIPELINE=1 runs
+    the three phases of FrameDecoder one after the other (dec_frame.cc:596-703).  Same pixels, bit for bit, same
+    coefficient type, for several worker counts -- and equal to the reference decoder's."""
+    import torch
+    from libjxl_amd import VarDctDecoder
+    rs = ref.RealStream(seed=31, **kw)
+    cs = rs.codestream.tobytes()
+    R = C.CDLL(abi.runner_library_path())
+    R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    runner = C.cast(R.JxlThreadParallelRunner, C.c_void_p)
+    dec = VarDctDecoder(0)
+    results = []
+    try:
+        for workers, barriers in ((2, False), (13, False), (13, True), (40, False)):
+            if barriers:
+                monkeypatch.setenv("JXLHIP_NO_PIPELINE", "1")
+            else:
+                monkeypatch.delenv("JXLHIP_NO_PIPELINE", raising=False)
+            pool = R.JxlThreadParallelRunnerCreate(None, workers)
+            try:
+                for rep in range(3):  # (a context decodes frame after frame: the offset tables and arenas alternate)
+                    info = abi.CodestreamInfo()
+                    out = torch.zeros((rs.ysize, rs.xsize, 3), dtype=torch.float32, device="cuda")
+                    rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, cs, len(cs), 1, None, out.data_ptr(), rs.xsize * 12, 0,
+                                                    C.byref(info))
+                    assert rc == 0, (workers, barriers, rc, L.jxlhip_last_error(dec.ctx))
+                    results.append((workers, barriers, info.coeff_type, out.cpu().numpy()))
+            finally:
+                R.JxlThreadParallelRunnerDestroy(pool)
+    finally:
+        dec.close()
+        monkeypatch.delenv("JXLHIP_NO_PIPELINE", raising=False)
+    first = results[0]
+    scale = max(1.0, float(np.abs(rs.rgb).max()))
+    assert float(np.abs(first[3] - rs.rgb).max()) / scale <= TIGHT
+    for r in results[1:]:
+        assert r[2] == first[2], (r[:3], first[:3])
+        assert np.array_equal(r[3], first[3]), r[:3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("barriers", [False, True])
+def test_redo_with_int32_coefficients(L, ref, barriers, monkeypatch):
+    """A coefficient beyond 16 bits on the optimistic 16-bit attempt: every AC group is decoded again into int32 buffers
+    (jxl_hip_entropy.h) -- from inside the single runner call (the AC groups stop, the DC groups go on) and from the
+    three-barrier path.  No stream of the reference encoder at ordinary settings gets there: the test hook
+    JXLHIP_TEST_RANGE_GROUP makes one group report it."""
+    import torch
+    from libjxl_amd import VarDctDecoder
+    rs = ref.RealStream(seed=31, xsize=2200, ysize=520, distance=1.5, speed_tier=4)
+    cs = rs.codestream.tobytes()
+    R = C.CDLL(abi.runner_library_path())
+    R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    runner = C.cast(R.JxlThreadParallelRunner, C.c_void_p)
+    pool = R.JxlThreadParallelRunnerCreate(None, 9)
+    dec = VarDctDecoder(0)
+    if barriers:
+        monkeypatch.setenv("JXLHIP_NO_PIPELINE", "1")
+    try:
+        got = []
+        for hook in (None, "11", None):
+            if hook:
+                monkeypatch.setenv("JXLHIP_TEST_RANGE_GROUP", hook)
+            else:
+                monkeypatch.delenv("JXLHIP_TEST_RANGE_GROUP", raising=False)
+            info = abi.CodestreamInfo()
+            out = torch.zeros((rs.ysize, rs.xsize, 3), dtype=torch.float32, device="cuda")
+            rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, cs, len(cs), 1, None, out.data_ptr(), rs.xsize * 12, 0, C.byref(info))
+            assert rc == 0, (hook, rc, L.jxlhip_last_error(dec.ctx))
+            got.append((info.coeff_type, out.cpu().numpy()))
+    finally:
+        dec.close()
+        R.JxlThreadParallelRunnerDestroy(pool)
+        monkeypatch.delenv("JXLHIP_TEST_RANGE_GROUP", raising=False)
+        monkeypatch.delenv("JXLHIP_NO_PIPELINE", raising=False)
+    assert [g[0] for g in got] == [0, 1, 0]  # JXLHIP_COEFF_I16, _I32, _I16 again on the same context
+    scale = max(1.0, float(np.abs(rs.rgb).max()))
+    for _, px in got:
+        assert float(np.abs(px - rs.rgb).max()) / scale <= TIGHT
+    assert np.array_equal(got[0][1], got[2][1])
+
+
+@pytest.mark.gpu
 def test_unsupported_streams_are_refused_not_misdecoded(L, ref):
     """A damaged section must surface as an error, never as pixels."""
     from libjxl_amd import VarDctDecoder
