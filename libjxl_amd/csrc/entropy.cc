@@ -565,6 +565,27 @@ class SymbolReader {  // ANSSymbolReader
   }
   bool Ok() const { return !code_->lz77.enabled || window_; }
   bool FinalStateOk() const { return state_ == (kAnsSignature << 16); }
+  // The same with the histogram's alias row and hybrid-uint config handed in (plain ANS): a caller that knows the TWO
+  // contexts the next symbol can have before this symbol's value is in looks both rows up ahead and only selects
+  // between them afterwards -- the context map and the row address leave the chain from one symbol to the next.
+  const AliasEntry* AliasRow(uint32_t ctx) const { return &code_->alias[(size_t)ctx << code_->log_alpha]; }
+  const HybridUint* Config(uint32_t ctx) const { return &code_->configs[ctx]; }
+  __attribute__((always_inline)) inline uint32_t ReadHybridUintAnsRow(const AliasEntry* t, const HybridUint& cfg, BitReader* br) {
+    br->Refill();
+    const uint32_t res = state_ & (kAnsTab - 1);
+    const uint32_t i = res >> log_entry_, pos = res & entry_mask_;
+    const AliasEntry& e = t[i];
+    const bool right = pos >= e.cutoff;
+    const uint32_t token = right ? e.right_value : i;
+    const uint32_t offset = (right ? e.offsets1 : 0u) + pos;
+    const uint32_t freq = right ? e.freq1 : e.freq0;
+    state_ = freq * (state_ >> kAnsLogTab) + offset;
+    if (state_ < (1u << 16)) {
+      state_ = (state_ << 16) | (uint32_t)br->Peek(16);
+      br->Consume(16);
+    }
+    return FinishHybridUint(cfg, token, br);
+  }
   // (loops that keep the ANS state in a register of their own: modular.inc's self-correcting-predictor track)
   uint32_t State() const { return state_; }
   void SetState(uint32_t s) { state_ = s; }
@@ -1095,11 +1116,8 @@ int DecodeGroupImpl(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint
           w = sink.ent[c] + sink.cnt[c];
           wend = sink.ent[c] + sink.cap[c];
         }
-        for (uint32_t k = covered; k < size && nzeros != 0; k++) {
-          const uint32_t left = (nzeros + covered - 1) >> log2c;
-          if (left >= 64) return kBad;  // more non-zeros than positions: invalid stream
-          const uint32_t ctx = zd.v[left][k >> log2c] + prev;
-          const uint32_t u = kPlainAns ? reader.ReadHybridUintAns(hmap[ctx], br) : reader.ReadHybridUint(hmap[ctx], br);
+        // one coefficient's value, placed (shared by the two forms of the loop below)
+        auto place = [&](uint32_t k, uint32_t u) __attribute__((always_inline)) {
           const uint32_t magnitude = u >> 1, neg = (~u) & 1;  // UnpackSigned
           const int32_t coeff = (int32_t)((magnitude ^ (neg - 1)) << shift);
           if constexpr (Sink::kSparse) {
@@ -1111,8 +1129,46 @@ int DecodeGroupImpl(const jxlhip_ac_pass* pass, uint32_t xsb, uint32_t ysb, uint
           } else {
             sink.Put(c, offset + order[k], coeff);
           }
-          prev = u != 0;
-          nzeros -= prev;
+        };
+        if constexpr (kPlainAns) {
+          // The context of a coefficient depends on the one before it twice over: on whether that one was zero (prev)
+          // and on the number of non-zeros still to come (entropy_coder.h:203-230, dec_group.cc:510-538) -- context map,
+          // histogram row and hybrid-uint config of the next symbol wait for this symbol's value.  But there are only two
+          // possibilities, known beforehand: both rows are looked up while this symbol is being decoded, and its value
+          // only selects one of them.  (nzeros <= size - covered was checked: left < 64 throughout.)
+          if (nzeros != 0 && covered < size) {
+            uint32_t k = covered;
+            const uint32_t first = hmap[zd.v[(nzeros + covered - 1) >> log2c][k >> log2c] + prev];
+            const AliasEntry* row = reader.AliasRow(first);
+            const HybridUint* cfg = reader.Config(first);
+            for (;;) {
+              const uint32_t kn = std::min((k + 1) >> log2c, 63u);  // (k + 1 == size: nothing is read with it)
+              const uint32_t c0 = hmap[zd.v[(nzeros + covered - 1) >> log2c][kn]];          // this one zero
+              const uint32_t c1 = hmap[zd.v[(nzeros + covered - 2) >> log2c][kn] + 1u];     // this one not
+              const AliasEntry* const row0 = reader.AliasRow(c0);
+              const AliasEntry* const row1 = reader.AliasRow(c1);
+              const HybridUint* const cfg0 = reader.Config(c0);
+              const HybridUint* const cfg1 = reader.Config(c1);
+              const uint32_t u = reader.ReadHybridUintAnsRow(row, *cfg, br);
+              place(k, u);
+              const bool nonzero = u != 0;
+              nzeros -= nonzero;
+              k++;
+              if (k >= size || nzeros == 0) break;
+              row = nonzero ? row1 : row0;
+              cfg = nonzero ? cfg1 : cfg0;
+            }
+          }
+        } else {
+          for (uint32_t k = covered; k < size && nzeros != 0; k++) {
+            const uint32_t left = (nzeros + covered - 1) >> log2c;
+            if (left >= 64) return kBad;  // more non-zeros than positions: invalid stream
+            const uint32_t ctx = zd.v[left][k >> log2c] + prev;
+            const uint32_t u = reader.ReadHybridUint(hmap[ctx], br);
+            place(k, u);
+            prev = u != 0;
+            nzeros -= prev;
+          }
         }
         if constexpr (Sink::kSparse) {
           sink.cnt[c] = (uint32_t)(w - sink.ent[c]);
