@@ -265,16 +265,16 @@ def e2e_block(torch, local):
     out = torch.empty((h, w, 3), dtype=torch.float32, device=f"cuda:{local}")
     # The host's share of the box: a cgroup CPU quota (cpu.max) throttles the whole process group once it has used its
     # slice of a 100 ms period -- every thread stops for tens of ms.  Back-to-back repetitions on 64 threads run into it
-    # (profiles/r04_e2e_cgroup.txt: 16 CPUs on the GPU boxes of this pool), so the repetitions are spaced by one period:
-    # `value` is the latency of ONE file on an idle decoder; `sustained_at_cpu_quota` is what the quota lets through,
-    # from the CPU seconds a file costs.
+    # (profiles/r04_e2e_cgroup.txt: 16 CPUs on the GPU boxes of this pool; a file costs ~0.2 s of CPU time), so the
+    # repetitions are spaced to stay under the quota (20 ms: warm threads, ~45 % of the slice): `value` is the latency
+    # of ONE file; `sustained_at_cpu_quota` is what the quota lets through, from the CPU seconds a file costs.
     quota_cpus = None
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
         quota_cpus = None if q == "max" else float(q) / float(per)
     except (OSError, ValueError):
         pass
-    gap = 0.12 if quota_cpus else 0.0
+    gap = 0.02 if quota_cpus else 0.0
     best = None
     for threads in sorted({t for t in (16, 32, 64, 128) if t <= ncpu}):
         pool = R.JxlThreadParallelRunnerCreate(None, threads)
@@ -306,7 +306,7 @@ def e2e_block(torch, local):
         "cpu_ms_per_file": round(best["cpu"] * 1e3, 1), "cpu_quota_cpus": quota_cpus,
         "sustained_at_cpu_quota": round(w * h / (best["cpu"] / quota_cpus) / 1e6, 1) if quota_cpus else None,
         "what": "jxlhip_decode_codestream: bytes -> linear f32 RGB in HBM, whole file; geomean of 7 repetitions after 3 warm-up ones, "
-                "one cgroup period apart (latency of one file).  dc_groups = until the last DC group ended; ac_groups = what "
+                "20 ms apart to stay under the cgroup CPU quota (latency of one file).  dc_groups = until the last DC group ended; ac_groups = what "
                 "of the single runner call came after that (the AC groups start as their DC group's block info is in)"}
     # ... and the same file on several contexts at once (a server decoding a queue of files: one context, one HIP stream
     # and one runner pool per file in flight, one host thread each -- the C call releases the GIL): the serial phases of
