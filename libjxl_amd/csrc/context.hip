@@ -34,6 +34,9 @@ constexpr int kMaxBands = 64;
 // of PCIe, but the runtime now and then sits on a queued copy for 10-30 ms -- profiles/r04_e2e_waits.txt -- and with 32
 // slots for 64 decoding threads that stall became every thread's.)
 constexpr int kStageSlots = 128, kStageSlotsFirst = 32;
+// (slots are pinned kStageChunk at a time: one hipHostMalloc of 12 MB takes a tenth of the time of 32 of 0.4 MB, and a
+// context's first frame -- all a one-shot tool ever decodes -- waited for them)
+constexpr int kStageChunk = 32;
 
 struct ProfSpan {
   hipEvent_t a, b;
@@ -126,7 +129,8 @@ struct jxlhip_ctx {
   void* stage[kStageSlots] = {nullptr};
   hipEvent_t stage_ev[kStageSlots] = {nullptr};
   int stage_state[kStageSlots] = {0};  // 0 free, 1 owned by a decoding thread, 2 upload queued (stage_ev)
-  int stage_count = 0;                 // slots allocated so far (<= kStageSlots)
+  int stage_count = 0;                 // slots allocated so far (<= kStageSlots), kStageChunk at a time
+  void* stage_chunk[kStageSlots / kStageChunk] = {nullptr};  // the allocations the slots are carved from
   size_t stage_bytes = 0;
   std::mutex stage_mu;
   std::condition_variable stage_cv;
@@ -432,7 +436,10 @@ void jxlhip_destroy(jxlhip_ctx* c) {
       if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
       (void)hipEventDestroy(c->stage_ev[i]);
     }
-    if (c->stage[i]) StageFree(c, c->stage[i]);
+  }
+  for (void*& chunk : c->stage_chunk) {
+    if (chunk) StageFree(c, chunk);
+    chunk = nullptr;
   }
   if (c->pinned_frame) StageFree(c, c->pinned_frame);
   if (c->sp_dev) (void)hipFree(c->sp_dev);
@@ -1077,11 +1084,18 @@ static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out) {
   int slot = -1;
   std::unique_lock<std::mutex> lock(c->stage_mu);
   if (hipSetDevice(c->device) != hipSuccess) return JXLHIP_ERR_HIP;
-  auto new_slot = [&](int i) -> int {
-    if (StageAlloc(c, &c->stage[i], c->stage_bytes) != JXLHIP_OK) return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
-    if (!c->stage_ev[i] && hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess)
-      return Fail(c, JXLHIP_ERR_HIP, "event creation failed");
-    c->stage_state[i] = 0;
+  // kStageChunk more slots (the chunk after the ones there are), free
+  auto grow = [&]() -> int {
+    const int k = c->stage_count / kStageChunk;
+    if (StageAlloc(c, &c->stage_chunk[k], (size_t)kStageChunk * c->stage_bytes) != JXLHIP_OK)
+      return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
+    for (int i = c->stage_count; i < c->stage_count + kStageChunk; i++) {
+      c->stage[i] = (char*)c->stage_chunk[k] + (size_t)(i - c->stage_count) * c->stage_bytes;
+      if (!c->stage_ev[i] && hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess)
+        return Fail(c, JXLHIP_ERR_HIP, "event creation failed");
+      c->stage_state[i] = 0;
+    }
+    c->stage_count += kStageChunk;
     return JXLHIP_OK;
   };
   if (c->stage_bytes < slot_bytes) {
@@ -1093,19 +1107,20 @@ static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out) {
     });
     if (c->stage_bytes < slot_bytes) {
       for (int i = 0; i < c->stage_count; i++) {
-        if (c->stage[i]) {
-          if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
-          StageFree(c, c->stage[i]);
-          c->stage[i] = nullptr;
-        }
+        if (c->stage_state[i] == 2) (void)hipEventSynchronize(c->stage_ev[i]);
+        c->stage[i] = nullptr;
         c->stage_state[i] = 0;
+      }
+      for (void*& chunk : c->stage_chunk) {
+        if (chunk) StageFree(c, chunk);
+        chunk = nullptr;
       }
       c->stage_bytes = slot_bytes;
       c->stage_count = 0;
-      for (int i = 0; i < kStageSlotsFirst; i++) {
-        const int rc = new_slot(i);
+      static_assert(kStageSlotsFirst % kStageChunk == 0 && kStageSlots % kStageChunk == 0, "whole chunks");
+      while (c->stage_count < kStageSlotsFirst) {
+        const int rc = grow();
         if (rc) return rc;
-        c->stage_count = i + 1;
       }
     }
   }
@@ -1119,10 +1134,10 @@ static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out) {
       }
     }
     if (slot >= 0) break;
-    if (c->stage_count < kStageSlots) {  // nothing free: one more slot rather than a wait
-      const int rc = new_slot(c->stage_count);
+    if (c->stage_count < kStageSlots) {  // nothing free: more slots rather than a wait
+      slot = c->stage_count;
+      const int rc = grow();
       if (rc) return rc;
-      slot = c->stage_count++;
     } else if (pending >= 0) {  // every slot is in flight: wait for one upload, without keeping the others out
       hipEvent_t ev = c->stage_ev[pending];
       lock.unlock();
