@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -403,6 +404,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the output stripes sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (N=1)")
+    ap.add_argument("--settle-ms", type=float, default=60.0,
+                    help="untimed steps for this long before the W warm-up steps: the device's clock ramp (0 = none)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-file block (N=1, default workload)")
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="N=1: decoder contexts (each on a HIP stream of its own) the steps rotate over, default 3: launch "
@@ -510,6 +513,21 @@ def main():
             t = float(tt.item())
         return t
 
+    # Device settle (set-up, before the W warm-up steps): the GPU takes tens of milliseconds of continuous work to reach
+    # the clocks it then holds -- measured: K = 20 steps after W = 5 give 100 Gpx/s, the same 20 steps after W = 100 give
+    # 121 (profiles/r04_short_runs.txt); a driver's short (W, K) would time the ramp, not the decoder.  The same steps as
+    # the timed ones, untimed, for --settle-ms (default 60 ms; 0 = off), reported in config.device_settle_ms / _steps.
+    settle_steps = 0
+    if args.settle_ms > 0:
+        # (a step count from the frame size, not from a clock: every rank must run the same number of collective steps)
+        est_ms = max(0.04, xs * ys / (100e9 * world) * 1e3)
+        settle_steps = int(math.ceil(args.settle_ms / est_ms))
+        fence()
+        for i in range(settle_steps):
+            step()
+            if i % 16 == 15:
+                dec.sync()
+        fence()
     dt = timed(step)
     if inflight > 1:
         dec.set_concurrency_hint(1)  # from here on `dec` runs alone: one frame at a time, the per-kernel pass
@@ -610,6 +628,7 @@ def main():
                                    f"coefficients, strategy mix {cfg['mix']}, intensity_target {cfg['intensity']:g}, "
                                    f"linear RGB f32 out",
                        "frames_in_flight": inflight,
+                       "device_settle_ms": args.settle_ms, "device_settle_steps": settle_steps,
                        "stripes": world, "halo_rows": dec.halo_rows(),
                        "gather_in_step": bool(gather),
                        "phase_ms_max_over_ranks": phase_ms,
