@@ -1,2 +1,2 @@
 #!/bin/bash
-bash tools/regen_profiles.sh r04 2bab729
+bash tools/regen_profiles.sh r04 5cd1181
