@@ -518,7 +518,20 @@ def main():
         b.copy_(a)
         torch.cuda.synchronize()
         del a, b
+    # Device settle (set-up, before the W warm-up steps of every timed measurement): the GPU takes tens of milliseconds of
+    # continuous work to reach the clocks it then holds -- measured: K = 20 steps after W = 5 give 100 Gpx/s, the same 20
+    # steps after W = 100 give 121 (profiles/r04_short_runs.txt); a driver's short (W, K) would time the ramp, not the
+    # decoder, and a measurement that follows host-side work (the PCIe and whole-file blocks) starts from idle clocks
+    # again.  The same steps as the timed ones, untimed, for --settle-ms (default 60 ms; 0 = off), reported in
+    # config.device_settle_ms / _steps.  (A step COUNT from the frame size, not from a clock: every rank must run the
+    # same number of collective steps.)
+    settle_steps = int(math.ceil(args.settle_ms / max(0.04, xs * ys / (100e9 * world) * 1e3))) if args.settle_ms > 0 else 0
+
     def timed(fn):
+        for i in range(settle_steps):
+            fn()
+            if i % 16 == 15:
+                dec.sync()
         for _ in range(args.warmup):
             fn()
         dec.sync()  # also surfaces stream errors
@@ -534,21 +547,6 @@ def main():
             t = float(tt.item())
         return t
 
-    # Device settle (set-up, before the W warm-up steps): the GPU takes tens of milliseconds of continuous work to reach
-    # the clocks it then holds -- measured: K = 20 steps after W = 5 give 100 Gpx/s, the same 20 steps after W = 100 give
-    # 121 (profiles/r04_short_runs.txt); a driver's short (W, K) would time the ramp, not the decoder.  The same steps as
-    # the timed ones, untimed, for --settle-ms (default 60 ms; 0 = off), reported in config.device_settle_ms / _steps.
-    settle_steps = 0
-    if args.settle_ms > 0:
-        # (a step count from the frame size, not from a clock: every rank must run the same number of collective steps)
-        est_ms = max(0.04, xs * ys / (100e9 * world) * 1e3)
-        settle_steps = int(math.ceil(args.settle_ms / est_ms))
-        fence()
-        for i in range(settle_steps):
-            step()
-            if i % 16 == 15:
-                dec.sync()
-        fence()
     dt = timed(step)
     if inflight > 1:
         dec.set_concurrency_hint(1)  # from here on `dec` runs alone: one frame at a time, the per-kernel pass
