@@ -108,13 +108,17 @@ def cpu_baseline(cfg, sample, threads):
         # the reference's group-parallel decode does not scale to every hardware thread of a 256-thread host: time
         # the thread count that is fastest on THIS host and say which
         best = (0.0, cores)
-        for thr in sorted({cores, max(16, cores // 2), max(16, cores // 4), max(16, cores // 8)}):
+        if quota:  # (more runnable threads than four times the CPUs the cgroup may use only queue behind each other)
+            cands = sorted({int(min(cores, 4 * quota)), int(min(cores, 2 * quota)), int(min(cores, max(1, quota)))})
+        else:
+            cands = sorted({cores, max(16, cores // 2), max(16, cores // 4), max(16, cores // 8)})
+        for thr in cands:
             paced(lambda: fr.decode_ref(threads=thr, **kw))
             sec = []
-            for _ in range(4):
+            for _ in range(5):
                 paced(lambda: fr.decode_ref(threads=thr, **kw))
                 sec.append(fr.last_decode_seconds())
-            rate = 1.0 / min(sec)  # the best of four: the host is shared with the GPU runtime's own threads
+            rate = 1.0 / sorted(sec)[2]  # the median of five: the host is shared (other tenants, the GPU runtime's own threads)
             if rate > best[0]:
                 best = (rate, thr)
         cores = best[1]
