@@ -1484,6 +1484,24 @@ int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint3
   f.fused_tiles = (fused && c->tiles_on) ? 1u : 0u;
   f.tile_tabs = c->tables + 1600 + 2048;
   ProfBegin(c);
+  if (fused && c->p.lf.epf_iters == 3) {
+    // EPF0 from the producer's slab into the second plane set (k_fused_pc0), EPF1 + EPF2 + output from there
+    float* dst[3];
+    const size_t plane_floats = (size_t)f.plane_tile_rows * f.tile_stride * 64;
+    for (int ch = 0; ch < 3; ch++) dst[ch] = c->planes2 + ch * plane_floats;
+    if (!LaunchFusedEpf0(f, fp, (int)c->p.lf.gab, dst, c->stream))
+      return Fail(c, JXLHIP_ERR_STATE, "fused EPF0 kernel refused a frame FusedEpf0Supported accepted");
+    ProfMark(c, JXLHIP_KERNEL_EPF0);
+    DevFrame f2 = f;
+    for (int ch = 0; ch < 3; ch++) f2.xyb[ch] = dst[ch];
+    f2.linear_stride = f.tile_stride * 32u;
+    if (!LaunchFiltersFast(f2, fp, 0, 2, (int)c->p.output_kind, c->stream))
+      return Fail(c, JXLHIP_ERR_STATE, "EPF1 + EPF2 march refused a frame the fused EPF0 march accepted");
+    ProfMark(c, JXLHIP_KERNEL_FILTERS);
+    ProfEnd(c);
+    HIPCHK(c, hipGetLastError());
+    return JXLHIP_OK;
+  }
   if (fused) {
     if (!LaunchFused(f, fp, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind, c->stream))
       return Fail(c, JXLHIP_ERR_STATE, "fused kernel refused a frame FusedSupported accepted");
@@ -1536,6 +1554,17 @@ bool WantFused(const jxlhip_ctx* c) {
   if (c->p.output_kind == JXLHIP_OUT_PACKED) {
     const jxlhip_output_format& o = c->p.out_format;
     packed_fixed = FastFixedFormat(o);
+  }
+  if (c->p.lf.epf_iters == 3) {
+    // three EPF iterations: EPF0 marches from the fused producer's slab (k_fused_pc0), the rest as before; whole frames
+    // only, and only with several frames in flight on the device (jxlhip_set_concurrency_hint): the producer / consumer
+    // form has half the marching waves of k_epf0 per CU and is slower on its own (8K d1.0: the EPF0 launch 0.33 against
+    // 0.23 ms, the step 0.651 against 0.623 ms of kernels), but it moves the DCT8 share's 24 bytes per pixel less, and a
+    // device kept busy by other frames is bound by traffic: 64.8 -> 67.0 Gpx/s with three in flight
+    // (profiles/r04_epf3_fused.txt)
+    const bool many = c->concurrency > 1 && (uint64_t)f.xsize * f.ysize >= (6ull << 20);
+    return (c->fuse > 0 || (c->fuse < 0 && many && has_dct8)) && !c->generic_filters && c->band_rows == 0 && c->planes2 &&
+           f.group_y0 == 0 && f.group_rows == f.ysg && FusedEpf0Supported(f, (int)c->p.lf.gab);
   }
   return (c->fuse > 0 || (c->fuse < 0 && big && has_dct8 && !packed_fixed)) && !c->generic_filters && c->band_rows == 0 &&
          FusedSupported(f, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind);

@@ -94,6 +94,11 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind);
 bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind);
 bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,
                  hipStream_t st);
+// epf_iters = 3 in fused mode (kernels_fused_epf0.hip): [Gaborish] + EPF0 marched from the producer's slab into the
+// second plane set, as LaunchEpf0 does from the planes; FusedEpf0Supported: whole frames it takes (decided before
+// k_prepare, like FusedSupported)
+bool FusedEpf0Supported(const DevFrame& f, int gab);
+bool LaunchFusedEpf0(const DevFrame& f, const FilterParams& p, int gab, float* const dst[3], hipStream_t st);
 
 // block-major plane rows <-> dense row-major staging
 void LaunchRowsCopy(const DevFrame& f, float* dense, int y_first, int nrows, int ncols,

@@ -31,6 +31,9 @@
 
 #include "blocks_common.h"
 #include "filters_march.h"
+#if defined(JXLHIP_FUSED_PART) && JXLHIP_FUSED_PART == 3
+#include "epf0_march.h"
+#endif
 
 #ifndef JXLHIP_FUSED_PART
 #define JXLHIP_FUSED_PART 0
@@ -373,7 +376,7 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
 #undef JXLHIP_FSTEP
 }
 
-#if JXLHIP_FUSED_PART == 2
+#if JXLHIP_FUSED_PART == 2 || JXLHIP_FUSED_PART == 3
 // ------------------------------------------------------------------------------------------------
 // k_fused_pc: the same window march with the two halves of the work on two WAVES of a workgroup.
 //
@@ -1262,7 +1265,7 @@ void LaunchFusedPcT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
   else
     hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int32_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, role_shift);
 }
-#endif  // JXLHIP_FUSED_PART == 2
+#endif  // JXLHIP_FUSED_PART == 2 || 3
 
 #ifndef JXLHIP_FUSED_WAVES
 #define JXLHIP_FUSED_WAVES 3
@@ -1364,11 +1367,11 @@ bool LaunchFusedB(const DevFrame& f, const FilterParams& p, int gab, int epf_ite
 // kernels_fused_pc.hip (PART 2): the producer / consumer form; false = no instantiation for this stage list / output
 bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st);
 
-#if JXLHIP_FUSED_PART == 0
-static bool FusedPcEnabled() {
+static inline bool FusedPcEnabled() {
   const char* e = getenv("JXLHIP_FUSED_PC");  // read per launch: the tests switch it
   return (e ? atoi(e) : JXLHIP_FUSED_PC_DEFAULT) != 0;
 }
+#if JXLHIP_FUSED_PART == 0
 // Frames the fused kernel takes (decided before k_prepare: it routes the DCT8 blocks).
 bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) {
   (void)output_kind;
@@ -1402,6 +1405,158 @@ bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind
 
 #endif  // JXLHIP_FUSED_PART == 0
 
+#if JXLHIP_FUSED_PART == 3
+// ------------------------------------------------------------------------------------------------
+// k_fused_pc0: epf_iters = 3.  [Gaborish] + EPF0 marched from the producer's slab -- the DCT8 cells decoded in the
+// producing wave, every other cell LDS-DMA'd from the planes, exactly as k_fused_pc's producer does it -- into the second
+// plane set (row-major), from which the EPF1 + EPF2 march (k_filters_fast<0, 2>, SRC_LINEAR) produces the pixels as
+// before.  What it saves over k_epf0: the DCT8 share of the frame never visits the first plane set (one write and one
+// read of 12 bytes per pixel).  The march is epf0_march.h's Step0 with its rows and its inv_sigma from LDS.
+template <int GAB, bool EDGE>
+__device__ __forceinline__ void MarchPC0(const DevFrame& f, const FilterParams& P, Lane& L, StripLds* w, int bc0, int y_begin,
+                                         int y_end, float* const (&dst)[3]) {
+  constexpr int HX = GAB + 3;
+  const int H = (int)f.ysize;
+  const int r_first = y_begin - 8;
+  const int r_last = y_end + HX - 1;
+  const int nb_last = (H - 1) >> 3;
+  const int G = PcGroups<HX>(y_begin, y_end);
+  State0 s;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      s.x[c][k] = v2f{0.0f, 0.0f};
+      s.g[c][k] = v2f{0.0f, 0.0f};
+    }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) s.hs[c][k] = v2f{0.0f, 0.0f};
+#pragma unroll
+    for (int d = 0; d < kNumD; d++) s.ps[d][k] = v2f{0.0f, 0.0f};
+  }
+#pragma unroll
+  for (int d = 0; d < kNumD; d++) s.dprev[d] = s.part[d] = v2f{0.0f, 0.0f};
+  float inv_sigma_blk = -1.0f;
+  const float __attribute__((address_space(3)))* const slab0 = L.slab;
+  const LdsF* sig0 = (const LdsF*)w->sigma[0] + ((int)(L.sx4 >> 2) - bc0);
+  int i = 0;
+  auto enter_group = [&](int g) -> float {  // after the barrier that publishes buffer g & 1
+    const int b = g & 1;
+    L.slab = slab0 + JXLHIP_PC_SLAB(b) * (3 * kSlabPlaneFloats);
+    return sig0[b * 16];
+  };
+#define JXLHIP_PSTEP0(K) Step0<GAB, K, EDGE, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk, dst, slab_y0, sigma_grp)
+  PcBarrierMarch();  // fill(0)
+  {  // the last HX rows of the block row above
+    const int r = r_first;
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    const float sigma_grp = enter_group(i);
+    {
+      const int row0 = Mirror1(r + 8 - HX, H) - slab_y0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][8 - HX] = LdsPair<EDGE>(L, c, row0);
+    }
+    if constexpr (HX >= 4) { JXLHIP_PSTEP0(4); }
+    JXLHIP_PSTEP0(5);
+    JXLHIP_PSTEP0(6);
+    JXLHIP_PSTEP0(7);
+    i++;
+    PcBarrierMarch();  // a whole group always follows
+  }
+  int r = y_begin;
+  for (; r_last - r >= HX; r += 8) {
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    const float sigma_grp = enter_group(i);
+    {
+      const int row0 = Mirror1(r, H) - slab_y0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
+    }
+    JXLHIP_PSTEP0(0);
+    JXLHIP_PSTEP0(1);
+    JXLHIP_PSTEP0(2);
+    JXLHIP_PSTEP0(3);
+    JXLHIP_PSTEP0(4);
+    JXLHIP_PSTEP0(5);
+    JXLHIP_PSTEP0(6);
+    JXLHIP_PSTEP0(7);
+    i++;
+    if (i < G) PcBarrierMarch();
+  }
+  if (r <= r_last) {  // the first HX rows of the block row below
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
+    const float sigma_grp = enter_group(i);
+    {
+      const int row0 = Mirror1(r, H) - slab_y0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
+    }
+    JXLHIP_PSTEP0(0);
+    JXLHIP_PSTEP0(1);
+    JXLHIP_PSTEP0(2);
+    if constexpr (HX >= 4) { JXLHIP_PSTEP0(3); }
+  }
+#undef JXLHIP_PSTEP0
+}
+
+// (the EPF0 window with Gaborish in front wants ~190 VGPRs: two waves per SIMD = four workgroups per CU, the occupancy
+// k_epf0 runs at; a spilling build must not ship -- the producing wave's asm loads, libjxl_amd/build.py)
+template <int GAB, typename CT>
+__global__ __launch_bounds__(128, GAB ? 2 : JXLHIP_PC_WAVES) void k_fused_pc0(DevFrame f, FilterParams P, int RH, int strips, int nwg, int oy0, int oy1,
+                                                                     float* d0, float* d1, float* d2) {
+  __shared__ StripLds lds;
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)(threadIdx.x >> 6);
+  const int per = (int)gridDim.x >> 3;
+  const int logical = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (logical >= nwg) return;
+  const int strip = logical % strips, chunk = logical / strips;
+  const int W = (int)f.xsize;
+  const int x_first = strip * kFusedUse;
+  const int y_begin = oy0 + chunk * RH;
+  const int y_end = min(y_begin + RH, oy1);
+  if (x_first >= W || y_begin >= y_end) return;  // (both waves)
+  const int x0 = x_first - kFusedHalo;
+  const int bc0 = x0 >> 3;
+  const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int HX = GAB + 3;
+  if (wave == 1) {
+#if JXLHIP_PC_PRODUCER_PRIO > 0
+    __builtin_amdgcn_s_setprio(JXLHIP_PC_PRODUCER_PRIO);
+#endif
+    if constexpr (sizeof(CT) == 2) ProducePC2<HX>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
+    else ProducePC<HX, CT>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
+    return;
+  }
+  Lane L;
+  L.gx = x0 + 2 * lane;
+  L.dither = nullptr;
+  const int m0 = MirrorF(L.gx, W), m1 = MirrorF(L.gx + 1, W);
+  int base = (m0 & ~1) - x0;
+  base = base < 0 ? 0 : (base > kSlabCols - 2 ? kSlabCols - 2 : base);
+  L.sel0 = m0 & 1;
+  L.sel1 = m1 & 1;
+  L.byte_off = 0;
+  L.slab = (const float __attribute__((address_space(3)))*)lds.slab[0] + base;
+  const bool edge = x0 < 0 || x0 + kSlabCols > W;
+  const bool lane_in = lane >= kFusedHalo / 2 && lane < 64 - kFusedHalo / 2;
+  L.out0 = lane_in && L.gx < W;
+  L.out1 = lane_in && L.gx + 1 < W;
+  const int gxc = L.gx < 0 ? 0 : (L.gx >= W ? W - 1 : L.gx);
+  L.sx4 = (uint32_t)(gxc >> 3) * 4u;
+  L.out_off = (uint32_t)gxc * 4u;
+  const int ix = gxc & 7;
+  L.mul = v2f{ix == 0 ? P.bsm[0] : P.sm[0], ix == 6 ? P.bsm[0] : P.sm[0]};
+  L.mul2 = L.mul;
+  L.fix_left = L.fix_right_even = L.fix_right_odd = false;
+  float* const dst[3] = {d0, d1, d2};
+  if (edge) MarchPC0<GAB, true>(f, P, L, &lds, bc0, y_begin, y_end, dst);
+  else MarchPC0<GAB, false>(f, P, L, &lds, bc0, y_begin, y_end, dst);
+}
+#endif  // JXLHIP_FUSED_PART == 3
+
 #define JXLHIP_FUSED(G, E)                                      \
   if (gab == G && epf_iters == E) {                             \
     if (output_kind == 0) LaunchFusedT<G, E, 0>(f, p, st);      \
@@ -1431,6 +1586,38 @@ bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_it
   JXLHIP_FUSED_PCX(1, 2)
 #endif
   return false;
+}
+#elif JXLHIP_FUSED_PART == 3
+// [Gaborish] + EPF0 of a frame whose phase 1 ran in fused mode (DevFrame::fused = 1: the DCT8 cells are not in the
+// planes), for the rows the following EPF1 + EPF2 march of rows [f.fy0, f.fy1) reads, into dst (row-major second plane
+// set, as LaunchEpf0).  false: geometry / configuration not covered (the caller then must not have skipped the DCT8 cells).
+bool FusedEpf0Supported(const DevFrame& f, int gab) {
+  (void)gab;
+  if (!FusedPcEnabled()) return false;
+  if (f.xsize < 16 || f.ysize < 16) return false;
+  const uint32_t tail = f.ysize & 7u;
+  if (tail >= 1 && tail <= 3) return false;  // (as FusedSupported: mirror rows below the frame leave the last block row)
+  if ((f.fy0 & 7u) != 0 || f.fy0 != 0 || f.fy1 != f.ysize) return false;  // whole frames
+  if ((uint64_t)f.plane_tile_rows * f.tile_stride * 256u >= (1ull << 32)) return false;
+  return true;
+}
+bool LaunchFusedEpf0(const DevFrame& f, const FilterParams& p, int gab, float* const dst[3], hipStream_t st) {
+  if (!FusedEpf0Supported(f, gab)) return false;
+  const int oy0 = 0, oy1 = (int)f.ysize;
+  const unsigned strips = (f.xsize + kFusedUse - 1) / kFusedUse;
+  const int RH = FusedRowsPC(strips, oy1 - oy0, gab ? 4 : JXLHIP_PC_PER_CU);
+  const unsigned nwg = strips * ((oy1 - oy0 + RH - 1) / RH);
+  const dim3 grid((nwg + 7) & ~7u);
+#define JXLHIP_PC0(G, CT) hipLaunchKernelGGL((k_fused_pc0<G, CT>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, oy0, oy1, dst[0], dst[1], dst[2])
+  if (f.coeff_type == JXLHIP_COEFF_I16) {
+    if (gab) JXLHIP_PC0(1, int16_t);
+    else JXLHIP_PC0(0, int16_t);
+  } else {
+    if (gab) JXLHIP_PC0(1, int32_t);
+    else JXLHIP_PC0(0, int32_t);
+  }
+#undef JXLHIP_PC0
+  return true;
 }
 #elif JXLHIP_FUSED_PART == 0
 bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,

@@ -524,6 +524,42 @@ def test_fused_tile_producer_matches_oracle(dq, oracle, gab, epf, out, size, coe
     assert not np.array_equal(outs["10"], outs["00"])       # ... and the matrix cores did the work
 
 
+@pytest.mark.parametrize("gab,out", [(1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("size,coeff_type,mix", [((1000, 520), 0, None), ((333, 268), 1, None), ((117, 68), 0, None),
+                                                  ((2048, 1029 - 5), 0, "all"), ((1500, 700), 1, "all"), ((258, 2100), 0, None)])
+def test_three_epf_iterations_through_the_fused_producer_match_oracle(dq, oracle, gab, out, size, coeff_type, mix, monkeypatch):
+    """epf_iters = 3 with the frame in fused mode (forced here; automatic from the whole-frame size rule): k_fused_pc0
+    marches [Gaborish] + EPF0 from the slab its producing wave fills -- the DCT8 cells decoded in the wave, never written
+    to the first plane set -- into the second plane set; EPF1 + EPF2 + output from there as in the two-phase path
+    (kernels_fused.hip part 3, epf0_march.h).  Against the oracle at the bar of every other path, and bit-equal to the
+    two-phase path (k_epf0): the same arithmetic on the same values, whichever kernel decoded the DCT8 blocks.  Sizes:
+    windows cut by the frame's edges, ragged bottoms, several row chunks per window, int32 coefficients; float RGB and
+    planar XYB outputs."""
+    xs, ys = size
+    kw = dict(coeff_type=1, amp=200000.0, decay=3.0) if coeff_type else {}
+    m = {None: synth.MIX_D1, "all": synth.MIX_ALL}[mix]
+    params, t, fr = frames.make_case(xs, ys, mix=m, gab=bool(gab), epf_iters=3, seed=57 + xs, output_kind=out, **kw)
+    outs, kernels = {}, {}
+    for fuse, rh in (("1", "0"), ("1", "40"), ("0", "0")):
+        monkeypatch.setenv("JXLHIP_FUSE", fuse)
+        monkeypatch.setenv("JXLHIP_FUSED_PC_RH", rh)
+        d = VarDctDecoder(0)
+        d.begin_frame(params)
+        d.set_inputs(to_dev(t), dq)
+        d.profile(True)
+        o = d.decode_frame()
+        d.sync()
+        outs[fuse + rh] = o.cpu().numpy()
+        kernels[fuse + rh] = d.profile_read()
+        d.close()
+    ref = fr.decode(threads=4)
+    for k, v in outs.items():
+        assert rel_err(v, ref) <= TIGHT, (k, np.argwhere(np.abs(v - ref) > 1e-3)[:5])
+    assert np.array_equal(outs["10"], outs["140"])  # the chunking does not change a sample
+    assert np.array_equal(outs["10"], outs["00"]), np.argwhere(outs["10"] != outs["00"])[:5]
+    assert "epf0" in kernels["10"] and "epf0" in kernels["00"]
+
+
 @pytest.mark.parametrize("coeff_type", [0, 1])
 @pytest.mark.parametrize("size,mix,want", [((8 * 4 + 256, 8 * 4 + 8), {5: 48.0, 0: 1.0}, (5,)),
                                            ((8 * 4 + 256, 8 * 4 + 8), {4: 48.0, 0: 1.0}, (4,)),
