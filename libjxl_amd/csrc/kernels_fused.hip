@@ -44,6 +44,9 @@
 #ifndef JXLHIP_FUSED_PC_DEFAULT
 #define JXLHIP_FUSED_PC_DEFAULT 1
 #endif
+#ifndef JXLHIP_FUSED_PC0_ROLE_DEFAULT
+#define JXLHIP_FUSED_PC0_ROLE_DEFAULT -1
+#endif
 // The producing wave runs at a raised wave priority (s_setprio): the marching wave waits for it at every block row's
 // barrier, and at equal priority the SIMD's arbiter lets the (longer, never-waiting) marches of OTHER windows take the
 // issue slots a producer needs to finish its block row.  Measured, 8K d1.0, two repetitions on one box
@@ -1505,10 +1508,11 @@ __device__ __forceinline__ void MarchPC0(const DevFrame& f, const FilterParams& 
 // k_epf0 runs at; a spilling build must not ship -- the producing wave's asm loads, libjxl_amd/build.py)
 template <int GAB, typename CT>
 __global__ __launch_bounds__(128, GAB ? 2 : JXLHIP_PC_WAVES) void k_fused_pc0(DevFrame f, FilterParams P, int RH, int strips, int nwg, int oy0, int oy1,
-                                                                     float* d0, float* d1, float* d2) {
+                                                                     float* d0, float* d1, float* d2, int role_shift) {
   __shared__ StripLds lds;
   const int lane = threadIdx.x & 63;
-  const int wave = (int)(threadIdx.x >> 6);
+  // (which wave marches: see k_fused_pc)
+  const int wave = (int)(threadIdx.x >> 6) ^ (role_shift >= 0 ? ((int)blockIdx.x >> role_shift) & 1 : 0);
   const int per = (int)gridDim.x >> 3;
   const int logical = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   if (logical >= nwg) return;
@@ -1608,7 +1612,10 @@ bool LaunchFusedEpf0(const DevFrame& f, const FilterParams& p, int gab, float* c
   const int RH = FusedRowsPC(strips, oy1 - oy0, gab ? 4 : JXLHIP_PC_PER_CU);
   const unsigned nwg = strips * ((oy1 - oy0 + RH - 1) / RH);
   const dim3 grid((nwg + 7) & ~7u);
-#define JXLHIP_PC0(G, CT) hipLaunchKernelGGL((k_fused_pc0<G, CT>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, oy0, oy1, dst[0], dst[1], dst[2])
+  const char* e = getenv("JXLHIP_FUSED_PC0_ROLE");  // experiments: -1 = wave 0 always marches
+  const int role_shift = e ? atoi(e) : JXLHIP_FUSED_PC0_ROLE_DEFAULT;
+#define JXLHIP_PC0(G, CT) \
+  hipLaunchKernelGGL((k_fused_pc0<G, CT>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, oy0, oy1, dst[0], dst[1], dst[2], role_shift)
   if (f.coeff_type == JXLHIP_COEFF_I16) {
     if (gab) JXLHIP_PC0(1, int16_t);
     else JXLHIP_PC0(0, int16_t);
