@@ -28,7 +28,10 @@ def test_fused_pc_kernels_have_no_scratch():
     assert len(pc) >= 12, sorted(ks)[:5]  # 6 stage lists x 2 outputs x 2 coefficient types
     bad = {k: v for k, v in pc.items() if v["scratch"] or v["spills"]}
     assert not bad, bad
-    assert max(v["vgprs"] for v in pc.values()) <= 168  # three waves per SIMD
+    # three waves per SIMD -- except k_fused_pc0 with Gaborish (epf_iters = 3: the EPF0 window), built for two
+    assert max(v["vgprs"] for k, v in pc.items() if "k_fused_pc0" not in k) <= 168
+    assert max(v["vgprs"] for k, v in pc.items() if "k_fused_pc0" in k) <= 256
+    assert any("k_fused_pc0" in k for k in pc)
 
 
 def test_a_build_with_scratch_in_the_fused_kernels_is_refused(tmp_path):
