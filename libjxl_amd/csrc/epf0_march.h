@@ -43,10 +43,14 @@ __device__ __forceinline__ v2f FmaRight2S(v2f w, v2f p, v2f a) {
 // are completed, EPF0 output row o = q - 3 leaves.  PH = step & 7.
 // SRC_LDS (k_fused_pc0): row r sits in slab row PH of the block row at image row slab_y0 and was requested one step ago;
 // sigma_lds = the producer's inv_sigma of the lane's cell for that block row (the marching wave issues no vector load).
-template <int GAB, int PH, bool EDGE, int SRC = SRC_PLANES>
+// PART_LDS (k_fused_pc0 with Gaborish): the first PART_LDS of the six running plus-sum parts live in LDS (part_lds: the
+// lane's pair of entry 0; entry k is 128 floats on) instead of registers -- read once and written once per step, and the
+// eight registers are what the kernel lacks to fit three waves per SIMD.
+template <int GAB, int PH, bool EDGE, int SRC = SRC_PLANES, int PART_LDS = 0>
 __device__ __forceinline__ void Step0(State0& s, int r, const DevFrame& f, const FilterParams& P, Lane& L,
                                       int prefetch_last_row, int y_begin, int y_end, float& inv_sigma_blk,
-                                      float* const (&dst)[3], int slab_y0 = 0, float sigma_lds = 0.0f) {
+                                      float* const (&dst)[3], int slab_y0 = 0, float sigma_lds = 0.0f,
+                                      float __attribute__((address_space(3)))* part_lds = nullptr) {
   constexpr int S0 = PH & 3, S1 = (PH + 3) & 3, S2 = (PH + 2) & 3;
   constexpr int X0 = PH & 7, X1 = (PH + 7) & 7, X2 = (PH + 6) & 7;
   const int H = (int)f.ysize;
@@ -118,10 +122,14 @@ __device__ __forceinline__ void Step0(State0& s, int r, const DevFrame& f, const
   // plus-sums: row q-1 is complete with D(q); row q's start with D(q-1) and its own three columns
 #pragma unroll
   for (int k = 0; k < kNumD; k++) {
-    s.ps[k][S0] = s.part[k] + dnew[k];
+    typedef v2f __attribute__((address_space(3))) * P2;
+    const v2f pk = k < PART_LDS ? *(P2)(part_lds + k * 128) : s.part[k];
+    s.ps[k][S0] = pk + dnew[k];
     v2f v = AddLeftS(s.dprev[k], dnew[k]);
     v = v + dnew[k];
-    s.part[k] = AddRightS(v, dnew[k]);
+    const v2f np = AddRightS(v, dnew[k]);
+    if (k < PART_LDS) *(P2)(part_lds + k * 128) = np;
+    else s.part[k] = np;
     s.dprev[k] = dnew[k];
   }
   // EPF0 output row o = q - 3: plus-sum rows o (slot S2), o + 1 (S1), o + 2 (S0)

@@ -47,6 +47,12 @@
 #ifndef JXLHIP_FUSED_PC0_ROLE_DEFAULT
 #define JXLHIP_FUSED_PC0_ROLE_DEFAULT -1
 #endif
+// k_fused_pc0 with Gaborish: running plus-sum parts kept in LDS (0: all in registers, 175 VGPRs, two waves per SIMD = four
+// windows per CU; 4: 167 VGPRs, three waves, six windows).  Measured, 8K d1.0 (profiles/r04_epf3_fused.txt): the kernel
+// 0.333 ms with 0, 0.364 ms with 4 -- six windows per CU are slower than four (65.3 against 67.0 Gpx/s in flight): 0.
+#ifndef JXLHIP_PC0_PART_LDS
+#define JXLHIP_PC0_PART_LDS 0
+#endif
 // The producing wave runs at a raised wave priority (s_setprio): the marching wave waits for it at every block row's
 // barrier, and at equal priority the SIMD's arbiter lets the (longer, never-waiting) marches of OTHER windows take the
 // issue slots a producer needs to finish its block row.  Measured, 8K d1.0, two repetitions on one box
@@ -1415,10 +1421,12 @@ bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind
 // plane set (row-major), from which the EPF1 + EPF2 march (k_filters_fast<0, 2>, SRC_LINEAR) produces the pixels as
 // before.  What it saves over k_epf0: the DCT8 share of the frame never visits the first plane set (one write and one
 // read of 12 bytes per pixel).  The march is epf0_march.h's Step0 with its rows and its inv_sigma from LDS.
+static constexpr int kPc0PartLds = JXLHIP_PC0_PART_LDS;  // (see k_fused_pc0)
 template <int GAB, bool EDGE>
 __device__ __forceinline__ void MarchPC0(const DevFrame& f, const FilterParams& P, Lane& L, StripLds* w, int bc0, int y_begin,
-                                         int y_end, float* const (&dst)[3]) {
+                                         int y_end, float* const (&dst)[3], LdsF* part_lds) {
   constexpr int HX = GAB + 3;
+  constexpr int PART_LDS = GAB ? kPc0PartLds : 0;
   const int H = (int)f.ysize;
   const int r_first = y_begin - 8;
   const int r_last = y_end + HX - 1;
@@ -1450,7 +1458,13 @@ __device__ __forceinline__ void MarchPC0(const DevFrame& f, const FilterParams& 
     L.slab = slab0 + JXLHIP_PC_SLAB(b) * (3 * kSlabPlaneFloats);
     return sig0[b * 16];
   };
-#define JXLHIP_PSTEP0(K) Step0<GAB, K, EDGE, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk, dst, slab_y0, sigma_grp)
+  if constexpr (PART_LDS > 0) {
+    typedef v2f __attribute__((address_space(3))) * P2;
+#pragma unroll
+    for (int k = 0; k < PART_LDS; k++) *(P2)(part_lds + k * 128) = v2f{0.0f, 0.0f};
+  }
+#define JXLHIP_PSTEP0(K) \
+  Step0<GAB, K, EDGE, SRC_LDS, PART_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk, dst, slab_y0, sigma_grp, part_lds)
   PcBarrierMarch();  // fill(0)
   {  // the last HX rows of the block row above
     const int r = r_first;
@@ -1504,12 +1518,15 @@ __device__ __forceinline__ void MarchPC0(const DevFrame& f, const FilterParams& 
 #undef JXLHIP_PSTEP0
 }
 
-// (the EPF0 window with Gaborish in front wants ~190 VGPRs: two waves per SIMD = four workgroups per CU, the occupancy
-// k_epf0 runs at; a spilling build must not ship -- the producing wave's asm loads, libjxl_amd/build.py)
+// (the EPF0 window with Gaborish in front wants 175 VGPRs, seven more than three waves per SIMD leave -- and a spilling
+// build must not ship: the producing wave's asm loads, libjxl_amd/build.py.  JXLHIP_PC0_PART_LDS = 4 puts four of the
+// march's six running plus-sum parts into LDS, 2 KB per window -- what six windows per CU leave of the 160 KB beside
+// their slabs -- and fits three waves; measured slower, see the macro.)
 template <int GAB, typename CT>
-__global__ __launch_bounds__(128, GAB ? 2 : JXLHIP_PC_WAVES) void k_fused_pc0(DevFrame f, FilterParams P, int RH, int strips, int nwg, int oy0, int oy1,
+__global__ __launch_bounds__(128, (GAB != 0 && JXLHIP_PC0_PART_LDS == 0) ? 2 : JXLHIP_PC_WAVES) void k_fused_pc0(DevFrame f, FilterParams P, int RH, int strips, int nwg, int oy0, int oy1,
                                                                      float* d0, float* d1, float* d2, int role_shift) {
   __shared__ StripLds lds;
+  __shared__ float part_store[(GAB != 0 && kPc0PartLds > 0) ? kPc0PartLds * 128 : 2];
   const int lane = threadIdx.x & 63;
   // (which wave marches: see k_fused_pc)
   const int wave = (int)(threadIdx.x >> 6) ^ (role_shift >= 0 ? ((int)blockIdx.x >> role_shift) & 1 : 0);
@@ -1556,8 +1573,9 @@ __global__ __launch_bounds__(128, GAB ? 2 : JXLHIP_PC_WAVES) void k_fused_pc0(De
   L.mul2 = L.mul;
   L.fix_left = L.fix_right_even = L.fix_right_odd = false;
   float* const dst[3] = {d0, d1, d2};
-  if (edge) MarchPC0<GAB, true>(f, P, L, &lds, bc0, y_begin, y_end, dst);
-  else MarchPC0<GAB, false>(f, P, L, &lds, bc0, y_begin, y_end, dst);
+  LdsF* const part_lds = (LdsF*)part_store + 2 * lane;
+  if (edge) MarchPC0<GAB, true>(f, P, L, &lds, bc0, y_begin, y_end, dst, part_lds);
+  else MarchPC0<GAB, false>(f, P, L, &lds, bc0, y_begin, y_end, dst, part_lds);
 }
 #endif  // JXLHIP_FUSED_PART == 3
 
@@ -1609,7 +1627,7 @@ bool LaunchFusedEpf0(const DevFrame& f, const FilterParams& p, int gab, float* c
   if (!FusedEpf0Supported(f, gab)) return false;
   const int oy0 = 0, oy1 = (int)f.ysize;
   const unsigned strips = (f.xsize + kFusedUse - 1) / kFusedUse;
-  const int RH = FusedRowsPC(strips, oy1 - oy0, gab ? 4 : JXLHIP_PC_PER_CU);
+  const int RH = FusedRowsPC(strips, oy1 - oy0, (gab != 0 && JXLHIP_PC0_PART_LDS == 0) ? 4 : JXLHIP_PC_PER_CU);
   const unsigned nwg = strips * ((oy1 - oy0 + RH - 1) / RH);
   const dim3 grid((nwg + 7) & ~7u);
   const char* e = getenv("JXLHIP_FUSED_PC0_ROLE");  // experiments: -1 = wave 0 always marches
