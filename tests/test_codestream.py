@@ -230,6 +230,67 @@ def test_redo_with_int32_coefficients(L, ref, barriers, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("barriers", [False, True])
+def test_damaged_streams_end_the_runner_call_and_leave_the_context_usable(L, ref, barriers, monkeypatch):
+    """Damage anywhere behind the headers -- DC groups, AC global, AC groups -- while the sections are being decoded on
+    the runner: the call returns (an error or, for damage the entropy coder cannot see, pixels), the tickets of the
+    single runner call drain (a DC group that fails after it announced its block info, an AC-global section that fails
+    while DC groups wait for it, AC groups that fail beside running DC groups), nothing hangs, and the same context
+    decodes the intact stream afterwards, bit for bit as before."""
+    import torch
+    from libjxl_amd import VarDctDecoder
+    rs = ref.RealStream(seed=31, xsize=2200, ysize=520, distance=1.5, speed_tier=4)
+    cs = np.frombuffer(rs.codestream.tobytes(), np.uint8)
+    R = C.CDLL(abi.runner_library_path())
+    R.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+    R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+    R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
+    runner = C.cast(R.JxlThreadParallelRunner, C.c_void_p)
+    pool = R.JxlThreadParallelRunnerCreate(None, 12)
+    dec = VarDctDecoder(0)
+    if barriers:
+        monkeypatch.setenv("JXLHIP_NO_PIPELINE", "1")
+    rng = np.random.default_rng(17)
+
+    def run(blob):
+        info = abi.CodestreamInfo()
+        out = torch.zeros((rs.ysize, rs.xsize, 3), dtype=torch.float32, device="cuda")
+        raw = blob.tobytes()
+        rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, raw, len(raw), 1, None, out.data_ptr(), rs.xsize * 12, 0, C.byref(info))
+        return rc, out
+
+    try:
+        rc, good = run(cs)
+        assert rc == 0
+        good = good.cpu().numpy()
+        failed = passed = 0
+        first = 200  # (behind the image / frame headers and the TOC of this stream: the sections)
+        for trial in range(60):
+            b = cs.copy()
+            where = trial % 3
+            lo, hi = [(first, len(b) // 6), (len(b) // 6, len(b) // 3), (len(b) // 3, len(b))][where]
+            for _ in range(int(rng.integers(1, 6))):
+                k = int(rng.integers(lo * 8, hi * 8))
+                b[k // 8] ^= np.uint8(1 << (k % 8))
+            if trial % 7 == 0:
+                b = b[: int(rng.integers(first, len(b)))].copy()
+            rc, _ = run(b)
+            failed += rc != 0
+            passed += rc == 0
+            if trial % 10 == 9:  # the context is still good for the intact stream
+                rc, again = run(cs)
+                assert rc == 0 and np.array_equal(again.cpu().numpy(), good), trial
+        assert failed > 20, (failed, passed)
+        rc, again = run(cs)
+        assert rc == 0 and np.array_equal(again.cpu().numpy(), good)
+    finally:
+        dec.close()
+        R.JxlThreadParallelRunnerDestroy(pool)
+        monkeypatch.delenv("JXLHIP_NO_PIPELINE", raising=False)
+
+
+@pytest.mark.gpu
 def test_unsupported_streams_are_refused_not_misdecoded(L, ref):
     """A damaged section must surface as an error, never as pixels."""
     from libjxl_amd import VarDctDecoder
