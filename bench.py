@@ -434,8 +434,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the whole-file block (N=1, default workload)")
     ap.add_argument("--frames-in-flight", type=int, default=None,
                     help="N=1: decoder contexts (each on a HIP stream of its own) the steps rotate over, default 3: launch "
-                         "gaps, k_prepare and kernel tails of one frame overlap the next frame's kernels.  1 = one frame "
-                         "at a time (also measured and reported as `one_frame_in_flight`)")
+                         "gaps, k_prepare and kernel tails of one frame overlap the next frame's kernels: the side figure "
+                         "`frames_in_flight` (1 = skip it).  `value` is always one context, one frame at a time")
     ap.add_argument("--calib-copy", action="store_true",
                     help="run one known-size (1 GiB) device copy so PMC passes can be calibrated")
     ap.add_argument("--cpu-sample", type=int, nargs=2, default=None)
@@ -479,23 +479,31 @@ def main():
     gather = world > 1 and not args.no_gather
     full = sd.alloc_gather(out) if gather else None
 
-    # N = 1: a pool of decoder contexts, one HIP stream each, over the same (read-only) inputs: step k runs on
-    # context k % F.  Every step is a whole frame -- k_prepare, transforms, fused filter kernel -- nothing is shared
-    # between steps but the inputs; what overlaps is one frame's launch gaps / tail with the next frame's kernels.
+    # N = 1, the side figure `frames_in_flight`: a pool of decoder contexts, one HIP stream each, every context with
+    # its OWN device copy of the coefficient stream, the side info and the dequant tables (round 4 shared one copy: frame
+    # k + 1's coefficient reads could then be served from the L2 / Infinity Cache that frame k had just filled): step k
+    # runs on context k % F.  Every step is a whole frame -- k_prepare, transforms, fused filter kernel -- nothing is
+    # shared between steps; what overlaps is one frame's launch gaps / tail with the next frame's kernels.
+    # `value` is NOT this: it is one context, one frame at a time (the figure of rounds 1-3).
     inflight = max(1, args.frames_in_flight if args.frames_in_flight is not None else (3 if world == 1 else 1))
     if world > 1:
         inflight = 1
+
+    def clone_inputs(tt):
+        return {k: ([x.clone() for x in v] if isinstance(v, (list, tuple)) else v.clone()) for k, v in tt.items()}
+
     slots = [(dec, out)]
+    private_inputs = []
     for _ in range(inflight - 1):
         st = torch.cuda.Stream()
         with torch.cuda.stream(st):
             d2 = VarDctDecoder(local)  # its launches go to st
         d2.begin_frame(params)
-        d2.set_inputs(t, dq)
+        t2, dq2 = clone_inputs(t), dq.clone()
+        private_inputs.append((t2, dq2))
+        d2.set_inputs(t2, dq2)
         slots.append((d2, d2.alloc_output()))
-    if inflight > 1:
-        for d, _ in slots:
-            d.set_concurrency_hint(inflight)  # (only moves the frame size from which the fused kernel is taken)
+    torch.cuda.synchronize()
     counter = [0]
 
     def step():
@@ -530,9 +538,10 @@ def main():
     # config.device_settle_ms / _steps.  (A step COUNT from the frame size, not from a clock: every rank must run the
     # same number of collective steps.)
     settle_steps = int(math.ceil(args.settle_ms / max(0.04, xs * ys / (100e9 * world) * 1e3))) if args.settle_ms > 0 else 0
+    settle_on = [True]
 
     def timed(fn):
-        for i in range(settle_steps):
+        for i in range(settle_steps if settle_on[0] else 0):
             fn()
             if i % 16 == 15:
                 dec.sync()
@@ -551,12 +560,24 @@ def main():
             t = float(tt.item())
         return t
 
-    dt = timed(step)
-    if inflight > 1:
-        dec.set_concurrency_hint(1)  # from here on `dec` runs alone: one frame at a time, the per-kernel pass
-    dt_one = timed(step_one) if (world == 1 and inflight > 1) else None
-    for d2, o2 in slots[1:]:
-        assert torch.equal(o2, out), "a pooled context decoded a different frame"
+    # Order: (1) `unsettled` -- the W warm-up steps and the K timed steps straight after set-up, the device at whatever
+    # clocks it idles at (what a driver's short (W, K) run sees without the settle phase); (2) `value` -- the same K
+    # steps on ONE context after the settle phase; (3) `frames_in_flight` -- the K steps rotated over the pool.
+    dt_unsettled = None
+    if world == 1 and settle_steps > 0:
+        settle_on[0] = False
+        dt_unsettled = timed(step_one)
+        settle_on[0] = True
+    dt = timed(step_one if world == 1 else step)
+    dt_flight = None
+    if world == 1 and inflight > 1:
+        for d, _ in slots:
+            d.set_concurrency_hint(inflight)  # (only moves the frame size from which the fused kernel is taken)
+        dt_flight = timed(step)
+        for d, _ in slots:
+            d.set_concurrency_hint(1)  # from here on `dec` runs alone again: the per-kernel pass
+        for d2, o2 in slots[1:]:
+            assert torch.equal(o2, out), "a pooled context decoded a different frame"
     # N > 1: the same frame with the output stripes left sharded in each GPU's HBM (a consumer on the device, or
     # every GPU writing its own stripe to the host): the form in which the split scales -- the gather of a 1.59 GB
     # float frame into ONE GPU is per-link bound
@@ -650,7 +671,7 @@ def main():
                                    f"epf_iters={cfg['epf']}, {'int32' if cfg['coeff32'] else 'int16'} "
                                    f"coefficients, strategy mix {cfg['mix']}, intensity_target {cfg['intensity']:g}, "
                                    f"linear RGB f32 out",
-                       "frames_in_flight": inflight,
+                       "frames_in_flight": 1,
                        "device_settle_ms": args.settle_ms, "device_settle_steps": settle_steps,
                        "stripes": world, "halo_rows": dec.halo_rows(),
                        "gather_in_step": bool(gather),
@@ -659,7 +680,8 @@ def main():
                        "kernel_ms": kern},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "what": "frame's algorithmic bytes / whole step (all launches + gaps)",
+                         "what": "frame's algorithmic bytes / whole step (all launches + gaps) of `value`: ONE frame in flight, "
+                                 "settled clocks",
                          "frac_dominant_kernel": round(b_alg / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "frac_kernel": round(b_own / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_kernel": traffic_kernel, "traffic_source": tsrc,
@@ -671,12 +693,23 @@ def main():
                          "algorithmic_bytes_frame": b_alg_frame,
                          "kernel_own_bytes_per_launch": b_own},
         }
-        if dt_one is not None:
-            line["one_frame_in_flight"] = {"value": round(px / (dt_one / args.steps) / 1e6, 1), "unit": "Mpixels/s",
-                                           "ms_per_step": round(dt_one / args.steps * 1e3, 4),
-                                           "what": "the same steps on ONE context / stream, a frame at a time (the figure of rounds 1-3); "
-                                                   "`value` rotates the steps over `frames_in_flight` contexts"}
-            line["roofline"]["frac_one_frame_in_flight"] = round(b_alg_frame / (dt_one / args.steps) / 1e9 / HBM_PEAK_GBS, 4)
+        if world == 1:
+            line["one_frame_in_flight"] = {"value": round(value, 1), "unit": "Mpixels/s", "ms_per_step": round(ms_step, 4),
+                                           "what": "= `value` (round 4 reported the frames-in-flight rate as `value` and this "
+                                                   "figure beside it; the series r1 79.5 / r2 89.6 / r3 98.7 / r4 106.9 is this one)"}
+        if dt_unsettled is not None:
+            line["unsettled"] = {"value": round(px / (dt_unsettled / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                                 "ms_per_step": round(dt_unsettled / args.steps * 1e3, 4),
+                                 "what": "the same W warm-up + K timed steps on one context straight after set-up, without the "
+                                         "device-settle phase (--settle-ms 0): the device's clocks still ramping"}
+        if dt_flight is not None:
+            line["frames_in_flight"] = {"value": round(px / (dt_flight / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                                        "ms_per_step": round(dt_flight / args.steps * 1e3, 4), "contexts": inflight,
+                                        "private_inputs": True,
+                                        "frac": round(b_alg_frame / (dt_flight / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "what": "aggregate rate of the same steps rotated over `contexts` decoder contexts, each "
+                                                "on its own HIP stream with its OWN device copy of coefficients / side info / "
+                                                "dequant tables (settled clocks); outputs asserted bit-equal"}
         if dt_sharded is not None:
             line["sharded"] = {"value": round(px / (dt_sharded / args.steps) / 1e6, 1), "unit": "Mpixels/s",
                                "ms_per_step": round(dt_sharded / args.steps * 1e3, 4),
@@ -688,14 +721,29 @@ def main():
             # what the reference encoder actually emits) -- the bench workload's mix is the contract's
             try:
                 rp, rt = synth.synth_frame(xs, ys, mix=resolve_mix("real4k"), gab=True, epf_iters=1, device=f"cuda:{local}")
-                for d, _ in slots:
-                    d.begin_frame(rp)
-                    d.set_inputs(rt, dq)
-                counter[0] = 0
-                rdt = timed(step)
+                dec.begin_frame(rp)
+                dec.set_inputs(rt, dq)
+                rdt = timed(step_one)
                 line["real_content_mix"] = {"value": round(px / (rdt / args.steps) / 1e6, 1), "unit": "Mpixels/s",
-                                            "ms_per_step": round(rdt / args.steps * 1e3, 4), "frames_in_flight": inflight,
-                                            "what": f"{xs}x{ys}, Gaborish + EPF1, strategy shares of tests/data/real_4k_d1.npz"}
+                                            "ms_per_step": round(rdt / args.steps * 1e3, 4), "frames_in_flight": 1,
+                                            "what": f"{xs}x{ys}, Gaborish + EPF1, strategy shares of tests/data/real_4k_d1.npz; "
+                                                    "one frame at a time, like `value`"}
+                if inflight > 1:
+                    keep = []
+                    for (d, _), (_, dq2) in zip(slots[1:], private_inputs):
+                        rt2 = clone_inputs(rt)
+                        keep.append(rt2)
+                        d.begin_frame(rp)
+                        d.set_inputs(rt2, dq2)
+                    for d, _ in slots:
+                        d.set_concurrency_hint(inflight)
+                    counter[0] = 0
+                    rdtf = timed(step)
+                    for d, _ in slots:
+                        d.set_concurrency_hint(1)
+                    line["real_content_mix"]["in_flight"] = {"value": round(px / (rdtf / args.steps) / 1e6, 1), "contexts": inflight,
+                                                              "ms_per_step": round(rdtf / args.steps * 1e3, 4), "private_inputs": True}
+                    del keep
                 del rt
             except Exception as ex:
                 line["real_content_mix"] = {"error": repr(ex)[:200]}

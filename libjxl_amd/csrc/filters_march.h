@@ -319,8 +319,13 @@ __device__ __forceinline__ void EmitPair(const v2f* v, Lane& L, int gy, char* ou
     // inside the image the two columns of a pair are written or skipped together (only column W-1
     // of an odd width separates them: an edge wave)
     if (EDGE ? (L.out0 && L.out1) : L.out0) {  // 24 contiguous bytes
+#ifdef JXLHIP_ABL_STORE_PLAIN  // experiment builds: ordinary (write-back) stores for the f32 RGB pair
+      *(f4u*)dst = f4u{o.p0.x, o.p0.y, o.p1.x, o.p1.y};
+      *(f2u*)(dst + 4) = f2u{o.p2.x, o.p2.y};
+#else
       __builtin_nontemporal_store(f4u{o.p0.x, o.p0.y, o.p1.x, o.p1.y}, (f4u*)dst);
       __builtin_nontemporal_store(f2u{o.p2.x, o.p2.y}, (f2u*)(dst + 4));
+#endif
     } else if (!EDGE) {
     } else if (L.out0) {
       __builtin_nontemporal_store(o.p0.x, dst);
@@ -353,7 +358,19 @@ __device__ __forceinline__ void EmitPair(const v2f* v, Lane& L, int gy, char* ou
 // p = q-1 = row whose plus-sums are completed, o = q-2 = EPF output row.
 // DBG: JXLHIP_DEBUG ablation bits of this kernel, compiled in only for the launch that asks for
 // them (4: no output stores, 8: input rows stay in L1).
-template <int GAB, int EPF, int OUTK, int FMT, int PH, bool EDGE, int DBG, int SRC = SRC_PLANES>
+//
+// KNOWN (fused kernel's marching wave, SRC_LDS, kernels_fused.hip MarchPC): what the caller knows about this step at
+// COMPILE time.  A wave issues one instruction of any kind per ~5 cycles (tools/probes/valu_issue.hip), and the
+// generic step spends a third of its issue slots on scalar bookkeeping -- is row o the first of a block row, is it a
+// border row of its block, does it lie inside [y_begin, y_end), is row r + 1 a mirror row -- that has ONE answer for
+// every chunk of rows that starts and ends on block rows and touches neither the frame's top nor its bottom:
+//   kStepInterior   r == PH (mod 8), rows r - 8 .. r + 8 lie inside the frame (no mirror rows), y_begin is a multiple
+//                   of 8: o & 7, the slab row of r + 1 and the top / bottom tests are constants
+//   kStepEmit       (with kStepInterior) the row leaving the stages is written -- otherwise it is not; no range test
+//   kStepFirst      (with kStepInterior) the first whole group of the chunk: EPF == 2 picks up the inv_sigma of the
+//                   block row above for the one row of it that the third stage reads
+enum StepKnown : int { kStepGeneric = 0, kStepInterior = 1, kStepEmit = 2, kStepFirst = 4 };
+template <int GAB, int EPF, int OUTK, int FMT, int PH, bool EDGE, int DBG, int SRC = SRC_PLANES, int KNOWN = kStepGeneric>
 __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const FilterParams& P,
                                      Lane& L, int prefetch_last_row, int y_begin, int y_end,
                                      float& inv_sigma_blk, float& inv_sigma_blk2, char* out_row, const XybConsts& K,
@@ -368,7 +385,8 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
     // fused kernel: row r (= slab row PH) was requested one step ago; request row r+1.  The first row
     // of the next block row is requested by the caller once the slab is refilled.
     if constexpr (PH < 7) {
-      const int nrow = Mirror1(r + 1, H) - slab_y0;  // slab row of image row r+1 (a mirror row near the frame's top / bottom)
+      // slab row of image row r+1 (a mirror row near the frame's top / bottom)
+      const int nrow = (KNOWN & kStepInterior) ? PH + 1 : Mirror1(r + 1, H) - slab_y0;
 #pragma unroll
       for (int c = 0; c < 3; c++) s.x[c][(PH + 1) & 7] = LdsPair<EDGE>(L, c, nrow);
     }
@@ -441,11 +459,14 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
     o = q - 2;
     const float kMinSigma = -3.90524291751269967465540850526868f;
     // first row whose result is used: y_begin, or the row above it when EPF2 reads it
-    if ((o & 7) == 0 || o == y_begin - (EPF == 2 ? 1 : 0)) {
+    constexpr bool kInt = (KNOWN & kStepInterior) != 0;
+    static_assert(!kInt || SRC == SRC_LDS, "kStepInterior: the fused kernel's march");
+    constexpr int kIy = (PH - GAB - 2 + 16) & 7;  // kInt: o & 7
+    if (kInt ? (kIy == 0 || (EPF == 2 && (KNOWN & kStepFirst) && kIy == 7)) : ((o & 7) == 0 || o == y_begin - (EPF == 2 ? 1 : 0))) {
       // fused kernel: the caller loaded the block row's value at the start of the group of 8 rows -- a load
       // here would wait (in-order vmcnt) for the LDS-DMA copies issued in between.  (Row y_begin - 1, which EPF2
       // reads as its first "north" row, lies in the block row of the previous group.)
-      float is = (o & 7) == 0 ? sigma_pre : sigma_prev;
+      float is = (kInt ? kIy == 0 : (o & 7) == 0) ? sigma_pre : sigma_prev;
       if constexpr (SRC != SRC_LDS) {
         const int oc = o < 0 ? 0 : (o >= H ? H - 1 : o);
         is = *(const float*)((const char*)(f.inv_sigma + (size_t)(oc >> 3) * f.xsb) + LaneOffset(L.sx4));
@@ -454,7 +475,7 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
       // -inf zeroes the four weights, and (c + 0) * rcp(1) == c exactly
       inv_sigma_blk = is < kMinSigma ? -__builtin_inff() : is;
     }
-    const int iy = o & 7;
+    const int iy = kInt ? kIy : (o & 7);
     const v2f mul = (iy == 0 || iy == 7) ? v2f{P.bsm[1], P.bsm[1]} : L.mul;
     const v2f inv_sigma = mul * inv_sigma_blk;
     const v2f wN = EpfW(s.pv[Q2], inv_sigma);
@@ -501,7 +522,8 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
       for (int c = 0; c < 3; c++) s.e[c][E0] = outv[c];
       s.dv[E0] = dv;
       const int o2 = o - 1;
-      if ((o2 & 7) == 0 || o2 == y_begin) {
+      constexpr int kIy2 = (kIy + 7) & 7;  // kInt: o2 & 7
+      if (kInt ? kIy2 == 0 : ((o2 & 7) == 0 || o2 == y_begin)) {
         float is = sigma_pre;
         if constexpr (SRC != SRC_LDS) {
           const int oc = o2 < 0 ? 0 : (o2 >= H ? H - 1 : o2);
@@ -509,11 +531,11 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
         }
         inv_sigma_blk2 = is < kMinSigma ? -__builtin_inff() : is;
       }
-      const int iy2 = o2 & 7;
+      const int iy2 = kInt ? kIy2 : (o2 & 7);
       const v2f mul2 = (iy2 == 0 || iy2 == 7) ? v2f{P.bsm[2], P.bsm[2]} : L.mul2;
       const v2f inv_sigma2 = mul2 * inv_sigma_blk2;
       // rows -1 and H are the mirrors of rows 0 and H-1: a zero difference, the centre as value
-      const bool top = o2 == 0, bottom = o2 == H - 1;
+      const bool top = !kInt && o2 == 0, bottom = !kInt && o2 == H - 1;
       const v2f zero = {0.0f, 0.0f};
       const v2f wN2 = EpfW(top ? zero : s.dv[E1], inv_sigma2);
       const v2f wW2 = EpfW(dh, inv_sigma2);
@@ -541,7 +563,7 @@ __device__ __forceinline__ void Step(State& s, int r, const DevFrame& f, const F
     for (int c = 0; c < 3; c++) outv[c] = gq[c];
   }
   // 4. emit
-  if (o >= y_begin && o < y_end && !((DBG & 4) && outv[0].x != 12345.678f)) {
+  if (((KNOWN & kStepInterior) ? (KNOWN & kStepEmit) != 0 : (o >= y_begin && o < y_end)) && !((DBG & 4) && outv[0].x != 12345.678f)) {
     EmitPair<OUTK, FMT, EDGE>(outv, L, o, out_row, P, K);
   }
 }

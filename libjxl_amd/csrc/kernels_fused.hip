@@ -61,6 +61,9 @@
 #ifndef JXLHIP_PC_PRODUCER_PRIO
 #define JXLHIP_PC_PRODUCER_PRIO 3
 #endif
+#ifndef JXLHIP_PC_INTERIOR  // 0: every chunk takes the generic march (experiments)
+#define JXLHIP_PC_INTERIOR 1
+#endif
 #ifndef JXLHIP_TILE_SLOTS  // units of the matrix-core producer whose loads are in flight together (16-bit coefficients)
 #define JXLHIP_TILE_SLOTS 6
 #endif
@@ -521,24 +524,92 @@ struct PcNext {  // cell info + inv_sigma of a block row, as requested (valid be
   int nb;
 };
 
-__device__ __forceinline__ void PcRequest(FrameArgs fa, PcNext& n, int nb, int bc0) {
-  const FrameArgs f = Fresh(fa);
+// Frame constants of the producing wave, read ONCE from the kernarg segment (round 5).  Rounds 2-4 re-read every field
+// at its point of use (Fresh above): right for the single-wave kernel, whose march wants every SGPR -- but the
+// producing wave of k_fused_pc runs no march, and each re-read was an s_load + s_waitcnt lgkmcnt(0) in the middle of
+// the fill (19 scalar round trips per block row).  The wave's ~35 SGPRs of constants stay resident instead, and every
+// load is SGPR base + 32-bit lane offset (no 64-bit VALU address arithmetic: 32 v_lshl_add_u64 per decode step before).
+struct PcK {
+  const char* coef[3];
+  const char* dc[3];
+  const char* cell_info;
+  const char* inv_sigma;
+  const float* xyb[3];
+  int xsb;
+  uint32_t tile_stride;
+  int plane_tile_row0;
+  float inv_global_scale, x_dm, b_dm, cfl_base_x, cfl_base_b, color_scale;
+  float bias[4];
+};
+__device__ __forceinline__ PcK MakePcK(FrameArgs f) {
+  PcK k;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    k.coef[c] = (const char*)f->coeffs[c];
+    k.dc[c] = (const char*)f->dc[c];
+    k.xyb[c] = f->xyb[c];
+  }
+  k.cell_info = (const char*)f->cell_info;
+  k.inv_sigma = (const char*)f->inv_sigma;
+  k.xsb = (int)f->xsb;
+  k.tile_stride = f->tile_stride;
+  k.plane_tile_row0 = f->plane_y0 >> 3;
+  k.inv_global_scale = f->inv_global_scale;
+  k.x_dm = f->x_dm;
+  k.b_dm = f->b_dm;
+  k.cfl_base_x = f->cfl_base_x;
+  k.cfl_base_b = f->cfl_base_b;
+  k.color_scale = f->color_scale;
+#pragma unroll
+  for (int i = 0; i < 4; i++) k.bias[i] = f->biases[i];
+  return k;
+}
+// loads at SGPR base + unsigned 32-bit lane offset; no compiler-placed wait (see above)
+__device__ __forceinline__ u4v AsmLoad4S(const char* base, uint32_t off) {
+  u4v r;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+  return r;
+}
+__device__ __forceinline__ u2v AsmLoad2S(const char* base, uint32_t off) {
+  u2v r;
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+  return r;
+}
+__device__ __forceinline__ uint32_t AsmLoad1S(const char* base, uint32_t off) {
+  uint32_t r;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+  return r;
+}
+
+// "These registers are defined HERE": placed right behind the wait (s_waitcnt vmcnt(0) / the barrier) that the data of
+// the asm loads above has landed at.  An asm load's result looks ready to the compiler from the load on, and nothing but
+// a data dependency keeps it from scheduling a plain VALU use of the register above the (volatile, but register-free)
+// wait -- it did exactly that with the first build of this round (a v_cmp of the cell info in front of the prologue's
+// s_waitcnt: a memory fault).  Volatile asm statements keep their order, so every use below depends on the wait.
+__device__ __forceinline__ void PcLanded(PcNext& n) { asm volatile("" : "+v"(n.ci), "+v"(n.sg)); }
+__device__ __forceinline__ void PcLanded(PcGroupRegs& R) {
+#pragma unroll
+  for (int s = 0; s < 2; s++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) asm volatile("" : "+v"(R.st[s].rows[c]), "+v"(R.st[s].dcv[c]));
+}
+
+__device__ __forceinline__ void PcRequest(const PcK& K, PcNext& n, int nb, int bc0) {
   const int lane = threadIdx.x & 63;
-  const int xsb = (int)f->xsb;
   int col = bc0 + (lane & 15);
-  col = col < 0 ? 0 : (col >= xsb ? xsb - 1 : col);  // lanes 16..63 and cells outside the frame: any valid address
+  col = col < 0 ? 0 : (col >= K.xsb ? K.xsb - 1 : col);  // lanes 16..63 and cells outside the frame: any valid address
+  const uint32_t cell = (uint32_t)(nb * K.xsb + col);  // (whole-frame cell index: < 2^26)
   n.nb = nb;
-  n.ci = AsmLoad2(f->cell_info + (size_t)nb * xsb + col);
-  n.sg = AsmLoad1(f->inv_sigma + (size_t)nb * xsb + col);
+  n.ci = AsmLoad2S(K.cell_info, cell * 8u);
+  n.sg = AsmLoad1S(K.inv_sigma, cell * 4u);
 }
 
 // n's registers are valid (a barrier has passed since PcRequest): masks, the DCT8 list, and the loads of the block
 // row's coefficient rows / DC values into R
-__device__ __forceinline__ void PcIssue(FrameArgs fa, LdsU* list, const PcNext& n, int bc0, PcGroupRegs& R) {
-  const FrameArgs f = Fresh(fa);
+__device__ __forceinline__ void PcIssue(const PcK& K, LdsU* list, const PcNext& n, int bc0, PcGroupRegs& R) {
   const int lane = threadIdx.x & 63;
   const int c16 = bc0 + (lane & 15);
-  const bool valid_cell = lane < 16 && c16 >= 0 && c16 < (int)f->xsb;
+  const bool valid_cell = lane < 16 && c16 >= 0 && c16 < K.xsb;
   const bool is_dct8 = valid_cell && n.ci.x != kCellFromPlanes;
   const uint32_t m8 = (uint32_t)__ballot(is_dct8) & 0xffffu;
   R.mp = (uint32_t)__ballot(valid_cell && !is_dct8) & 0xffffu;
@@ -561,19 +632,40 @@ __device__ __forceinline__ void PcIssue(FrameArgs fa, LdsU* list, const PcNext& 
       const uint32_t off = list[bb * 4 + 1];
       R.st[s].qc = list[bb * 4 + 2];
       R.st[s].cell = cell;
-      const size_t elem = (size_t)off * 64u + (size_t)j * 8u;
-      const size_t dc_at = (size_t)n.nb * f->xsb + (size_t)(bc0 + cell);
+      // 16-bit coefficients: 128 bytes per block, 16 per matrix row (the offset stays below 2^32: a channel's
+      // coefficient buffer is frame pixels x 2 bytes)
+      const uint32_t elem_bytes = off * 128u + (uint32_t)j * 16u;
+      const uint32_t dc_bytes = (uint32_t)(n.nb * K.xsb + bc0 + cell) * 4u;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        R.st[s].rows[c] = AsmLoad4((const int16_t*)f->coeffs[c] + elem);
-        R.st[s].dcv[c] = AsmLoad1(f->dc[c] + dc_at);
+        R.st[s].rows[c] = AsmLoad4S(K.coef[c], elem_bytes);
+        R.st[s].dcv[c] = AsmLoad1S(K.dc[c], dc_bytes);
       }
     }
   }
 }
 
-__device__ __forceinline__ void PcDecode(FrameArgs fa, LdsF* slab, const PcGroupRegs& R, const float (&tab)[3][8]) {
-  const FrameArgs f = Fresh(fa);
+// Plane cells of block row nb, the four slab row pairs, all three channels: twelve LDS-DMA instructions of 1 KB
+// (DmaPlaneRows above, with the producer's resident constants)
+__device__ __forceinline__ void PcDmaPlanes(const PcK& K, LdsF* slab, uint32_t mp, int nb, int bc0) {
+#ifdef JXLHIP_ABL_NODMA
+  return;
+#endif
+  if (mp == 0) return;  // wave-uniform
+  const int lane = threadIdx.x & 63;
+  const int cell = (lane & 31) >> 1;
+  if ((mp >> cell) & 1u) {
+    const uint32_t tile = (uint32_t)(nb - K.plane_tile_row0) * K.tile_stride + (uint32_t)(bc0 + cell);
+    const uint32_t at0 = tile * 64u + (uint32_t)(lane >> 5) * 8u + (uint32_t)(lane & 1) * 4u;  // floats; < 2^30 (FusedSupported)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++)
+        __builtin_amdgcn_global_load_lds(K.xyb[ch] + (at0 + 16u * k), slab + ch * kSlabPlaneFloats + 2 * k * kSlabCols, 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroupRegs& R, const float (&tab)[3][8]) {
   const int lane = threadIdx.x & 63;
   const int j = lane >> 3;
   const bool bit3 = (lane & 8) != 0;
@@ -585,14 +677,14 @@ __device__ __forceinline__ void PcDecode(FrameArgs fa, LdsF* slab, const PcGroup
       float sx, sy, sb, x_cc, b_cc;
       {
         const int quant = (int)(T.qc & 0xffffu);
-        const float sq = f->inv_global_scale / (float)quant;  // dec_group.cc:164
-        sx = sq * f->x_dm;
+        const float sq = K.inv_global_scale / (float)quant;  // dec_group.cc:164
+        sx = sq * K.x_dm;
         sy = sq;
-        sb = sq * f->b_dm;
-        x_cc = f->cfl_base_x + (float)(int8_t)((T.qc >> 16) & 0xffu) * f->color_scale;
-        b_cc = f->cfl_base_b + (float)(int8_t)(T.qc >> 24) * f->color_scale;
+        sb = sq * K.b_dm;
+        x_cc = K.cfl_base_x + (float)(int8_t)((T.qc >> 16) & 0xffu) * K.color_scale;
+        b_cc = K.cfl_base_b + (float)(int8_t)(T.qc >> 24) * K.color_scale;
       }
-      const float bias0 = f->biases[0], bias1 = f->biases[1], bias2 = f->biases[2], bias3 = f->biases[3];
+      const float bias0 = K.bias[0], bias1 = K.bias[1], bias2 = K.bias[2], bias3 = K.bias[3];
       auto unpack = [](const u4v r, int32_t* q) {
         const uint32_t wv[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -644,15 +736,15 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
   const int lane = threadIdx.x & 63;
   const int r_first = HX ? y_begin - 8 : y_begin;
   const int G = PcGroups<HX>(y_begin, y_end);
+  const PcK K = MakePcK(fa);
   // this lane's 8 entries of the three DCT8 dequant matrices, once per wave (DequantLane, dec_group.cc:115-153)
   float tab[3][8];
   {
-    const FrameArgs f = Fresh(fa);
     const int j = lane >> 3;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      const float4 t0 = *(const float4*)(f->dequant + c * 64 + j * 8);
-      const float4 t1 = *(const float4*)(f->dequant + c * 64 + j * 8 + 4);
+      const float4 t0 = *(const float4*)(fa->dequant + c * 64 + j * 8);
+      const float4 t1 = *(const float4*)(fa->dequant + c * 64 + j * 8 + 4);
       tab[c][0] = t0.x, tab[c][1] = t0.y, tab[c][2] = t0.z, tab[c][3] = t0.w;
       tab[c][4] = t1.x, tab[c][5] = t1.y, tab[c][6] = t1.z, tab[c][7] = t1.w;
     }
@@ -663,31 +755,32 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
   PcNext n0, n1;
   uint32_t sg_a = 0, sg_b = 0;
   // prologue: block row 0's loads and block row 1's cell info, then everything has landed
-  PcRequest(fa, n0, group_nb(0), bc0);
+  PcRequest(K, n0, group_nb(0), bc0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PcIssue(fa, list, n0, bc0, A);
+  PcLanded(n0);
+  PcIssue(K, list, n0, bc0, A);
   sg_a = n0.sg;
-  PcRequest(fa, n1, group_nb(1), bc0);
+  PcRequest(K, n1, group_nb(1), bc0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PcLanded(A);
+  PcLanded(n1);
   // one fill: CUR holds block row g (loaded behind an earlier barrier), NXT receives block row g+1,
   // nn = cell info of block row g+1 (valid), refilled with block row g+2's
   auto body = [&](int g, PcGroupRegs& CUR, PcGroupRegs& NXT, uint32_t& sg_cur, uint32_t& sg_nxt, PcNext& nn) {
     LdsF* slab = (LdsF*)w->slab[JXLHIP_PC_SLAB(g & 1)];  // free: the march left it before the previous barrier
-    PcIssue(fa, list, nn, bc0, NXT);     // block row g+1 (the last block row again behind the end: harmless)
+    // the plane cells of block row g first: of everything this fill waits for at its barrier, these copies were the last
+    // to be issued (behind the list round trip of PcIssue) -- now they have the whole decode to land
+    PcDmaPlanes(K, slab, CUR.mp, CUR.nb, bc0);
+    PcIssue(K, list, nn, bc0, NXT);     // block row g+1 (the last block row again behind the end: harmless)
     sg_nxt = nn.sg;
-    PcRequest(fa, nn, group_nb(g + 2), bc0);
-    {
-      NextRow cur;  // what DmaPlaneRows reads
-      cur.nb = CUR.nb;
-      cur.mp = CUR.mp;
-      cur.m8 = 0;
-      cur.ci = make_uint2(0u, 0u);
-#pragma unroll
-      for (int k = 0; k < 4; k++) DmaPlaneRows(fa, slab, cur, bc0, k);
-    }
-    PcDecode(fa, slab, CUR, tab);
+    PcRequest(K, nn, group_nb(g + 2), bc0);
+#ifndef JXLHIP_ABL_PC_NODECODE  // ablation builds (timing only): the producer without its DCT8 arithmetic
+    PcDecode(K, slab, CUR, tab);
+#endif
     if (lane < 16) ((LdsU*)w->sigma[g & 1])[lane] = sg_cur;
     PcBarrierProducer();
+    PcLanded(NXT);
+    PcLanded(nn);
   };
   for (int g = 0; g < G; g += 2) {
     body(g, A, B, sg_a, sg_b, n1);
@@ -1050,10 +1143,40 @@ __device__ __forceinline__ void ProduceTiles(FrameArgs fa, StripLds* w, int bc0,
   }
 }
 
-template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, int NB = 2>
+// ablation builds (timing only): JXLHIP_ABL_PC_PAD_S / _V extra scalar / vector instructions per row step of the
+// marching wave that compute nothing -- does the kernel's time follow the marching wave's INSTRUCTION COUNT (a wave
+// issues one instruction of any kind per ~5 cycles: tools/probes/valu_issue.hip) or the SIMD's VALU work?
+#ifndef JXLHIP_ABL_PC_PAD_S
+#define JXLHIP_ABL_PC_PAD_S 0
+#endif
+#ifndef JXLHIP_ABL_PC_PAD_V
+#define JXLHIP_ABL_PC_PAD_V 0
+#endif
+__device__ __forceinline__ void PcPadIssue() {
+#pragma unroll
+  for (int i = 0; i < JXLHIP_ABL_PC_PAD_S; i++) {
+    uint32_t d = 0;
+    asm volatile("s_mov_b32 %0, %0" : "+s"(d));
+  }
+#pragma unroll
+  for (int i = 0; i < JXLHIP_ABL_PC_PAD_V; i++) {
+    uint32_t d = 0;
+    asm volatile("v_mov_b32 %0, %0" : "+v"(d));
+  }
+}
+
+// INTERIOR (wave-uniform, chosen by the kernel): the chunk starts and ends on block rows and touches neither the frame's
+// top nor its bottom -- every row step then knows its place in the block row, whether it writes, and that no row is a
+// mirror row at COMPILE time (filters_march.h, StepKnown): the scalar bookkeeping of the generic step, a third of the
+// marching wave's instruction issues, is gone.  The first whole group is peeled: its first HX steps still complete rows
+// of the chunk above (not written here), every later step of the chunk writes.
+template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, bool INTERIOR, int NB = 2>
 __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P, Lane& L, StripLdsT<NB>* w, int bc0,
                                         int y_begin, int y_end) {
   constexpr int HX = MarchGeom<GAB, EPF>::HX;
+  constexpr int KI = INTERIOR ? (int)kStepInterior : 0;                  // a step that writes nothing
+  constexpr int KE = INTERIOR ? (int)(kStepInterior | kStepEmit) : 0;   // a step that writes its row
+  constexpr int KF = INTERIOR ? (int)kStepFirst : 0;
   const int H = (int)f.ysize;
   const int r_first = HX ? y_begin - 8 : y_begin;
   const int r_last = y_end + HX - 1;
@@ -1093,18 +1216,41 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
     return EPF ? sig0[b * 16] : 0.0f;
   };
 #ifdef JXLHIP_ABL_PC_NOMARCH  // ablation builds: the producing wave alone
-#define JXLHIP_PSTEP(K) (void)slab_y0, (void)sigma_pre, (void)sigma_prev
+#define JXLHIP_PSTEPK(K, KN) (void)slab_y0, (void)sigma_pre, (void)sigma_prev
 #else
 #ifdef JXLHIP_ABL_PC_NOSTORE  // ablation builds: the march without its output stores
 #define JXLHIP_PC_DBG 4
 #else
 #define JXLHIP_PC_DBG 0
 #endif
-#define JXLHIP_PSTEP(K)                                                                                     \
-  Step<GAB, EPF, OUTK, FMT, K, EDGE, JXLHIP_PC_DBG, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk,      \
-                                                  inv_sigma_blk2, out_row, KC, slab_y0, sigma_pre, sigma_prev); \
+#define JXLHIP_PSTEPK(K, KN)                                                                                          \
+  Step<GAB, EPF, OUTK, FMT, K, EDGE, JXLHIP_PC_DBG, SRC_LDS, KN>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk, \
+                                                                 inv_sigma_blk2, out_row, KC, slab_y0, sigma_pre,     \
+                                                                 sigma_prev);                                         \
+  PcPadIssue();                                                                                                       \
   out_row += out_row_bytes
 #endif
+// a whole group of 8 rows starting at image row r (a multiple of 8): steps 0 .. HX-1 take KLOW, the others KHIGH
+#define JXLHIP_PGROUP(KLOW, KHIGH)                                                       \
+  {                                                                                      \
+    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;                                   \
+    const float sigma_prev = sigma_last;                                                 \
+    const float sigma_pre = enter_group(i);                                              \
+    sigma_last = sigma_pre;                                                              \
+    {                                                                                    \
+      const int row0 = INTERIOR ? 0 : Mirror1(r, H) - slab_y0;                           \
+      _Pragma("unroll") for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0); \
+    }                                                                                    \
+    JXLHIP_PSTEPK(0, (0 < HX ? (KLOW) : (KHIGH)));                                       \
+    JXLHIP_PSTEPK(1, (1 < HX ? (KLOW) : (KHIGH)));                                       \
+    JXLHIP_PSTEPK(2, (2 < HX ? (KLOW) : (KHIGH)));                                       \
+    JXLHIP_PSTEPK(3, (3 < HX ? (KLOW) : (KHIGH)));                                       \
+    JXLHIP_PSTEPK(4, (KHIGH));                                                           \
+    JXLHIP_PSTEPK(5, (KHIGH));                                                           \
+    JXLHIP_PSTEPK(6, (KHIGH));                                                           \
+    JXLHIP_PSTEPK(7, (KHIGH));                                                           \
+    i++;                                                                                 \
+  }
   PcBarrierMarch();  // fill(0)
   if constexpr (HX > 0) {  // the last HX rows of the block row above
     const int r = r_first;
@@ -1113,56 +1259,49 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
     const float sigma_pre = enter_group(i);
     sigma_last = sigma_pre;
     {
-      const int row0 = Mirror1(r + 8 - HX, H) - slab_y0;
+      const int row0 = INTERIOR ? 8 - HX : Mirror1(r + 8 - HX, H) - slab_y0;
 #pragma unroll
       for (int c = 0; c < 3; c++) s.x[c][8 - HX] = LdsPair<EDGE>(L, c, row0);
     }
     out_row += (8 - HX) * out_row_bytes;
-    if constexpr (HX >= 4) { JXLHIP_PSTEP(4); }
-    if constexpr (HX >= 3) { JXLHIP_PSTEP(5); }
-    if constexpr (HX >= 2) { JXLHIP_PSTEP(6); }
-    JXLHIP_PSTEP(7);
+    if constexpr (HX >= 4) { JXLHIP_PSTEPK(4, KI); }
+    if constexpr (HX >= 3) { JXLHIP_PSTEPK(5, KI); }
+    if constexpr (HX >= 2) { JXLHIP_PSTEPK(6, KI); }
+    JXLHIP_PSTEPK(7, KI);
     i++;
     PcBarrierMarch();  // a whole group always follows
   }
   int r = HX ? y_begin : r_first;
-  for (; r_last - r >= HX; r += 8) {
-    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
-    const float sigma_prev = sigma_last;
-    const float sigma_pre = enter_group(i);
-    sigma_last = sigma_pre;
-    {
-      const int row0 = Mirror1(r, H) - slab_y0;
-#pragma unroll
-      for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
-    }
-    JXLHIP_PSTEP(0);
-    JXLHIP_PSTEP(1);
-    JXLHIP_PSTEP(2);
-    JXLHIP_PSTEP(3);
-    JXLHIP_PSTEP(4);
-    JXLHIP_PSTEP(5);
-    JXLHIP_PSTEP(6);
-    JXLHIP_PSTEP(7);
-    i++;
+  if constexpr (INTERIOR) {
+    JXLHIP_PGROUP(KI | KF, KE | KF)
     if (i < G) PcBarrierMarch();
+    for (r += 8; r < y_end; r += 8) {
+      JXLHIP_PGROUP(KE, KE)
+      if (i < G) PcBarrierMarch();
+    }
+  } else {
+    for (; r_last - r >= HX; r += 8) {
+      JXLHIP_PGROUP(0, 0)
+      if (i < G) PcBarrierMarch();
+    }
   }
-  if (HX > 0 && r <= r_last) {  // the first HX rows of the block row below
+  if (HX > 0 && (INTERIOR || r <= r_last)) {  // the first HX rows of the block row below
     const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
     const float sigma_prev = sigma_last;
     const float sigma_pre = enter_group(i);
     sigma_last = sigma_pre;
     {
-      const int row0 = Mirror1(r, H) - slab_y0;
+      const int row0 = INTERIOR ? 0 : Mirror1(r, H) - slab_y0;
 #pragma unroll
       for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
     }
-    JXLHIP_PSTEP(0);
-    if constexpr (HX >= 2) { JXLHIP_PSTEP(1); }
-    if constexpr (HX >= 3) { JXLHIP_PSTEP(2); }
-    if constexpr (HX >= 4) { JXLHIP_PSTEP(3); }
+    JXLHIP_PSTEPK(0, KE);
+    if constexpr (HX >= 2) { JXLHIP_PSTEPK(1, KE); }
+    if constexpr (HX >= 3) { JXLHIP_PSTEPK(2, KE); }
+    if constexpr (HX >= 4) { JXLHIP_PSTEPK(3, KE); }
   }
-#undef JXLHIP_PSTEP
+#undef JXLHIP_PGROUP
+#undef JXLHIP_PSTEPK
 }
 
 // blockIdx.x is dispatched round-robin over the 8 XCDs: logical workgroup = (xcd, slot) -> xcd * per + slot, so
@@ -1237,8 +1376,18 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
 #ifdef JXLHIP_PC_MARCH_PRIO  // experiment builds: the marching wave ahead of the producing waves at the SIMD's issue arbiter
   __builtin_amdgcn_s_setprio(JXLHIP_PC_MARCH_PRIO);
 #endif
-  if (edge) MarchPC<GAB, EPF, OUTK, FMT, true>(f, P, L, &lds, bc0, y_begin, y_end);
-  else MarchPC<GAB, EPF, OUTK, FMT, false>(f, P, L, &lds, bc0, y_begin, y_end);
+  // a chunk of whole block rows that needs no mirror row: the march with its row bookkeeping resolved at compile time
+  constexpr int HXk = MarchGeom<GAB, EPF>::HX;
+  const bool interior = JXLHIP_PC_INTERIOR != 0 && (y_begin & 7) == 0 && ((y_end - y_begin) & 7) == 0 && y_begin >= 8 &&
+                        y_end + 8 <= (int)f.ysize;
+  (void)HXk;
+  if (interior) {
+    if (edge) MarchPC<GAB, EPF, OUTK, FMT, true, true>(f, P, L, &lds, bc0, y_begin, y_end);
+    else MarchPC<GAB, EPF, OUTK, FMT, false, true>(f, P, L, &lds, bc0, y_begin, y_end);
+  } else {
+    if (edge) MarchPC<GAB, EPF, OUTK, FMT, true, false>(f, P, L, &lds, bc0, y_begin, y_end);
+    else MarchPC<GAB, EPF, OUTK, FMT, false, false>(f, P, L, &lds, bc0, y_begin, y_end);
+  }
 }
 
 // rows per window chunk: a multiple of 8 that fills whole generations of resident workgroups (6 per CU)
@@ -1395,6 +1544,8 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) 
   if (tail >= 1 && tail <= 3) return false;        // mirror rows below the frame leave the last block row
   if ((f.fy0 & 7u) != 0) return false;
   if ((uint64_t)f.plane_tile_rows * f.tile_stride * 256u >= (1ull << 32)) return false;
+  // the producing wave addresses coefficients as buffer base + 32-bit byte offset (PcIssue)
+  if ((uint64_t)f.xsg * f.ysg * f.coef_stride64 * 64u * (f.coeff_type == JXLHIP_COEFF_I16 ? 2u : 4u) >= (1ull << 32)) return false;
   return true;
 }
 

@@ -4,7 +4,7 @@ ctrs="$1"; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcx
-timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/pmcx -- python $R/bench.py --no-cpu-baseline --frames-in-flight 1 --steps 3 --warmup 1 "$@" > /tmp/pmcx.log 2>&1
+timeout ${PMC_TIMEOUT:-600} rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d /tmp/pmcx -- python $R/bench.py --no-cpu-baseline --frames-in-flight 1 --steps 3 --warmup 1 "$@" > /tmp/pmcx.log 2>&1
 f=$(find /tmp/pmcx -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
