@@ -230,6 +230,11 @@ JXLHIP_EXPORT int jxlhip_create_multi(const int* devices, int num_devices,
                                       const JxlMemoryManagerHip* memory_manager, jxlhip_ctx** out);
 JXLHIP_EXPORT void jxlhip_destroy(jxlhip_ctx* ctx);
 JXLHIP_EXPORT const char* jxlhip_last_error(const jxlhip_ctx* ctx);
+/* The library reads its debug / test switches (JXLHIP_WP_GENERAL, JXLHIP_NO_PIPELINE, JXLHIP_TEST_RANGE_GROUP,
+ * JXLHIP_CODESTREAM_VERBOSE, JXLHIP_MULTI_INTERIOR_FIRST, JXLHIP_DC_TREE) from the environment ONCE per process, at
+ * their first use; a test that changes one of them afterwards calls this to have them read again.  Decoding never
+ * calls getenv for them (no reference counterpart: libjxl has no run-time switches on this path). */
+JXLHIP_EXPORT void jxlhip_debug_reload_env(void);
 /* external != 0: all launches go to the caller's hipStream_t `hip_stream`
  * (NULL = the device's default stream, which is what torch's default stream
  * is); external == 0: back to the context's own non-blocking stream. */

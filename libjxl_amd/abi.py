@@ -222,7 +222,7 @@ EXPORTS = [
     "jxlhip_covered_blocks_x", "jxlhip_covered_blocks_y",
     "jxlhip_log2_covered_blocks", "jxlhip_quant_table_of_strategy",
     "jxlhip_dequant_table_offset", "jxlhip_status_string", "jxlhip_create", "jxlhip_create_ex", "jxlhip_create_multi",
-    "jxlhip_destroy", "jxlhip_last_error", "jxlhip_set_stream",
+    "jxlhip_destroy", "jxlhip_last_error", "jxlhip_debug_reload_env", "jxlhip_set_stream",
     "jxlhip_frame_begin", "jxlhip_frame_set_inputs", "jxlhip_upload_side_info",
     "jxlhip_submit_group", "jxlhip_set_alpha", "jxlhip_alpha_staging", "jxlhip_decode_blocks", "jxlhip_halo_rows",
     "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_filters_rows", "jxlhip_decode_frame",
@@ -265,6 +265,8 @@ def load_library():
     L.jxlhip_status_string.restype = C.c_char_p
     L.jxlhip_last_error.restype = C.c_char_p
     L.jxlhip_last_error.argtypes = [vp]
+    L.jxlhip_debug_reload_env.restype = None
+    L.jxlhip_debug_reload_env.argtypes = []
     L.jxlhip_create.argtypes = [i32, C.POINTER(vp)]
     L.jxlhip_create_ex.argtypes = [i32, vp, C.POINTER(vp)]
     L.jxlhip_create_multi.argtypes = [vp, i32, vp, C.POINTER(vp)]

@@ -22,6 +22,26 @@
 #include "kernels.h"
 #include "dither_pattern.inc"
 
+#include "env_switches.h"
+namespace jxlhip_env {
+Switches g;
+void LoadLocked() {
+  g.wp_general.store(getenv("JXLHIP_WP_GENERAL") != nullptr);
+  g.dc_tree.store(getenv("JXLHIP_DC_TREE") != nullptr);
+  g.codestream_verbose.store(getenv("JXLHIP_CODESTREAM_VERBOSE") != nullptr);
+  g.no_pipeline.store(getenv("JXLHIP_NO_PIPELINE") != nullptr);
+  const char* e = getenv("JXLHIP_TEST_RANGE_GROUP");
+  g.test_range_group.store(e ? atoll(e) : -1);
+  const char* ife = getenv("JXLHIP_MULTI_INTERIOR_FIRST");
+  g.multi_interior_first.store(!ife || atoi(ife) != 0 ? 1 : 0);
+  g.loaded.store(true, std::memory_order_release);
+}
+}  // namespace jxlhip_env
+extern "C" __attribute__((visibility("default"))) void jxlhip_debug_reload_env(void) {
+  std::lock_guard<std::mutex> lock(jxlhip_env::g.mu);
+  jxlhip_env::LoadLocked();
+}
+
 using namespace jxlhip;
 
 namespace {
@@ -129,7 +149,9 @@ struct jxlhip_ctx {
   void* stage[kStageSlots] = {nullptr};
   hipEvent_t stage_ev[kStageSlots] = {nullptr};
   int stage_state[kStageSlots] = {0};  // 0 free, 1 owned by a decoding thread, 2 upload queued (stage_ev)
-  int stage_count = 0;                 // slots allocated so far (<= kStageSlots), kStageChunk at a time
+  int stage_count = 0;                 // slots allocated so far (<= stage_cap), kStageChunk at a time
+  int stage_cap = kStageSlots;         // JXLHIP_STAGE_SLOTS (read at jxlhip_create): pinned host memory per context is at
+                                       // most stage_cap x 0.8 MB -- several contexts per device share the host's lockable memory
   void* stage_chunk[kStageSlots / kStageChunk] = {nullptr};  // the allocations the slots are carved from
   size_t stage_bytes = 0;
   std::mutex stage_mu;
@@ -355,6 +377,10 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
     if (fu) c->fuse = atoi(fu) != 0 ? 1 : 0;
     const char* mf = getenv("JXLHIP_MFMA");
     if (mf) c->mfma = atoi(mf) != 0 ? 1 : 0;
+    if (const char* ss = getenv("JXLHIP_STAGE_SLOTS")) {  // whole chunks, at least the first allocation
+      const int v = (atoi(ss) + kStageChunk - 1) / kStageChunk * kStageChunk;
+      c->stage_cap = v < kStageSlotsFirst ? kStageSlotsFirst : (v > kStageSlots ? kStageSlots : v);
+    }
     const char* br = getenv("JXLHIP_BAND_ROWS");
     if (br) c->band_rows = atoi(br);
     if (c->band_rows < 0) c->band_rows = 0;
@@ -465,7 +491,10 @@ const char* jxlhip_last_error(const jxlhip_ctx* c) { return c ? c->err : ""; }
 int jxlhip_set_stream(jxlhip_ctx* c, void* hip_stream, int external) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->children.empty()) return jxlhip_set_stream(c->children[0], hip_stream, external);  // the frame's consumer is on devices[0]
-  c->stream = external ? (hipStream_t)hip_stream : c->own_stream;
+  const hipStream_t st = external ? (hipStream_t)hip_stream : c->own_stream;
+  // the zeroing of the next frame's counter block is ordered on the OLD stream only: a new stream starts with a memset
+  if (st != c->stream) c->counts_clean[0] = c->counts_clean[1] = false;
+  c->stream = st;
   return JXLHIP_OK;
 }
 
@@ -1087,12 +1116,19 @@ static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out) {
   // kStageChunk more slots (the chunk after the ones there are), free
   auto grow = [&]() -> int {
     const int k = c->stage_count / kStageChunk;
-    if (StageAlloc(c, &c->stage_chunk[k], (size_t)kStageChunk * c->stage_bytes) != JXLHIP_OK)
-      return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
-    for (int i = c->stage_count; i < c->stage_count + kStageChunk; i++) {
-      c->stage[i] = (char*)c->stage_chunk[k] + (size_t)(i - c->stage_count) * c->stage_bytes;
+    if (c->stage_count + kStageChunk > c->stage_cap)
+      return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging: the cap of %d slots (JXLHIP_STAGE_SLOTS) is reached", c->stage_cap);
+    // the events first, then the chunk, and only then is anything published: a failure half way leaves nothing
+    // behind that a later grow() would overwrite (an event that exists already is simply kept)
+    for (int i = c->stage_count; i < c->stage_count + kStageChunk; i++)
       if (!c->stage_ev[i] && hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming) != hipSuccess)
         return Fail(c, JXLHIP_ERR_HIP, "event creation failed");
+    void* chunk = nullptr;
+    if (StageAlloc(c, &chunk, (size_t)kStageChunk * c->stage_bytes) != JXLHIP_OK)
+      return Fail(c, JXLHIP_ERR_OUT_OF_MEMORY, "pinned staging allocation failed");
+    c->stage_chunk[k] = chunk;
+    for (int i = c->stage_count; i < c->stage_count + kStageChunk; i++) {
+      c->stage[i] = (char*)chunk + (size_t)(i - c->stage_count) * c->stage_bytes;
       c->stage_state[i] = 0;
     }
     c->stage_count += kStageChunk;
@@ -1134,7 +1170,7 @@ static int AcquireSlot(jxlhip_ctx* c, size_t slot_bytes, int* out) {
       }
     }
     if (slot >= 0) break;
-    if (c->stage_count < kStageSlots) {  // nothing free: more slots rather than a wait
+    if (c->stage_count < c->stage_cap) {  // nothing free: more slots rather than a wait
       slot = c->stage_count;
       const int rc = grow();
       if (rc) return rc;
@@ -1250,7 +1286,7 @@ int GroupsInit(void* opaque, size_t num_threads) {
     j->scratch.assign(num_threads ? num_threads : 1, std::vector<uint8_t>());
   }
   j->dense.assign(num_threads ? num_threads : 1, std::vector<uint8_t>());
-  if (const char* e = getenv("JXLHIP_TEST_RANGE_GROUP")) j->test_range_group = atoll(e);
+  j->test_range_group = jxlhip_env::Get().test_range_group.load(std::memory_order_relaxed);
   return 0;
 }
 // A section this large carries more non-zeros than a chroma list of the sparse form takes (kSparseCap; the stream above:
@@ -1382,7 +1418,7 @@ int jxlhip_ac_groups_decode_submit_ex(jxlhip_ctx* c, jxlhip_parallel_runner runn
     job.order.resize(job.num_groups);
     for (uint32_t t = 0; t < job.num_groups; t++) job.order[t] = ~(uint32_t)key[t];
   }
-  const bool verbose = getenv("JXLHIP_CODESTREAM_VERBOSE") != nullptr;
+  const bool verbose = jxlhip_env::Get().codestream_verbose.load(std::memory_order_relaxed);
   if (verbose) {
     job.timeline.assign(3 * (size_t)job.num_groups, 0.0f);
     job.t0 = std::chrono::steady_clock::now();
@@ -1760,8 +1796,10 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   if (rc) return rc;
   if (one_band && !c->counts_clean[slot])
     HIPCHK(c, hipMemsetAsync(c->counts + (size_t)slot * kCountStride, 0, sizeof(uint32_t) * kCountStride, c->stream));
+  // From here on block `slot` is in use: whatever happens below (a failed launch after k_prepare ran), it must not be
+  // taken for clean by the next frame.  Block slot ^ 1 becomes clean only when the launches that zero it succeeded.
+  if (one_band) c->counts_clean[slot] = false;
   auto rotate = [&]() {  // after a successful LaunchBlocksBand(.., slot, .., slot ^ 1)
-    c->counts_clean[slot] = false;
     c->counts_clean[slot ^ 1] = true;
     c->counts_slot = slot ^ 1;
   };

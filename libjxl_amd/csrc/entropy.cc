@@ -7,6 +7,7 @@
 //
 // Behavioural specification: ISO/IEC 18181-1 annexes C (entropy coding) and
 // I.3.5-I.3.7, as implemented by the reference at the lines cited per function.
+#include "env_switches.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>

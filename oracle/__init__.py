@@ -499,6 +499,20 @@ def ref_quant_dc_contexts(quant_dc):
 Frame.encode_ac_ref = _encode_ac_ref
 
 
+def feature_stream(feature, xsize=600, ysize=400, seed=5, distance=1.0):
+    """A small codestream written by the REFERENCE ENCODER (oracle/ref_real_stream.cc: FeatureStream) that uses one
+    feature the product's seam declines or handles specially: "noise" | "splines" | "patches" | "modular" | "animation" |
+    "progressive" | "plain" (the control).  Describes an 8-bit sRGB original.  Test infrastructure."""
+    L = ref_lib()
+    L.jxr_feature_stream.restype = C.c_size_t
+    L.jxr_feature_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_char_p, C.c_void_p, C.c_size_t]
+    buf = C.create_string_buffer(max(1 << 20, 4 * xsize * ysize))
+    n = L.jxr_feature_stream(xsize, ysize, seed, distance, feature.encode(), buf, len(buf))
+    if not n:
+        raise ValueError("reference encoder failed for feature %r" % feature)
+    return buf.raw[:n]
+
+
 class RealStream:
     """A genuine VarDCT codestream written by the REFERENCE's own encoder
     (jxl::EncodeFrame on a procedural image, oracle/ref_real_stream.cc), the

@@ -38,6 +38,9 @@
 #include "lib/jxl/memory_manager_internal.h"
 #include "lib/jxl/passes_state.h"
 #include "lib/jxl/quantizer.h"
+#include "lib/jxl/splines.h"
+
+#include <string>
 
 #include "jxl_oracle.h"
 
@@ -188,8 +191,8 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
   // that JxlDecoder's default output is sRGB-encoded integer samples (tests/test_djxl.py); the pixels handed to the
   // encoder stay linear either way (no CMS in this build)
   if (const char* e = getenv("JXR_ORIGINAL")) {
-    if (!strcmp(e, "srgb8") || !strcmp(e, "srgb16")) {
-      metadata.m.SetUintSamples(!strcmp(e, "srgb8") ? 8 : 16);
+    if (!strcmp(e, "srgb8") || !strcmp(e, "srgb16") || !strcmp(e, "srgb10") || !strcmp(e, "srgb12")) {  // (bit depth of the original)
+      metadata.m.SetUintSamples(static_cast<uint32_t>(atoi(e + 4)));
       metadata.m.color_encoding = ColorEncoding::SRGB(/*is_gray=*/false);
     }
     // other enumerated originals: the decoder adapts the inverse opsin matrix to their primaries / white point
@@ -557,6 +560,139 @@ Status Run(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_ti
 }
 
 }  // namespace
+
+// ---- streams with the features the product's seam DECLINES (round 5, tests/test_djxl.py) ------------------------------
+// PreparePipeline adds noise / patches / splines stages when the frame header asks (dec_cache.cc:124,193-200); Modular
+// frames, multi-frame files and progressive passes take other paths again.  The reference ENCODER writes one small stream
+// per feature here; the GPU suite runs djxl_ref and djxl_hip on them with a device present.
+//   feature: "noise" (photon noise, ISO 6400), "splines" (two hand-made splines), "patches" (screenshot-like content: a
+//   flat page with repeated glyphs -> a reference frame + patches), "modular" (a lossless Modular frame), "animation" (two
+//   VarDCT frames, 10 ticks per second), "progressive" (AC passes by frequency band), "plain" (none: the control)
+namespace {
+void FillPage(Image3F* img, uint32_t seed) {  // a flat page with rows of repeated 6x9 dot-matrix glyphs
+  const size_t xs = img->xsize(), ys = img->ysize();
+  uint32_t s = seed * 747796405u + 2891336453u;
+  uint64_t glyph[6];
+  for (auto& g : glyph) {
+    s = s * 1664525u + 1013904223u;
+    const uint64_t a = s;
+    s = s * 1664525u + 1013904223u;
+    g = (a << 32) | s;
+  }
+  for (size_t y = 0; y < ys; y++) {
+    float* rows[3] = {img->PlaneRow(0, y), img->PlaneRow(1, y), img->PlaneRow(2, y)};
+    for (size_t x = 0; x < xs; x++) {
+      float v = 0.85f;
+      const size_t cx = x / 10, cy = y / 16, ix = x % 10, iy = y % 16;
+      if (cx >= 2 && cx + 2 < xs / 10 && cy >= 1 && cy + 1 < ys / 16 && ix < 6 && iy >= 3 && iy < 12 && (cy % 3) != 2) {
+        const uint64_t g = glyph[(cx * 7 + cy * 3) % 6];
+        if ((g >> ((iy - 3) * 6 + ix)) & 1u) v = 0.05f;
+      }
+      for (int c = 0; c < 3; c++) rows[c][x] = v;
+    }
+  }
+}
+
+Status FeatureStream(uint32_t xs, uint32_t ys, uint32_t seed, float distance, const char* feature,
+                     std::vector<uint8_t>* out) {
+  const std::string f = feature;
+  JxlMemoryManager mm;
+  JXL_RETURN_IF_ERROR(MemoryManagerInit(&mm, nullptr));
+  const bool modular = f == "modular";
+  const bool animation = f == "animation";
+  CodecMetadata metadata;
+  metadata.m.SetUintSamples(8);  // an 8-bit sRGB original, what cjxl writes for a PNG: djxl's default output is then a PPM
+  metadata.m.xyb_encoded = !modular;
+  metadata.m.color_encoding = ColorEncoding::SRGB(/*is_gray=*/false);
+  JXL_RETURN_IF_ERROR(metadata.size.Set(xs, ys));
+  if (animation) {
+    metadata.m.have_animation = true;
+    metadata.m.animation.tps_numerator = 10;
+    metadata.m.animation.tps_denominator = 1;
+    metadata.m.animation.num_loops = 0;
+    metadata.m.animation.have_timecodes = false;
+  }
+  // the lossy encoder is handed linear pixels under a "linear sRGB" copy of the metadata (no CMS in this build, as in
+  // Run above); the lossless one takes the 8-bit samples as they are, in the original's own encoding
+  CodecMetadata metadata_enc = metadata;
+  if (!modular) metadata_enc.m.color_encoding = ColorEncoding::LinearSRGB(false);
+  CompressParams cparams;
+  cparams.butteraugli_distance = distance;
+  cparams.speed_tier = SpeedTier::kSquirrel;
+  cparams.patches = Override::kOff;
+  cparams.dots = Override::kOff;
+  cparams.noise = Override::kOff;
+  cparams.color_transform = ColorTransform::kXYB;
+  std::vector<QuantizedSpline> qsplines;
+  std::vector<Spline::Point> starts;
+  if (f == "noise") cparams.photon_noise_iso = 6400.0f;
+  if (f == "patches") cparams.patches = Override::kOn;
+  if (f == "progressive") cparams.progressive_mode = Override::kOn;
+  if (f == "splines") {
+    for (int k = 0; k < 2; k++) {
+      Spline sp;
+      for (int i = 0; i < 5; i++)
+        sp.control_points.emplace_back(xs * (0.1f + 0.2f * i), ys * (k ? 0.25f + 0.1f * ((i * 3) % 4) : 0.8f - 0.12f * ((i * 2) % 5)));
+      for (auto& d : sp.color_dct) d.fill(0.0f);
+      sp.sigma_dct.fill(0.0f);
+      sp.color_dct[1][0] = k ? 0.35f : 0.2f;   // Y
+      sp.color_dct[0][0] = k ? 0.01f : -0.02f;  // X
+      sp.color_dct[2][0] = k ? 0.1f : 0.25f;   // B
+      sp.color_dct[1][1] = 0.05f;
+      sp.sigma_dct[0] = k ? 4.5f : 3.0f;
+      sp.sigma_dct[1] = 0.5f;
+      JXL_ASSIGN_OR_RETURN(QuantizedSpline q, QuantizedSpline::Create(sp, /*quantization_adjustment=*/0, 0.0f, 1.0f));
+      qsplines.push_back(std::move(q));
+      starts.push_back(sp.control_points[0]);
+    }
+    cparams.custom_splines.splines = Span<const QuantizedSpline>(qsplines.data(), qsplines.size());
+    cparams.custom_splines.starting_points = Span<const Spline::Point>(starts.data(), starts.size());
+  }
+  if (modular) {
+    cparams.SetLossless();
+  }
+  JXL_RETURN_IF_ERROR(ParamsPostInit(&cparams));
+  BitWriter writer{&mm};
+  JXL_RETURN_IF_ERROR(WriteCodestreamHeaders(&metadata, &writer, nullptr));
+  JXL_RETURN_IF_ERROR(writer.WithMaxBits(8, LayerType::Header, nullptr, [&] {
+    writer.ZeroPadToByte();
+    return true;
+  }));
+  JxlCmsInterface no_cms{};
+  const int frames = animation ? 2 : 1;
+  for (int fi = 0; fi < frames; fi++) {
+    ImageBundle ib(&mm, &metadata_enc.m);
+    JXL_ASSIGN_OR_RETURN(Image3F img, Image3F::Create(&mm, xs, ys));
+    if (f == "patches") FillPage(&img, seed);
+    else FillImage(&img, seed + 31u * fi);
+    if (modular) {  // 8-bit samples of an sRGB original: quantise, so that "lossless" has integers to keep
+      for (int c = 0; c < 3; c++)
+        for (size_t y = 0; y < ys; y++) {
+          float* r = img.PlaneRow(c, y);
+          for (size_t x = 0; x < xs; x++) r[x] = std::floor(std::min(1.0f, std::max(0.0f, r[x])) * 255.0f + 0.5f) / 255.0f;
+        }
+    }
+    JXL_RETURN_IF_ERROR(ib.SetFromImage(std::move(img), modular ? ColorEncoding::SRGB(false) : ColorEncoding::LinearSRGB(false)));
+    FrameInfo info;
+    info.is_last = fi + 1 == frames;
+    if (animation) info.duration = 1 + fi;
+    JXL_RETURN_IF_ERROR(EncodeFrame(&mm, cparams, info, &metadata_enc, ib, no_cms, nullptr, &writer, nullptr));
+  }
+  PaddedBytes bytes = std::move(writer).TakeBytes();
+  out->assign(bytes.data(), bytes.data() + bytes.size());
+  return true;
+}
+}  // namespace
+
+// -> bytes written (0 = failed, or `cap` too small: call again with the returned size... the streams are < 1 MB)
+JXR_EXPORT size_t jxr_feature_stream(uint32_t xs, uint32_t ys, uint32_t seed, float distance, const char* feature,
+                                     uint8_t* out, size_t cap) {
+  std::vector<uint8_t> bytes;
+  if (!FeatureStream(xs, ys, seed, distance, feature, &bytes)) return 0;
+  if (bytes.size() > cap) return 0;
+  memcpy(out, bytes.data(), bytes.size());
+  return bytes.size();
+}
 
 JXR_EXPORT void* jxr_real_case_create(uint32_t xs, uint32_t ys, uint32_t seed, float distance, int speed_tier,
                                       int epf, int progressive) {

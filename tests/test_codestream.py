@@ -161,8 +161,10 @@ def test_one_runner_call_equals_three_barriers(L, ref, kw, monkeypatch):
         for workers, barriers in ((2, False), (13, False), (13, True), (40, False)):
             if barriers:
                 monkeypatch.setenv("JXLHIP_NO_PIPELINE", "1")
+                abi.load_library().jxlhip_debug_reload_env()
             else:
                 monkeypatch.delenv("JXLHIP_NO_PIPELINE", raising=False)
+                abi.load_library().jxlhip_debug_reload_env()
             pool = R.JxlThreadParallelRunnerCreate(None, workers)
             try:
                 for rep in range(3):  # (a context decodes frame after frame: the offset tables and arenas alternate)
@@ -177,6 +179,7 @@ def test_one_runner_call_equals_three_barriers(L, ref, kw, monkeypatch):
     finally:
         dec.close()
         monkeypatch.delenv("JXLHIP_NO_PIPELINE", raising=False)
+        abi.load_library().jxlhip_debug_reload_env()
     first = results[0]
     scale = max(1.0, float(np.abs(rs.rgb).max()))
     assert float(np.abs(first[3] - rs.rgb).max()) / scale <= TIGHT
@@ -205,13 +208,16 @@ def test_redo_with_int32_coefficients(L, ref, barriers, monkeypatch):
     dec = VarDctDecoder(0)
     if barriers:
         monkeypatch.setenv("JXLHIP_NO_PIPELINE", "1")
+        abi.load_library().jxlhip_debug_reload_env()
     try:
         got = []
         for hook in (None, "11", None):
             if hook:
                 monkeypatch.setenv("JXLHIP_TEST_RANGE_GROUP", hook)
+                abi.load_library().jxlhip_debug_reload_env()
             else:
                 monkeypatch.delenv("JXLHIP_TEST_RANGE_GROUP", raising=False)
+                abi.load_library().jxlhip_debug_reload_env()
             info = abi.CodestreamInfo()
             out = torch.zeros((rs.ysize, rs.xsize, 3), dtype=torch.float32, device="cuda")
             rc = L.jxlhip_decode_codestream(dec.ctx, runner, pool, cs, len(cs), 1, None, out.data_ptr(), rs.xsize * 12, 0, C.byref(info))
@@ -221,7 +227,9 @@ def test_redo_with_int32_coefficients(L, ref, barriers, monkeypatch):
         dec.close()
         R.JxlThreadParallelRunnerDestroy(pool)
         monkeypatch.delenv("JXLHIP_TEST_RANGE_GROUP", raising=False)
+        abi.load_library().jxlhip_debug_reload_env()
         monkeypatch.delenv("JXLHIP_NO_PIPELINE", raising=False)
+        abi.load_library().jxlhip_debug_reload_env()
     assert [g[0] for g in got] == [0, 1, 0]  # JXLHIP_COEFF_I16, _I32, _I16 again on the same context
     scale = max(1.0, float(np.abs(rs.rgb).max()))
     for _, px in got:
@@ -251,6 +259,7 @@ def test_damaged_streams_end_the_runner_call_and_leave_the_context_usable(L, ref
     dec = VarDctDecoder(0)
     if barriers:
         monkeypatch.setenv("JXLHIP_NO_PIPELINE", "1")
+        abi.load_library().jxlhip_debug_reload_env()
     rng = np.random.default_rng(17)
 
     def run(blob):
@@ -288,6 +297,7 @@ def test_damaged_streams_end_the_runner_call_and_leave_the_context_usable(L, ref
         dec.close()
         R.JxlThreadParallelRunnerDestroy(pool)
         monkeypatch.delenv("JXLHIP_NO_PIPELINE", raising=False)
+        abi.load_library().jxlhip_debug_reload_env()
 
 
 @pytest.mark.gpu

@@ -122,8 +122,10 @@ def _dc_groups_both_ways(L, fh, sections, monkeypatch, damage=None):
         for general in (False, True):
             if general:
                 monkeypatch.setenv("JXLHIP_WP_GENERAL", "1")
+                abi.load_library().jxlhip_debug_reload_env()
             else:
                 monkeypatch.delenv("JXLHIP_WP_GENERAL", raising=False)
+                abi.load_library().jxlhip_debug_reload_env()
             qdc = [np.zeros(xsb * ysb, np.int32) for _ in range(3)]
             acs, rq, sharp = np.zeros(xsb * ysb, np.uint8), np.zeros(xsb * ysb, np.int32), np.zeros(xsb * ysb, np.uint8)
             ytox, ytob = np.zeros(cw * chh, np.int8), np.zeros(cw * chh, np.int8)
@@ -140,6 +142,7 @@ def _dc_groups_both_ways(L, fh, sections, monkeypatch, damage=None):
     finally:
         L.jxlhip_modular_tree_destroy(tree)
         monkeypatch.delenv("JXLHIP_WP_GENERAL", raising=False)
+        abi.load_library().jxlhip_debug_reload_env()
     return results
 
 

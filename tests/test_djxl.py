@@ -205,6 +205,12 @@ CASES = [
     # ICC originals (8-bit samples): no CMS in either build, so both write linear sRGB (dec_xyb.cc:160-164)
     (dict(seed=15, xsize=520, ysize=300, distance=1.0, speed_tier=3, icc="rgb"), "srgb8", None, ("ppm", "npy", "pfm")),
     (dict(seed=16, xsize=456, ysize=280, distance=1.5, speed_tier=4, icc="grey", alpha_bits=8), "gray8", None, ("pam", "npy")),
+    # round 5: the remaining orientations (2 flip, 4 flip vertical, 7 anti-transpose; 1 is every case without one), 10- and
+    # 12-bit originals (16-bit PNM with maxval 1023 / 4095), sizes that are multiples of nothing
+    (dict(seed=17, xsize=517, ysize=301, distance=1.0, speed_tier=3), "srgb8", 2, ("ppm", "npy")),
+    (dict(seed=18, xsize=333, ysize=267, distance=1.5, speed_tier=4), "srgb10", 4, ("ppm", "npy")),
+    (dict(seed=19, xsize=601, ysize=299, distance=0.7, speed_tier=3, alpha_bits=8), "srgb12", 7, ("pam", "npy")),
+    (dict(seed=20, xsize=259, ysize=131, distance=1.0, speed_tier=3), "srgb12", None, ("ppm", "pfm")),
 ]
 
 
@@ -291,3 +297,64 @@ def test_conformance_mini_corpus_through_djxl_hip(tools, ref, tmp_path):
     assert len(res) == len(inputs) and all(res.values()), (res, log[-20:])
     for tid, err in errs.items():
         assert "jxlhip seam: frame" in err, (tid, err[-800:])
+
+
+
+# ---- frames the seam declines (round 5) -----------------------------------------------------------------------------
+# PreparePipeline adds noise / patches / splines stages when the frame header asks (lib/jxl/dec_cache.cc:124,193-200); a
+# Modular frame, a frame that is not the file's only regular frame and passes that arrive one by one take other paths of
+# the reference.  The seam hands such frames back to libjxl's CPU path (integration/hip_seam.cc: decline): the pixels must
+# be the reference's, with no device (CPU suite) and WITH a device present (GPU suite), and the log must say why.
+# feature -> (decline lines expected, frames that run on the device when there is one)
+FEATURES = {
+    "noise": (["noise / patches / splines / DC frame"], 0),
+    "splines": (["noise / patches / splines / DC frame"], 0),
+    # the encoder writes the patch sources as a reference-only frame in front of the frame that uses them
+    "patches": (["not an XYB VarDCT frame", "noise / patches / splines / DC frame"], 0),
+    "modular": (["not an XYB VarDCT frame"], 0),
+    "animation": (["not a single regular frame"], 1),   # the last frame of the two is an ordinary VarDCT frame
+    "progressive": ([], 1),                              # whole file at hand: every pass at once, on the device
+    "plain": ([], 1),
+}
+
+
+def feature_file(ref, tmp_path, feature):
+    p = tmp_path / f"{feature}.jxl"
+    p.write_bytes(ref.feature_stream(feature, xsize=600, ysize=400, seed=5, distance=1.0))
+    return str(p)
+
+
+def check_feature(tools, ref, tmp_path, feature, device):
+    djxl_ref, djxl_hip = tools
+    declines, on_device = FEATURES[feature]
+    jxl = feature_file(ref, tmp_path, feature)
+    for ext in ("ppm", "npy"):
+        run(djxl_ref, [jxl, str(tmp_path / f"r.{ext}")])
+        err = run(djxl_hip, [jxl, str(tmp_path / f"h.{ext}")], verbose=True)
+        said = [l.split("declines the frame: ", 1)[1] for l in err.splitlines() if "jxlhip seam declines the frame" in l]
+        took = [l for l in err.splitlines() if l.startswith("jxlhip seam: frame")]
+        if device:
+            assert said == declines, (feature, err[-1500:])
+            assert len(took) == on_device, (feature, err[-1500:])
+        else:  # without a device the frames the seam would take are declined last of all: "no device"
+            assert said == declines + ["no device"] * on_device and not took, (feature, err[-1500:])
+        if device and on_device:
+            compare(str(tmp_path / f"r.{ext}"), str(tmp_path / f"h.{ext}"), ext)
+        else:  # libjxl's own path in both tools: the same bytes
+            assert (tmp_path / f"r.{ext}").read_bytes() == (tmp_path / f"h.{ext}").read_bytes(), (feature, ext)
+
+
+@pytest.mark.parametrize("feature", sorted(FEATURES))
+def test_declined_features_without_a_device(tools, ref, tmp_path, feature):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: see the GPU suite")
+    check_feature(tools, ref, tmp_path, feature, device=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("feature", sorted(FEATURES))
+def test_declined_features_with_a_device_present(tools, ref, tmp_path, feature):
+    """The same files through djxl_hip on a box WITH a device: the declined frames still come out as djxl_ref's bytes,
+    the frames beside them (the animation's last frame) run on the HIP back-end in the same process."""
+    check_feature(tools, ref, tmp_path, feature, device=True)

@@ -75,6 +75,7 @@ def test_multi_context_matches_single_context(oracle, monkeypatch, nstripes, gat
     # interior rows first (the default: they are filtered while the halo rows travel) or everything behind the exchange
     # (round 3's order): the same pixels
     monkeypatch.setenv("JXLHIP_MULTI_INTERIOR_FIRST", "0")
+    abi.load_library().jxlhip_debug_reload_env()
     assert np.array_equal(run_multi(L, devices, params, t, table_host, host_out), single)
 
 

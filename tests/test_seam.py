@@ -214,3 +214,39 @@ def test_rgba_stream_through_the_patched_jxldecoder(libs, ref, kw, orientation, 
                 assert np.array_equal(got[..., 3], want[..., 3])
     finally:
         R.JxlThreadParallelRunnerDestroy(pool)
+
+
+@pytest.mark.gpu
+def test_declined_frames_keep_the_reference_pixels_with_a_context_alive(libs, ref):
+    """Round 5: the frames the seam hands back to libjxl's CPU path (noise / splines / patches stages of PreparePipeline,
+    lib/jxl/dec_cache.cc:124,193-200; Modular frames; frames of a multi-frame file) decoded IN THE SAME PROCESS as frames
+    that ran on the device, the back-end's context alive in between: bit-identical to the unpatched decoder, the counter of
+    device frames untouched -- and the device path still works afterwards."""
+    Lr, Lh = load(libs[0]), load(libs[1])
+    R, runner, pool = hip_runner()
+    try:
+        plain = ref.feature_stream("plain")
+        n = Lh.jxlhip_seam_frames_decoded()
+        first = jxl_decode(Lh, plain, runner, pool)
+        assert Lh.jxlhip_seam_frames_decoded() == n + 1, "the control frame did not go through the HIP back-end"
+        want = jxl_decode(Lr, plain, runner, pool)
+        assert float(np.abs(first - want).max()) / max(1.0, float(np.abs(want).max())) <= TIGHT
+        for feature in ("noise", "splines", "patches", "modular"):
+            cs = ref.feature_stream(feature)
+            want = jxl_decode(Lr, cs, runner, pool)
+            n = Lh.jxlhip_seam_frames_decoded()
+            got = jxl_decode(Lh, cs, runner, pool)
+            assert Lh.jxlhip_seam_frames_decoded() == n, feature + ": a frame the seam must decline ran on the device"
+            assert np.array_equal(got, want), feature
+        # two frames: the first is declined (not the file's only frame), the last is an ordinary frame -> device
+        cs = ref.feature_stream("animation")
+        want = jxl_decode(Lr, cs, runner, pool)
+        n = Lh.jxlhip_seam_frames_decoded()
+        got = jxl_decode(Lh, cs, runner, pool)
+        assert Lh.jxlhip_seam_frames_decoded() == n + 1
+        assert float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max())) <= TIGHT
+        n = Lh.jxlhip_seam_frames_decoded()
+        again = jxl_decode(Lh, plain, runner, pool)
+        assert Lh.jxlhip_seam_frames_decoded() == n + 1 and np.array_equal(again, first)
+    finally:
+        R.JxlThreadParallelRunnerDestroy(pool)
