@@ -62,7 +62,7 @@ def available():
 
 
 def outputs():
-    return [os.path.join(B.OUT, n) for n in ("djxl_ref", "djxl_hip", "libjxl_threads_ref.so")]
+    return [os.path.join(B.OUT, n) for n in ("djxl_ref", "djxl_hip", "libjxl_threads_ref.so", "djxl_ref_v8")]
 
 
 def build(verbose=False):
@@ -107,6 +107,10 @@ def build(verbose=False):
     link([B.CXX, "-o", os.path.join(B.OUT, "djxl_ref")] + tool_objs + [dec_ref, thr_so] + libs + ["-lpthread", "-lm"] + rpath)
     link([B.CXX, "-o", os.path.join(B.OUT, "djxl_hip")] + tool_objs +
          [dec_hip, os.path.join(HIPLIB_DIR, "libjxl_threads_hip.so")] + libs + ["-lpthread", "-lm"] + rpath)
+    # djxl_ref_v8: the same tool on the decoder whose hot path runs libjxl's 8-lane SIMD code (bench.py's e2e block: the
+    # honest CPU partner of djxl_hip; the tests keep the one-lane djxl_ref as their checker)
+    dec_ref_v8 = S.build_ref_v8()
+    link([B.CXX, "-o", os.path.join(B.OUT, "djxl_ref_v8")] + tool_objs + [dec_ref_v8, thr_so] + libs + ["-lpthread", "-lm"] + rpath)
     if verbose:
         print("built", outputs())
     return outputs()[:2]

@@ -39,10 +39,13 @@ DECL = ("namespace jxl {\n"
         "                         const std::vector<std::vector<size_t>>& ac_group_sec,\n"
         "                         const std::vector<size_t>& desired_num_ac_passes, size_t ac_global_sec,\n"
         "                         size_t ac_global_bit, FrameDecoder::SectionStatus* section_status, bool* done);\n"
+        "void JxlHipNoteSectionsBegin();  // a timestamp for the seam's own clock (JXLHIP_SEAM_VERBOSE)\n"
         "}  // namespace jxl\n")
 PATCH = [
     # the declaration: after the file's own includes (FrameDecoder is complete there)
     ("namespace jxl {", DECL),
+    ("  std::fill(section_status, section_status + num, SectionStatus::kSkipped);",
+     "  JxlHipNoteSectionsBegin();  // jxlhip seam: clock only\n"),
     ("  if (finalized_dc_ && ac_global_sec != num && !decoded_ac_global_) {",
      "  // jxlhip seam: where AC global starts in its reader (a one-section frame shares the reader)\n"
      "  const size_t jxlhip_ac_global_bit = ac_global_sec != num ? sections[ac_global_sec].br->TotalBitsConsumed() : 0;\n"),
@@ -143,5 +146,36 @@ def build(verbose=False):
     return ref_so, hip_so
 
 
+def build_ref_v8(verbose=False):
+    """oracle/_ref/libjxl_dec_ref_v8.so: the unpatched reference decoder with the decode hot path (dec_group.cc and the
+    transforms it includes, the Gaborish / EPF / XYB / write stages) compiled against the 8-lane Highway stand-in
+    (oracle/build_ref.py variant "v8": libjxl's SIMD code paths, what bench.py's cpu_baseline times) -- for
+    oracle/_ref/djxl_ref_v8, the CPU partner of djxl_hip in bench.py's e2e block.  The checker of the test suite stays the
+    one-lane djxl_ref (bit-identical to the -O2 oracle build)."""
+    global FLAGS
+    so = os.path.join(B.OUT, "libjxl_dec_ref_v8.so")
+    if not B.available():
+        if os.path.exists(so):
+            return so
+        raise RuntimeError("reference tree not present and no prebuilt libjxl_dec_ref_v8.so")
+    objs = B.build(only_compile=True, variant="v8")
+    FLAGS = [f for f in B.FLAGS if f != "-O2"] + B.VARIANT_FLAGS["v8"] + ["-DJPEGXL_ENABLE_BOXES=0", "-DJPEGXL_ENABLE_TRANSCODE_JPEG=0"]
+    os.makedirs(SEAM, exist_ok=True)
+    extra_objs = []
+    for f in EXTRA_TUS:
+        o = os.path.join(SEAM, f.replace("/", "__")[:-3] + ".o")
+        _cc(os.path.join(B.REF, "lib", f), o)
+        extra_objs.append(o)
+    objs = [o for o in objs if not o.endswith("jxl__encode.o")]
+    link = ["-Wl,--gc-sections", "-Wl,-Bsymbolic", "-Wl,--no-undefined", "-lpthread", "-lm"]
+    r = subprocess.run([B.CXX, "-shared", "-fPIC", "-o", so] + objs + extra_objs + link, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("link %s failed:\n%s" % (so, r.stderr[-6000:]))
+    if verbose:
+        print("built", so)
+    return so
+
+
 if __name__ == "__main__":
     build(verbose=True)
+    build_ref_v8(verbose=True)

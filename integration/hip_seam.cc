@@ -64,6 +64,13 @@ __attribute__((visibility("default"))) int jxlhip_seam_frames_decoded() { return
 namespace jxl {
 
 namespace {
+// the seam's own clock (JXLHIP_SEAM_VERBOSE): when the current ProcessSections call began, when the last frame left
+double NowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+std::atomic<double> g_sections_begin{0.0}, g_last_frame_end{0.0};
+}  // namespace
+void JxlHipNoteSectionsBegin() { g_sections_begin.store(NowMs(), std::memory_order_relaxed); }
+
+namespace {
 jxlhip_ctx* Context() {
   static jxlhip_ctx* ctx = [] {
     jxlhip_ctx* c = nullptr;
@@ -523,9 +530,13 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   }
   if (verbose)
     fprintf(stderr, "jxlhip seam: frame %zux%zu decoded on the HIP back-end (%s, %u-bit sample type %u, %u channels); ms: "
-                    "side info %.2f, AC global + entropy decode + uploads %.2f, kernels + copy out %.2f, row callbacks %.2f\n",
+                    "side info %.2f, AC global + entropy decode + uploads %.2f, kernels + copy out %.2f, row callbacks %.2f; "
+                    "before the seam: libjxl's DC global + DC groups in this ProcessSections call %.2f, the caller + headers "
+                    "since the previous frame left %.2f\n",
             static_cast<size_t>(dim.xsize), static_cast<size_t>(dim.ysize), to_callback ? "callback" : "buffer", bits,
-            sample_type, out_nc, t_side - t_begin, t_entropy - t_side, t_decode - t_entropy, now() - t_decode);
+            sample_type, out_nc, t_side - t_begin, t_entropy - t_side, t_decode - t_entropy, now() - t_decode,
+            t_begin - g_sections_begin.load(), g_last_frame_end.load() > 0 ? g_sections_begin.load() - g_last_frame_end.load() : 0.0);
+  g_last_frame_end.store(now());
   for (size_t g = 0; g < dim.num_groups; g++) {
     fd->decoded_passes_per_ac_group_[g] = static_cast<uint8_t>(np);
     for (size_t ps = 0; ps < np && !single; ps++) section_status[ac_group_sec[g][ps]] = FrameDecoder::SectionStatus::kDone;
