@@ -603,6 +603,30 @@ def main():
     # float frame into ONE GPU is per-link bound
     dt_sharded = timed(lambda: sd.decode(out)) if gather else None
 
+    # N > 1: what the HOST spends per step to enqueue a rank's work (three calls into the library + one batch of
+    # sends / receives; no synchronisation inside the loop) -- on a 16K frame over 8 GPUs a rank's kernels take ~170 us,
+    # and a step is host-bound as soon as this figure comes near that -- and the step when every stripe leaves through its
+    # OWN GPU's PCIe link into pinned host memory instead of being gathered on one device (`host_sharded`: the consumer
+    # is the host)
+    host_enqueue_us, dt_host_sharded = None, None
+    if world > 1:
+        fence()
+        n_h = max(4, min(args.steps, 20))
+        t0 = time.perf_counter()
+        for _ in range(n_h):
+            sd.decode(out)
+        th = (time.perf_counter() - t0) / n_h
+        fence()
+        tt = torch.tensor([th], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        host_enqueue_us = round(float(tt.item()) * 1e6, 1)
+        pinned = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+
+        def step_host_sharded():
+            sd.decode(out)
+            pinned.copy_(out, non_blocking=True)
+        dt_host_sharded = timed(step_host_sharded)
+
     # N > 1: where a step's time goes on each rank (HIP events on the compute stream around the phases of
     # StripeDecoder.decode and the gather; average over the steps, then the MAX over ranks): blocks = phase 1,
     # interior = halo export + posting the sends + the rows that need no halo, halo_wait = what is left of the exchange
@@ -696,6 +720,7 @@ def main():
                        "stripes": world, "halo_rows": dec.halo_rows(),
                        "gather_in_step": bool(gather),
                        "phase_ms_max_over_ranks": phase_ms,
+                       "host_enqueue_us_per_step_max_over_ranks": host_enqueue_us,
                        "interior_first": os.environ.get("JXLHIP_STRIPES_INTERIOR_FIRST", "1") != "0" if world > 1 else None,
                        "kernel_ms": kern},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -734,6 +759,11 @@ def main():
             line["sharded"] = {"value": round(px / (dt_sharded / args.steps) / 1e6, 1), "unit": "Mpixels/s",
                                "ms_per_step": round(dt_sharded / args.steps * 1e3, 4),
                                "what": "the same frame, output stripes left in each GPU's HBM (no gather)"}
+        if dt_host_sharded is not None:
+            line["host_sharded"] = {"value": round(px / (dt_host_sharded / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                                    "ms_per_step": round(dt_host_sharded / args.steps * 1e3, 4),
+                                    "what": "the same frame, every rank copying its output stripe to pinned host memory over "
+                                            "its own GPU's PCIe link (no gather on one device)"}
         if pcie:
             line["pcie_inclusive"] = pcie
         if world == 1 and name == "c3" and not custom and not args.no_cpu_baseline:

@@ -320,6 +320,16 @@ JXLHIP_EXPORT int jxlhip_decode_filters(jxlhip_ctx* ctx, void* out,
  * last row; the pixels do not depend on how the rows are cut. */
 JXLHIP_EXPORT int jxlhip_decode_filters_rows(jxlhip_ctx* ctx, void* out, size_t out_stride, size_t out_plane_stride,
                                              uint32_t y_begin, uint32_t y_end);
+/* One stripe step in three calls (what libjxl_amd/stripes.py enqueues per rank and frame): jxlhip_stripe_begin = phase 1
+ * (jxlhip_decode_blocks) + the stripe's boundary rows into send_up / send_down (jxlhip_halo_export; NULL = no neighbour
+ * on that side); the caller then posts its sends / receives and filters the interior rows with
+ * jxlhip_decode_filters_rows while they travel; jxlhip_stripe_finish = the neighbours' rows installed
+ * (jxlhip_halo_import) + phase 2 of the rows outside [y_interior_begin, y_interior_end) (equal: of every row).
+ * Reference: the neighbour hand-off of lib/jxl/dec_group_border.cc:68-187 around the render pipeline. */
+JXLHIP_EXPORT int jxlhip_stripe_begin(jxlhip_ctx* ctx, float* send_up, float* send_down);
+JXLHIP_EXPORT int jxlhip_stripe_finish(jxlhip_ctx* ctx, const float* recv_up, const float* recv_down, void* out,
+                                       size_t out_stride, size_t out_plane_stride, uint32_t y_interior_begin,
+                                       uint32_t y_interior_end);
 
 /* Both phases (single GPU).  When the context holds the whole frame (no stripe)
  * and the stage list has at most two EPF passes this runs FUSED

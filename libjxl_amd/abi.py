@@ -225,7 +225,8 @@ EXPORTS = [
     "jxlhip_destroy", "jxlhip_last_error", "jxlhip_debug_reload_env", "jxlhip_set_stream",
     "jxlhip_frame_begin", "jxlhip_frame_set_inputs", "jxlhip_upload_side_info",
     "jxlhip_submit_group", "jxlhip_set_alpha", "jxlhip_alpha_staging", "jxlhip_decode_blocks", "jxlhip_halo_rows",
-    "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_filters_rows", "jxlhip_decode_frame",
+    "jxlhip_halo_export", "jxlhip_halo_import", "jxlhip_decode_filters", "jxlhip_decode_filters_rows", "jxlhip_stripe_begin",
+    "jxlhip_stripe_finish", "jxlhip_decode_frame",
     "jxlhip_decode_frame_host", "jxlhip_decode_frame_pinned",
     "jxlhip_sync", "jxlhip_export_xyb", "jxlhip_get_sigma",
     "jxlhip_set_concurrency_hint", "jxlhip_profile_enable", "jxlhip_profile_read",
@@ -326,6 +327,8 @@ def load_library():
     L.jxlhip_halo_import.argtypes = [vp, i32, vp]
     L.jxlhip_decode_filters.argtypes = [vp, vp, sz, sz]
     L.jxlhip_decode_filters_rows.argtypes = [vp, vp, sz, sz, u32, u32]
+    L.jxlhip_stripe_begin.argtypes = [vp, vp, vp]
+    L.jxlhip_stripe_finish.argtypes = [vp, vp, vp, vp, sz, sz, u32, u32]
     L.jxlhip_decode_frame.argtypes = [vp, vp, sz, sz]
     L.jxlhip_decode_frame_host.argtypes = [vp, vp, sz, sz]
     L.jxlhip_decode_frame_pinned.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]

@@ -1745,6 +1745,34 @@ int jxlhip_decode_filters_rows(jxlhip_ctx* c, void* out, size_t out_stride, size
   return LaunchFiltersRows(c, fp, y_begin, y_end, c->blocks_fused);
 }
 
+// ---- one stripe step in three calls (round 5) ----------------------------------------------------
+// What a rank of the striped decode (libjxl_amd/stripes.py: one process per GPU) enqueues around its halo exchange was
+// seven to nine C calls per frame -- phase 1, two exports, up to three row ranges of phase 2, two imports -- each
+// through the host language's FFI: on a 16K frame over 8 GPUs a rank's kernels take ~170 us, and the host must not take
+// as long to enqueue them.  jxlhip_stripe_begin = phase 1 + both exports; [the caller posts its sends / receives, then
+// jxlhip_decode_filters_rows for the interior]; jxlhip_stripe_finish = both imports + the boundary block rows.
+// send_* / recv_* = dense [3][halo][xsize] device buffers, nullptr = no neighbour on that side.
+int jxlhip_stripe_begin(jxlhip_ctx* c, float* send_up, float* send_down) {
+  int rc = jxlhip_decode_blocks(c);
+  if (rc) return rc;
+  if (send_up && (rc = jxlhip_halo_export(c, 0, send_up))) return rc;
+  if (send_down && (rc = jxlhip_halo_export(c, 1, send_down))) return rc;
+  return JXLHIP_OK;
+}
+
+// y_interior_begin / _end: the rows jxlhip_decode_filters_rows has filtered already between the two calls (equal:
+// none -- everything is filtered here, behind the imports)
+int jxlhip_stripe_finish(jxlhip_ctx* c, const float* recv_up, const float* recv_down, void* out, size_t out_stride,
+                         size_t out_plane_stride, uint32_t y_interior_begin, uint32_t y_interior_end) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  int rc;
+  if (recv_up && (rc = jxlhip_halo_import(c, 0, recv_up))) return rc;
+  if (recv_down && (rc = jxlhip_halo_import(c, 1, recv_down))) return rc;
+  if (y_interior_begin >= y_interior_end) return jxlhip_decode_filters(c, out, out_stride, out_plane_stride);
+  if ((rc = jxlhip_decode_filters_rows(c, out, out_stride, out_plane_stride, c->f.y0, y_interior_begin))) return rc;
+  return jxlhip_decode_filters_rows(c, out, out_stride, out_plane_stride, y_interior_end, c->f.y1);
+}
+
 // Both phases.  With JXLHIP_BAND_ROWS = n > 0 the stripe is walked in bands of n
 // group rows -- blocks(b) then filters(b-1) -- which was meant to keep a band's
 // XYB planes in the 256 MB Infinity Cache; measured on MI355X it only loses

@@ -190,6 +190,21 @@ class VarDctDecoder:
         assert tuple(buf.shape) == (3, self.halo_rows(), self.params.xsize)
         _check(self.L, self.ctx, self.L.jxlhip_halo_import(self.ctx, which, C.c_void_p(buf.data_ptr())), "halo_import")
 
+    def stripe_begin(self, send_up=None, send_down=None):
+        """Phase 1 of the stripe + its boundary rows into the dense [3, halo, xsize] send buffers (None = no neighbour
+        on that side): one call (jxlhip_stripe_begin)."""
+        a = C.c_void_p(send_up.data_ptr()) if send_up is not None else None
+        b = C.c_void_p(send_down.data_ptr()) if send_down is not None else None
+        _check(self.L, self.ctx, self.L.jxlhip_stripe_begin(self.ctx, a, b), "stripe_begin")
+
+    def stripe_finish(self, out, recv_up=None, recv_down=None, interior=None):
+        """The neighbours' rows installed + phase 2 of every row outside interior = (y_begin, y_end), which
+        decode_filters(rows=interior) has filtered already (None: of every row): one call (jxlhip_stripe_finish)."""
+        a = C.c_void_p(recv_up.data_ptr()) if recv_up is not None else None
+        b = C.c_void_p(recv_down.data_ptr()) if recv_down is not None else None
+        ya, yb = (int(interior[0]), int(interior[1])) if interior else (0, 0)
+        _check(self.L, self.ctx, self.L.jxlhip_stripe_finish(self.ctx, a, b, *self._out_args(out), ya, yb), "stripe_finish")
+
     def set_concurrency_hint(self, frames_in_flight):
         """How many contexts the caller keeps busy on this device at a time (a pool of decoders): moves the frame size
         from which decode_frame takes the fused kernel (12 Mpx alone, 6 Mpx with several frames in flight)."""

@@ -272,6 +272,50 @@ def test_stripes_through_the_fused_kernel_equal_whole_frame(dq, oracle, gab, epf
 
 
 @pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("gab,epf,interior", [(1, 1, True), (1, 2, False), (1, 3, False), (0, 0, True)])
+def test_stripe_step_in_three_calls_equals_whole_frame(dq, oracle, gab, epf, interior, fuse, monkeypatch):
+    """jxlhip_stripe_begin (phase 1 + both exports) / jxlhip_decode_filters_rows (the interior) / jxlhip_stripe_finish
+    (both imports + the boundary block rows): what libjxl_amd.stripes issues per rank since round 5.  Three stripes on
+    one device, the send buffers of one handed to the other as its receive buffers: bit-equal to the whole frame."""
+    monkeypatch.setenv("JXLHIP_FUSE", fuse)
+    params, t, fr = frames.make_case(600, 1100, mix=synth.MIX_D1, gab=bool(gab), epf_iters=epf, seed=29)
+    devt = to_dev(t)
+    d0 = VarDctDecoder(0)
+    d0.begin_frame(params)
+    d0.set_inputs(devt, dq)
+    whole = d0.decode_frame().clone()
+    d0.sync()
+    d0.close()
+    parts = [(0, 2), (2, 1), (3, 2)]
+    decs, bufs, outs = [], [], []
+    for (g0, gr) in parts:
+        d = VarDctDecoder(0)
+        d.begin_frame(dict(params, stripe_group_y0=g0, stripe_group_rows=gr))
+        d.set_inputs(devt, dq)
+        h = d.halo_rows()
+        mk = lambda: torch.full((3, h, 600), float("nan"), dtype=torch.float32, device="cuda")  # noqa: E731
+        up, dn = g0 > 0, g0 + gr < 5
+        b = dict(up=mk() if up and h else None, dn=mk() if dn and h else None)
+        d.stripe_begin(b["up"], b["dn"])
+        out = d.alloc_output()
+        y0, y1 = d.stripe_rows()
+        rows = (y0 + 8 if up else y0, y1 - 8 if dn else y1)
+        if interior:
+            d.decode_filters(out, rows=rows)
+        decs.append(d), bufs.append(b), outs.append((out, rows if interior else None))
+    torch.cuda.synchronize()
+    for i, d in enumerate(decs):  # a stripe receives the rows its neighbours exported towards it
+        d.stripe_finish(outs[i][0], bufs[i - 1]["dn"] if i > 0 else None, bufs[i + 1]["up"] if i + 1 < len(decs) else None,
+                        outs[i][1])
+        d.sync()
+    got = torch.cat([o for o, _ in outs], dim=0)
+    assert torch.equal(got, whole)
+    assert rel_err(whole.cpu().numpy(), fr.decode(threads=4)) <= TIGHT
+    for d in decs:
+        d.close()
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
 @pytest.mark.parametrize("gab,epf", [(1, 1), (1, 2), (0, 1)])
 def test_stripe_interior_rows_before_the_halo_arrives(dq, oracle, gab, epf, fuse, monkeypatch):
     """jxlhip_decode_filters_rows: a stripe filters the rows whose support stays inside it BEFORE its neighbours' halo

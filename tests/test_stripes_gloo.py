@@ -130,7 +130,31 @@ class _RecordingDecoder:
         self.calls.append(("filters", rows))
 
 
-def _flow_worker(rank, world, port, result_dir, interior_first):
+class _RecordingDecoderFast(_RecordingDecoder):
+    """... with the three-call form of round 5 (jxlhip_stripe_begin / _finish): the same sequence, recorded as the C side
+    runs it (context.hip)."""
+
+    def stripe_begin(self, send_up=None, send_down=None):
+        self.calls.append(("blocks",))
+        if send_up is not None:
+            self.halo_export(0, send_up)
+        if send_down is not None:
+            self.halo_export(1, send_down)
+
+    def stripe_finish(self, out, recv_up=None, recv_down=None, interior=None):
+        if recv_up is not None:
+            self.halo_import(0, recv_up)
+        if recv_down is not None:
+            self.halo_import(1, recv_down)
+        y0, y1 = self.frame["stripe_group_y0"] * 256, min(self.frame["ysize"], (self.frame["stripe_group_y0"] + self.frame["stripe_group_rows"]) * 256)
+        if interior is None:
+            self.decode_filters(out)
+        else:
+            self.decode_filters(out, rows=(y0, interior[0]))
+            self.decode_filters(out, rows=(interior[1], y1))
+
+
+def _flow_worker(rank, world, port, result_dir, interior_first, fast=False, timed=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -138,9 +162,14 @@ def _flow_worker(rank, world, port, result_dir, interior_first):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from libjxl_amd import stripes
     xs, ys = 300, 256 * 7
-    d = _RecordingDecoder(rank, xs)
+    d = (_RecordingDecoderFast if fast else _RecordingDecoder)(rank, xs)
     sd = stripes.StripeDecoder(d, dict(xsize=xs, ysize=ys), rank, world)
-    sd.decode(torch.zeros(1))
+    timing = {} if timed else None
+    sd.decode(torch.zeros(1), timing=timing)
+    if timed:  # bench.py's per-phase pass: one stamp per phase, in this order, through the split calls
+        order = ["t0", "blocks", "interior", "halo_wait", "boundary"]
+        stamps = [timing[k][0] for k in order]
+        assert list(timing) == order and stamps == sorted(stamps), timing
     y0, y1 = sd.rows[rank]
     up, dn = rank > 0, rank + 1 < world
     filt = [c[1] for c in d.calls if c[0] == "filters"]
@@ -168,5 +197,16 @@ def test_stripe_decoder_call_sequence_over_gloo(tmp_path, interior_first):
     neighbours' rows."""
     port = 29500 + (os.getpid() + 7 + int(interior_first)) % 2000
     mp.spawn(_flow_worker, args=(3, port, str(tmp_path), interior_first), nprocs=3, join=True)
+    for r in range(3):
+        assert (tmp_path / ("r%d" % r)).read_text() == "ok", (tmp_path / ("r%d" % r)).read_text()
+
+
+@pytest.mark.parametrize("fast,timed", [(True, False), (True, True), (False, True)])
+def test_stripe_decoder_three_call_form_and_timed_pass_over_gloo(tmp_path, fast, timed):
+    """The three-call form (stripe_begin, the interior rows, stripe_finish: round 5) issues the same sequence as the
+    split calls -- exports before the sends, the interior rows before the imports -- and bench.py's per-phase pass
+    (timing = {}) takes the split calls and leaves one stamp per phase, in order."""
+    port = 29500 + (os.getpid() + 23 + 2 * int(fast) + int(timed)) % 2000
+    mp.spawn(_flow_worker, args=(3, port, str(tmp_path), True, fast, timed), nprocs=3, join=True)
     for r in range(3):
         assert (tmp_path / ("r%d" % r)).read_text() == "ok", (tmp_path / ("r%d" % r)).read_text()
