@@ -473,10 +473,19 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the VarDCT back-end has no CPU path")
+    # (smoke tests of the N > 1 path on a one-GPU box: JXLHIP_BENCH_DEVICE=0 puts every rank on that device and
+    # JXLHIP_BENCH_BACKEND=gloo moves the halo rows through the host -- RCCL refuses two ranks on one GPU.  Timings of such
+    # a run mean nothing; the driver's runs use neither variable.)
+    if os.environ.get("JXLHIP_BENCH_DEVICE") is not None:
+        local = int(os.environ["JXLHIP_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("JXLHIP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     name = args.config or ("c3" if world == 1 else "c4")
     cfg = dict(CONFIGS[name])
@@ -539,6 +548,13 @@ def main():
     def step_one():
         dec.decode_frame(out)
 
+    red_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"  # (gloo smoke runs reduce on the host)
+    trace = os.environ.get("JXLHIP_BENCH_TRACE") is not None
+
+    def note(msg):
+        if trace:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -575,7 +591,7 @@ def main():
         fence()
         t = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([t], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([t], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
         return t
@@ -588,7 +604,9 @@ def main():
         settle_on[0] = False
         dt_unsettled = timed(step_one)
         settle_on[0] = True
+    note("set-up done; timed steps")
     dt = timed(step_one if world == 1 else step)
+    note("timed steps done")
     dt_flight = None
     if world == 1 and inflight > 1:
         for d, _ in slots:
@@ -602,6 +620,7 @@ def main():
     # every GPU writing its own stripe to the host): the form in which the split scales -- the gather of a 1.59 GB
     # float frame into ONE GPU is per-link bound
     dt_sharded = timed(lambda: sd.decode(out)) if gather else None
+    note("sharded steps done")
 
     # N > 1: what the HOST spends per step to enqueue a rank's work (three calls into the library + one batch of
     # sends / receives; no synchronisation inside the loop) -- on a 16K frame over 8 GPUs a rank's kernels take ~170 us,
@@ -617,7 +636,7 @@ def main():
             sd.decode(out)
         th = (time.perf_counter() - t0) / n_h
         fence()
-        tt = torch.tensor([th], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([th], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         host_enqueue_us = round(float(tt.item()) * 1e6, 1)
         pinned = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
@@ -626,6 +645,7 @@ def main():
             sd.decode(out)
             pinned.copy_(out, non_blocking=True)
         dt_host_sharded = timed(step_host_sharded)
+        note("host-sharded steps done")
 
     # N > 1: where a step's time goes on each rank (HIP events on the compute stream around the phases of
     # StripeDecoder.decode and the gather; average over the steps, then the MAX over ranks): blocks = phase 1,
@@ -650,10 +670,11 @@ def main():
                 vals.append(sum(x.elapsed_time(y) for x, y in zip(T[a], T[b])) / len(T[a]))
             else:
                 vals.append(0.0)
-        tt = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        tt = torch.tensor(vals, dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         phase_ms = {k: round(float(v), 4) for k, v in zip(order[1:], tt.tolist())}
 
+    note("per-phase pass done")
     # per-kernel device time with HIP events on the launch stream (own pass)
     dec.profile(True)
     for _ in range(args.steps):

@@ -40,12 +40,21 @@ DECL = ("namespace jxl {\n"
         "                         const std::vector<size_t>& desired_num_ac_passes, size_t ac_global_sec,\n"
         "                         size_t ac_global_bit, FrameDecoder::SectionStatus* section_status, bool* done);\n"
         "void JxlHipNoteSectionsBegin();  // a timestamp for the seam's own clock (JXLHIP_SEAM_VERBOSE)\n"
+        "void JxlHipAfterDcGlobal(FrameDecoder* fd, const BitReader* br);\n"
+        "Status JxlHipDcGroup(FrameDecoder* fd, size_t dc_group, BitReader* br, bool* handled);\n"
         "}  // namespace jxl\n")
 PATCH = [
     # the declaration: after the file's own includes (FrameDecoder is complete there)
     ("namespace jxl {", DECL),
     ("  std::fill(section_status, section_status + num, SectionStatus::kSkipped);",
      "  JxlHipNoteSectionsBegin();  // jxlhip seam: clock only\n"),
+    # the DC groups through the product's host front-end, written into the reference's own state
+    ("      section_status[dc_global_sec] = SectionStatus::kDone;",
+     "      JxlHipAfterDcGlobal(this, sections[dc_global_sec].br);  // jxlhip seam\n"),
+    ("        JXL_RETURN_IF_ERROR(ProcessDCGroup(i, sections[dc_group_sec[i]].br));",
+     "        bool jxlhip_dc = false;  // jxlhip seam: the product's DC-group decoder when it takes the section\n"
+     "        JXL_RETURN_IF_ERROR(JxlHipDcGroup(this, i, sections[dc_group_sec[i]].br, &jxlhip_dc));\n"
+     "        if (!jxlhip_dc)\n"),
     ("  if (finalized_dc_ && ac_global_sec != num && !decoded_ac_global_) {",
      "  // jxlhip seam: where AC global starts in its reader (a one-section frame shares the reader)\n"
      "  const size_t jxlhip_ac_global_bit = ac_global_sec != num ? sections[ac_global_sec].br->TotalBitsConsumed() : 0;\n"),

@@ -78,6 +78,41 @@ def gather_stripes(stripe, rows_per_rank, rank, world, dst=0, group=None):
     return None
 
 
+class _HostStaged:
+    """Point-to-point transfers of device tensors over a backend that moves host memory only (gloo): the sends are
+    copied to the host when posted, the receives copied back by wait().  Only for smoke-testing the N > 1 flow on a box
+    with one GPU (bench.py JXLHIP_BENCH_BACKEND=gloo); with RCCL the device tensors travel as they are."""
+
+    def __init__(self, sends, recvs, group):
+        if sends and sends[0][0].is_cuda:
+            torch.cuda.synchronize()
+        self.recvs = [(t, torch.empty(t.shape, dtype=t.dtype), peer) for t, peer in recvs]
+        ops = [dist.P2POp(dist.isend, t.detach().to("cpu").contiguous(), peer, group) for t, peer in sends]
+        ops += [dist.P2POp(dist.irecv, h, peer, group) for _, h, peer in self.recvs]
+        self.reqs = dist.batch_isend_irecv(ops) if ops else []
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
+        for t, h, _ in self.recvs:
+            t.copy_(h)
+
+
+def _post(sends, recvs, group, staged):
+    """sends / recvs: [(tensor, peer)].  Returns an object with wait()."""
+    if staged:
+        return _HostStaged(sends, recvs, group)
+    ops = [dist.P2POp(dist.isend, t, peer, group) for t, peer in sends]
+    ops += [dist.P2POp(dist.irecv, t, peer, group) for t, peer in recvs]
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+
+    class _Reqs:
+        def wait(self):
+            for r in reqs:
+                r.wait()
+    return _Reqs()
+
+
 class StripeDecoder:
     """VarDctDecoder for this rank's stripe + the halo exchange."""
 
@@ -89,6 +124,9 @@ class StripeDecoder:
         self.rows = [stripe_pixel_rows(params["ysize"], a, b) for a, b in self.parts]
         decoder.begin_frame(self.params)
         self._halo = None  # persistent send / receive buffers of the halo exchange
+        # device tensors over a host-only backend (a one-GPU smoke test): staged through the host
+        self.staged = bool(world > 1 and dist.is_initialized() and dist.get_backend(group) == "gloo" and
+                           getattr(decoder, "tensor_device", "cuda") != "cpu")
         import os
         self.interior_first = os.environ.get("JXLHIP_STRIPES_INTERIOR_FIRST", "1") != "0"
 
@@ -118,12 +156,10 @@ class StripeDecoder:
         if self.rank == 0:
             a, b = self.rows[0]
             full[a:b].copy_(stripe)
-            ops = [dist.P2POp(dist.irecv, full[self.rows[r][0]:self.rows[r][1]], r, self.group)
-                   for r in range(1, self.world)]
+            req = _post([], [(full[self.rows[r][0]:self.rows[r][1]], r) for r in range(1, self.world)], self.group, self.staged)
         else:
-            ops = [dist.P2POp(dist.isend, stripe, 0, self.group)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+            req = _post([(stripe, 0)], [], self.group, self.staged)
+        req.wait()
         return full
 
     def decode(self, out, timing=None):
@@ -162,18 +198,19 @@ class StripeDecoder:
             d.decode_filters(out)
             mark("interior")
             return out
-        ops = []
+        sends, recvs = [], []
         if up:
             if not fast:
                 d.halo_export(0, b["up_send"])
-            ops += [dist.P2POp(dist.isend, b["up_send"], self.rank - 1, self.group),
-                    dist.P2POp(dist.irecv, b["up_recv"], self.rank - 1, self.group)]
+            sends.append((b["up_send"], self.rank - 1))
+            recvs.append((b["up_recv"], self.rank - 1))
         if dn:
             if not fast:
                 d.halo_export(1, b["dn_send"])
-            ops += [dist.P2POp(dist.isend, b["dn_send"], self.rank + 1, self.group),
-                    dist.P2POp(dist.irecv, b["dn_recv"], self.rank + 1, self.group)]
-        reqs = dist.batch_isend_irecv(ops)
+            sends.append((b["dn_send"], self.rank + 1))
+            recvs.append((b["dn_recv"], self.rank + 1))
+        # (send up / receive from up / send down / receive from down: the order the ranks' batches pair up in)
+        req = _post(sends, recvs, self.group, self.staged)
         # INTERIOR FIRST: while the halo messages fly, filter the rows whose support stays inside the stripe -- all
         # but the first / last block row next to a neighbour (8 rows >= LoopFilter::Padding(), loop_filter.h:26-29;
         # the reference overlaps its neighbour hand-off as well, dec_group_border.cc:68-187).  (Enqueued AFTER the
@@ -185,8 +222,7 @@ class StripeDecoder:
         if split:
             d.decode_filters(out, rows=(ya, yb))
         mark("interior")
-        for req in reqs:
-            req.wait()
+        req.wait()
         mark("halo_wait")
         if fast:
             d.stripe_finish(out, b["up_recv"] if up else None, b["dn_recv"] if dn else None, (ya, yb) if split else None)

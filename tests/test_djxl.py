@@ -149,6 +149,37 @@ def test_both_tools_agree_without_a_device(tools, ref, tmp_path):
     assert mx == 255 and a.shape == (120, 200, 4) and len(np.unique(a[..., 3])) > 16
 
 
+def test_dc_groups_through_the_product_front_end_leave_the_reference_state(tools, ref, tmp_path, monkeypatch):
+    """Round 5: a VarDCT frame's DC groups are decoded by the product's host front-end (jxlhip_dc_group_decode) and written
+    into libjxl's own state (integration/hip_seam.cc: JxlHipDcGroup) -- FrameDecoder::ProcessDCGroup is not called for
+    them.  Without a device everything behind runs on libjxl's CPU path FROM THAT STATE: the bytes must be djxl_ref's.
+    JXLHIP_SEAM_LIBJXL_DC=1 leaves the DC groups to libjxl (the control)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: see the GPU suite")
+    djxl_ref, djxl_hip = tools
+    for name, data in (("rgb", stream(ref, original="srgb8", seed=21, xsize=2200, ysize=300, distance=1.0)),
+                       ("rgba", stream(ref, original="srgb16", seed=22, xsize=520, ysize=300, distance=1.5, alpha_bits=8)),
+                       ("prog", ref.feature_stream("progressive"))):
+        jxl = tmp_path / f"{name}.jxl"
+        jxl.write_bytes(data)
+        ext = "pam" if name == "rgba" else "ppm"
+        run(djxl_ref, [str(jxl), str(tmp_path / f"r.{ext}")])
+        for libjxl_dc in (False, True):
+            if libjxl_dc:
+                monkeypatch.setenv("JXLHIP_SEAM_LIBJXL_DC", "1")
+            else:
+                monkeypatch.delenv("JXLHIP_SEAM_LIBJXL_DC", raising=False)
+            err = run(djxl_hip, [str(jxl), str(tmp_path / f"h.{ext}")], verbose=True)
+            took = [l for l in err.splitlines() if "DC groups decoded by the product's front-end" in l]
+            if libjxl_dc:
+                assert not took, err[-800:]
+            else:
+                n = 2 if name == "rgb" else 1
+                assert took and took[0].startswith(f"jxlhip seam: {n} of {n} DC groups"), err[-800:]
+            assert (tmp_path / f"r.{ext}").read_bytes() == (tmp_path / f"h.{ext}").read_bytes(), (name, libjxl_dc)
+
+
 def test_conformance_runner_agrees_with_the_reference_script(tools, ref, tmp_path):
     """Build container only: the corpus tools/conformance_hip.py writes is accepted by libjxl's own conformance.py,
     the corpus libjxl's generator.py writes is accepted by tools/conformance_hip.py, and both report a damaged
