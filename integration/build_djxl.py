@@ -5,7 +5,7 @@
                          codecs compile to their "not available" stubs) on oracle/_ref/libjxl_dec_ref.so (the
                          reference decoder, unpatched) and oracle/_ref/libjxl_threads_ref.so (lib/threads)
   oracle/_ref/djxl_hip   the same objects on oracle/_ref/libjxl_dec_hip.so (the reference decoder with the
-                         three-statement seam of integration/build_seam.py -> libjxl_hip.so) and the product's runner
+                         seam of integration/build_seam.py -> libjxl_hip.so) and the product's runner
                          libjxl_amd/csrc/libjxl_threads_hip.so
 
 Every translation unit is compiled in place from /root/reference (g++, the Highway shim of oracle/hwy_shim);

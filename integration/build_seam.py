@@ -11,7 +11,8 @@ reference translation units oracle/build_ref.py builds (objects reused from orac
                                   oracle/_build/seam/, git-ignored, never committed) + integration/hip_seam.cc,
                                   linked against libjxl_amd/csrc/libjxl_hip.so
 
-The patch is three inserted statements, applied by anchor (PATCH below) -- the reference file is read where it
+The patch is six insertions (declarations, the seam's clock, the DC-group hook of round 5 -- JxlHipAfterDcGlobal /
+JxlHipDcGroup --, AC global's bit position, JxlHipTryAcGroups), applied by anchor (PATCH below) -- the reference file is read where it
 lies under /root/reference; nothing of it is stored in this repository.  tests/test_seam.py drives both libraries
 through JxlDecoderProcessInput on genuine codestreams with the JxlParallelRunner of libjxl_threads_hip.so and
 holds their pixels to 2e-5 of each other.

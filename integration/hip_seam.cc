@@ -2,9 +2,10 @@
 // HIP back-end behind JxlDecoder (built into oracle/_ref/libjxl_dec_hip.so by integration/build_seam.py, on the reference
 // sources where they lie; libjxl_hip.so itself never links or loads it).
 //
-// integration/build_seam.py makes a patched COPY of the reference's lib/jxl/dec_frame.cc (two inserted statements,
-// see there) in which FrameDecoder::ProcessSections, once DC global / DC groups / AC global are decoded by the
-// reference's own code and every AC section of the frame is present, calls JxlHipTryAcGroups() below instead of
+// integration/build_seam.py makes a patched COPY of the reference's lib/jxl/dec_frame.cc (six insertions, see there)
+// in which FrameDecoder::ProcessSections (1) hands a VarDCT frame's DC groups to JxlHipDcGroup() below -- the product's
+// host front-end decodes them and writes the reference's own state -- and (2), once DC global / DC groups / AC global
+// are in and every AC section of the frame is present, calls JxlHipTryAcGroups() below instead of
 // running DecodeGroup + the CPU render pipeline per group (lib/jxl/dec_frame.cc:694-731).  This function is the
 // ~150 lines a libjxl maintainer would write: it lifts the per-frame state out of PassesSharedState /
 // PassesDecoderState (dec_cache.h:86-229, passes_state.h:48-95) into the C ABI of include/jxl_hip.h, hands the
@@ -443,16 +444,27 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
   std::vector<int32_t> rq(nb);
   std::vector<int8_t> ytox(xt * yt), ytob(xt * yt);
   std::vector<float> dc(3 * nb);
+  // the dense arrays are at hand already when every DC group came through the product's front-end (JxlHipDcGroup)
+  const bool dense_at_hand = dc_state && dc_state->groups_taken.load() == dim.num_dc_groups && dc_state->acs.size() == nb;
+  if (dense_at_hand) {
+    acs.swap(dc_state->acs);
+    rq.swap(dc_state->rq);
+    sharp.swap(dc_state->sharp);
+    ytox.swap(dc_state->ytox);
+    ytob.swap(dc_state->ytob);
+  }
   for (size_t y = 0; y < ysb; y++) {
-    const AcStrategyRow row = sh.ac_strategy.ConstRow(y);
-    for (size_t x = 0; x < xsb; x++)
-      acs[y * xsb + x] = static_cast<uint8_t>((row[x].RawStrategy() << 1) | (row[x].IsFirstBlock() ? 1 : 0));
-    memcpy(&rq[y * xsb], sh.raw_quant_field.ConstRow(y), xsb * sizeof(int32_t));
-    memcpy(&sharp[y * xsb], sh.epf_sharpness.ConstRow(y), xsb);
+    if (!dense_at_hand) {
+      const AcStrategyRow row = sh.ac_strategy.ConstRow(y);
+      for (size_t x = 0; x < xsb; x++)
+        acs[y * xsb + x] = static_cast<uint8_t>((row[x].RawStrategy() << 1) | (row[x].IsFirstBlock() ? 1 : 0));
+      memcpy(&rq[y * xsb], sh.raw_quant_field.ConstRow(y), xsb * sizeof(int32_t));
+      memcpy(&sharp[y * xsb], sh.epf_sharpness.ConstRow(y), xsb);
+    }
     memcpy(&qctx[y * xsb], sh.quant_dc.ConstRow(y), xsb);
     for (int c = 0; c < 3; c++) memcpy(&dc[c * nb + y * xsb], sh.dc->ConstPlaneRow(c, y), xsb * sizeof(float));
   }
-  for (size_t y = 0; y < yt; y++) {
+  for (size_t y = 0; y < yt && !dense_at_hand; y++) {
     memcpy(&ytox[y * xt], sh.cmap.ytox_map.ConstRow(y), xt);
     memcpy(&ytob[y * xt], sh.cmap.ytob_map.ConstRow(y), xt);
   }

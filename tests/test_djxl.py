@@ -1,7 +1,7 @@
 """djxl, unmodified, on the HIP back-end (integration/build_djxl.py).
 
   oracle/_ref/djxl_ref : tools/djxl_main.cc + lib/extras on the reference decoder + lib/threads
-  oracle/_ref/djxl_hip : the SAME objects on libjxl_dec_hip.so (reference JxlDecoder + the three-statement seam ->
+  oracle/_ref/djxl_hip : the SAME objects on libjxl_dec_hip.so (reference JxlDecoder + the seam ->
                          libjxl_hip.so) + libjxl_threads_hip.so (the product's JxlParallelRunner)
 
 djxl always decodes through an image-out CALLBACK (lib/extras/dec/jxl.h:64, jxl.cc:543-556) and asks for the
