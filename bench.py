@@ -607,6 +607,37 @@ def main():
     note("set-up done; timed steps")
     dt = timed(step_one if world == 1 else step)
     note("timed steps done")
+    # `graph_replay`: the frame's launches recorded ONCE into a hipGraph (stream capture around jxlhip_decode_frame) and
+    # replayed per step -- what a caller that decodes frame after frame of one geometry (video, a tile server) can do;
+    # the library needs nothing but to keep its per-frame state inside the graph (context.hip: DecodeFrameCoded).
+    dt_graph = None
+    if world == 1 and not os.environ.get("JXLHIP_BENCH_NO_GRAPH"):
+        try:
+            cs = torch.cuda.Stream()
+            main_stream = torch.cuda.current_stream()
+            cs.wait_stream(main_stream)
+            dec.set_stream(cs)
+            with torch.cuda.stream(cs):
+                dec.decode_frame(out)  # (buffers sized, nothing left to allocate inside the capture)
+            cs.synchronize()
+            note("graph: warm-up on the capture stream done")
+            keep = out.clone()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=cs):
+                dec.decode_frame(out)
+            note("graph: captured")
+            out.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            note("graph: first replay done")
+            assert torch.equal(out, keep), "the replayed graph decoded a different frame"
+            dt_graph = timed(graph.replay)
+            note("graph: timed replays done")
+            del keep
+        except Exception as ex:  # (the figure is a side measurement: the line must come out)
+            dt_graph = repr(ex)[:200]
+        finally:
+            dec.set_stream(main_stream)
     dt_flight = None
     if world == 1 and inflight > 1:
         for d, _ in slots:
@@ -768,6 +799,14 @@ def main():
                                  "ms_per_step": round(dt_unsettled / args.steps * 1e3, 4),
                                  "what": "the same W warm-up + K timed steps on one context straight after set-up, without the "
                                          "device-settle phase (--settle-ms 0): the device's clocks still ramping"}
+        if isinstance(dt_graph, float):
+            line["graph_replay"] = {"value": round(px / (dt_graph / args.steps) / 1e6, 1), "unit": "Mpixels/s",
+                                    "ms_per_step": round(dt_graph / args.steps * 1e3, 4),
+                                    "frac": round(b_alg_frame / (dt_graph / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "what": "one context, one frame at a time, the frame's three launches captured once into a "
+                                            "hipGraph and replayed per step (pixels checked against the direct call)"}
+        elif dt_graph is not None:
+            line["graph_replay"] = {"error": dt_graph}
         if dt_flight is not None:
             line["frames_in_flight"] = {"value": round(px / (dt_flight / args.steps) / 1e6, 1), "unit": "Mpixels/s",
                                         "ms_per_step": round(dt_flight / args.steps * 1e3, 4), "contexts": inflight,

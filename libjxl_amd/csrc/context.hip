@@ -22,21 +22,7 @@
 #include "kernels.h"
 #include "dither_pattern.inc"
 
-#include "env_switches.h"
-namespace jxlhip_env {
-Switches g;
-void LoadLocked() {
-  g.wp_general.store(getenv("JXLHIP_WP_GENERAL") != nullptr);
-  g.dc_tree.store(getenv("JXLHIP_DC_TREE") != nullptr);
-  g.codestream_verbose.store(getenv("JXLHIP_CODESTREAM_VERBOSE") != nullptr);
-  g.no_pipeline.store(getenv("JXLHIP_NO_PIPELINE") != nullptr);
-  const char* e = getenv("JXLHIP_TEST_RANGE_GROUP");
-  g.test_range_group.store(e ? atoll(e) : -1);
-  const char* ife = getenv("JXLHIP_MULTI_INTERIOR_FIRST");
-  g.multi_interior_first.store(!ife || atoi(ife) != 0 ? 1 : 0);
-  g.loaded.store(true, std::memory_order_release);
-}
-}  // namespace jxlhip_env
+#include "env_switches.h"  // (the switches themselves live in entropy.cc: that file is also built alone, by the fuzz harnesses)
 extern "C" __attribute__((visibility("default"))) void jxlhip_debug_reload_env(void) {
   std::lock_guard<std::mutex> lock(jxlhip_env::g.mu);
   jxlhip_env::LoadLocked();
@@ -1634,7 +1620,14 @@ int BeginDecode(jxlhip_ctx* c, uint32_t nbands) {
   }
   if (nbands > (uint32_t)kMaxBands) nbands = kMaxBands;
   if (nbands) {
-    HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kCountStride * nbands, st));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap == hipStreamCaptureStatusActive) {  // (see LaunchZeroU32: no memset node at the root of a frame graph)
+      LaunchZeroU32(c->counts, (uint32_t)(kCountStride * nbands), st);
+      HIPCHK(c, hipGetLastError());
+    } else {
+      HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kCountStride * nbands, st));
+    }
     c->counts_clean[0] = c->counts_clean[1] = false;  // used by the bands that follow
   }
   return JXLHIP_OK;
@@ -1818,7 +1811,13 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   while ((f.group_rows + br - 1) / br > (uint32_t)kMaxBands) br++;
   // one band (the default): the counter blocks 0 / 1 alternate and k_prepare zeroes the next frame's -- no memset launch
   const uint32_t nbands = (f.group_rows + br - 1) / br;
-  const bool one_band = nbands == 1;
+  // Under stream capture -- the caller records the frame's launches into a hipGraph and replays it (bench.py's
+  // `graph_replay`: the command processor's ~5-8 us per dependent launch are paid once per graph instead) -- every
+  // replay must find the SAME counter block zeroed by a node of the graph itself: the alternating blocks assume that
+  // consecutive frames are consecutive calls.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(c->stream, &cap);
+  const bool one_band = nbands == 1 && cap != hipStreamCaptureStatusActive;
   const int slot = one_band ? c->counts_slot : 0;
   int rc = BeginDecode(c, one_band ? 0 : nbands);
   if (rc) return rc;

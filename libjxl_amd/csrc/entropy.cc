@@ -8,6 +8,21 @@
 // Behavioural specification: ISO/IEC 18181-1 annexes C (entropy coding) and
 // I.3.5-I.3.7, as implemented by the reference at the lines cited per function.
 #include "env_switches.h"
+#include <stdlib.h>
+namespace jxlhip_env {
+Switches g;
+void LoadLocked() {
+  g.wp_general.store(getenv("JXLHIP_WP_GENERAL") != nullptr);
+  g.dc_tree.store(getenv("JXLHIP_DC_TREE") != nullptr);
+  g.codestream_verbose.store(getenv("JXLHIP_CODESTREAM_VERBOSE") != nullptr);
+  g.no_pipeline.store(getenv("JXLHIP_NO_PIPELINE") != nullptr);
+  const char* e = getenv("JXLHIP_TEST_RANGE_GROUP");
+  g.test_range_group.store(e ? atoll(e) : -1);
+  const char* ife = getenv("JXLHIP_MULTI_INTERIOR_FIRST");
+  g.multi_interior_first.store(!ife || atoi(ife) != 0 ? 1 : 0);
+  g.loaded.store(true, std::memory_order_release);
+}
+}  // namespace jxlhip_env
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>

@@ -19,8 +19,8 @@ struct Switches {
   std::atomic<int> multi_interior_first{1};
   std::mutex mu;
 };
-extern Switches g;  // defined in context.hip
-void LoadLocked();  // context.hip
+extern Switches g;  // defined in entropy.cc
+void LoadLocked();  // entropy.cc
 static inline const Switches& Get() {
   if (!g.loaded.load(std::memory_order_acquire)) {
     std::lock_guard<std::mutex> lock(g.mu);

@@ -101,6 +101,7 @@ bool FusedEpf0Supported(const DevFrame& f, int gab);
 bool LaunchFusedEpf0(const DevFrame& f, const FilterParams& p, int gab, float* const dst[3], hipStream_t st);
 
 // block-major plane rows <-> dense row-major staging
+void LaunchZeroU32(uint32_t* p, uint32_t n, hipStream_t st);  // (kernels_tables.hip: a kernel, for captured graphs)
 void LaunchRowsCopy(const DevFrame& f, float* dense, int y_first, int nrows, int ncols,
                     size_t dense_stride, size_t dense_plane, int nch, bool to_dense,
                     hipStream_t st);

@@ -317,6 +317,18 @@ __global__ __launch_bounds__(1024) void k_expand_sparse(const uint8_t* __restric
   }
 }
 
+// Zeroes n 32-bit words with a KERNEL (not hipMemsetAsync): the first node of a captured frame graph.  A memset node at
+// the root of a hipGraph was observed (ROCm 7.2, MI355X) to start before the previous launch of the same graph on the
+// same stream had finished -- it zeroed the work-list counters under the previous frame's transform kernel (memory
+// fault); a kernel node keeps stream order.
+__global__ __launch_bounds__(256) void k_zero_u32(uint32_t* __restrict__ p, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+void LaunchZeroU32(uint32_t* p, uint32_t n, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_zero_u32, dim3((n + 255u) / 256u), dim3(256), 0, st, p, n);
+}
+
 void LaunchExpandSparse(const uint8_t* sparse, const uint32_t* offsets, int16_t* dense, uint32_t g0, uint32_t n, hipStream_t st) {
   if (n) hipLaunchKernelGGL(k_expand_sparse, dim3(n), dim3(1024), 0, st, sparse, offsets, dense, g0);
 }

@@ -190,6 +190,10 @@ class VarDctDecoder:
         assert tuple(buf.shape) == (3, self.halo_rows(), self.params.xsize)
         _check(self.L, self.ctx, self.L.jxlhip_halo_import(self.ctx, which, C.c_void_p(buf.data_ptr())), "halo_import")
 
+    def set_stream(self, stream):
+        """All launches of this context go to `stream` (a torch.cuda.Stream) from now on."""
+        _check(self.L, self.ctx, self.L.jxlhip_set_stream(self.ctx, C.c_void_p(stream.cuda_stream), 1), "set_stream")
+
     def stripe_begin(self, send_up=None, send_down=None):
         """Phase 1 of the stripe + its boundary rows into the dense [3, halo, xsize] send buffers (None = no neighbour
         on that side): one call (jxlhip_stripe_begin)."""
