@@ -49,9 +49,11 @@ def run_case(dec, ref, xs, ys, **kw):
     dec.sync()
     got = out.cpu().numpy()
     npy = {k: ([x.cpu().numpy() for x in v] if isinstance(v, list) else v.cpu().numpy()) for k, v in t.items()}
+    # the reference decodes with ITS OWN dequant tables (DequantMatrices::EnsureComputed), not with the product's: a
+    # wrong table on the device cannot cancel out (test_dequant_tables_bit_identical_to_reference pins the two besides)
     fr = ref.Frame(frames.to_oracle_params(abi.make_params(params)), npy["coeffs"], npy["ac_strategy"],
                    npy["raw_quant"], npy["epf_sharpness"], npy["ytox_map"], npy["ytob_map"], npy["dc"],
-                   dq.cpu().numpy())
+                   ref.ref_default_dequant_tables())
     want = fr.decode_ref(threads=THREADS)
     assert got.shape == want.shape
     scale = max(1.0, float(np.abs(want).max()))

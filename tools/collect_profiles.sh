@@ -5,7 +5,7 @@ for cfg in c1 c2 c3 c4 c5 real8k c3_epf3; do
   for f in bench.json kernel_stats.csv; do [ -s gpurun_out/${tag}_${cfg}_$f ] && cp gpurun_out/${tag}_${cfg}_$f profiles/${tag}_${cfg}_$f; done
   [ -s gpurun_out/pmc_traffic_${tag}_$cfg.json ] && cp gpurun_out/pmc_traffic_${tag}_$cfg.json profiles/${tag}_${cfg}_pmc_traffic.json
 done
-for f in c3_bench_full.json c5_mfma_counters.txt c3_mfma_counters.txt commit.txt frames_in_flight_sweep.txt; do [ -s gpurun_out/${tag}_$f ] && cp gpurun_out/${tag}_$f profiles/${tag}_$f; done
+for f in c3_bench_full.json c5_mfma_counters.txt c3_mfma_counters.txt commit.txt; do [ -s gpurun_out/${tag}_$f ] && cp gpurun_out/${tag}_$f profiles/${tag}_$f; done
 # the file bench.py replays for roofline.traffic: the c3 passes, stamped with the commit they were taken at
 python3 - <<PY
 import json

@@ -2,6 +2,7 @@
 # GPU box: per-kernel durations of one bench.py configuration (rocprofv3 --kernel-trace --stats)
 # usage: tools/kstats.sh "<ENV=.. ENV=..>" [bench args]
 envs="$1"; shift
+export JXLHIP_BENCH_NO_GRAPH=1  # (profiling / experiment runs: no hipGraph side measurement)
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p

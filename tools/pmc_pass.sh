@@ -1,6 +1,7 @@
 #!/bin/bash
 # Usage (GPU box): tools/pmc_pass.sh "<counter list>" [bench args]  -> per-kernel averages
 ctrs="$1"; shift
+export JXLHIP_BENCH_NO_GRAPH=1  # (profiling / experiment runs: no hipGraph side measurement)
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmcx

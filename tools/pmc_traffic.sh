@@ -4,6 +4,7 @@
 # share a pass; FETCH_SIZE under-counts wide streaming reads 2x on gfx950 -- the
 # run also times a known-size copy to calibrate both).
 tag=${1:-run}; shift
+export JXLHIP_BENCH_NO_GRAPH=1  # (profiling / experiment runs: no hipGraph side measurement)
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 mkdir -p $O

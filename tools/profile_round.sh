@@ -4,6 +4,7 @@
 # (--frames-in-flight 1: one context, so that rocprofv3's per-kernel durations are those of kernels running alone --
 # with several frames in flight launches of different streams overlap and the profiler's durations include the wait)
 tag=$1; shift
+export JXLHIP_BENCH_NO_GRAPH=1  # (profiling / experiment runs: no hipGraph side measurement)
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag

@@ -16,7 +16,7 @@ run c5 --config c5
 run real8k --mix real4k
 run c3_epf3 --epf 3
 timeout 1200 python bench.py > $O/${tag}_c3_bench_full.json 2> /dev/null
-for f in 1 2 3 4; do timeout 300 python bench.py --no-cpu-baseline --no-pcie --steps 200 --frames-in-flight $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('frames in flight $f:', d['value'], 'Mpx/s', d['ms_per_step'], 'ms')"; done > $O/${tag}_frames_in_flight_sweep.txt; cat $O/${tag}_frames_in_flight_sweep.txt
+# (frames in flight: the default bench line above carries `frames_in_flight` with private inputs per context)
 # matrix cores: the shipped c5 kernel (k_transform_mfma32<EMIT>) and the c3 step (no MFMA instruction in it)
 for cfg in c5 c3; do
   extra=""; [ $cfg = c5 ] && extra="--config c5"
