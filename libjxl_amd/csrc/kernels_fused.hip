@@ -1335,6 +1335,12 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
   const int x0 = x_first - kFusedHalo;
   const int bc0 = x0 >> 3;
   const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
+#ifdef JXLHIP_PC_STAGGER  // experiment builds: windows start up to 7 x JXLHIP_PC_STAGGER x 64 cycles apart, so that the
+  {                       // chip's windows do not all fill / march / store in the same phase of their block-row period
+    const int k = ((int)blockIdx.x >> 3) & 7;
+    for (int i = 0; i < k; i++) __builtin_amdgcn_s_sleep(JXLHIP_PC_STAGGER);
+  }
+#endif
   if (wave == 1) {
 #if JXLHIP_PC_PRODUCER_PRIO > 0
     __builtin_amdgcn_s_setprio(JXLHIP_PC_PRODUCER_PRIO);
