@@ -272,6 +272,46 @@ def test_stripes_through_the_fused_kernel_equal_whole_frame(dq, oracle, gab, epf
 
 
 @pytest.mark.parametrize("fuse", ["1", "0"])
+def test_decode_frame_under_stream_capture_replays_bit_identically(dq, oracle, fuse, monkeypatch):
+    """A caller may record jxlhip_decode_frame into a hipGraph and replay it (bench.py's `graph_replay`): under capture
+    the library keeps its per-frame state inside the graph -- the work-list counters are zeroed by a KERNEL node of the
+    graph (a memset node at the root was seen to overtake the previous replay of the same graph: a memory fault), and
+    the alternating counter blocks of consecutive direct calls are not used.  Five replays back to back, then a direct
+    call again: the same pixels every time."""
+    monkeypatch.setenv("JXLHIP_FUSE", fuse)
+    params, t, fr = frames.make_case(1000, 520, mix=synth.MIX_D1, gab=True, epf_iters=1, seed=61)
+    d = VarDctDecoder(0)
+    d.begin_frame(params)
+    d.set_inputs(to_dev(t), dq)
+    want = d.decode_frame().clone()
+    d.sync()
+    assert rel_err(want.cpu().numpy(), fr.decode(threads=4)) <= TIGHT
+    cs = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    cs.wait_stream(main)
+    d.set_stream(cs)
+    out = d.alloc_output()
+    with torch.cuda.stream(cs):
+        d.decode_frame(out)  # (everything allocated before the capture)
+    cs.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cs):
+        d.decode_frame(out)
+    for _ in range(5):
+        out.zero_()
+        g.replay()
+        g.replay()  # back to back, no synchronisation in between
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+    d.set_stream(main)
+    out.zero_()
+    d.decode_frame(out)
+    d.sync()
+    assert torch.equal(out, want)
+    d.close()
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
 @pytest.mark.parametrize("gab,epf,interior", [(1, 1, True), (1, 2, False), (1, 3, False), (0, 0, True)])
 def test_stripe_step_in_three_calls_equals_whole_frame(dq, oracle, gab, epf, interior, fuse, monkeypatch):
     """jxlhip_stripe_begin (phase 1 + both exports) / jxlhip_decode_filters_rows (the interior) / jxlhip_stripe_finish
