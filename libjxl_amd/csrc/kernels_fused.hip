@@ -61,6 +61,12 @@
 #ifndef JXLHIP_PC_PRODUCER_PRIO
 #define JXLHIP_PC_PRODUCER_PRIO 3
 #endif
+// 1 (experiment builds): the producer's slab writes under an EXEC mask inside one asm statement, as the march's output
+// stores -- measured: 2362 -> 2261 instructions per two block rows, the kernel 189.1 -> 189.7 us: nothing, so the
+// compiler's own exec branches stay
+#ifndef JXLHIP_PC_DECODE_ONE_BLOCK
+#define JXLHIP_PC_DECODE_ONE_BLOCK 0
+#endif
 #ifndef JXLHIP_PC_INTERIOR  // 0: every chunk takes the generic march (experiments)
 #define JXLHIP_PC_INTERIOR 1
 #endif
@@ -674,6 +680,8 @@ __device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroup
     if (s * 8 < R.n8) {  // wave-uniform
       const PcStepRegs& T = R.st[s];
       const bool valid = s * 8 + (lane & 7) < R.n8;
+      const unsigned long long valid_mask = __ballot(valid);
+      (void)valid_mask;
       float sx, sy, sb, x_cc, b_cc;
       {
         const int quant = (int)(T.qc & 0xffffu);
@@ -719,13 +727,30 @@ __device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroup
         IdctReg<8>(v);
         Transpose8Lanes(v, bit3);
         IdctReg<8>(v);
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        LdsF* dst = slab + c * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
+#if JXLHIP_PC_DECODE_ONE_BLOCK
+        {  // the two slab writes under an EXEC mask inside one asm statement: the step's three channels stay ONE basic
+           // block (as the march's output stores, filters_march.h) and their independent chains interleave
+          unsigned long long saved;
+          const f4v lo = f4v{v[0], v[1], v[2], v[3]}, hi = f4v{v[4], v[5], v[6], v[7]};
+          const uint32_t addr = (uint32_t)(uintptr_t)dst;
+          asm volatile(
+              "s_and_saveexec_b64 %0, %1\n\t"
+              "ds_write_b128 %2, %3\n\t"
+              "ds_write_b128 %2, %4 offset:16\n\t"
+              "s_mov_b64 exec, %0"
+              : "=&s"(saved)
+              : "s"(valid_mask), "v"(addr), "v"(lo), "v"(hi)
+              : "memory", "scc");
+        }
+#else
         if (valid) {
-          typedef float f4v __attribute__((ext_vector_type(4)));
           typedef f4v __attribute__((address_space(3))) * P4;
-          LdsF* dst = slab + c * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
           *(P4)dst = f4v{v[0], v[1], v[2], v[3]};
           *(P4)(dst + 4) = f4v{v[4], v[5], v[6], v[7]};
         }
+#endif
       }
     }
   }
