@@ -189,8 +189,14 @@ def test_one_runner_call_equals_three_barriers(L, ref, kw, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("barriers", [False, True])
-def test_redo_with_int32_coefficients(L, ref, barriers, monkeypatch):
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("barriers,workers,group", [(False, 9, "11"), (True, 9, "11"),
+                                                   # two worker threads, the reporting group under either DC group of
+                                                   # the frame (9 x 3 AC groups, 2 DC groups: columns 0-7 and 8): whichever
+                                                   # DC group ends last, the tickets waiting on it must be woken (the
+                                                   # wake-up is sent under the job's mutex since round 5)
+                                                   (False, 2, "8"), (False, 2, "0"), (False, 2, "26"), (False, 1, "17")])
+def test_redo_with_int32_coefficients(L, ref, barriers, workers, group, monkeypatch):
     """A coefficient beyond 16 bits on the optimistic 16-bit attempt: every AC group is decoded again into int32 buffers
     (jxl_hip_entropy.h) -- from inside the single runner call (the AC groups stop, the DC groups go on) and from the
     three-barrier path.  No stream of the reference encoder at ordinary settings gets there: the test hook
@@ -204,14 +210,14 @@ def test_redo_with_int32_coefficients(L, ref, barriers, monkeypatch):
     R.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
     R.JxlThreadParallelRunnerDestroy.argtypes = [C.c_void_p]
     runner = C.cast(R.JxlThreadParallelRunner, C.c_void_p)
-    pool = R.JxlThreadParallelRunnerCreate(None, 9)
+    pool = R.JxlThreadParallelRunnerCreate(None, workers)
     dec = VarDctDecoder(0)
     if barriers:
         monkeypatch.setenv("JXLHIP_NO_PIPELINE", "1")
         abi.load_library().jxlhip_debug_reload_env()
     try:
         got = []
-        for hook in (None, "11", None):
+        for hook in (None, group, None):
             if hook:
                 monkeypatch.setenv("JXLHIP_TEST_RANGE_GROUP", hook)
                 abi.load_library().jxlhip_debug_reload_env()
