@@ -1517,7 +1517,9 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     if (grid_8 && !merged_r) hipLaunchKernelGGL((k_transform_8<CT>), dim3(grid_8), dim3(256), 0, s0, f, wl);
   }
   if (merged_r) {  // -10 us per 8K d1.0 frame against two launches, -15 us more with family A inside
-    const uint32_t big_wgs = have_big ? (grid_a < 512u ? grid_a : 512u) : 0u;
+    uint32_t big_cap = 512u;
+    if (const char* e = getenv("JXLHIP_BIG_WGS")) big_cap = (uint32_t)atoi(e);  // experiments: workgroups of the 64-point family
+    const uint32_t big_wgs = have_big ? (grid_a < big_cap ? grid_a : big_cap) : 0u;
     const uint32_t special_wgs = specials_in_r ? grid_specials : 0u;
     const uint32_t dct8_wgs = dct8_in_r ? grid_dct8 : 0u;
     hipLaunchKernelGGL((k_transform_r<CT>), dim3(special_wgs + big_wgs + grid_r16 + dct8_wgs), dim3(256), 0, s0, f, wl,
