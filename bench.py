@@ -611,7 +611,9 @@ def main():
     # replayed per step -- what a caller that decodes frame after frame of one geometry (video, a tile server) can do;
     # the library needs nothing but to keep its per-frame state inside the graph (context.hip: DecodeFrameCoded).
     dt_graph = None
-    if world == 1 and not os.environ.get("JXLHIP_BENCH_NO_GRAPH"):
+    # OPT-IN (JXLHIP_BENCH_GRAPH=1): measured slower than direct launches (profiles/r05_graph_replay_bench.json: 0.291 vs
+    # 0.282 ms), and a side figure must not be able to take the whole line down with it.
+    if world == 1 and os.environ.get("JXLHIP_BENCH_GRAPH") and not os.environ.get("JXLHIP_BENCH_NO_GRAPH"):
         try:
             cs = torch.cuda.Stream()
             main_stream = torch.cuda.current_stream()
