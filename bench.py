@@ -406,7 +406,7 @@ def e2e_block(torch, local):
                 for threads in sorted({t for t in (16, 64) if t <= ncpu}):
                     try:
                         r = subprocess.run([exe] + args + ["--num_reps", "10", "--num_threads", str(threads)],
-                                           capture_output=True, text=True, env=env, timeout=600)
+                                           capture_output=True, text=True, env=env, timeout=120)
                     except subprocess.TimeoutExpired:
                         continue
                     m = re.search(r"([0-9.]+) MP/s", r.stderr)
