@@ -439,15 +439,70 @@ __device__ __forceinline__ int PcGroups(int y_begin, int y_end) {
   return (HX > 0 ? 1 : 0) + whole + (tail ? 1 : 0);
 }
 
+// -DJXLHIP_PC_TIMING (experiment builds, tools/r05/pc_timing.py): every wave adds up the shader-clock ticks it spends
+// (a) waiting for its own loads / LDS operations in front of a barrier and (b) inside s_barrier waiting for the other
+// wave, and leaves the sums -- with its total run time -- in the first words of the frame's inv_sigma table (read back
+// through jxlhip_get_sigma; the pixels of such a build are garbage near the frame's corner).
+#ifdef JXLHIP_PC_TIMING
+struct PcClock {
+  unsigned long long wait_mem = 0, wait_barrier = 0, t_begin = 0;
+};
+__device__ PcClock* g_pc_clock_unused;  // (keeps the type referenced in builds without a user)
+#define JXLHIP_PC_CLOCK_ARG , PcClock& clk
+#define JXLHIP_PC_CLOCK_PASS , clk
+__device__ __forceinline__ void PcBarrierProducer(PcClock& clk) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  asm volatile("s_barrier" ::: "memory");
+  const unsigned long long t2 = __builtin_readcyclecounter();
+  clk.wait_mem += t1 - t0;
+  clk.wait_barrier += t2 - t1;
+}
+__device__ __forceinline__ void PcBarrierMarch(PcClock& clk) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  asm volatile("s_barrier" ::: "memory");
+  const unsigned long long t2 = __builtin_readcyclecounter();
+  clk.wait_mem += t1 - t0;
+  clk.wait_barrier += t2 - t1;
+}
+__device__ __forceinline__ void PcClockReport(float* inv_sigma, const PcClock& clk, int role) {
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* out = (unsigned long long*)inv_sigma + 4 * role;
+    atomicAdd(out + 0, __builtin_readcyclecounter() - clk.t_begin);
+    atomicAdd(out + 1, clk.wait_mem);
+    atomicAdd(out + 2, clk.wait_barrier);
+    atomicAdd(out + 3, 1ull);
+    // where the wave ran: HW_REG_HW_ID (wave, SIMD, CU, shader array / engine, XCC ids), one word per wave
+    uint32_t hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    ((uint32_t*)inv_sigma)[64 + 2 * (2 * (int)blockIdx.x + role) + 0] = hw;
+    ((uint32_t*)inv_sigma)[64 + 2 * (2 * (int)blockIdx.x + role) + 1] = xcc;
+  }
+}
+#define PcBarrierProducer() PcBarrierProducer(clk)
+#define PcBarrierMarch() PcBarrierMarch(clk)
+#else
+#define JXLHIP_PC_CLOCK_ARG
+#define JXLHIP_PC_CLOCK_PASS
 __device__ __forceinline__ void PcBarrierProducer() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ void PcBarrierMarch() {  // no vmcnt: the output stores stay in flight
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+#endif
 
 template <int HX, typename CT>
 __device__ __forceinline__ void ProducePC(FrameArgs fa, StripLds* w, int bc0, int y_begin, int y_end, int nb_last) {
+#ifdef JXLHIP_PC_TIMING
+  PcClock clk;
+  clk.t_begin = __builtin_readcyclecounter();
+#endif
   const int lane = threadIdx.x & 63;
   const int r_first = HX ? y_begin - 8 : y_begin;
   const int G = PcGroups<HX>(y_begin, y_end);
@@ -758,6 +813,10 @@ __device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroup
 
 template <int HX>
 __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, int y_begin, int y_end, int nb_last) {
+#ifdef JXLHIP_PC_TIMING
+  PcClock clk;
+  clk.t_begin = __builtin_readcyclecounter();
+#endif
   const int lane = threadIdx.x & 63;
   const int r_first = HX ? y_begin - 8 : y_begin;
   const int G = PcGroups<HX>(y_begin, y_end);
@@ -811,6 +870,9 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
     body(g, A, B, sg_a, sg_b, n1);
     if (g + 1 < G) body(g + 1, B, A, sg_b, sg_a, n1);
   }
+#ifdef JXLHIP_PC_TIMING
+  PcClockReport(fa->inv_sigma, clk, 1);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1071,6 +1133,10 @@ __device__ __forceinline__ void TileCompute(FrameArgs fa, LdsF* slab, const LdsU
 
 template <int HX, typename CT>
 __device__ __forceinline__ void ProduceTiles(FrameArgs fa, StripLds* w, int bc0, int y_begin, int y_end, int nb_last) {
+#ifdef JXLHIP_PC_TIMING
+  PcClock clk;
+  clk.t_begin = __builtin_readcyclecounter();
+#endif
   constexpr int kSlots = sizeof(CT) == 2 ? JXLHIP_TILE_SLOTS : 3;
   const int lane = threadIdx.x & 63;
   const int l15 = lane & 15, h = lane >> 4;
@@ -1198,6 +1264,10 @@ __device__ __forceinline__ void PcPadIssue() {
 template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, bool INTERIOR, int NB = 2>
 __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P, Lane& L, StripLdsT<NB>* w, int bc0,
                                         int y_begin, int y_end) {
+#ifdef JXLHIP_PC_TIMING
+  PcClock clk;
+  clk.t_begin = __builtin_readcyclecounter();
+#endif
   constexpr int HX = MarchGeom<GAB, EPF>::HX;
   constexpr int KI = INTERIOR ? (int)kStepInterior : 0;                  // a step that writes nothing
   constexpr int KE = INTERIOR ? (int)(kStepInterior | kStepEmit) : 0;   // a step that writes its row
@@ -1327,6 +1397,9 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
   }
 #undef JXLHIP_PGROUP
 #undef JXLHIP_PSTEPK
+#ifdef JXLHIP_PC_TIMING
+  PcClockReport(f.inv_sigma, clk, 0);
+#endif
 }
 
 // blockIdx.x is dispatched round-robin over the 8 XCDs: logical workgroup = (xcd, slot) -> xcd * per + slot, so
@@ -1351,6 +1424,9 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
   const int per = (int)gridDim.x >> 3;
   const int logical = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   if (logical >= nwg) return;
+#ifdef JXLHIP_PC_TIMING  // (the sums are added when the waves end, a hundred microseconds from here)
+  if (logical == 0 && threadIdx.x < 8) ((unsigned long long*)f.inv_sigma)[threadIdx.x] = 0ull;
+#endif
   const int strip = logical % strips, chunk = logical / strips;
   const int W = (int)f.xsize;
   const int x_first = strip * kFusedUse;
@@ -1607,6 +1683,10 @@ static constexpr int kPc0PartLds = JXLHIP_PC0_PART_LDS;  // (see k_fused_pc0)
 template <int GAB, bool EDGE>
 __device__ __forceinline__ void MarchPC0(const DevFrame& f, const FilterParams& P, Lane& L, StripLds* w, int bc0, int y_begin,
                                          int y_end, float* const (&dst)[3], LdsF* part_lds) {
+#ifdef JXLHIP_PC_TIMING
+  PcClock clk;
+  clk.t_begin = __builtin_readcyclecounter();
+#endif
   constexpr int HX = GAB + 3;
   constexpr int PART_LDS = GAB ? kPc0PartLds : 0;
   const int H = (int)f.ysize;
