@@ -480,8 +480,10 @@ __device__ __forceinline__ void PcClockReport(float* inv_sigma, const PcClock& c
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    ((uint32_t*)inv_sigma)[64 + 2 * (2 * (int)blockIdx.x + role) + 0] = hw;
-    ((uint32_t*)inv_sigma)[64 + 2 * (2 * (int)blockIdx.x + role) + 1] = xcc;
+    ((uint32_t*)inv_sigma)[64 + 4 * (2 * (int)blockIdx.x + role) + 0] = hw;
+    ((uint32_t*)inv_sigma)[64 + 4 * (2 * (int)blockIdx.x + role) + 1] = xcc;
+    ((uint32_t*)inv_sigma)[64 + 4 * (2 * (int)blockIdx.x + role) + 2] = (uint32_t)(__builtin_readcyclecounter() - clk.t_begin);
+    ((uint32_t*)inv_sigma)[64 + 4 * (2 * (int)blockIdx.x + role) + 3] = (uint32_t)clk.wait_barrier;
   }
 }
 #define PcBarrierProducer() PcBarrierProducer(clk)
@@ -1408,6 +1410,13 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
 template <int GAB, int EPF, int OUTK, int FMT, typename CT>
 __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, FilterParams P, int RH, int strips, int nwg, int role_shift) {
   __shared__ StripLds lds;
+#ifdef JXLHIP_PC_LDS_PAD  // experiment builds: fewer windows per CU (how fast is a march with its SIMD to itself?)
+  __shared__ char lds_pad[JXLHIP_PC_LDS_PAD];
+  {
+    volatile char* vp = lds_pad;  // (keeps the array)
+    if (threadIdx.x == 0) vp[JXLHIP_PC_LDS_PAD - 1] = (char)blockIdx.x;
+  }
+#endif
   // which of the two waves marches: swapped on every 2^role_shift-th workgroup (in dispatch order), so that the
   // SIMDs of a CU -- which receive a workgroup's waves in turn -- each get marching and producing waves
   const int lane = threadIdx.x & 63;

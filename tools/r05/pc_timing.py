@@ -26,16 +26,22 @@ for name, m in (("c3 (d1 mix)", mix), ("genuine-content mix", bench.resolve_mix(
             print(f"{name}: {label}: {n} waves, run {total / n:9.0f} ticks; waiting for own memory / LDS in front of a barrier "
                   f"{100.0 * wmem / total:5.1f} %, inside s_barrier {100.0 * wbar / total:5.1f} %, computing {100.0 * (total - wmem - wbar) / total:5.1f} %")
     # placement: which waves shared a SIMD?  HW_ID (gfx9): wave [3:0], simd [5:4], pipe [7:6], cu [11:8], sh [12], se [15:13]
-    words = dec.sigma().cpu().numpy().reshape(-1)[64:64 + 4 * 1536 * 2 + 64].view(np.uint32)
+    words = dec.sigma().cpu().numpy().reshape(-1)[64:64 + 8 * 1536 * 2 + 64].view(np.uint32)
     import collections
     simds = collections.defaultdict(list)
     for wg in range(1536):
         for role in (0, 1):
-            hw, xcc = int(words[2 * (2 * wg + role)]), int(words[2 * (2 * wg + role) + 1])
+            hw, xcc, run, wbar = [int(words[4 * (2 * wg + role) + k]) for k in range(4)]
             if hw == 0 and xcc == 0:
                 continue
             key = (xcc & 0xf, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf, (hw >> 4) & 3)
-            simds[key].append(role)
-    comp = collections.Counter((r.count(0), r.count(1)) for r in simds.values())
+            simds[key].append((role, run, wbar))
+    comp = collections.Counter((sum(1 for r in v if r[0] == 0), sum(1 for r in v if r[0] == 1)) for v in simds.values())
     print(f"{name}: SIMDs by (marching waves, producing waves) resident on them:", dict(sorted(comp.items())), "on", len(simds), "SIMDs")
+    for kind in ((2, 1), (1, 2)):
+        runs = [r[1] - r[2] for v in simds.values() if (sum(1 for r in v if r[0] == 0), sum(1 for r in v if r[0] == 1)) == kind
+                for r in v if r[0] == 0]
+        if runs:
+            print(f"{name}: marching waves on SIMDs with {kind[0]} marches + {kind[1]} producers: {len(runs)} waves, run minus barrier "
+                  f"time mean {np.mean(runs):9.0f} ticks (min {np.min(runs)}, max {np.max(runs)})")
     dec.close()
