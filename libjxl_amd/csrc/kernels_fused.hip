@@ -67,6 +67,14 @@
 #ifndef JXLHIP_PC_DECODE_ONE_BLOCK
 #define JXLHIP_PC_DECODE_ONE_BLOCK 0
 #endif
+// 1 (experiment builds): the producer's X and B channels as the halves of packed fp32 operations (PcDecode).  Measured:
+// 2032 -> 1761 VALU instructions per two block rows, bit-identical pixels, the kernel 189.7 -> 189.2 us: nothing -- a
+// packed fp32 instruction occupies the SIMD ~1.6x as long as a plain one (tools/probes/valu_issue.hip: 2.75 against 1.76
+// cycles), so pairing two plain operations into one packed one buys a fifth of their time, not half.  The scalar form
+// stays the shipped one.
+#ifndef JXLHIP_PC_PACKED_XB
+#define JXLHIP_PC_PACKED_XB 0
+#endif
 #ifndef JXLHIP_PC_INTERIOR  // 0: every chunk takes the generic march (experiments)
 #define JXLHIP_PC_INTERIOR 1
 #endif
@@ -728,7 +736,67 @@ __device__ __forceinline__ void PcDmaPlanes(const PcK& K, LdsF* slab, uint32_t m
   }
 }
 
-__device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroupRegs& R, const float (&tab)[3][8]) {
+// The X and B channels of a decode step as the two halves of packed fp32 operations (round 5): the SIMDs' instruction
+// throughput bounds k_fused_pc (profiles/r05_fused_pc_issue_analysis.txt, sections 4-5), and the producing wave spent
+// 2 x 64 instructions per step on the two chroma channels' 8-point IDCTs and 2 x 72 on their dequantisation.  Packed
+// operations are IEEE per element: every value goes through the same operations in the same order as in the scalar form
+// (IdctReg<8>, AdjustQuantBias) -- the pixels are bit-identical.  LAST = the second pass: its final butterfly level is
+// left scalar so that each channel's eight results sit in consecutive registers for the two ds_write_b128.
+typedef float pc2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pc2f PcFma2(float m, pc2f a, pc2f b) { return __builtin_elementwise_fma(pc2f{m, m}, a, b); }
+template <int N>
+__device__ __forceinline__ void IdctReg2(pc2f* __restrict__ v) {
+  if constexpr (N == 2) {
+    const pc2f a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  } else {
+    constexpr int H = N / 2;
+    pc2f e[H], o[H];
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      e[i] = v[2 * i];
+      o[i] = v[2 * i + 1];
+    }
+    IdctReg2<H>(e);
+#pragma unroll
+    for (int i = H - 1; i > 0; i--) o[i] = o[i] + o[i - 1];
+    o[0] = o[0] * pc2f{kSqrt2, kSqrt2};
+    IdctReg2<H>(o);
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      const float mul = kWcHost[N + i];
+      v[i] = PcFma2(mul, o[i], e[i]);
+      v[N - 1 - i] = PcFma2(-mul, o[i], e[i]);
+    }
+  }
+}
+// the 8-point IDCT of both channels with the last level scalar: x[8], b[8] = the .x / .y results
+__device__ __forceinline__ void Idct8PackedSplit(const pc2f* __restrict__ v, float* __restrict__ x, float* __restrict__ b) {
+  pc2f e[4], o[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    e[i] = v[2 * i];
+    o[i] = v[2 * i + 1];
+  }
+  IdctReg2<4>(e);
+#pragma unroll
+  for (int i = 3; i > 0; i--) o[i] = o[i] + o[i - 1];
+  o[0] = o[0] * pc2f{kSqrt2, kSqrt2};
+  IdctReg2<4>(o);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float mul = kWcHost[8 + i];
+    x[i] = __builtin_fmaf(mul, o[i].x, e[i].x);
+    x[7 - i] = __builtin_fmaf(-mul, o[i].x, e[i].x);
+    b[i] = __builtin_fmaf(mul, o[i].y, e[i].y);
+    b[7 - i] = __builtin_fmaf(-mul, o[i].y, e[i].y);
+  }
+}
+
+__device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroupRegs& R, const float (&tab)[3][8],
+                                         const pc2f (&tabxb)[8]) {
+  (void)tabxb;
   const int lane = threadIdx.x & 63;
   const int j = lane >> 3;
   const bool bit3 = (lane & 8) != 0;
@@ -763,6 +831,61 @@ __device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroup
       unpack(T.rows[1], q);
 #pragma unroll
       for (int k = 0; k < 8; k++) vy[k] = AdjustQuantBias(q[k], bias1, bias3) * (tab[1][k] * sy);
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      typedef f4v __attribute__((address_space(3))) * P4;
+#if JXLHIP_PC_PACKED_XB
+      {
+        // X | B: AdjustQuantBias (quantizer-inl.h:34-67) + table x scale + chroma from luma on both at once
+        int32_t qb[8];
+        unpack(T.rows[0], q);
+        unpack(T.rows[2], qb);
+        pc2f xb[8];
+        const pc2f bias02 = pc2f{bias0, bias2}, nb3 = pc2f{-bias3, -bias3}, cc2 = pc2f{x_cc, b_cc}, sc2 = pc2f{sx, sb};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const pc2f quant = pc2f{(float)q[k], (float)qb[k]};
+          const pc2f small = bias02 * quant;
+          const pc2f rc = pc2f{__builtin_amdgcn_rcpf(quant.x), __builtin_amdgcn_rcpf(quant.y)};
+          const pc2f big = __builtin_elementwise_fma(nb3, rc, quant);
+          const pc2f adj = pc2f{__builtin_fabsf(quant.x) < 1.125f ? small.x : big.x, __builtin_fabsf(quant.y) < 1.125f ? small.y : big.y};
+          const pc2f d = adj * (tabxb[k] * sc2);
+          xb[k] = __builtin_elementwise_fma(cc2, pc2f{vy[k], vy[k]}, d);
+        }
+        if (j == 0) xb[0] = pc2f{__uint_as_float(T.dcv[0]), __uint_as_float(T.dcv[2])};
+        IdctReg2<8>(xb);
+        float tx[8], tb[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          tx[k] = xb[k].x;
+          tb[k] = xb[k].y;
+        }
+        Transpose8Lanes(tx, bit3);
+        Transpose8Lanes(tb, bit3);
+#pragma unroll
+        for (int k = 0; k < 8; k++) xb[k] = pc2f{tx[k], tb[k]};
+        Idct8PackedSplit(xb, tx, tb);
+        if (valid) {
+          LdsF* dx = slab + 0 * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
+          LdsF* db = slab + 2 * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
+          *(P4)dx = f4v{tx[0], tx[1], tx[2], tx[3]};
+          *(P4)(dx + 4) = f4v{tx[4], tx[5], tx[6], tx[7]};
+          *(P4)db = f4v{tb[0], tb[1], tb[2], tb[3]};
+          *(P4)(db + 4) = f4v{tb[4], tb[5], tb[6], tb[7]};
+        }
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = vy[k];
+        if (j == 0) v[0] = __uint_as_float(T.dcv[1]);
+        IdctReg<8>(v);
+        Transpose8Lanes(v, bit3);
+        IdctReg<8>(v);
+        if (valid) {
+          LdsF* dy = slab + 1 * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
+          *(P4)dy = f4v{v[0], v[1], v[2], v[3]};
+          *(P4)(dy + 4) = f4v{v[4], v[5], v[6], v[7]};
+        }
+      }
+#else
 #pragma unroll
       for (int ci3 = 0; ci3 < 3; ci3++) {
         const int c = ci3 == 0 ? 1 : (ci3 == 1 ? 0 : 2);
@@ -784,7 +907,6 @@ __device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroup
         IdctReg<8>(v);
         Transpose8Lanes(v, bit3);
         IdctReg<8>(v);
-        typedef float f4v __attribute__((ext_vector_type(4)));
         LdsF* dst = slab + c * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
 #if JXLHIP_PC_DECODE_ONE_BLOCK
         {  // the two slab writes under an EXEC mask inside one asm statement: the step's three channels stay ONE basic
@@ -803,12 +925,12 @@ __device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroup
         }
 #else
         if (valid) {
-          typedef f4v __attribute__((address_space(3))) * P4;
           *(P4)dst = f4v{v[0], v[1], v[2], v[3]};
           *(P4)(dst + 4) = f4v{v[4], v[5], v[6], v[7]};
         }
 #endif
       }
+#endif  // JXLHIP_PC_PACKED_XB
     }
   }
 }
@@ -834,6 +956,13 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
       tab[c][0] = t0.x, tab[c][1] = t0.y, tab[c][2] = t0.z, tab[c][3] = t0.w;
       tab[c][4] = t1.x, tab[c][5] = t1.y, tab[c][6] = t1.z, tab[c][7] = t1.w;
     }
+  }
+  // (the X | B entries as register PAIRS, the operand form of the packed dequantisation)
+  pc2f tabxb[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    tabxb[k] = pc2f{tab[0][k], tab[2][k]};
+    asm volatile("" : "+v"(tabxb[k]));
   }
   LdsU* list = (LdsU*)w->list[0];
   auto group_nb = [&](int g) { return GroupBlockRow(r_first + 8 * (g < G ? g : G - 1), nb_last); };
@@ -861,7 +990,7 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
     sg_nxt = nn.sg;
     PcRequest(K, nn, group_nb(g + 2), bc0);
 #ifndef JXLHIP_ABL_PC_NODECODE  // ablation builds (timing only): the producer without its DCT8 arithmetic
-    PcDecode(K, slab, CUR, tab);
+    PcDecode(K, slab, CUR, tab, tabxb);
 #endif
     if (lane < 16) ((LdsU*)w->sigma[g & 1])[lane] = sg_cur;
     PcBarrierProducer();
