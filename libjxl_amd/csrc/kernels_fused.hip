@@ -962,7 +962,9 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     tabxb[k] = pc2f{tab[0][k], tab[2][k]};
+#if JXLHIP_PC_PACKED_XB
     asm volatile("" : "+v"(tabxb[k]));
+#endif
   }
   LdsU* list = (LdsU*)w->list[0];
   auto group_nb = [&](int g) { return GroupBlockRow(r_first + 8 * (g < G ? g : G - 1), nb_last); };
