@@ -230,10 +230,12 @@ JXLHIP_EXPORT int jxlhip_create_multi(const int* devices, int num_devices,
                                       const JxlMemoryManagerHip* memory_manager, jxlhip_ctx** out);
 JXLHIP_EXPORT void jxlhip_destroy(jxlhip_ctx* ctx);
 JXLHIP_EXPORT const char* jxlhip_last_error(const jxlhip_ctx* ctx);
-/* The library reads its debug / test switches (JXLHIP_WP_GENERAL, JXLHIP_NO_PIPELINE, JXLHIP_TEST_RANGE_GROUP,
- * JXLHIP_CODESTREAM_VERBOSE, JXLHIP_MULTI_INTERIOR_FIRST, JXLHIP_DC_TREE) from the environment ONCE per process, at
- * their first use; a test that changes one of them afterwards calls this to have them read again.  Decoding never
- * calls getenv for them (no reference counterpart: libjxl has no run-time switches on this path). */
+/* The library samples its debug / test switches (JXLHIP_WP_GENERAL, JXLHIP_NO_PIPELINE, JXLHIP_TEST_RANGE_GROUP,
+ * JXLHIP_CODESTREAM_VERBOSE, JXLHIP_MULTI_INTERIOR_FIRST, JXLHIP_DC_TREE, and the kernels' launch-geometry knobs
+ * JXLHIP_FUSED_PC, JXLHIP_FUSED_PC_RH, JXLHIP_FUSED_PC_ROLE, JXLHIP_FUSED_PC0_ROLE, JXLHIP_FUSED_TILES, JXLHIP_BIG_WGS,
+ * JXLHIP_DEBUG) from the environment when a context is created (jxlhip_create / _ex / _multi) and at their first use
+ * before that; a test that changes one of them under a live context calls this to have them read again.  Decoding and
+ * kernel launches never call getenv (no reference counterpart: libjxl has no run-time switches on this path). */
 JXLHIP_EXPORT void jxlhip_debug_reload_env(void);
 /* external != 0: all launches go to the caller's hipStream_t `hip_stream`
  * (NULL = the device's default stream, which is what torch's default stream

@@ -352,6 +352,10 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
   jxlhip_ctx* c = NewCtx(memory_manager);
   if (!c) return JXLHIP_ERR_OUT_OF_MEMORY;
   c->device = device;
+  {  // the debug / test switches follow the environment as it is when a context is created (and at no other time)
+    std::lock_guard<std::mutex> lock(jxlhip_env::g.mu);
+    jxlhip_env::LoadLocked();
+  }
   {
     const char* e = getenv("JXLHIP_FILTERS");
     c->generic_filters = e && !strcmp(e, "generic");
@@ -593,10 +597,7 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   if ((rc = Grow(c, &c->inv_sigma, &c->sigma_floats, (size_t)f.xsb * f.ysb))) return rc;
   f.inv_sigma = c->inv_sigma;
   f.error_flag = c->error_flag;
-  {
-    const char* e = getenv("JXLHIP_DEBUG");
-    f.debug = e ? (uint32_t)atoi(e) : 0;
-  }
+  f.debug = (uint32_t)jxlhip_env::Get().debug_bits.load(std::memory_order_relaxed);
   // work lists, worst case per class
   const size_t cells = (size_t)f.xsg * f.group_rows * 1024;
   size_t total = 0;

@@ -20,6 +20,17 @@ void LoadLocked() {
   g.test_range_group.store(e ? atoll(e) : -1);
   const char* ife = getenv("JXLHIP_MULTI_INTERIOR_FIRST");
   g.multi_interior_first.store(!ife || atoi(ife) != 0 ? 1 : 0);
+  auto num = [](const char* name, int unset) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : unset;
+  };
+  g.fused_pc.store(num("JXLHIP_FUSED_PC", Switches::kUnset));
+  g.fused_pc_rh.store(num("JXLHIP_FUSED_PC_RH", 0));
+  g.fused_pc_role.store(num("JXLHIP_FUSED_PC_ROLE", Switches::kUnset));
+  g.fused_pc0_role.store(num("JXLHIP_FUSED_PC0_ROLE", Switches::kUnset));
+  g.fused_tiles.store(num("JXLHIP_FUSED_TILES", 0));
+  g.big_wgs.store(num("JXLHIP_BIG_WGS", Switches::kUnset));
+  g.debug_bits.store(num("JXLHIP_DEBUG", 0));
   g.loaded.store(true, std::memory_order_release);
 }
 }  // namespace jxlhip_env

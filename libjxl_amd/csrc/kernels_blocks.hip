@@ -18,6 +18,7 @@
 #include <initializer_list>
 
 #include "blocks_common.h"
+#include "env_switches.h"
 
 namespace jxlhip {
 
@@ -1518,7 +1519,8 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
   }
   if (merged_r) {  // -10 us per 8K d1.0 frame against two launches, -15 us more with family A inside
     uint32_t big_cap = 512u;
-    if (const char* e = getenv("JXLHIP_BIG_WGS")) big_cap = (uint32_t)atoi(e);  // experiments: workgroups of the 64-point family
+    const int big_env = jxlhip_env::Get().big_wgs.load(std::memory_order_relaxed);  // experiments: workgroups of the 64-point family
+    if (big_env != jxlhip_env::Switches::kUnset) big_cap = (uint32_t)big_env;
     const uint32_t big_wgs = have_big ? (grid_a < big_cap ? grid_a : big_cap) : 0u;
     const uint32_t special_wgs = specials_in_r ? grid_specials : 0u;
     const uint32_t dct8_wgs = dct8_in_r ? grid_dct8 : 0u;

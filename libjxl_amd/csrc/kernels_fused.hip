@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "blocks_common.h"
+#include "env_switches.h"
 #include "filters_march.h"
 #if defined(JXLHIP_FUSED_PART) && JXLHIP_FUSED_PART == 3
 #include "epf0_march.h"
@@ -1639,8 +1640,7 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
 
 // rows per window chunk: a multiple of 8 that fills whole generations of resident workgroups (6 per CU)
 int FusedRowsPC(unsigned strips, unsigned rows, unsigned per_cu = JXLHIP_PC_PER_CU) {
-  const char* e = getenv("JXLHIP_FUSED_PC_RH");  // experiments / tests: rows per window chunk
-  const int forced = e ? atoi(e) : 0;
+  const int forced = jxlhip_env::Get().fused_pc_rh.load(std::memory_order_relaxed);  // experiments / tests: rows per window chunk
   if (forced > 0) return (forced + 7) & ~7;
   const unsigned resident = 256u * per_cu;
   int best = 64;
@@ -1663,8 +1663,8 @@ void LaunchFusedPcT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
   const int RH = FusedRowsPC(strips, f.fy1 - f.fy0);
   const unsigned nwg = strips * ((f.fy1 - f.fy0 + RH - 1) / RH);
   const dim3 grid((nwg + 7) & ~7u);
-  const char* e = getenv("JXLHIP_FUSED_PC_ROLE");  // experiments: -1 = wave 0 always marches
-  const int role_shift = e ? atoi(e) : JXLHIP_FUSED_PC_ROLE_DEFAULT;
+  const int role_env = jxlhip_env::Get().fused_pc_role.load(std::memory_order_relaxed);  // experiments: -1 = wave 0 always marches
+  const int role_shift = role_env != jxlhip_env::Switches::kUnset ? role_env : JXLHIP_FUSED_PC_ROLE_DEFAULT;
   if (f.coeff_type == JXLHIP_COEFF_I16)
     hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int16_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, role_shift);
   else
@@ -1773,8 +1773,8 @@ bool LaunchFusedB(const DevFrame& f, const FilterParams& p, int gab, int epf_ite
 bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st);
 
 static inline bool FusedPcEnabled() {
-  const char* e = getenv("JXLHIP_FUSED_PC");  // read per launch: the tests switch it
-  return (e ? atoi(e) : JXLHIP_FUSED_PC_DEFAULT) != 0;
+  const int e = jxlhip_env::Get().fused_pc.load(std::memory_order_relaxed);  // (sampled when a context is created)
+  return (e != jxlhip_env::Switches::kUnset ? e : JXLHIP_FUSED_PC_DEFAULT) != 0;
 }
 #if JXLHIP_FUSED_PART == 0
 // Frames the fused kernel takes (decided before k_prepare: it routes the DCT8 blocks).
@@ -1805,8 +1805,7 @@ bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind
   // the row-per-lane DCT8 producer 12 M; this producer is 72 M -- 300 per unit of four cells, of which the transform
   // itself (24 MFMAs) is none: dequantisation is 9 instructions per coefficient whatever decodes it, and a 16 x 16 unit
   // amortises its addressing / quantiser / LLF / emit overhead over 12 coefficients per lane only.
-  const char* e = getenv("JXLHIP_FUSED_TILES");
-  if (!e || atoi(e) == 0) return false;
+  if (jxlhip_env::Get().fused_tiles.load(std::memory_order_relaxed) == 0) return false;
   return FusedPcEnabled() && output_kind != JXLHIP_OUT_PACKED && FusedSupported(f, gab, epf_iters, output_kind);
 }
 
@@ -2032,8 +2031,8 @@ bool LaunchFusedEpf0(const DevFrame& f, const FilterParams& p, int gab, float* c
   const int RH = FusedRowsPC(strips, oy1 - oy0, (gab != 0 && JXLHIP_PC0_PART_LDS == 0) ? 4 : JXLHIP_PC_PER_CU);
   const unsigned nwg = strips * ((oy1 - oy0 + RH - 1) / RH);
   const dim3 grid((nwg + 7) & ~7u);
-  const char* e = getenv("JXLHIP_FUSED_PC0_ROLE");  // experiments: -1 = wave 0 always marches
-  const int role_shift = e ? atoi(e) : JXLHIP_FUSED_PC0_ROLE_DEFAULT;
+  const int role_env = jxlhip_env::Get().fused_pc0_role.load(std::memory_order_relaxed);  // experiments: -1 = wave 0 always marches
+  const int role_shift = role_env != jxlhip_env::Switches::kUnset ? role_env : JXLHIP_FUSED_PC0_ROLE_DEFAULT;
 #define JXLHIP_PC0(G, CT) \
   hipLaunchKernelGGL((k_fused_pc0<G, CT>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, oy0, oy1, dst[0], dst[1], dst[2], role_shift)
   if (f.coeff_type == JXLHIP_COEFF_I16) {
