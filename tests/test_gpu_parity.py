@@ -542,15 +542,17 @@ def test_fused_kernel_matches_two_phase_and_oracle(dq, oracle, gab, epf, size, m
 
 @pytest.mark.parametrize("gab,epf", [(1, 1), (0, 0)])
 @pytest.mark.parametrize("size,coeff_type", [((1000, 520), 0), ((333, 268), 1), ((112, 64), 0), ((2048, 1029 - 5), 0),
-                                             ((1500, 2100), 0)])
+                                             ((1500, 2100), 0), ((113, 40), 0), ((225, 24), "dct8"), ((964, 300), "dct8")])
 def test_fused_producer_consumer_form_is_bit_identical(dq, oracle, gab, epf, size, coeff_type, monkeypatch):
     """k_fused_pc (kernels_fused.hip, JXLHIP_FUSED_PC=1): the window march split over a producing and a marching
     wave with a double-buffered slab.  Same arithmetic in the same order as the single-wave kernel: the pixels are
     bit-identical, and within 2e-5 of the oracle.  Sizes: several row chunks per window (1500x2100), one block row,
-    edge windows, a last block row of 4 rows, int32 coefficients."""
+    edge windows, one column / one cell past a window (113, 225), a last block row of 4 rows, int32 coefficients, frames
+    of DCT8 only (every cell of every block row through the producer's two decode steps, no plane copies)."""
     xs, ys = size
-    kw = dict(coeff_type=1, amp=200000.0, decay=3.0) if coeff_type else {}
-    params, t, fr = frames.make_case(xs, ys, mix=synth.MIX_D1, gab=bool(gab), epf_iters=epf, seed=31 + xs, **kw)
+    kw = dict(coeff_type=1, amp=200000.0, decay=3.0) if coeff_type == 1 else {}
+    mix = {0: 100} if coeff_type == "dct8" else synth.MIX_D1
+    params, t, fr = frames.make_case(xs, ys, mix=mix, gab=bool(gab), epf_iters=epf, seed=31 + xs, **kw)
     ref = fr.decode(threads=4)
     outs = {}
     monkeypatch.setenv("JXLHIP_FUSE", "1")
@@ -577,8 +579,8 @@ TILE_MIX = {0: 30, 4: 25, 6: 20, 7: 20, 5: 3, 13: 2}   # the four classes the pr
 @pytest.mark.parametrize("size,coeff_type,mix", [((1000, 520), 0, None), ((333, 268), 1, "tile"), ((117, 68), 0, "tile"),
                                                   ((2048, 1029 - 5), 0, "all"), ((1500, 2100), 0, "tile"), ((1500, 700), 1, None)])
 def test_fused_tile_producer_matches_oracle(dq, oracle, gab, epf, out, size, coeff_type, mix, monkeypatch):
-    """k_fused_pc's matrix-core producer (kernels_fused.hip ProduceTiles, DevFrame::fused_tiles; the default for whole
-    frames through the fused kernel): DCT8, DCT8X16, DCT16X8 and DCT16X16 are decoded by the producing wave as two
+    """k_fused_pc's matrix-core producer (kernels_fused.hip ProduceTiles, DevFrame::fused_tiles; opt-in with
+    JXLHIP_FUSED_TILES=1, the row-per-lane DCT8 producer is the default): DCT8, DCT8X16, DCT16X8 and DCT16X16 are decoded by the producing wave as two
     v_mfma_f32_16x16x4_f32 products per channel, the other classes come from the planes.  Against the oracle at the
     bar of every other path; JXLHIP_FUSED_TILES=0 (the row-per-lane DCT8 producer) must be as close and must differ in
     the last bits -- a dense product rounds differently from the butterflies -- which shows that the producer engaged.
