@@ -785,7 +785,7 @@ def main():
                          "frac_kernel": round(b_own / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_kernel": traffic_kernel, "traffic_source": tsrc,
                          "kernel": {"filters": "k_filters_fast",
-                                    "fused": "k_fused" if os.environ.get("JXLHIP_FUSED_PC", "1") == "0" else "k_fused_pc",
+                                    "fused": "k_fused_pc",
                                     "blocks": "k_transform_mfma32<EMIT>"}.get(dom, dom),
                          "kernel_ms": kern[dom],
                          "algorithmic_bytes_per_launch": b_alg,

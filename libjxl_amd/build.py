@@ -13,7 +13,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 LIB_SOURCES = ["context.hip", "kernels_blocks.hip", "kernels_filters.hip", "kernels_filters_fast.hip", "kernels_filters_fast_b.hip", "kernels_filters_fast_c.hip",
                "kernels_filters_fast_d.hip",
-               "kernels_fused.hip", "kernels_fused_b.hip", "kernels_fused_pc.hip", "kernels_fused_epf0.hip", "kernels_mfma.hip", "kernels_epf0.hip", "kernels_tables.hip", "entropy.cc"]
+               "kernels_fused.hip", "kernels_fused_epf0.hip", "kernels_mfma.hip", "kernels_epf0.hip", "kernels_tables.hip", "entropy.cc"]
 RUNNER_SOURCES = ["runner.cc"]
 
 
@@ -36,7 +36,7 @@ def _stale(target, sources):
 def _compile(src):
     obj = os.path.join(BUILD, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    extra = [os.path.join(CSRC, "kernels_fused.hip")] if src in ("kernels_fused_b.hip", "kernels_fused_pc.hip", "kernels_fused_epf0.hip") else []  # they #include it
+    extra = [os.path.join(CSRC, "kernels_fused.hip")] if src == "kernels_fused_epf0.hip" else []  # it #includes it
     if src.startswith("kernels_filters_fast_"):
         extra = [os.path.join(CSRC, "kernels_filters_fast.hip")]
     if _stale(obj, [path] + extra + _deps()):

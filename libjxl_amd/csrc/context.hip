@@ -35,6 +35,13 @@ namespace {
 constexpr int kPoolStreams = 8;
 constexpr int kMaxBlockStreams = 8;
 constexpr int kMaxBands = 64;
+// Counter blocks (kCountStride u32 each): [0, kMaxBands) the bands of a direct decode (one-band frames alternate between
+// blocks 0 and 1, each frame's k_prepare zeroing the next one's); a frame recorded into a hipGraph uses the same indices
+// + kCaptureBase, blocks no direct call ever touches -- a replay dirties its blocks behind the host's back, and the
+// host's "clean" flags describe blocks 0 / 1 only (round 5 put captured frames on block 0: a replay between two direct
+// calls left k_prepare starting on non-zero counters).
+constexpr int kCaptureBase = kMaxBands;
+constexpr int kCountBlocks = 2 * kMaxBands;
 // pinned staging buffers of jxlhip_ac_group_decode_submit (0.4 / 0.8 MB each): kStageSlotsFirst at first use, one more
 // whenever a thread would otherwise have to wait for an upload to finish, up to kStageSlots.  (An upload is microseconds
 // of PCIe, but the runtime now and then sits on a queued copy for 10-30 ms -- profiles/r04_e2e_waits.txt -- and with 32
@@ -77,7 +84,6 @@ struct jxlhip_ctx {
   double cs_phase_ms[8] = {};  // jxlhip_codestream_phase_ms
   int concurrency = 1;  // jxlhip_set_concurrency_hint: contexts the caller keeps busy on this device at a time
   bool handover_fresh = false;  // frame_begin started the hand-over and upload_side_info has not been called since
-  bool tiles_on = false;     // the last LaunchBlocksBand ran k_prepare in tile mode (DevFrame::fused_tiles)
   bool blocks_fused = false;  // jxlhip_decode_blocks ran in fused-stripe mode: the planes lack the inner DCT8 blocks
   jxlhip_frame_params p{};
   DevFrame f{};
@@ -398,9 +404,9 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
   if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->frame_ev, hipEventDisableTiming) != hipSuccess)
     return fail(JXLHIP_ERR_HIP);
-  if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kCountStride * kMaxBands) != hipSuccess ||
+  if (hipMalloc((void**)&c->counts, sizeof(uint32_t) * kCountStride * kCountBlocks) != hipSuccess ||
       hipMalloc((void**)&c->error_flag, sizeof(int32_t) * 2) != hipSuccess ||
-      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024 + 2048 + 512)) != hipSuccess ||
+      hipMalloc((void**)&c->tables, sizeof(float) * (512 + 64 + 1024 + 2048 + 256)) != hipSuccess ||
       hipMalloc((void**)&c->quant_enc, sizeof(jxlhip_quant_encoding) * JXLHIP_NUM_QUANT_TABLES) != hipSuccess)
     return fail(JXLHIP_ERR_OUT_OF_MEMORY);
   if (hipMemset(c->error_flag, 0, sizeof(int32_t) * 2) != hipSuccess ||
@@ -411,9 +417,9 @@ int jxlhip_create_ex(int device, const JxlMemoryManagerHip* memory_manager, jxlh
           hipSuccess)
     return fail(JXLHIP_ERR_HIP);
   {
-    float mfma_tab[2048 + 512];  // the 16-point table is the first half of the tile producer's pair
+    float mfma_tab[2048 + 256];
     MfmaDct32Constants(mfma_tab);
-    TileProducerConstants(mfma_tab + 2048);
+    MfmaDct16Constants(mfma_tab + 2048);
     if (hipMemcpy(c->tables + 1600, mfma_tab, sizeof(mfma_tab), hipMemcpyHostToDevice) != hipSuccess)
       return fail(JXLHIP_ERR_HIP);
   }
@@ -597,7 +603,6 @@ int jxlhip_frame_begin(jxlhip_ctx* c, const jxlhip_frame_params* p) {
   if ((rc = Grow(c, &c->inv_sigma, &c->sigma_floats, (size_t)f.xsb * f.ysb))) return rc;
   f.inv_sigma = c->inv_sigma;
   f.error_flag = c->error_flag;
-  f.debug = (uint32_t)jxlhip_env::Get().debug_bits.load(std::memory_order_relaxed);
   // work lists, worst case per class
   const size_t cells = (size_t)f.xsg * f.group_rows * 1024;
   size_t total = 0;
@@ -1451,10 +1456,6 @@ int LaunchBlocksBand(jxlhip_ctx* c, uint32_t g0, uint32_t g1, int band, int fuse
   f.band_g1 = g1;
   f.fused = (uint32_t)fused;
   f.cell_info = c->cell_info;
-  // whole frames through k_fused_pc: DCT8 and the 16-point classes on the producing wave's matrix cores
-  c->tiles_on = fused == 1 && FusedTilesWanted(f, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind);
-  f.fused_tiles = c->tiles_on ? 1u : 0u;
-  f.tile_tabs = c->tables + 1600 + 2048;
   {
     constexpr uint32_t kOthers32 = (1u << 8) | (1u << 9) | (1u << 10) | (1u << 11);  // 32x8 .. 16x32
     const bool lone32 = (f.used_acs & (1u << 5)) && !(f.used_acs & kOthers32);
@@ -1504,8 +1505,6 @@ int LaunchFiltersRows(jxlhip_ctx* c, const FilterParams& fp, uint32_t fy0, uint3
   f.fy1 = fy1;
   f.fused = fused ? 1u : 0u;
   f.cell_info = c->cell_info;
-  f.fused_tiles = (fused && c->tiles_on) ? 1u : 0u;
-  f.tile_tabs = c->tables + 1600 + 2048;
   ProfBegin(c);
   if (fused && c->p.lf.epf_iters == 3) {
     // EPF0 from the producer's slab into the second plane set (k_fused_pc0), EPF1 + EPF2 + output from there
@@ -1593,7 +1592,7 @@ bool WantFused(const jxlhip_ctx* c) {
          FusedSupported(f, (int)c->p.lf.gab, (int)c->p.lf.epf_iters, (int)c->p.output_kind);
 }
 
-int BeginDecode(jxlhip_ctx* c, uint32_t nbands) {
+int BeginDecode(jxlhip_ctx* c, uint32_t nbands, uint32_t first_block = 0) {
   if (!c->have_frame || !c->have_inputs)
     return Fail(c, JXLHIP_ERR_STATE, "decode needs frame_begin + inputs");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1623,13 +1622,14 @@ int BeginDecode(jxlhip_ctx* c, uint32_t nbands) {
   if (nbands) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cap);
+    uint32_t* blocks = c->counts + (size_t)first_block * kCountStride;
     if (cap == hipStreamCaptureStatusActive) {  // (see LaunchZeroU32: no memset node at the root of a frame graph)
-      LaunchZeroU32(c->counts, (uint32_t)(kCountStride * nbands), st);
+      LaunchZeroU32(blocks, (uint32_t)(kCountStride * nbands), st);
       HIPCHK(c, hipGetLastError());
     } else {
-      HIPCHK(c, hipMemsetAsync(c->counts, 0, sizeof(uint32_t) * kCountStride * nbands, st));
+      HIPCHK(c, hipMemsetAsync(blocks, 0, sizeof(uint32_t) * kCountStride * nbands, st));
     }
-    c->counts_clean[0] = c->counts_clean[1] = false;  // used by the bands that follow
+    if (first_block == 0) c->counts_clean[0] = c->counts_clean[1] = false;  // used by the bands that follow
   }
   return JXLHIP_OK;
 }
@@ -1814,13 +1814,15 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   const uint32_t nbands = (f.group_rows + br - 1) / br;
   // Under stream capture -- the caller records the frame's launches into a hipGraph and replays it (bench.py's
   // `graph_replay`: the command processor's ~5-8 us per dependent launch are paid once per graph instead) -- every
-  // replay must find the SAME counter block zeroed by a node of the graph itself: the alternating blocks assume that
-  // consecutive frames are consecutive calls.
+  // replay must find the SAME counter blocks zeroed by a node of the graph itself, and must not touch a block the direct
+  // calls keep a "clean" flag for: captured frames use the blocks from kCaptureBase on (see there).
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(c->stream, &cap);
-  const bool one_band = nbands == 1 && cap != hipStreamCaptureStatusActive;
-  const int slot = one_band ? c->counts_slot : 0;
-  int rc = BeginDecode(c, one_band ? 0 : nbands);
+  const bool capturing = cap == hipStreamCaptureStatusActive;
+  const bool one_band = nbands == 1 && !capturing;
+  const int block0 = capturing ? kCaptureBase : 0;
+  const int slot = one_band ? c->counts_slot : block0;
+  int rc = BeginDecode(c, one_band ? 0 : nbands, (uint32_t)block0);
   if (rc) return rc;
   if (one_band && !c->counts_clean[slot])
     HIPCHK(c, hipMemsetAsync(c->counts + (size_t)slot * kCountStride, 0, sizeof(uint32_t) * kCountStride, c->stream));
@@ -1866,7 +1868,7 @@ static int DecodeFrameCoded(jxlhip_ctx* c, void* out, size_t out_stride, size_t 
   int band = 0;
   for (uint32_t g0 = f.group_y0; g0 < g_end; g0 += br, band++) {
     const uint32_t g1 = g0 + br < g_end ? g0 + br : g_end;
-    rc = one_band ? LaunchBlocksBand(c, g0, g1, slot, 0, nullptr, slot ^ 1) : LaunchBlocksBand(c, g0, g1, band);
+    rc = one_band ? LaunchBlocksBand(c, g0, g1, slot, 0, nullptr, slot ^ 1) : LaunchBlocksBand(c, g0, g1, block0 + band);
     if (rc) return rc;
     if (one_band) rotate();
     if (g0 > f.group_y0) {  // rows of the previous band: its lower halo now exists

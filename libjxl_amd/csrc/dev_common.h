@@ -135,8 +135,6 @@ struct DevFrame {
   uint32_t plane_tile_rows;
   float* inv_sigma;       // xsb*ysb, whole frame indexing
   int32_t* error_flag;
-  uint32_t debug;  // JXLHIP_DEBUG ablation bits of the phase-2 kernel (4: no output stores, 8: input rows
-                   // stay in L1), compiled in only for the launch that asks for them
   // Fused mode (kernels_fused.hip): varblocks of the classes the fused kernel decodes itself (DCT8)
   // are not put on a work list and never reach the XYB planes; k_prepare leaves their coefficient
   // offset and quant / CfL word in cell_info[cell] (xsb*ysb entries, whole frame indexing; every
@@ -151,26 +149,10 @@ struct DevFrame {
   // != 0: xyb[] are plain row-major planes of this many bytes per row, first row plane_y0 (k_epf0's output
   // as the EPF1 + EPF2 march reads it, filters_march.h SRC_LINEAR)
   uint32_t linear_stride;
-  // Fused mode, whole frames through k_fused_pc (kernels_fused.hip, ProduceTiles): the varblocks of DCT8, DCT8X16,
-  // DCT16X8 and DCT16X16 are decoded by the producing wave on the matrix cores and never reach the XYB planes;
-  // k_prepare leaves, in EVERY cell such a varblock covers, the varblock's coefficient offset (cell_info.x) and its
-  // quant / CfL word with a tag in bits 12..15 (cell_info.y: kTile* below); every other cell says kCellFromPlanes
-  uint32_t fused_tiles;
-  const float* tile_tabs;  // TileProducerConstants (kernels_mfma.hip): 2 x 256 floats
   // != nullptr: k_prepare's first workgroup zeroes these kCountStride counters -- the counter block the NEXT frame's
   // k_prepare will use (two blocks alternate), which saves a memset launch per frame
   uint32_t* zero_counts;
 };
-// cell_info.y of a tile-mode cell: raw_quant in bits 0..8 (1..256, dec_modular.cc:551-552), tag in bits 12..15,
-// ytox / ytob in bits 16..31
-static constexpr uint32_t kTileQuantMask = 0xfffu;
-static constexpr int kTileTagShift = 12;
-enum TileKind : uint32_t { kTileDct8 = 0, kTileDct8x16 = 1, kTileDct16x8 = 2, kTileDct16x16 = 3 };
-// strategy -> tile kind, -1 = not decoded by the producer
-__host__ __device__ constexpr int TileKindOfStrategy(uint32_t s) {
-  return s == 0 ? (int)kTileDct8 : (s == 7 ? (int)kTileDct8x16 : (s == 6 ? (int)kTileDct16x8 : (s == 4 ? (int)kTileDct16x16 : -1)));
-}
-
 // address of pixel (y, x) of channel c in the block-major planes
 __device__ __forceinline__ size_t PlaneOffset(const DevFrame& f, int y, int x) {
   const uint32_t ry = (uint32_t)(y - f.plane_y0);

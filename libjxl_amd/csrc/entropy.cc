@@ -13,7 +13,6 @@ namespace jxlhip_env {
 Switches g;
 void LoadLocked() {
   g.wp_general.store(getenv("JXLHIP_WP_GENERAL") != nullptr);
-  g.dc_tree.store(getenv("JXLHIP_DC_TREE") != nullptr);
   g.codestream_verbose.store(getenv("JXLHIP_CODESTREAM_VERBOSE") != nullptr);
   g.no_pipeline.store(getenv("JXLHIP_NO_PIPELINE") != nullptr);
   const char* e = getenv("JXLHIP_TEST_RANGE_GROUP");
@@ -24,13 +23,17 @@ void LoadLocked() {
     const char* v = getenv(name);
     return v ? atoi(v) : unset;
   };
-  g.fused_pc.store(num("JXLHIP_FUSED_PC", Switches::kUnset));
   g.fused_pc_rh.store(num("JXLHIP_FUSED_PC_RH", 0));
-  g.fused_pc_role.store(num("JXLHIP_FUSED_PC_ROLE", Switches::kUnset));
-  g.fused_pc0_role.store(num("JXLHIP_FUSED_PC0_ROLE", Switches::kUnset));
-  g.fused_tiles.store(num("JXLHIP_FUSED_TILES", 0));
+  g.filter_rh.store(num("JXLHIP_FILTER_RH", 0));
   g.big_wgs.store(num("JXLHIP_BIG_WGS", Switches::kUnset));
-  g.debug_bits.store(num("JXLHIP_DEBUG", 0));
+  g.multi_force_gather.store(getenv("JXLHIP_MULTI_FORCE_GATHER") != nullptr);
+  {
+    // unparsable / empty / 0: the default (2^30 pixels = four 16K frames' worth), not "refuse every frame"
+    const char* mp = getenv("JXLHIP_MAX_PIXELS");
+    char* end = nullptr;
+    const unsigned long long v = mp ? strtoull(mp, &end, 10) : 0ull;
+    g.max_pixels.store((mp && end != mp && v != 0) ? v : (1ull << 30));
+  }
   g.loaded.store(true, std::memory_order_release);
 }
 }  // namespace jxlhip_env

@@ -12,7 +12,6 @@ namespace jxlhip_env {
 struct Switches {
   std::atomic<bool> loaded{false};
   std::atomic<bool> wp_general{false};        // JXLHIP_WP_GENERAL: Modular channels through the general loop only
-  std::atomic<bool> dc_tree{false};           // JXLHIP_DC_TREE (with -DJXLHIP_DC_TIMING): print the channel's tree
   std::atomic<bool> codestream_verbose{false};
   std::atomic<bool> no_pipeline{false};       // JXLHIP_NO_PIPELINE: DC groups, then AC groups (two runner calls)
   std::atomic<long long> test_range_group{-1};  // JXLHIP_TEST_RANGE_GROUP: fault injector of tests/test_codestream.py
@@ -20,13 +19,11 @@ struct Switches {
   // launch geometry / path switches of the kernels (experiments and the parity tests; kUnset = the built-in default).
   // Sampled when a context is created (jxlhip_create_ex reloads), never on a launch.
   static constexpr int kUnset = -2147483647 - 1;
-  std::atomic<int> fused_pc{kUnset};        // JXLHIP_FUSED_PC: 0 = the single-wave fused kernel
   std::atomic<int> fused_pc_rh{0};          // JXLHIP_FUSED_PC_RH: rows per window chunk (0 = fill the device)
-  std::atomic<int> fused_pc_role{kUnset};   // JXLHIP_FUSED_PC_ROLE: which wave marches (-1 = always wave 0)
-  std::atomic<int> fused_pc0_role{kUnset};  // JXLHIP_FUSED_PC0_ROLE
-  std::atomic<int> fused_tiles{0};          // JXLHIP_FUSED_TILES: the matrix-core producer
+  std::atomic<int> filter_rh{0};            // JXLHIP_FILTER_RH: rows per wave of the two-phase filter march (0 = fill the device)
   std::atomic<int> big_wgs{kUnset};         // JXLHIP_BIG_WGS: workgroups of the 64-point family in k_transform_r
-  std::atomic<int> debug_bits{0};           // JXLHIP_DEBUG: ablation bits of the phase-2 kernels
+  std::atomic<bool> multi_force_gather{false};  // JXLHIP_MULTI_FORCE_GATHER: one-device boxes exercise the gather copies
+  std::atomic<unsigned long long> max_pixels{1ull << 30};  // JXLHIP_MAX_PIXELS: what jxlhip_decode_codestream allocates for at most
   std::mutex mu;
 };
 extern Switches g;  // defined in entropy.cc

@@ -68,14 +68,8 @@ __device__ __forceinline__ uint32_t LaneOffset(uint32_t& v) {
 // Measured on MI355X, 8K d1.0, kernel time: (kAhead, kBurst) = (2, 1) 0.237 ms, (1, 2) 0.238,
 // (2, 2) 0.229, (1, 4) 0.215; prefetching further ahead with single-row requests is slower
 // ((3, 1) 0.248, (4, 1) 0.251).
-#ifndef JXLHIP_FILTER_AHEAD
-#define JXLHIP_FILTER_AHEAD 1
-#endif
-static constexpr int kAhead = JXLHIP_FILTER_AHEAD;
-#ifndef JXLHIP_FILTER_BURST
-#define JXLHIP_FILTER_BURST 4
-#endif
-static constexpr int kBurst = JXLHIP_FILTER_BURST;  // 1, 2 or 4
+static constexpr int kAhead = 1;
+static constexpr int kBurst = 4;  // 1, 2 or 4
 static_assert(kAhead >= 1 && kAhead + kBurst <= 5 && (kBurst == 1 || kBurst == 2 || kBurst == 4),
               "input ring of 8: rows r-3 .. r+kAhead+kBurst-1 must fit");
 
@@ -195,9 +189,6 @@ __device__ __forceinline__ v2f LoadPair(const char* rowp, Lane& L) {
   return v2f{L.sel0 ? v.y : v.x, L.sel1 ? v.y : v.x};
 }
 
-#ifndef JXLHIP_STORE_ONE_BLOCK
-#define JXLHIP_STORE_ONE_BLOCK 1
-#endif
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -321,7 +312,6 @@ __device__ __forceinline__ void EmitPair(const v2f* v, Lane& L, int gy, char* ou
     const RgbPairs o = XybToRgbPair(v, P, K);
     // inside the image the two columns of a pair are written or skipped together (only column W-1
     // of an odd width separates them: an edge wave)
-#if JXLHIP_STORE_ONE_BLOCK
     // The pair's two stores under an EXEC mask set and restored inside ONE asm statement: no s_cbranch_execz around
     // them, so the eight row steps of a group form ONE basic block -- the scheduler then fills the DPP / transcendental
     // hazard slots with useful instructions (k_fused_pc's interior loop: 63 -> 2 s_nop, 132 -> 60 scalar instructions
@@ -342,15 +332,9 @@ __device__ __forceinline__ void EmitPair(const v2f* v, Lane& L, int gy, char* ou
           : "memory", "scc");
       return;
     }
-#endif
     if (EDGE ? (L.out0 && L.out1) : L.out0) {  // 24 contiguous bytes
-#ifdef JXLHIP_ABL_STORE_PLAIN  // experiment builds: ordinary (write-back) stores for the f32 RGB pair
-      *(f4u*)dst = f4u{o.p0.x, o.p0.y, o.p1.x, o.p1.y};
-      *(f2u*)(dst + 4) = f2u{o.p2.x, o.p2.y};
-#else
       __builtin_nontemporal_store(f4u{o.p0.x, o.p0.y, o.p1.x, o.p1.y}, (f4u*)dst);
       __builtin_nontemporal_store(f2u{o.p2.x, o.p2.y}, (f2u*)(dst + 4));
-#endif
     } else if (!EDGE) {
     } else if (L.out0) {
       __builtin_nontemporal_store(o.p0.x, dst);

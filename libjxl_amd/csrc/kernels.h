@@ -79,7 +79,6 @@ bool LaunchOrient(const void* src, size_t src_stride, uint32_t xsize, uint32_t y
 // Matrix-core 32x32 IDCT (kernels_mfma.hip), opt-in through DevFrame::mfma32
 void MfmaDct32Constants(float* host /* 2048 floats */);
 void MfmaDct16Constants(float* host /* 256 floats */);
-void TileProducerConstants(float* host /* 512 floats */);
 // emit != nullptr: the frame is DCT32X32 only and has no loop filter -- the kernel writes linear float RGB to
 // emit->out itself (rows f.y0 .. f.y1) instead of XYB planes
 void LaunchMfma32(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st, const FilterParams* emit = nullptr);
@@ -90,8 +89,6 @@ void LaunchMfma16(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStr
 // filter wave itself, other classes copied from the planes).  FusedSupported: frames it takes --
 // decided before k_prepare, which routes the DCT8 blocks (DevFrame::fused).
 bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind);
-// ... with the 8- and 16-point classes decoded by its producing wave on the matrix cores (DevFrame::fused_tiles)
-bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind);
 bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,
                  hipStream_t st);
 // epf_iters = 3 in fused mode (kernels_fused_epf0.hip): [Gaborish] + EPF0 marched from the producer's slab into the
@@ -99,6 +96,9 @@ bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iter
 // k_prepare, like FusedSupported)
 bool FusedEpf0Supported(const DevFrame& f, int gab);
 bool LaunchFusedEpf0(const DevFrame& f, const FilterParams& p, int gab, float* const dst[3], hipStream_t st);
+// compute units of the device the calling thread has current (hipDeviceAttributeMultiprocessorCount, cached): what the
+// generation-filling launch geometries are sized from (256 on a whole MI355X, fewer on a CPX / DPX partition)
+unsigned DeviceCus();
 
 // block-major plane rows <-> dense row-major staging
 void LaunchZeroU32(uint32_t* p, uint32_t n, hipStream_t st);  // (kernels_tables.hip: a kernel, for captured graphs)

@@ -33,7 +33,6 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   __shared__ uint16_t wave_cls[16][kNumClasses];  // per-wave class counts -> bases
   __shared__ uint32_t wg_base[kNumClasses];
   __shared__ float cell_sq[1024];                 // sigma_quant of the covering varblock
-  __shared__ uint2 cell_ci[1024];                 // tile mode: cell_info of the group's cells
   const uint32_t tid = threadIdx.x;
   const uint32_t lane = tid & 63, wave = tid >> 6;
   const uint32_t gx = blockIdx.x % f.xsg;
@@ -58,7 +57,6 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   bool first = raw & 1;
   uint32_t s = raw >> 1;
   bool bad = false;
-  if (f.fused_tiles) cell_ci[tid] = make_uint2(kCellFromPlanes, 0u);
   static_assert(kCountStride == 1024, "one counter per thread");
   if (f.zero_counts && blockIdx.x == 0) f.zero_counts[tid] = 0;
   if (s >= JXLHIP_NUM_STRATEGIES) {
@@ -88,9 +86,7 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   const int cls_frame = first ? (int)kClassLut.v[s] : -1;
   const bool edge_row = f.fused == 2 && ((aby == (f.y0 >> 3) && f.group_y0 > 0) ||
                                          (aby == ((f.y1 - 1) >> 3) && f.group_y0 + f.group_rows < f.ysg));
-  // Tile mode (whole frames only): DCT8, DCT8X16, DCT16X8 and DCT16X16 are decoded by the fused kernel's producer
-  const int tile_kind = (f.fused_tiles && first) ? TileKindOfStrategy(s) : -1;
-  const int cls = ((f.fused && cls_frame == kClsDct8 && !edge_row) || tile_kind >= 0) ? -1 : cls_frame;
+  const int cls = (f.fused && cls_frame == kClsDct8 && !edge_row) ? -1 : cls_frame;
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t rank_in_wave = 0;
 #pragma unroll
@@ -118,11 +114,7 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     uint32_t n = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) n += wave_cls[w][tid];
-#ifdef JXLHIP_ABL_PREPARE_NOATOMIC  // ablation build (timing only: lists are garbage): what do the contended atomics cost?
-    wg_base[tid] = (n && in_stripe && group_ok) ? blockIdx.x * 8u : 0;
-#else
     wg_base[tid] = (n && in_stripe && group_ok) ? atomicAdd(&wl.count[tid * kCounterPad], n) : 0;
-#endif
   }
   // sigma_quant of each varblock, scattered to the cells it covers
   if (with_sigma && first) {
@@ -131,17 +123,9 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     for (uint32_t iy = 0; iy < cy; iy++)
       for (uint32_t ix = 0; ix < cx; ix++) cell_sq[(by + iy) * gw + bx + ix] = sigma_quant;
   }
-  if (tile_kind >= 0 && in_stripe && group_ok) {  // every cell of the varblock: offset, quant / CfL word, kind and position
-    const uint32_t qc = ((uint32_t)cell_q & 0xffffu) | cell_cfl;
-    for (uint32_t iy = 0; iy < cy; iy++)
-      for (uint32_t ix = 0; ix < cx; ix++)
-        cell_ci[(by + iy) * gw + bx + ix] =
-            make_uint2(g * f.coef_stride64 + off64, qc | (((uint32_t)tile_kind | (ix << 2) | (iy << 3)) << kTileTagShift));
-  }
   __syncthreads();
-  if (f.fused_tiles && valid) f.cell_info[cell] = cell_ci[tid];
   // whole frame through the fused kernel: EVERY cell says what it is (no memset of the table in front of this kernel)
-  if (f.fused == 1 && !f.fused_tiles && valid) {
+  if (f.fused == 1 && valid) {
     const bool own = in_stripe && group_ok && cls_frame == kClsDct8;
     f.cell_info[cell] = own ? make_uint2(g * f.coef_stride64 + off64, ((uint32_t)cell_q & 0xffffu) | cell_cfl) : make_uint2(kCellFromPlanes, 0u);
   }
@@ -1393,11 +1377,8 @@ static constexpr FamilyEntry kFamilyR[8] = {{kClsMedium0 + 7, 8},  {kClsMedium0 
 // The 50 KB of LDS every workgroup of this launch then reserves cost the row-per-lane units
 // nothing: three workgroups per CU is what their registers allow anyway.  As a launch of its own
 // family A is ~22 us of pure latency per 8K d1.0 frame.
-#ifndef JXLHIP_R_WAVES
-#define JXLHIP_R_WAVES 3
-#endif
 template <typename CT>
-__global__ __launch_bounds__(256, sizeof(CT) == 2 ? JXLHIP_R_WAVES : 2) void k_transform_r(DevFrame f, WorkLists wl, uint32_t big_wgs,
+__global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(DevFrame f, WorkLists wl, uint32_t big_wgs,
                                                                                uint32_t special_wgs, uint32_t r_wgs,
                                                                                uint32_t dct8_wgs) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
@@ -1420,13 +1401,7 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? JXLHIP_R_WAVES : 2) void k_t
   const uint32_t np = big_wgs + r_wgs;
   const uint32_t i = blockIdx.x - special_wgs;
   const uint32_t need8 = (wl.count[kClsDct8 * kCounterPad] + Dct8Geom<CT>::kPerWg - 1) / Dct8Geom<CT>::kPerWg;
-#if defined(JXLHIP_DCT8_STATIC)  // (experiment builds: every workgroup of the bound alternates / only those with work)
-  const uint32_t d8 = dct8_wgs;
-#elif defined(JXLHIP_DCT8_DYNAMIC)
-  const uint32_t d8 = need8 < dct8_wgs ? need8 : dct8_wgs;
-#else
   const uint32_t d8 = need8 * 4 < dct8_wgs ? need8 : dct8_wgs;
-#endif
   const uint32_t pairs = np < d8 ? np : d8;
   bool is_dct8;
   uint32_t idx;
@@ -1492,10 +1467,9 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
       if (f.used_acs & (1u << st)) return true;
     return false;
   };
-  // tile mode: the 16-point classes are decoded inside the fused kernel (their lists stay empty)
-  const bool need_r16 = !f.fused_tiles && (any({6, 7}) || (!f.mfma16 && any({4})));
+  const bool need_r16 = any({6, 7}) || (!f.mfma16 && any({4}));
   const bool need_r32 = any({8, 9, 10, 11}) || (!f.mfma32 && any({5}));
-  const bool merged_r = f.fused_tiles ? need_r32 : (need_r16 && need_r32);
+  const bool merged_r = need_r16 && need_r32;
   const bool have_big = any({18, 19, 20});
   bool specials_in_r = false, dct8_in_r = false;
   uint32_t grid_specials = 0, grid_dct8 = 0;
@@ -1520,7 +1494,7 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
   if (merged_r) {  // -10 us per 8K d1.0 frame against two launches, -15 us more with family A inside
     uint32_t big_cap = 512u;
     const int big_env = jxlhip_env::Get().big_wgs.load(std::memory_order_relaxed);  // experiments: workgroups of the 64-point family
-    if (big_env != jxlhip_env::Switches::kUnset) big_cap = (uint32_t)big_env;
+    if (big_env >= 1 && big_env <= 4096) big_cap = (uint32_t)big_env;  // (anything else: the built-in cap)
     const uint32_t big_wgs = have_big ? (grid_a < big_cap ? grid_a : big_cap) : 0u;
     const uint32_t special_wgs = specials_in_r ? grid_specials : 0u;
     const uint32_t dct8_wgs = dct8_in_r ? grid_dct8 : 0u;
@@ -1531,7 +1505,7 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     if (need_r32) hipLaunchKernelGGL((k_transform_r32<CT>), dim3(grid_r32), dim3(256), 0, s0, f, wl);
   }
   if (f.mfma32 && any({5})) LaunchMfma32(f, wl, cells, s1, emit);
-  if (f.mfma16 && any({4}) && !f.fused_tiles) LaunchMfma16(f, wl, cells, s1);
+  if (f.mfma16 && any({4})) LaunchMfma16(f, wl, cells, s1);
   if (cells >= 256 && any({21, 22, 23, 24, 25, 26}))
     hipLaunchKernelGGL(k_large<CT>, dim3(grid_l), dim3(256), 0, s1, f, wl.list[kClsLarge],
                        wl.count + kClsLarge * kCounterPad, wc, resample);

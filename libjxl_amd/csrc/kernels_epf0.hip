@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void k_epf0(DevFrame f, FilterParams P, int
 
 // see FilterRowsPerWave (kernels_filters_fast.hip); two workgroups per CU
 int Epf0RowsPerWave(unsigned wgx, unsigned rows, int hx) {
-  const unsigned resident = 256u * 2u;
+  const unsigned resident = DeviceCus() * 2u;
   int best = 64;
   double best_cost = 1e30;
   for (int rh = 16; rh <= 512; rh++) {

@@ -47,6 +47,8 @@
 // itself (Lane::fix_*).  Frames narrower or lower than 16 px use the generic kernel (kernels_filters.hip).
 #include <stdlib.h>
 
+#include "env_switches.h"
+
 #include "filters_march.h"
 
 // This file is compiled four times: as itself (part 0: the entry points, the float / planar outputs, the general
@@ -189,19 +191,13 @@ __global__ __launch_bounds__(256, EPF == 2 ? 2 : 3) void k_filters_fast(DevFrame
 // Rows per wave.  Every wave costs (RH + 2*HX) row steps and all waves of a
 // launch take the same time, so the launch runs in ceil(workgroups / resident
 // workgroups) generations: pick the RH that minimises generations * steps
-// instead of leaving a mostly empty last generation.  Resident capacity: 256
-// CUs x 3 workgroups (3 waves per SIMD at <= 168 VGPRs).  JXLHIP_FILTER_RH /
-// JXLHIP_FILTER_RESIDENT override.
+// instead of leaving a mostly empty last generation.  Resident capacity: two
+// workgroups per compute unit of the device.  JXLHIP_FILTER_RH (sampled when a
+// context is created, env_switches.h) overrides.
 int FilterRowsPerWave(unsigned wgx, unsigned rows, int hx) {
-  static const int forced = [] {
-    const char* e = getenv("JXLHIP_FILTER_RH");
-    return e ? atoi(e) : 0;
-  }();
+  const int forced = jxlhip_env::Get().filter_rh.load(std::memory_order_relaxed);
   if (forced > 0) return forced;
-  static const unsigned resident = [] {
-    const char* e = getenv("JXLHIP_FILTER_RESIDENT");
-    return e ? (unsigned)atoi(e) : 256u * 2u;
-  }();
+  const unsigned resident = DeviceCus() * 2u;
   int best = 64;
   double best_cost = 1e30;
   for (int rh = 16; rh <= 512; rh += 1) {
@@ -234,22 +230,6 @@ void LaunchFastT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
   const unsigned wgx = (strips + 3) / 4;
   const int RH = FilterRowsPerWave(wgx, f.fy1 - f.fy0, G::HX);
   const dim3 grid(wgx, (f.fy1 - f.fy0 + RH - 1) / RH);
-  // JXLHIP_DEBUG ablations (bits 4 / 8) exist for the BASELINE stage list with float output only
-  if constexpr (GAB == 1 && EPF == 1 && OUTK == 1) {
-    const int dbg = (int)(f.debug & 12u);
-    if (dbg == 4) {
-      hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 4>), grid, dim3(256), 0, st, f, p, RH);
-      return;
-    }
-    if (dbg == 8) {
-      hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 8>), grid, dim3(256), 0, st, f, p, RH);
-      return;
-    }
-    if (dbg == 12) {
-      hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 12>), grid, dim3(256), 0, st, f, p, RH);
-      return;
-    }
-  }
   hipLaunchKernelGGL((k_filters_fast<GAB, EPF, OUTK, FMT, 0>), grid, dim3(256), 0, st, f, p, RH);
 }
 

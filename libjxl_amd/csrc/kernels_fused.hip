@@ -32,56 +32,18 @@
 #include "blocks_common.h"
 #include "env_switches.h"
 #include "filters_march.h"
-#if defined(JXLHIP_FUSED_PART) && JXLHIP_FUSED_PART == 3
-#include "epf0_march.h"
-#endif
-
+// Two translation units (this file compiles for minutes): kernels_fused.hip itself (part 2: k_fused_pc and the entry
+// points) and kernels_fused_epf0.hip (part 3: k_fused_pc0, the epf_iters = 3 form), which includes this file.
 #ifndef JXLHIP_FUSED_PART
-#define JXLHIP_FUSED_PART 0
+#define JXLHIP_FUSED_PART 2
 #endif
-#ifndef JXLHIP_FUSED_PC_ROLE_DEFAULT
-#define JXLHIP_FUSED_PC_ROLE_DEFAULT -1
-#endif
-#ifndef JXLHIP_FUSED_PC_DEFAULT
-#define JXLHIP_FUSED_PC_DEFAULT 1
-#endif
-#ifndef JXLHIP_FUSED_PC0_ROLE_DEFAULT
-#define JXLHIP_FUSED_PC0_ROLE_DEFAULT -1
-#endif
-// k_fused_pc0 with Gaborish: running plus-sum parts kept in LDS (0: all in registers, 175 VGPRs, two waves per SIMD = four
-// windows per CU; 4: 167 VGPRs, three waves, six windows).  Measured, 8K d1.0 (profiles/r04_epf3_fused.txt): the kernel
-// 0.333 ms with 0, 0.364 ms with 4 -- six windows per CU are slower than four (65.3 against 67.0 Gpx/s in flight): 0.
-#ifndef JXLHIP_PC0_PART_LDS
-#define JXLHIP_PC0_PART_LDS 0
+#if JXLHIP_FUSED_PART == 3
+#include "epf0_march.h"
 #endif
 // The producing wave runs at a raised wave priority (s_setprio): the marching wave waits for it at every block row's
 // barrier, and at equal priority the SIMD's arbiter lets the (longer, never-waiting) marches of OTHER windows take the
-// issue slots a producer needs to finish its block row.  Measured, 8K d1.0, two repetitions on one box
-// (profiles/r04_setprio.txt): producer at 3: k_fused_pc 203.5 -> 196 us, 105.1 -> 107.6 Gpx/s one frame at a time,
-// 119.8 -> 122.7 with three in flight; the MARCH at 3: no change (203).
-#ifndef JXLHIP_PC_PRODUCER_PRIO
-#define JXLHIP_PC_PRODUCER_PRIO 3
-#endif
-// 1 (experiment builds): the producer's slab writes under an EXEC mask inside one asm statement, as the march's output
-// stores -- measured: 2362 -> 2261 instructions per two block rows, the kernel 189.1 -> 189.7 us: nothing, so the
-// compiler's own exec branches stay
-#ifndef JXLHIP_PC_DECODE_ONE_BLOCK
-#define JXLHIP_PC_DECODE_ONE_BLOCK 0
-#endif
-// 1 (experiment builds): the producer's X and B channels as the halves of packed fp32 operations (PcDecode).  Measured:
-// 2032 -> 1761 VALU instructions per two block rows, bit-identical pixels, the kernel 189.7 -> 189.2 us: nothing -- a
-// packed fp32 instruction occupies the SIMD ~1.6x as long as a plain one (tools/probes/valu_issue.hip: 2.75 against 1.76
-// cycles), so pairing two plain operations into one packed one buys a fifth of their time, not half.  The scalar form
-// stays the shipped one.
-#ifndef JXLHIP_PC_PACKED_XB
-#define JXLHIP_PC_PACKED_XB 0
-#endif
-#ifndef JXLHIP_PC_INTERIOR  // 0: every chunk takes the generic march (experiments)
-#define JXLHIP_PC_INTERIOR 1
-#endif
-#ifndef JXLHIP_TILE_SLOTS  // units of the matrix-core producer whose loads are in flight together (16-bit coefficients)
-#define JXLHIP_TILE_SLOTS 6
-#endif
+// issue slots a producer needs to finish its block row (8K d1.0: k_fused_pc 203.5 -> 196 us, profiles/r04_setprio.txt).
+static constexpr int kProducerPrio = 3;
 
 namespace jxlhip {
 
@@ -104,11 +66,6 @@ __device__ __forceinline__ FrameArgs Fresh(FrameArgs q) {
   asm volatile("" : "+s"(q));
   return q;
 }
-
-struct __attribute__((aligned(16))) WaveLds {
-  float slab[3 * kSlabPlaneFloats];  // [channel][row 0..7][column 0..127]
-  uint32_t list[16 * 4];             // DCT8 cells of the block row: (cell, coefficient offset, quant / CfL word)
-};
 
 // What a wave knows about the block row it fills next: the cell info of its 16 cells (lanes 0..15)
 // and, once that load has returned, which cells it decodes itself / copies from the planes.
@@ -143,9 +100,6 @@ __device__ __forceinline__ void NextRowMasks(FrameArgs fa, NextRow& n, int bc0) 
 // consecutive 128-float slab rows are).  Called when rows 2k, 2k+1 of the CURRENT block row have
 // been consumed: the copy overlaps the march over the remaining rows.
 __device__ __forceinline__ void DmaPlaneRows(FrameArgs fa, LdsF* slab, const NextRow& n, int bc0, int k) {
-#ifdef JXLHIP_ABL_NODMA  // ablation builds: what do the plane copies cost?  (8K d1.0: 26 of 240 us)
-  return;
-#endif
   if (n.mp == 0) return;  // wave-uniform
   const FrameArgs f = Fresh(fa);
   const int lane = threadIdx.x & 63;
@@ -173,13 +127,9 @@ __device__ __forceinline__ void FinishSlab(FrameArgs fa, LdsF* slab, LdsU* list,
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int k = first_plane_k; k < 4; k++) DmaPlaneRows(fa, slab, n, bc0, k);
   const uint32_t m8 = n.m8;
-#ifdef JXLHIP_ABL_NODECODE  // ablation builds: what does the in-wave DCT8 decode cost?  (62 of 240 us.  Neither
-  if (false) {             // requesting the coefficients two march steps early, nor warming the caches, nor running
-#else                      // the X / B channels as packed pairs (-25 % VALU) changed the kernel time: the SIMDs are
                            // ~50 % busy; a wave cannot overlap its own fill with its own march, and registers + LDS
                            // cap the SIMD at three waves)
   if (m8) {  // wave-uniform
-#endif
     const bool is_dct8 = lane < 16 && ((m8 >> lane) & 1u);
     if (is_dct8) {
       const uint32_t rank = __builtin_popcount(m8 & ((1u << lane) - 1u));
@@ -274,136 +224,6 @@ __device__ __forceinline__ int GroupBlockRow(int r, int nb_last) {
   return nb > nb_last ? nb_last : nb;
 }
 
-// inv_sigma of the lane's block column in the block row of image row r (clamped into the frame): the value every
-// EPF stage of a group of 8 rows starting at r picks up (Step, SRC_LDS).  Loaded at the start of the group: a load
-// at the point of use waits, in the in-order vmcnt queue, for the LDS-DMA copies issued in between (-3 us at 8K).
-__device__ __forceinline__ float GroupSigma(FrameArgs fa, Lane& L, int r) {
-  const FrameArgs f = Fresh(fa);
-  const int H = (int)f->ysize;
-  const int rc = r < 0 ? 0 : (r >= H ? H - 1 : r);
-  return *(const float*)((const char*)(f->inv_sigma + (size_t)(rc >> 3) * f->xsb) + LaneOffset(L.sx4));
-}
-
-template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, typename CT>
-__device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, const FilterParams& P, Lane& L, WaveLds* w, int bc0,
-                                           int y_begin, int y_end) {
-  constexpr int HX = MarchGeom<GAB, EPF>::HX;
-  const int H = (int)f.ysize;
-  // y_begin is a multiple of 8: groups of 8 rows = block rows.  The stages need HX rows above y_begin and below
-  // y_end: of the block row above only its last HX rows are marched over (a peeled partial group in front of
-  // the loop), of the one below only the first HX (a peeled tail) -- 2 HX steps instead of 16 per wave (10 of
-  // 120 at 8K).  The partial groups are straight-line copies of the steps they run: guarding the steps of the
-  // loop body instead (if (r + K >= r_start) ...) made the register allocator spill 300 bytes per lane.
-  const int r_first = HX ? y_begin - 8 : y_begin;
-  const int r_last = y_end + HX - 1;
-  const int nb_last = (H - 1) >> 3;
-  LdsF* slab = (LdsF*)w->slab;
-  State s;
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-#pragma unroll
-    for (int c = 0; c < 3; c++) s.x[c][k] = v2f{0.0f, 0.0f};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      s.hs[c][k] = v2f{0.0f, 0.0f};
-      s.g[c][k] = v2f{0.0f, 0.0f};
-      s.e[c][k] = v2f{0.0f, 0.0f};
-    }
-    s.du[k] = v2f{0.0f, 0.0f};
-    s.dl[k] = v2f{0.0f, 0.0f};
-    s.pv[k] = v2f{0.0f, 0.0f};
-    s.ph[k] = v2f{0.0f, 0.0f};
-    s.dv[k] = v2f{0.0f, 0.0f};
-  }
-  float inv_sigma_blk = -1.0f, inv_sigma_blk2 = -1.0f;
-  float sigma_last = -1.0f;  // GroupSigma of the previous group of 8 rows
-  const XybConsts KC = MakeXybConsts(P);
-  const size_t out_row_bytes = OUTK == JXLHIP_OUT_XYB_PLANAR ? P.out_stride * 4 : P.out_stride;
-  char* out_row = (char*)P.out + (ptrdiff_t)(r_first - HX - (int)f.y0) * (ptrdiff_t)out_row_bytes;
-  // first block row: nothing to overlap with
-  NextRow nx;
-  NextRowRequest(fa, nx, GroupBlockRow(r_first, nb_last), bc0);
-  NextRowMasks(fa, nx, bc0);
-  FinishSlab<CT>(fa, slab, (LdsU*)w->list, nx, bc0, 0);
-#define JXLHIP_FSTEP(K)                                                                                     \
-  Step<GAB, EPF, OUTK, FMT, K, EDGE, 0, SRC_LDS>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk,      \
-                                                  inv_sigma_blk2, out_row, KC, slab_y0, sigma_pre, sigma_prev); \
-  out_row += out_row_bytes
-  if constexpr (HX > 0) {  // the last HX rows of the block row above
-    const int r = r_first;
-    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
-    const float sigma_prev = sigma_last;
-    const float sigma_pre = EPF ? GroupSigma(fa, L, r) : 0.0f;
-    sigma_last = sigma_pre;
-    {
-      const int row0 = Mirror1(r + 8 - HX, H) - slab_y0;
-#pragma unroll
-      for (int c = 0; c < 3; c++) s.x[c][8 - HX] = LdsPair<EDGE>(L, c, row0);
-    }
-    out_row += (8 - HX) * out_row_bytes;
-    NextRowRequest(fa, nx, GroupBlockRow(r + 8, nb_last), bc0);
-    if constexpr (HX >= 4) { JXLHIP_FSTEP(4); }
-    if constexpr (HX >= 3) { JXLHIP_FSTEP(5); }
-    NextRowMasks(fa, nx, bc0);
-    DmaPlaneRows(fa, slab, nx, bc0, 0);  // rows 0 .. 3 of this block row are not read at all
-    DmaPlaneRows(fa, slab, nx, bc0, 1);
-    if constexpr (HX >= 2) { JXLHIP_FSTEP(6); }
-    JXLHIP_FSTEP(7);
-    FinishSlab<CT>(fa, slab, (LdsU*)w->list, nx, bc0, 2);
-  }
-  int r = HX ? y_begin : r_first;
-  for (; r_last - r >= HX; r += 8) {  // whole groups (HX = 0: r <= r_last)
-    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
-    const float sigma_prev = sigma_last;
-    const float sigma_pre = EPF ? GroupSigma(fa, L, r) : 0.0f;
-    sigma_last = sigma_pre;
-    {
-      const int row0 = Mirror1(r, H) - slab_y0;
-#pragma unroll
-      for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
-    }
-    // The next block row is prepared while this one is marched over: its cell info is requested now, its
-    // plane tiles are DMA'd two slab rows at a time as soon as the march has consumed them (a group
-    // that reads mirror rows is followed by one from the SAME block row: the early copies then rewrite
-    // identical bytes), and what is left for the end -- the last two plane rows and the DCT8 cells --
-    // is FinishSlab.
-    const bool more = r + 8 <= r_last;
-    NextRowRequest(fa, nx, more ? GroupBlockRow(r + 8, nb_last) : -1, bc0);
-    JXLHIP_FSTEP(0);
-    JXLHIP_FSTEP(1);
-    NextRowMasks(fa, nx, bc0);
-    JXLHIP_FSTEP(2);
-    DmaPlaneRows(fa, slab, nx, bc0, 0);  // rows 0, 1: their reads completed in steps 0 / 1
-    JXLHIP_FSTEP(3);
-    JXLHIP_FSTEP(4);
-    DmaPlaneRows(fa, slab, nx, bc0, 1);
-    JXLHIP_FSTEP(5);
-    JXLHIP_FSTEP(6);
-    DmaPlaneRows(fa, slab, nx, bc0, 2);
-    JXLHIP_FSTEP(7);
-    if (more) FinishSlab<CT>(fa, slab, (LdsU*)w->list, nx, bc0, 3);
-  }
-  if (HX > 0 && r <= r_last) {  // the first HX rows of the block row below (y_end a multiple of 8)
-    const int slab_y0 = GroupBlockRow(r, nb_last) * 8;
-    const float sigma_prev = sigma_last;
-    const float sigma_pre = EPF ? GroupSigma(fa, L, r) : 0.0f;
-    sigma_last = sigma_pre;
-    {
-      const int row0 = Mirror1(r, H) - slab_y0;
-#pragma unroll
-      for (int c = 0; c < 3; c++) s.x[c][0] = LdsPair<EDGE>(L, c, row0);
-    }
-    JXLHIP_FSTEP(0);
-    if constexpr (HX >= 2) { JXLHIP_FSTEP(1); }
-    if constexpr (HX >= 3) { JXLHIP_FSTEP(2); }
-    if constexpr (HX >= 4) { JXLHIP_FSTEP(3); }
-  }
-#undef JXLHIP_FSTEP
-}
-
-#if JXLHIP_FUSED_PART == 2 || JXLHIP_FUSED_PART == 3
 // ------------------------------------------------------------------------------------------------
 // k_fused_pc: the same window march with the two halves of the work on two WAVES of a workgroup.
 //
@@ -420,20 +240,11 @@ __device__ __forceinline__ void MarchFused(const DevFrame& f, FrameArgs fa, cons
 //                     It issues no store, so its vmcnt waits cover loads only.
 // One s_barrier per block row joins the two (fill(i) done / march(i-1) done).  Workgroup = 128 threads = one
 // window; six workgroups per CU (three waves per SIMD by registers, 24.7 KB of LDS each).
-#ifdef JXLHIP_ABL_PC_ONEBUF  // ablation builds (timing only, garbage pixels): both "buffers" are the same 12 KB, eight
-#define JXLHIP_PC_SLABS 1    // workgroups per CU fit the LDS -- what would twice as many, shorter marches per CU buy?
-#define JXLHIP_PC_SLAB(b) 0
-#define JXLHIP_PC_WAVES 4
-#define JXLHIP_PC_PER_CU 8
-#else
-#define JXLHIP_PC_SLABS NB
-#define JXLHIP_PC_SLAB(b) (b)
-#define JXLHIP_PC_WAVES 3
-#define JXLHIP_PC_PER_CU 6
-#endif
+static constexpr int kPcWaves = 3;   // waves per SIMD the kernels below are compiled for (<= 168 VGPRs)
+static constexpr int kPcPerCu = 6;   // windows resident per CU
 template <int NB>
 struct __attribute__((aligned(16))) StripLdsT {
-  float slab[JXLHIP_PC_SLABS][3 * kSlabPlaneFloats];  // [buffer][channel][row 0..7][column 0..127]
+  float slab[NB][3 * kSlabPlaneFloats];  // [buffer][channel][row 0..7][column 0..127]
   float sigma[NB][16];                   // [buffer][cell]: inv_sigma of the block row's 16 cells (columns clamped into the frame)
   uint32_t list[NB - 1][16 * 4];         // per producer: the DCT8 cells of the block row being filled
 };
@@ -448,72 +259,15 @@ __device__ __forceinline__ int PcGroups(int y_begin, int y_end) {
   return (HX > 0 ? 1 : 0) + whole + (tail ? 1 : 0);
 }
 
-// -DJXLHIP_PC_TIMING (experiment builds, tools/r05/pc_timing.py): every wave adds up the shader-clock ticks it spends
-// (a) waiting for its own loads / LDS operations in front of a barrier and (b) inside s_barrier waiting for the other
-// wave, and leaves the sums -- with its total run time -- in the first words of the frame's inv_sigma table (read back
-// through jxlhip_get_sigma; the pixels of such a build are garbage near the frame's corner).
-#ifdef JXLHIP_PC_TIMING
-struct PcClock {
-  unsigned long long wait_mem = 0, wait_barrier = 0, t_begin = 0;
-};
-__device__ PcClock* g_pc_clock_unused;  // (keeps the type referenced in builds without a user)
-#define JXLHIP_PC_CLOCK_ARG , PcClock& clk
-#define JXLHIP_PC_CLOCK_PASS , clk
-__device__ __forceinline__ void PcBarrierProducer(PcClock& clk) {
-  const unsigned long long t0 = __builtin_readcyclecounter();
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  const unsigned long long t1 = __builtin_readcyclecounter();
-  asm volatile("s_barrier" ::: "memory");
-  const unsigned long long t2 = __builtin_readcyclecounter();
-  clk.wait_mem += t1 - t0;
-  clk.wait_barrier += t2 - t1;
-}
-__device__ __forceinline__ void PcBarrierMarch(PcClock& clk) {
-  const unsigned long long t0 = __builtin_readcyclecounter();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const unsigned long long t1 = __builtin_readcyclecounter();
-  asm volatile("s_barrier" ::: "memory");
-  const unsigned long long t2 = __builtin_readcyclecounter();
-  clk.wait_mem += t1 - t0;
-  clk.wait_barrier += t2 - t1;
-}
-__device__ __forceinline__ void PcClockReport(float* inv_sigma, const PcClock& clk, int role) {
-  if ((threadIdx.x & 63) == 0) {
-    unsigned long long* out = (unsigned long long*)inv_sigma + 4 * role;
-    atomicAdd(out + 0, __builtin_readcyclecounter() - clk.t_begin);
-    atomicAdd(out + 1, clk.wait_mem);
-    atomicAdd(out + 2, clk.wait_barrier);
-    atomicAdd(out + 3, 1ull);
-    // where the wave ran: HW_REG_HW_ID (wave, SIMD, CU, shader array / engine, XCC ids), one word per wave
-    uint32_t hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    ((uint32_t*)inv_sigma)[64 + 4 * (2 * (int)blockIdx.x + role) + 0] = hw;
-    ((uint32_t*)inv_sigma)[64 + 4 * (2 * (int)blockIdx.x + role) + 1] = xcc;
-    ((uint32_t*)inv_sigma)[64 + 4 * (2 * (int)blockIdx.x + role) + 2] = (uint32_t)(__builtin_readcyclecounter() - clk.t_begin);
-    ((uint32_t*)inv_sigma)[64 + 4 * (2 * (int)blockIdx.x + role) + 3] = (uint32_t)clk.wait_barrier;
-  }
-}
-#define PcBarrierProducer() PcBarrierProducer(clk)
-#define PcBarrierMarch() PcBarrierMarch(clk)
-#else
-#define JXLHIP_PC_CLOCK_ARG
-#define JXLHIP_PC_CLOCK_PASS
 __device__ __forceinline__ void PcBarrierProducer() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 __device__ __forceinline__ void PcBarrierMarch() {  // no vmcnt: the output stores stay in flight
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-#endif
 
 template <int HX, typename CT>
 __device__ __forceinline__ void ProducePC(FrameArgs fa, StripLds* w, int bc0, int y_begin, int y_end, int nb_last) {
-#ifdef JXLHIP_PC_TIMING
-  PcClock clk;
-  clk.t_begin = __builtin_readcyclecounter();
-#endif
   const int lane = threadIdx.x & 63;
   const int r_first = HX ? y_begin - 8 : y_begin;
   const int G = PcGroups<HX>(y_begin, y_end);
@@ -537,13 +291,8 @@ __device__ __forceinline__ void ProducePC(FrameArgs fa, StripLds* w, int bc0, in
       NextRowRequest(fa, nx, nb, bc0);
       sg = sigma_request(nb);
     }
-    LdsF* slab = (LdsF*)w->slab[JXLHIP_PC_SLAB(i & 1)];
-#ifndef JXLHIP_ABL_PC_NOFILL  // ablation builds (tools/build_variant.py): the marching wave alone
+    LdsF* slab = (LdsF*)w->slab[(i & 1)];
     FinishSlab<CT>(fa, slab, (LdsU*)w->list[0], cur, bc0, 0);  // four plane row pairs by LDS-DMA + the DCT8 cells; ends on vmcnt(0)
-#else
-    (void)slab;
-    (void)cur;
-#endif
     if (lane < 16) ((LdsF*)w->sigma[i & 1])[lane] = sg_cur;
     PcBarrierProducer();
   }
@@ -720,9 +469,6 @@ __device__ __forceinline__ void PcIssue(const PcK& K, LdsU* list, const PcNext& 
 // Plane cells of block row nb, the four slab row pairs, all three channels: twelve LDS-DMA instructions of 1 KB
 // (DmaPlaneRows above, with the producer's resident constants)
 __device__ __forceinline__ void PcDmaPlanes(const PcK& K, LdsF* slab, uint32_t mp, int nb, int bc0) {
-#ifdef JXLHIP_ABL_NODMA
-  return;
-#endif
   if (mp == 0) return;  // wave-uniform
   const int lane = threadIdx.x & 63;
   const int cell = (lane & 31) >> 1;
@@ -737,67 +483,7 @@ __device__ __forceinline__ void PcDmaPlanes(const PcK& K, LdsF* slab, uint32_t m
   }
 }
 
-// The X and B channels of a decode step as the two halves of packed fp32 operations (round 5): the SIMDs' instruction
-// throughput bounds k_fused_pc (profiles/r05_fused_pc_issue_analysis.txt, sections 4-5), and the producing wave spent
-// 2 x 64 instructions per step on the two chroma channels' 8-point IDCTs and 2 x 72 on their dequantisation.  Packed
-// operations are IEEE per element: every value goes through the same operations in the same order as in the scalar form
-// (IdctReg<8>, AdjustQuantBias) -- the pixels are bit-identical.  LAST = the second pass: its final butterfly level is
-// left scalar so that each channel's eight results sit in consecutive registers for the two ds_write_b128.
-typedef float pc2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pc2f PcFma2(float m, pc2f a, pc2f b) { return __builtin_elementwise_fma(pc2f{m, m}, a, b); }
-template <int N>
-__device__ __forceinline__ void IdctReg2(pc2f* __restrict__ v) {
-  if constexpr (N == 2) {
-    const pc2f a = v[0], b = v[1];
-    v[0] = a + b;
-    v[1] = a - b;
-  } else {
-    constexpr int H = N / 2;
-    pc2f e[H], o[H];
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-      e[i] = v[2 * i];
-      o[i] = v[2 * i + 1];
-    }
-    IdctReg2<H>(e);
-#pragma unroll
-    for (int i = H - 1; i > 0; i--) o[i] = o[i] + o[i - 1];
-    o[0] = o[0] * pc2f{kSqrt2, kSqrt2};
-    IdctReg2<H>(o);
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-      const float mul = kWcHost[N + i];
-      v[i] = PcFma2(mul, o[i], e[i]);
-      v[N - 1 - i] = PcFma2(-mul, o[i], e[i]);
-    }
-  }
-}
-// the 8-point IDCT of both channels with the last level scalar: x[8], b[8] = the .x / .y results
-__device__ __forceinline__ void Idct8PackedSplit(const pc2f* __restrict__ v, float* __restrict__ x, float* __restrict__ b) {
-  pc2f e[4], o[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    e[i] = v[2 * i];
-    o[i] = v[2 * i + 1];
-  }
-  IdctReg2<4>(e);
-#pragma unroll
-  for (int i = 3; i > 0; i--) o[i] = o[i] + o[i - 1];
-  o[0] = o[0] * pc2f{kSqrt2, kSqrt2};
-  IdctReg2<4>(o);
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float mul = kWcHost[8 + i];
-    x[i] = __builtin_fmaf(mul, o[i].x, e[i].x);
-    x[7 - i] = __builtin_fmaf(-mul, o[i].x, e[i].x);
-    b[i] = __builtin_fmaf(mul, o[i].y, e[i].y);
-    b[7 - i] = __builtin_fmaf(-mul, o[i].y, e[i].y);
-  }
-}
-
-__device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroupRegs& R, const float (&tab)[3][8],
-                                         const pc2f (&tabxb)[8]) {
-  (void)tabxb;
+__device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroupRegs& R, const float (&tab)[3][8]) {
   const int lane = threadIdx.x & 63;
   const int j = lane >> 3;
   const bool bit3 = (lane & 8) != 0;
@@ -806,8 +492,6 @@ __device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroup
     if (s * 8 < R.n8) {  // wave-uniform
       const PcStepRegs& T = R.st[s];
       const bool valid = s * 8 + (lane & 7) < R.n8;
-      const unsigned long long valid_mask = __ballot(valid);
-      (void)valid_mask;
       float sx, sy, sb, x_cc, b_cc;
       {
         const int quant = (int)(T.qc & 0xffffu);
@@ -834,59 +518,6 @@ __device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroup
       for (int k = 0; k < 8; k++) vy[k] = AdjustQuantBias(q[k], bias1, bias3) * (tab[1][k] * sy);
       typedef float f4v __attribute__((ext_vector_type(4)));
       typedef f4v __attribute__((address_space(3))) * P4;
-#if JXLHIP_PC_PACKED_XB
-      {
-        // X | B: AdjustQuantBias (quantizer-inl.h:34-67) + table x scale + chroma from luma on both at once
-        int32_t qb[8];
-        unpack(T.rows[0], q);
-        unpack(T.rows[2], qb);
-        pc2f xb[8];
-        const pc2f bias02 = pc2f{bias0, bias2}, nb3 = pc2f{-bias3, -bias3}, cc2 = pc2f{x_cc, b_cc}, sc2 = pc2f{sx, sb};
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const pc2f quant = pc2f{(float)q[k], (float)qb[k]};
-          const pc2f small = bias02 * quant;
-          const pc2f rc = pc2f{__builtin_amdgcn_rcpf(quant.x), __builtin_amdgcn_rcpf(quant.y)};
-          const pc2f big = __builtin_elementwise_fma(nb3, rc, quant);
-          const pc2f adj = pc2f{__builtin_fabsf(quant.x) < 1.125f ? small.x : big.x, __builtin_fabsf(quant.y) < 1.125f ? small.y : big.y};
-          const pc2f d = adj * (tabxb[k] * sc2);
-          xb[k] = __builtin_elementwise_fma(cc2, pc2f{vy[k], vy[k]}, d);
-        }
-        if (j == 0) xb[0] = pc2f{__uint_as_float(T.dcv[0]), __uint_as_float(T.dcv[2])};
-        IdctReg2<8>(xb);
-        float tx[8], tb[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          tx[k] = xb[k].x;
-          tb[k] = xb[k].y;
-        }
-        Transpose8Lanes(tx, bit3);
-        Transpose8Lanes(tb, bit3);
-#pragma unroll
-        for (int k = 0; k < 8; k++) xb[k] = pc2f{tx[k], tb[k]};
-        Idct8PackedSplit(xb, tx, tb);
-        if (valid) {
-          LdsF* dx = slab + 0 * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
-          LdsF* db = slab + 2 * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
-          *(P4)dx = f4v{tx[0], tx[1], tx[2], tx[3]};
-          *(P4)(dx + 4) = f4v{tx[4], tx[5], tx[6], tx[7]};
-          *(P4)db = f4v{tb[0], tb[1], tb[2], tb[3]};
-          *(P4)(db + 4) = f4v{tb[4], tb[5], tb[6], tb[7]};
-        }
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = vy[k];
-        if (j == 0) v[0] = __uint_as_float(T.dcv[1]);
-        IdctReg<8>(v);
-        Transpose8Lanes(v, bit3);
-        IdctReg<8>(v);
-        if (valid) {
-          LdsF* dy = slab + 1 * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
-          *(P4)dy = f4v{v[0], v[1], v[2], v[3]};
-          *(P4)(dy + 4) = f4v{v[4], v[5], v[6], v[7]};
-        }
-      }
-#else
 #pragma unroll
       for (int ci3 = 0; ci3 < 3; ci3++) {
         const int c = ci3 == 0 ? 1 : (ci3 == 1 ? 0 : 2);
@@ -909,39 +540,17 @@ __device__ __forceinline__ void PcDecode(const PcK& K, LdsF* slab, const PcGroup
         Transpose8Lanes(v, bit3);
         IdctReg<8>(v);
         LdsF* dst = slab + c * kSlabPlaneFloats + j * kSlabCols + T.cell * 8;
-#if JXLHIP_PC_DECODE_ONE_BLOCK
-        {  // the two slab writes under an EXEC mask inside one asm statement: the step's three channels stay ONE basic
-           // block (as the march's output stores, filters_march.h) and their independent chains interleave
-          unsigned long long saved;
-          const f4v lo = f4v{v[0], v[1], v[2], v[3]}, hi = f4v{v[4], v[5], v[6], v[7]};
-          const uint32_t addr = (uint32_t)(uintptr_t)dst;
-          asm volatile(
-              "s_and_saveexec_b64 %0, %1\n\t"
-              "ds_write_b128 %2, %3\n\t"
-              "ds_write_b128 %2, %4 offset:16\n\t"
-              "s_mov_b64 exec, %0"
-              : "=&s"(saved)
-              : "s"(valid_mask), "v"(addr), "v"(lo), "v"(hi)
-              : "memory", "scc");
-        }
-#else
         if (valid) {
           *(P4)dst = f4v{v[0], v[1], v[2], v[3]};
           *(P4)(dst + 4) = f4v{v[4], v[5], v[6], v[7]};
         }
-#endif
       }
-#endif  // JXLHIP_PC_PACKED_XB
     }
   }
 }
 
 template <int HX>
 __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, int y_begin, int y_end, int nb_last) {
-#ifdef JXLHIP_PC_TIMING
-  PcClock clk;
-  clk.t_begin = __builtin_readcyclecounter();
-#endif
   const int lane = threadIdx.x & 63;
   const int r_first = HX ? y_begin - 8 : y_begin;
   const int G = PcGroups<HX>(y_begin, y_end);
@@ -957,15 +566,6 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
       tab[c][0] = t0.x, tab[c][1] = t0.y, tab[c][2] = t0.z, tab[c][3] = t0.w;
       tab[c][4] = t1.x, tab[c][5] = t1.y, tab[c][6] = t1.z, tab[c][7] = t1.w;
     }
-  }
-  // (the X | B entries as register PAIRS, the operand form of the packed dequantisation)
-  pc2f tabxb[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    tabxb[k] = pc2f{tab[0][k], tab[2][k]};
-#if JXLHIP_PC_PACKED_XB
-    asm volatile("" : "+v"(tabxb[k]));
-#endif
   }
   LdsU* list = (LdsU*)w->list[0];
   auto group_nb = [&](int g) { return GroupBlockRow(r_first + 8 * (g < G ? g : G - 1), nb_last); };
@@ -985,16 +585,14 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
   // one fill: CUR holds block row g (loaded behind an earlier barrier), NXT receives block row g+1,
   // nn = cell info of block row g+1 (valid), refilled with block row g+2's
   auto body = [&](int g, PcGroupRegs& CUR, PcGroupRegs& NXT, uint32_t& sg_cur, uint32_t& sg_nxt, PcNext& nn) {
-    LdsF* slab = (LdsF*)w->slab[JXLHIP_PC_SLAB(g & 1)];  // free: the march left it before the previous barrier
+    LdsF* slab = (LdsF*)w->slab[(g & 1)];  // free: the march left it before the previous barrier
     // the plane cells of block row g first: of everything this fill waits for at its barrier, these copies were the last
     // to be issued (behind the list round trip of PcIssue) -- now they have the whole decode to land
     PcDmaPlanes(K, slab, CUR.mp, CUR.nb, bc0);
     PcIssue(K, list, nn, bc0, NXT);     // block row g+1 (the last block row again behind the end: harmless)
     sg_nxt = nn.sg;
     PcRequest(K, nn, group_nb(g + 2), bc0);
-#ifndef JXLHIP_ABL_PC_NODECODE  // ablation builds (timing only): the producer without its DCT8 arithmetic
-    PcDecode(K, slab, CUR, tab, tabxb);
-#endif
+    PcDecode(K, slab, CUR, tab);
     if (lane < 16) ((LdsU*)w->sigma[g & 1])[lane] = sg_cur;
     PcBarrierProducer();
     PcLanded(NXT);
@@ -1003,390 +601,6 @@ __device__ __forceinline__ void ProducePC2(FrameArgs fa, StripLds* w, int bc0, i
   for (int g = 0; g < G; g += 2) {
     body(g, A, B, sg_a, sg_b, n1);
     if (g + 1 < G) body(g + 1, B, A, sg_b, sg_a, n1);
-  }
-#ifdef JXLHIP_PC_TIMING
-  PcClockReport(fa->inv_sigma, clk, 1);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
-// The producer on the MATRIX CORES (round 4): DCT8, DCT8X16, DCT16X8 and DCT16X16 -- 77 % of a d1.0 frame -- are
-// decoded by the producing wave, whatever their mix inside the window; their pixels never exist in HBM.
-//
-// A row-per-lane step (ProducePC2 above, k_transform_r) wants 8 - 16 varblocks of ONE class, and a window's block row
-// holds one or two of each 16-point class: as butterflies every class would cost a nearly empty step per block row.
-// As two dense products on v_mfma_f32_16x16x4_f32 the decode costs the same whatever the class: the wave works on
-// UNITS of one 16 x 16 coefficient tile M,
-//     pixels = L M R        (L, R: the 16-point IDCT matrix B16, or diag(B8, B8) = two 8-point IDCTs side by side)
-//   4 x DCT8      M = [[a, b], [c, d]]  (four independent blocks, any four DCT8 cells of the block row)   L = R = diag(B8, B8)
-//   2 x DCT16X8   M = [a; b]  (stored transposed, 8 x 16 each: rows = horizontal frequency)              L = diag(B8, B8), R = B16
-//   2 x DCT8X16   M = [a; b]  (8 x 16 each: rows = vertical frequency)                                     R = B16, then diag(B8, B8) from the right of the transpose
-//   1 x DCT16X16  M = the block (stored transposed)                                                        L = R = B16
-// with the lane layout of k_transform_mfma16 (kernels_mfma.hip): lane (m = lane % 16, h = lane / 16) holds M[m][4 h ..
-// 4 h + 3] -- one 8- or 16-byte load per lane and channel --, dequantises in place (dec_group.cc:115-181), product 1's
-// accumulator feeds product 2 as it stands, and the result is four consecutive pixels of one row per lane: one
-// ds_write_b128 into the slab.  The class only selects per-lane addresses, two of three preloaded dequant-table register
-// sets and which of the two constant operand tables each product takes -- data, not code.
-//
-// A varblock two block rows high is decoded once per block row it crosses and only the eight rows of the block row
-// being filled are written (stateless: the slab stays one block row x two buffers, six windows per CU as before); a
-// varblock two cells wide that straddles the window's edge is decoded whole and only its cells inside the window are
-// written.  k_prepare (DevFrame::fused_tiles) leaves in every cell such a varblock covers the varblock's coefficient
-// offset, quant / CfL word, kind and the cell's position inside it; every other cell comes from the planes by LDS-DMA
-// as before (the 32- and 64-point classes and the nine special 8x8 kinds, decoded by k_transform_r).
-// Reference: DequantBlock + LowestFrequenciesFromDC + TransformToPixels (dec_group.cc:115-181,431-450,
-// dec_transforms-inl.h:456-818, dct-inl.h:376-397).
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-template <typename CT>
-struct TileSlot {  // what one unit needs from memory
-  typedef typename std::conditional<sizeof(CT) == 2, uint2, uint4>::type Raw;
-  Raw raw[3];  // M[m][4 h .. 4 h + 3] of the lane's block, per channel
-  float dcv;   // lane 16 r + 4 c + 2 dy + dx: DC (channel c, row dy, column dx) of the patch of the unit's r-th varblock
-};
-
-struct TileRow {  // wave-uniform: the block row being filled
-  int nb;         // block row
-  int n[4];       // varblocks of each kind that the window sees in this block row (its representatives' count)
-  int base[4];    // their first entry in the LDS list
-};
-struct TileUnit {  // wave-uniform
-  int kind, r0, nr;
-};
-__device__ __forceinline__ int TileUnits(const TileRow& R) { return ((R.n[0] + 3) >> 2) + ((R.n[1] + 1) >> 1) + ((R.n[2] + 1) >> 1) + R.n[3]; }
-__device__ __forceinline__ TileUnit TileUnitOf(const TileRow& R, int u) {
-  const int u0 = (R.n[0] + 3) >> 2, u1 = (R.n[1] + 1) >> 1, u2 = (R.n[2] + 1) >> 1;
-  TileUnit t;
-  if (u < u0) {
-    t.kind = 0, t.r0 = R.base[0] + 4 * u, t.nr = min(4, R.n[0] - 4 * u);
-  } else if (u < u0 + u1) {
-    u -= u0;
-    t.kind = 1, t.r0 = R.base[1] + 2 * u, t.nr = min(2, R.n[1] - 2 * u);
-  } else if (u < u0 + u1 + u2) {
-    u -= u0 + u1;
-    t.kind = 2, t.r0 = R.base[2] + 2 * u, t.nr = min(2, R.n[2] - 2 * u);
-  } else {
-    u -= u0 + u1 + u2;
-    t.kind = 3, t.r0 = R.base[3] + u, t.nr = 1;
-  }
-  return t;
-}
-// the lane's input varblock of a unit (which of its nr) and its first coefficient inside that varblock
-__device__ __forceinline__ int TileRepIn(int kind, int l15, int h) { return kind == 0 ? 2 * (l15 >> 3) + (h >> 1) : (kind == 3 ? 0 : l15 >> 3); }
-__device__ __forceinline__ int TileIntra(int kind, int l15, int h) {
-  return kind == 0 ? (l15 & 7) * 8 + (h & 1) * 4 : (kind == 3 ? l15 * 16 + 4 * h : (l15 & 7) * 16 + 4 * h);
-}
-
-template <typename CT>
-__device__ __forceinline__ void TileLoad(FrameArgs fa, const LdsU* list, const TileRow& R, const TileUnit U, int bc0, TileSlot<CT>& S) {
-  const FrameArgs f = Fresh(fa);
-  typedef typename TileSlot<CT>::Raw Raw;
-  const int lane = threadIdx.x & 63;
-  const int l15 = lane & 15, h = lane >> 4;
-  {
-    const int rep = min(TileRepIn(U.kind, l15, h), U.nr - 1);
-    const uint32_t off = list[(U.r0 + rep) * 4 + 1];
-    const size_t elem = (size_t)off * 64u + (size_t)TileIntra(U.kind, l15, h);
-#pragma unroll
-    for (int c = 0; c < 3; c++) S.raw[c] = *(const Raw*)((const CT*)f->coeffs[c] + elem);
-  }
-  {
-    // DC patch of varblock r = lane / 16 (CY x CX = (1 + kind / 2) x (1 + kind % 2) values per channel)
-    const int rep = min(h, U.nr - 1);
-    const int cell = (int)list[(U.r0 + rep) * 4 + 0];
-    const uint32_t tag = list[(U.r0 + rep) * 4 + 2] >> kTileTagShift;
-    const int aby = R.nb - (int)((tag >> 3) & 1u), abx = bc0 + cell - (int)((tag >> 2) & 1u);
-    const int k = min(l15, 11);
-    const int dy = min((k >> 1) & 1, U.kind >> 1), dx = min(k & 1, U.kind & 1);
-    S.dcv = f->dc[k >> 2][(size_t)(aby + dy) * f->xsb + (size_t)(abx + dx)];
-  }
-}
-
-// DequantLane + chroma from luma (dec_group.cc:115-181) of the lane's four coefficients of the three channels
-template <typename CT>
-__device__ __forceinline__ void TileDequant(const TileSlot<CT>& S, const float (&tab)[3][4], float sx, float sy, float sb, float x_cc,
-                                            float b_cc, float bias0, float bias1, float bias2, float bias3, float (&v)[3][4]) {
-  auto unpack = [](const typename TileSlot<CT>::Raw& r, int32_t* q) {
-    if constexpr (sizeof(CT) == 2) {
-      q[0] = (int32_t)(int16_t)(r.x & 0xffffu);
-      q[1] = (int32_t)r.x >> 16;
-      q[2] = (int32_t)(int16_t)(r.y & 0xffffu);
-      q[3] = (int32_t)r.y >> 16;
-    } else {
-      q[0] = (int32_t)r.x;
-      q[1] = (int32_t)r.y;
-      q[2] = (int32_t)r.z;
-      q[3] = (int32_t)r.w;
-    }
-  };
-  {
-    int32_t q[4];
-    unpack(S.raw[1], q);
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[1][k] = AdjustQuantBias(q[k], bias1, bias3) * (tab[1][k] * sy);
-  }
-#pragma unroll
-  for (int c = 0; c < 3; c += 2) {
-    const float sc = c == 0 ? sx : sb;
-    const float cc = c == 0 ? x_cc : b_cc;
-    int32_t q[4];
-    unpack(S.raw[c], q);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const float d = AdjustQuantBias(q[k], c == 0 ? bias0 : bias2, bias3) * (tab[c][k] * sc);
-      v[c][k] = __builtin_fmaf(cc, v[1][k], d);
-    }
-  }
-}
-
-// tabs: the lane's entries of the dequant matrices of DCT8 [0], DCT16X8 = DCT8X16 [1] and DCT16X16 [2] (per channel,
-// the four entries matching the lane's coefficients); t16 / t8: the two operand tables
-template <typename CT>
-__device__ __forceinline__ void TileCompute(FrameArgs fa, LdsF* slab, const LdsU* list, const TileUnit U, const TileSlot<CT>& S,
-                                            const float (&tabs)[3][3][4], const float (&t16)[4], const float (&t8)[4]) {
-  const FrameArgs f = Fresh(fa);
-  const int lane = threadIdx.x & 63;
-  const int l15 = lane & 15, h = lane >> 4;
-  const int kind = U.kind;
-  const int rep_in = min(TileRepIn(kind, l15, h), U.nr - 1);
-  const uint32_t qc = list[(U.r0 + rep_in) * 4 + 2];
-  float sx, sy, sb, x_cc, b_cc;
-  {
-    const int quant = (int)(qc & kTileQuantMask);
-    const float sq = f->inv_global_scale / (float)quant;  // dec_group.cc:164
-    sx = sq * f->x_dm;
-    sy = sq;
-    sb = sq * f->b_dm;
-    x_cc = f->cfl_base_x + (float)(int8_t)((qc >> 16) & 0xffu) * f->color_scale;
-    b_cc = f->cfl_base_b + (float)(int8_t)(qc >> 24) * f->color_scale;
-  }
-  const float bias0 = f->biases[0], bias1 = f->biases[1], bias2 = f->biases[2], bias3 = f->biases[3];
-  // (one copy of the dequantisation per table set, picked by a wave-uniform branch: selecting the table values
-  // per coefficient made the compiler keep the 36 values in scratch and index them)
-  float v[3][4];
-  if (kind == 0) TileDequant<CT>(S, tabs[0], sx, sy, sb, x_cc, b_cc, bias0, bias1, bias2, bias3, v);
-  else if (kind == 3) TileDequant<CT>(S, tabs[2], sx, sy, sb, x_cc, b_cc, bias0, bias1, bias2, bias3, v);
-  else TileDequant<CT>(S, tabs[1], sx, sy, sb, x_cc, b_cc, bias0, bias1, bias2, bias3, v);
-  // lowest frequencies from the DC patch (LowestFrequenciesFromDC, dec_transforms-inl.h:691-818; the operation order of
-  // RowLaneUnit, kernels_blocks.hip): the lane holding the corner M[0][0 .. 1] of its varblock (DCT16X16: the lanes of rows
-  // 0 and 1) fetches the patch from the lanes that loaded it
-  {
-    constexpr float r1 = kResampleUpHost[1], r2 = kResampleUpHost[2], r3 = kResampleUpHost[3];
-    const int src = 16 * rep_in;
-    if (kind == 0) {
-      const bool corner = (l15 & 7) == 0 && (h & 1) == 0;
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const float d = __shfl(S.dcv, src + 4 * c, 64);
-        if (corner) v[c][0] = d;
-      }
-    } else if (kind == 3) {
-      const bool corner = h == 0 && l15 < 2;
-      const float rx = l15 == 0 ? r2 : r3;
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        float d[2][2];
-#pragma unroll
-        for (int i = 0; i < 4; i++) d[i >> 1][i & 1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S.dcv), 4 * c + i));
-        float dp[2][2];
-#pragma unroll
-        for (int x = 0; x < 2; x++) {
-          dp[0][x] = 0.5f * (d[0][x] + d[1][x]);
-          dp[1][x] = 0.5f * (d[0][x] - d[1][x]);
-        }
-#pragma unroll
-        for (int y = 0; y < 2; y++) {
-          const float val = 0.5f * (l15 == 0 ? dp[y][0] + dp[y][1] : dp[y][0] - dp[y][1]);
-          const float llf = val * rx * (y == 0 ? r2 : r3);
-          if (corner) v[c][y] = llf;
-        }
-      }
-    } else {
-      const bool corner = (l15 & 7) == 0 && h == 0;
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        // kind 1 (DCT8X16, 1 x 2 patch): the two values of row 0; kind 2 (DCT16X8, 2 x 1): those of column 0
-        const float d0 = __shfl(S.dcv, src + 4 * c, 64);
-        const float d1 = __shfl(S.dcv, src + 4 * c + (kind == 1 ? 1 : 2), 64);
-        const float a = 0.5f * (d0 + d1), b = 0.5f * (d0 - d1);
-        // DCT8X16: val * ry * R[CX + x] with ry = R[1]; DCT16X8: val * R[CX + 0] * R[CY + y] with R[1] in front
-        const float l0 = a * r1 * r2;
-        const float l1 = b * r1 * r3;
-        if (corner) {
-          v[c][0] = l0;
-          v[c][1] = l1;
-        }
-      }
-    }
-  }
-  // the two products.  Product 1: A = the coefficients, B = B16 (diag(B8, B8) for DCT8).  Product 2: A = the constant
-  // table, B = product 1's accumulator (DCT8X16: A = the accumulator read as its transpose, B = diag(B8, B8))
-  v4f p[3];
-  {
-    v4f q[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) q[c] = v4f{0, 0, 0, 0};
-#pragma unroll
-    for (int kk = 3; kk >= 0; kk--) {
-      const float b1 = kind == 0 ? t8[kk] : t16[kk];
-#pragma unroll
-      for (int c = 0; c < 3; c++) q[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c][kk], b1, q[c], 0, 0, 0);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) p[c] = v4f{0, 0, 0, 0};
-    if (kind == 1) {
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) p[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c][i], t8[i], p[c], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const float a2 = kind == 3 ? t16[i] : t8[i];
-#pragma unroll
-        for (int c = 0; c < 3; c++) p[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, q[c][i], p[c], 0, 0, 0);
-      }
-    }
-  }
-  // the lane holds four consecutive pixels of row (lane % 8) of a cell: which varblock of the unit, which of its cells
-  {
-    const int rep_out = kind == 0 ? 2 * (h >> 1) + (l15 >> 3) : (kind == 1 ? l15 >> 3 : (kind == 2 ? h >> 1 : 0));
-    const int ro = min(rep_out, U.nr - 1);
-    const int cell = (int)list[(U.r0 + ro) * 4 + 0];
-    const uint32_t tag = list[(U.r0 + ro) * 4 + 2] >> kTileTagShift;
-    const int cell_out = cell - (int)((tag >> 2) & 1u) + ((kind & 1) ? (h >> 1) : 0);
-    const bool half_ok = kind < 2 || (uint32_t)(l15 >> 3) == ((tag >> 3) & 1u);
-    if (rep_out < U.nr && cell_out >= 0 && cell_out < 16 && half_ok) {
-      typedef v4f __attribute__((address_space(3))) * P4;
-      LdsF* dst = slab + (l15 & 7) * kSlabCols + cell_out * 8 + 4 * (h & 1);
-#pragma unroll
-      for (int c = 0; c < 3; c++) *(P4)(dst + c * kSlabPlaneFloats) = p[c];
-    }
-  }
-}
-
-template <int HX, typename CT>
-__device__ __forceinline__ void ProduceTiles(FrameArgs fa, StripLds* w, int bc0, int y_begin, int y_end, int nb_last) {
-#ifdef JXLHIP_PC_TIMING
-  PcClock clk;
-  clk.t_begin = __builtin_readcyclecounter();
-#endif
-  constexpr int kSlots = sizeof(CT) == 2 ? JXLHIP_TILE_SLOTS : 3;
-  const int lane = threadIdx.x & 63;
-  const int l15 = lane & 15, h = lane >> 4;
-  const int r_first = HX ? y_begin - 8 : y_begin;
-  const int G = PcGroups<HX>(y_begin, y_end);
-  // per lane, once per wave: its entries of the three dequant-matrix sets (DequantLane, dec_group.cc:115-153) and of the
-  // two operand tables
-  float tabs[3][3][4], t16[4], t8[4];
-  {
-    const FrameArgs f = Fresh(fa);
-#pragma unroll
-    for (int ts = 0; ts < 3; ts++) {
-      const int kind = ts == 0 ? 0 : (ts == 1 ? 1 : 3);
-      const uint32_t base = ts == 0 ? DequantOffset(0) : (ts == 1 ? DequantOffset(6) : DequantOffset(4));
-      const uint32_t size = ts == 0 ? 64u : (ts == 1 ? 128u : 256u);
-      const int intra = TileIntra(kind, l15, h);
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const float4 t = *(const float4*)(f->dequant + base + c * size + intra);
-        tabs[ts][c][0] = t.x, tabs[ts][c][1] = t.y, tabs[ts][c][2] = t.z, tabs[ts][c][3] = t.w;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      t16[i] = f->tile_tabs[i * 64 + lane];
-      t8[i] = f->tile_tabs[256 + i * 64 + lane];
-    }
-  }
-  LdsU* list = (LdsU*)w->list[0];
-  auto request = [&](int nb, uint2& ci, float& sg) {
-    const FrameArgs f = Fresh(fa);
-    const int xsb = (int)f->xsb;
-    int col = bc0 + (lane & 15);
-    col = col < 0 ? 0 : (col >= xsb ? xsb - 1 : col);
-    ci = f->cell_info[(size_t)nb * xsb + col];
-    sg = f->inv_sigma[(size_t)nb * xsb + col];
-  };
-  uint2 ci;
-  float sg;
-  int nb = GroupBlockRow(r_first, nb_last);
-  request(nb, ci, sg);
-  for (int g = 0; g < G; g++) {
-    LdsF* slab = (LdsF*)w->slab[JXLHIP_PC_SLAB(g & 1)];  // free: the march left it before the previous barrier
-    // the block row's cells: from the planes / decoded here; of each varblock decoded here the leftmost of its cells
-    // inside the window represents it
-    TileRow R;
-    R.nb = nb;
-    NextRow cur;
-    {
-      const FrameArgs f = Fresh(fa);
-      const int c16 = bc0 + lane;
-      const bool valid_cell = lane < 16 && c16 >= 0 && c16 < (int)f->xsb;
-      const bool inker = valid_cell && ci.x != kCellFromPlanes;
-      const uint32_t tag = ci.y >> kTileTagShift;
-      const int kind = (int)(tag & 3u);
-      const bool rep = inker && ((kind & 1) == 0 || ((tag >> 2) & 1u) == 0 || lane == 0);
-      cur.nb = nb;
-      cur.mp = (uint32_t)__ballot(valid_cell && !inker) & 0xffffu;
-      cur.m8 = 0;
-      cur.ci = make_uint2(0u, 0u);
-      int base = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t m = (uint32_t)__ballot(rep && kind == k) & 0xffffu;
-        R.n[k] = __builtin_popcount(m);
-        R.base[k] = base;
-        if (kind == k && rep) {
-          const int rank = base + __builtin_popcount(m & ((1u << lane) - 1u));
-          list[rank * 4 + 0] = (uint32_t)lane;
-          list[rank * 4 + 1] = ci.x;
-          list[rank * 4 + 2] = ci.y;
-        }
-        base += R.n[k];
-      }
-    }
-    const float sg_cur = sg;
-    if (g + 1 < G) {  // the next block row's cell info / sigma travel while this one is decoded
-      nb = GroupBlockRow(r_first + 8 * (g + 1), nb_last);
-      request(nb, ci, sg);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) DmaPlaneRows(fa, slab, cur, bc0, k);
-    const int units = TileUnits(R);
-    for (int ub = 0; ub < units; ub += kSlots) {  // all loads of up to kSlots units first, then their arithmetic
-      TileSlot<CT> S[kSlots];
-#pragma unroll
-      for (int s = 0; s < kSlots; s++)
-        if (ub + s < units) TileLoad<CT>(fa, list, R, TileUnitOf(R, ub + s), bc0, S[s]);
-#pragma unroll
-      for (int s = 0; s < kSlots; s++)
-        if (ub + s < units) TileCompute<CT>(fa, slab, list, TileUnitOf(R, ub + s), S[s], tabs, t16, t8);
-    }
-    if (lane < 16) ((LdsF*)w->sigma[g & 1])[lane] = sg_cur;
-    PcBarrierProducer();
-  }
-}
-
-// ablation builds (timing only): JXLHIP_ABL_PC_PAD_S / _V extra scalar / vector instructions per row step of the
-// marching wave that compute nothing -- does the kernel's time follow the marching wave's INSTRUCTION COUNT (a wave
-// issues one instruction of any kind per ~5 cycles: tools/probes/valu_issue.hip) or the SIMD's VALU work?
-#ifndef JXLHIP_ABL_PC_PAD_S
-#define JXLHIP_ABL_PC_PAD_S 0
-#endif
-#ifndef JXLHIP_ABL_PC_PAD_V
-#define JXLHIP_ABL_PC_PAD_V 0
-#endif
-__device__ __forceinline__ void PcPadIssue() {
-#pragma unroll
-  for (int i = 0; i < JXLHIP_ABL_PC_PAD_S; i++) {
-    uint32_t d = 0;
-    asm volatile("s_mov_b32 %0, %0" : "+s"(d));
-  }
-#pragma unroll
-  for (int i = 0; i < JXLHIP_ABL_PC_PAD_V; i++) {
-    uint32_t d = 0;
-    asm volatile("v_mov_b32 %0, %0" : "+v"(d));
   }
 }
 
@@ -1398,10 +612,6 @@ __device__ __forceinline__ void PcPadIssue() {
 template <int GAB, int EPF, int OUTK, int FMT, bool EDGE, bool INTERIOR, int NB = 2>
 __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P, Lane& L, StripLdsT<NB>* w, int bc0,
                                         int y_begin, int y_end) {
-#ifdef JXLHIP_PC_TIMING
-  PcClock clk;
-  clk.t_begin = __builtin_readcyclecounter();
-#endif
   constexpr int HX = MarchGeom<GAB, EPF>::HX;
   constexpr int KI = INTERIOR ? (int)kStepInterior : 0;                  // a step that writes nothing
   constexpr int KE = INTERIOR ? (int)(kStepInterior | kStepEmit) : 0;   // a step that writes its row
@@ -1441,24 +651,14 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
   int i = 0;
   auto enter_group = [&](int g) -> float {  // after the barrier that publishes buffer g % NB
     const int b = NB == 2 ? (g & 1) : g % NB;
-    L.slab = slab0 + JXLHIP_PC_SLAB(b) * (3 * kSlabPlaneFloats);
+    L.slab = slab0 + b * (3 * kSlabPlaneFloats);
     return EPF ? sig0[b * 16] : 0.0f;
   };
-#ifdef JXLHIP_ABL_PC_NOMARCH  // ablation builds: the producing wave alone
-#define JXLHIP_PSTEPK(K, KN) (void)slab_y0, (void)sigma_pre, (void)sigma_prev
-#else
-#ifdef JXLHIP_ABL_PC_NOSTORE  // ablation builds: the march without its output stores
-#define JXLHIP_PC_DBG 4
-#else
-#define JXLHIP_PC_DBG 0
-#endif
 #define JXLHIP_PSTEPK(K, KN)                                                                                          \
-  Step<GAB, EPF, OUTK, FMT, K, EDGE, JXLHIP_PC_DBG, SRC_LDS, KN>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk, \
+  Step<GAB, EPF, OUTK, FMT, K, EDGE, 0, SRC_LDS, KN>(s, r + K, f, P, L, 0, y_begin, y_end, inv_sigma_blk, \
                                                                  inv_sigma_blk2, out_row, KC, slab_y0, sigma_pre,     \
                                                                  sigma_prev);                                         \
-  PcPadIssue();                                                                                                       \
   out_row += out_row_bytes
-#endif
 // a whole group of 8 rows starting at image row r (a multiple of 8): steps 0 .. HX-1 take KLOW, the others KHIGH
 #define JXLHIP_PGROUP(KLOW, KHIGH)                                                       \
   {                                                                                      \
@@ -1531,28 +731,16 @@ __device__ __forceinline__ void MarchPC(const DevFrame& f, const FilterParams& P
   }
 #undef JXLHIP_PGROUP
 #undef JXLHIP_PSTEPK
-#ifdef JXLHIP_PC_TIMING
-  PcClockReport(f.inv_sigma, clk, 0);
-#endif
 }
 
 // blockIdx.x is dispatched round-robin over the 8 XCDs: logical workgroup = (xcd, slot) -> xcd * per + slot, so
 // that an XCD's L2 sees neighbouring windows of the same rows (they share two block columns of coefficients and
 // plane tiles); the grid is padded to a multiple of 8
 template <int GAB, int EPF, int OUTK, int FMT, typename CT>
-__global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, FilterParams P, int RH, int strips, int nwg, int role_shift) {
+__global__ __launch_bounds__(128, kPcWaves) void k_fused_pc(DevFrame f, FilterParams P, int RH, int strips, int nwg) {
   __shared__ StripLds lds;
-#ifdef JXLHIP_PC_LDS_PAD  // experiment builds: fewer windows per CU (how fast is a march with its SIMD to itself?)
-  __shared__ char lds_pad[JXLHIP_PC_LDS_PAD];
-  {
-    volatile char* vp = lds_pad;  // (keeps the array)
-    if (threadIdx.x == 0) vp[JXLHIP_PC_LDS_PAD - 1] = (char)blockIdx.x;
-  }
-#endif
-  // which of the two waves marches: swapped on every 2^role_shift-th workgroup (in dispatch order), so that the
-  // SIMDs of a CU -- which receive a workgroup's waves in turn -- each get marching and producing waves
   const int lane = threadIdx.x & 63;
-  const int wave = (int)(threadIdx.x >> 6) ^ (role_shift >= 0 ? ((int)blockIdx.x >> role_shift) & 1 : 0);
+  const int wave = (int)(threadIdx.x >> 6);  // 0 marches, 1 produces
   const float __attribute__((address_space(3)))* dither_lds = nullptr;
   if constexpr (OUTK == JXLHIP_OUT_PACKED) {
     __shared__ float s_dither[1024];
@@ -1565,9 +753,6 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
   const int per = (int)gridDim.x >> 3;
   const int logical = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   if (logical >= nwg) return;
-#ifdef JXLHIP_PC_TIMING  // (the sums are added when the waves end, a hundred microseconds from here)
-  if (logical == 0 && threadIdx.x < 8) ((unsigned long long*)f.inv_sigma)[threadIdx.x] = 0ull;
-#endif
   const int strip = logical % strips, chunk = logical / strips;
   const int W = (int)f.xsize;
   const int x_first = strip * kFusedUse;
@@ -1577,24 +762,10 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
   const int x0 = x_first - kFusedHalo;
   const int bc0 = x0 >> 3;
   const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
-#ifdef JXLHIP_PC_STAGGER  // experiment builds: windows start up to 7 x JXLHIP_PC_STAGGER x 64 cycles apart, so that the
-  {                       // chip's windows do not all fill / march / store in the same phase of their block-row period
-    const int k = ((int)blockIdx.x >> 3) & 7;
-    for (int i = 0; i < k; i++) __builtin_amdgcn_s_sleep(JXLHIP_PC_STAGGER);
-  }
-#endif
   if (wave == 1) {
-#if JXLHIP_PC_PRODUCER_PRIO > 0
-    __builtin_amdgcn_s_setprio(JXLHIP_PC_PRODUCER_PRIO);
-#endif
-    if (f.fused_tiles) {  // uniform
-      ProduceTiles<MarchGeom<GAB, EPF>::HX, CT>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
-      return;
-    }
-#ifndef JXLHIP_PC_PRODUCER_V1
+    __builtin_amdgcn_s_setprio(kProducerPrio);
     if constexpr (sizeof(CT) == 2) ProducePC2<MarchGeom<GAB, EPF>::HX>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
     else
-#endif
       ProducePC<MarchGeom<GAB, EPF>::HX, CT>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
     return;
   }
@@ -1621,12 +792,9 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
   L.fix_left = L.gx == -2;
   L.fix_right_even = L.gx == W;
   L.fix_right_odd = L.gx == W - 1;
-#ifdef JXLHIP_PC_MARCH_PRIO  // experiment builds: the marching wave ahead of the producing waves at the SIMD's issue arbiter
-  __builtin_amdgcn_s_setprio(JXLHIP_PC_MARCH_PRIO);
-#endif
   // a chunk of whole block rows that needs no mirror row: the march with its row bookkeeping resolved at compile time
   constexpr int HXk = MarchGeom<GAB, EPF>::HX;
-  const bool interior = JXLHIP_PC_INTERIOR != 0 && (y_begin & 7) == 0 && ((y_end - y_begin) & 7) == 0 && y_begin >= 8 &&
+  const bool interior = (y_begin & 7) == 0 && ((y_end - y_begin) & 7) == 0 && y_begin >= 8 &&
                         y_end + 8 <= (int)f.ysize;
   (void)HXk;
   if (interior) {
@@ -1639,10 +807,10 @@ __global__ __launch_bounds__(128, JXLHIP_PC_WAVES) void k_fused_pc(DevFrame f, F
 }
 
 // rows per window chunk: a multiple of 8 that fills whole generations of resident workgroups (6 per CU)
-int FusedRowsPC(unsigned strips, unsigned rows, unsigned per_cu = JXLHIP_PC_PER_CU) {
+int FusedRowsPC(unsigned strips, unsigned rows, unsigned per_cu = kPcPerCu) {
   const int forced = jxlhip_env::Get().fused_pc_rh.load(std::memory_order_relaxed);  // experiments / tests: rows per window chunk
   if (forced > 0) return (forced + 7) & ~7;
-  const unsigned resident = 256u * per_cu;
+  const unsigned resident = DeviceCus() * per_cu;
   int best = 64;
   double best_cost = 1e30;
   for (int rh = 16; rh <= 1024; rh += 8) {
@@ -1663,129 +831,24 @@ void LaunchFusedPcT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
   const int RH = FusedRowsPC(strips, f.fy1 - f.fy0);
   const unsigned nwg = strips * ((f.fy1 - f.fy0 + RH - 1) / RH);
   const dim3 grid((nwg + 7) & ~7u);
-  const int role_env = jxlhip_env::Get().fused_pc_role.load(std::memory_order_relaxed);  // experiments: -1 = wave 0 always marches
-  const int role_shift = role_env != jxlhip_env::Switches::kUnset ? role_env : JXLHIP_FUSED_PC_ROLE_DEFAULT;
   if (f.coeff_type == JXLHIP_COEFF_I16)
-    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int16_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, role_shift);
+    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int16_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg);
   else
-    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int32_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, role_shift);
-}
-#endif  // JXLHIP_FUSED_PART == 2 || 3
-
-#ifndef JXLHIP_FUSED_WAVES
-#define JXLHIP_FUSED_WAVES 3
-#endif
-template <int GAB, int EPF, int OUTK, int FMT, typename CT>
-__global__ __launch_bounds__(256, (EPF == 2 || OUTK == 2) ? 2 : JXLHIP_FUSED_WAVES) void k_fused(DevFrame f, FilterParams P, int RH) {
-  __shared__ WaveLds lds[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float __attribute__((address_space(3)))* dither_lds = nullptr;
-  if constexpr (OUTK == JXLHIP_OUT_PACKED) {  // before any wave leaves: whole-workgroup barrier
-    __shared__ float s_dither[1024];
-    if (P.fmt.sample_type == JXLHIP_SAMPLE_U8) {  // uniform
-      for (int i = threadIdx.x; i < 1024; i += 256) s_dither[i] = P.dither[i];
-      __syncthreads();
-    }
-    dither_lds = (const float __attribute__((address_space(3)))*)s_dither;
-  }
-  const int strip = blockIdx.x * 4 + wave;
-  const int W = (int)f.xsize;
-  const int x_first = strip * kFusedUse;  // first output column of the wave
-  if (x_first >= W) return;
-  const int y_begin = (int)f.fy0 + blockIdx.y * RH;
-  const int y_end = min(y_begin + RH, (int)f.fy1);
-  if (y_begin >= y_end) return;
-  const int x0 = x_first - kFusedHalo;  // first window column: a multiple of 8
-  Lane L;
-  L.gx = x0 + 2 * lane;
-  L.dither = dither_lds;
-  const int m0 = MirrorF(L.gx, W), m1 = MirrorF(L.gx + 1, W);
-  int base = (m0 & ~1) - x0;  // slab column of the aligned pair holding both mirrored columns
-  base = base < 0 ? 0 : (base > kSlabCols - 2 ? kSlabCols - 2 : base);  // lanes far outside the image: any address inside the slab
-  L.sel0 = m0 & 1;
-  L.sel1 = m1 & 1;
-  L.byte_off = 0;
-  L.slab = (const float __attribute__((address_space(3)))*)lds[wave].slab + base;
-  const bool edge = x0 < 0 || x0 + kSlabCols > W;  // wave-uniform
-  const bool lane_in = lane >= kFusedHalo / 2 && lane < 64 - kFusedHalo / 2;
-  L.out0 = lane_in && L.gx < W;
-  L.out1 = lane_in && L.gx + 1 < W;
-  const int gxc = L.gx < 0 ? 0 : (L.gx >= W ? W - 1 : L.gx);
-  L.sx4 = (uint32_t)(gxc >> 3) * 4u;
-  L.out_off = (uint32_t)(L.gx < 0 ? 0 : L.gx) * (OUTK == JXLHIP_OUT_LINEAR_RGB_F32 ? 12u : 4u);
-  const int ix = gxc & 7;
-  L.mul = v2f{ix == 0 ? P.bsm[1] : P.sm[1], ix == 6 ? P.bsm[1] : P.sm[1]};
-  L.mul2 = v2f{ix == 0 ? P.bsm[2] : P.sm[2], ix == 6 ? P.bsm[2] : P.sm[2]};
-  L.fix_left = L.gx == -2;
-  L.fix_right_even = L.gx == W;
-  L.fix_right_odd = L.gx == W - 1;
-  const int bc0 = x0 >> 3;  // arithmetic shift: -1 for the first window
-  const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
-  if (edge) MarchFused<GAB, EPF, OUTK, FMT, true, CT>(f, fa, P, L, &lds[wave], bc0, y_begin, y_end);
-  else MarchFused<GAB, EPF, OUTK, FMT, false, CT>(f, fa, P, L, &lds[wave], bc0, y_begin, y_end);
-}
-
-// rows per wave: a multiple of 8 (groups of 8 rows = block rows) that fills whole generations of
-// resident workgroups (2 per CU by registers)
-int FusedRowsPerWave(unsigned wgx, unsigned rows) {
-  static const int forced = [] {
-    const char* e = getenv("JXLHIP_FUSED_RH");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced > 0) return (forced + 7) & ~7;
-  static const unsigned resident = [] {
-    const char* e = getenv("JXLHIP_FUSED_RESIDENT");
-    return e ? (unsigned)atoi(e) : 256u * 3u;
-  }();
-  int best = 64;
-  double best_cost = 1e30;
-  for (int rh = 16; rh <= 512; rh += 8) {
-    const unsigned wgs = wgx * ((rows + rh - 1) / rh);
-    const unsigned gens = (wgs + resident - 1) / resident;
-    const double cost = (double)gens * (rh + 6 + 10);  // 2 x HX marched rows + three block-row fills' worth
-    if (cost < best_cost) {
-      best_cost = cost;
-      best = rh;
-    }
-  }
-  return best;
-}
-
-template <int GAB, int EPF, int OUTK, int FMT = -1>
-void LaunchFusedT(const DevFrame& f, const FilterParams& p, hipStream_t st) {
-  const unsigned strips = (f.xsize + kFusedUse - 1) / kFusedUse;
-  const unsigned wgx = (strips + 3) / 4;
-  const int RH = FusedRowsPerWave(wgx, f.fy1 - f.fy0);
-  const dim3 grid(wgx, (f.fy1 - f.fy0 + RH - 1) / RH);
-  if (f.coeff_type == JXLHIP_COEFF_I16)
-    hipLaunchKernelGGL((k_fused<GAB, EPF, OUTK, FMT, int16_t>), grid, dim3(256), 0, st, f, p, RH);
-  else
-    hipLaunchKernelGGL((k_fused<GAB, EPF, OUTK, FMT, int32_t>), grid, dim3(256), 0, st, f, p, RH);
+    hipLaunchKernelGGL((k_fused_pc<GAB, EPF, OUTK, FMT, int32_t>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg);
 }
 
 }  // namespace
 
-// The instantiations are spread over two translation units (this file compiles for minutes): kernels_fused.hip
-// itself (JXLHIP_FUSED_PART 0: the entry points + the stage lists without EPF1 alone) and kernels_fused_b.hip
-// (PART 1, which includes this file: EPF1 with and without Gaborish -- the BASELINE list).
-bool LaunchFusedB(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st);
-// kernels_fused_pc.hip (PART 2): the producer / consumer form; false = no instantiation for this stage list / output
-bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st);
-
-static inline bool FusedPcEnabled() {
-  const int e = jxlhip_env::Get().fused_pc.load(std::memory_order_relaxed);  // (sampled when a context is created)
-  return (e != jxlhip_env::Switches::kUnset ? e : JXLHIP_FUSED_PC_DEFAULT) != 0;
-}
-#if JXLHIP_FUSED_PART == 0
+#if JXLHIP_FUSED_PART == 2
 // Frames the fused kernel takes (decided before k_prepare: it routes the DCT8 blocks).
 bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) {
-  (void)output_kind;
+  (void)gab;
   if (epf_iters > 2) return false;                 // EPF0: k_epf0 + the EPF1 + EPF2 march (kernels_epf0.hip)
-  // Gaborish + EPF1 + EPF2 on top of the in-wave DCT8 decode is past what two waves per SIMD hide: measured
-  // on the 8K d1.0 mix, fused 0.479 ms per frame against 0.431 two-phase (every other stage list gains
-  // 5-15 % from fusion: profiles/r02_fused_vs_twophase.txt)
-  // ... as ONE wave; k_fused_pc takes it for the planar / f32 outputs: 0.367 ms against 0.43 ms (round 3)
-  if (gab && epf_iters == 2 && (output_kind == JXLHIP_OUT_PACKED || !FusedPcEnabled())) return false;
+  // Packed outputs stay two-phase: their emit code doubles the march's instruction count, and k_fused_pc has the march
+  // on half of a workgroup's waves (8K d1.0: sRGB RGBA8 0.50 ms fused against 0.42 ms two-phase,
+  // profiles/r03_packed_paths.txt).  (Rounds 2-5 also shipped a single-wave fused kernel for the general packed
+  // formats; removed in round 6 with the other never-default forms.)
+  if (output_kind == JXLHIP_OUT_PACKED) return false;
   if (f.xsize < 16 || f.ysize < 16) return false;  // multiply mirrored columns / rows
   const uint32_t tail = f.ysize & 7u;
   if (tail >= 1 && tail <= 3) return false;        // mirror rows below the frame leave the last block row
@@ -1795,21 +858,7 @@ bool FusedSupported(const DevFrame& f, int gab, int epf_iters, int output_kind) 
   if ((uint64_t)f.xsg * f.ysg * f.coef_stride64 * 64u * (f.coeff_type == JXLHIP_COEFF_I16 ? 2u : 4u) >= (1ull << 32)) return false;
   return true;
 }
-
-// Does the frame's fused launch run the matrix-core producer (ProduceTiles)?  Decided with FusedSupported, before
-// k_prepare (DevFrame::fused_tiles routes the 8- and 16-point classes): whole frames whose fused kernel is k_fused_pc.
-bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind) {
-  // OPT-IN (JXLHIP_FUSED_TILES=1; read per frame: the tests switch it).  Measured on MI355X, 8K d1.0 Gaborish + EPF1
-  // (profiles/r04_tile_producer.txt): phase 1 93 -> 55 us, the fused kernel 187 -> 353 us, the step 109 -> 78 Gpx/s.
-  // The fused kernel is bound by VALU issue (59 % busy in both forms): the march is 56 M wave-instructions per frame,
-  // the row-per-lane DCT8 producer 12 M; this producer is 72 M -- 300 per unit of four cells, of which the transform
-  // itself (24 MFMAs) is none: dequantisation is 9 instructions per coefficient whatever decodes it, and a 16 x 16 unit
-  // amortises its addressing / quantiser / LLF / emit overhead over 12 coefficients per lane only.
-  if (jxlhip_env::Get().fused_tiles.load(std::memory_order_relaxed) == 0) return false;
-  return FusedPcEnabled() && output_kind != JXLHIP_OUT_PACKED && FusedSupported(f, gab, epf_iters, output_kind);
-}
-
-#endif  // JXLHIP_FUSED_PART == 0
+#endif  // JXLHIP_FUSED_PART == 2
 
 #if JXLHIP_FUSED_PART == 3
 // ------------------------------------------------------------------------------------------------
@@ -1818,14 +867,11 @@ bool FusedTilesWanted(const DevFrame& f, int gab, int epf_iters, int output_kind
 // plane set (row-major), from which the EPF1 + EPF2 march (k_filters_fast<0, 2>, SRC_LINEAR) produces the pixels as
 // before.  What it saves over k_epf0: the DCT8 share of the frame never visits the first plane set (one write and one
 // read of 12 bytes per pixel).  The march is epf0_march.h's Step0 with its rows and its inv_sigma from LDS.
-static constexpr int kPc0PartLds = JXLHIP_PC0_PART_LDS;  // (see k_fused_pc0)
+static constexpr int kPc0PartLds = 0;  // running plus-sum parts of the march kept in LDS: none (4 fits three waves per
+                                        // SIMD and measured slower, profiles/r04_epf3_fused.txt)
 template <int GAB, bool EDGE>
 __device__ __forceinline__ void MarchPC0(const DevFrame& f, const FilterParams& P, Lane& L, StripLds* w, int bc0, int y_begin,
                                          int y_end, float* const (&dst)[3], LdsF* part_lds) {
-#ifdef JXLHIP_PC_TIMING
-  PcClock clk;
-  clk.t_begin = __builtin_readcyclecounter();
-#endif
   constexpr int HX = GAB + 3;
   constexpr int PART_LDS = GAB ? kPc0PartLds : 0;
   const int H = (int)f.ysize;
@@ -1856,7 +902,7 @@ __device__ __forceinline__ void MarchPC0(const DevFrame& f, const FilterParams& 
   int i = 0;
   auto enter_group = [&](int g) -> float {  // after the barrier that publishes buffer g & 1
     const int b = g & 1;
-    L.slab = slab0 + JXLHIP_PC_SLAB(b) * (3 * kSlabPlaneFloats);
+    L.slab = slab0 + b * (3 * kSlabPlaneFloats);
     return sig0[b * 16];
   };
   if constexpr (PART_LDS > 0) {
@@ -1920,17 +966,16 @@ __device__ __forceinline__ void MarchPC0(const DevFrame& f, const FilterParams& 
 }
 
 // (the EPF0 window with Gaborish in front wants 175 VGPRs, seven more than three waves per SIMD leave -- and a spilling
-// build must not ship: the producing wave's asm loads, libjxl_amd/build.py.  JXLHIP_PC0_PART_LDS = 4 puts four of the
+// build must not ship: the producing wave's asm loads, libjxl_amd/build.py.  Keeping four of the
 // march's six running plus-sum parts into LDS, 2 KB per window -- what six windows per CU leave of the 160 KB beside
 // their slabs -- and fits three waves; measured slower, see the macro.)
 template <int GAB, typename CT>
-__global__ __launch_bounds__(128, (GAB != 0 && JXLHIP_PC0_PART_LDS == 0) ? 2 : JXLHIP_PC_WAVES) void k_fused_pc0(DevFrame f, FilterParams P, int RH, int strips, int nwg, int oy0, int oy1,
-                                                                     float* d0, float* d1, float* d2, int role_shift) {
+__global__ __launch_bounds__(128, GAB != 0 ? 2 : kPcWaves) void k_fused_pc0(DevFrame f, FilterParams P, int RH, int strips, int nwg, int oy0, int oy1,
+                                                                     float* d0, float* d1, float* d2) {
   __shared__ StripLds lds;
   __shared__ float part_store[(GAB != 0 && kPc0PartLds > 0) ? kPc0PartLds * 128 : 2];
   const int lane = threadIdx.x & 63;
-  // (which wave marches: see k_fused_pc)
-  const int wave = (int)(threadIdx.x >> 6) ^ (role_shift >= 0 ? ((int)blockIdx.x >> role_shift) & 1 : 0);
+  const int wave = (int)(threadIdx.x >> 6);  // 0 marches, 1 produces
   const int per = (int)gridDim.x >> 3;
   const int logical = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   if (logical >= nwg) return;
@@ -1945,9 +990,7 @@ __global__ __launch_bounds__(128, (GAB != 0 && JXLHIP_PC0_PART_LDS == 0) ? 2 : J
   const FrameArgs fa = (FrameArgs)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int HX = GAB + 3;
   if (wave == 1) {
-#if JXLHIP_PC_PRODUCER_PRIO > 0
-    __builtin_amdgcn_s_setprio(JXLHIP_PC_PRODUCER_PRIO);
-#endif
+    __builtin_amdgcn_s_setprio(kProducerPrio);
     if constexpr (sizeof(CT) == 2) ProducePC2<HX>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
     else ProducePC<HX, CT>(fa, &lds, bc0, y_begin, y_end, ((int)f.ysize - 1) >> 3);
     return;
@@ -1980,34 +1023,22 @@ __global__ __launch_bounds__(128, (GAB != 0 && JXLHIP_PC0_PART_LDS == 0) ? 2 : J
 }
 #endif  // JXLHIP_FUSED_PART == 3
 
-#define JXLHIP_FUSED(G, E)                                      \
-  if (gab == G && epf_iters == E) {                             \
-    if (output_kind == 0) LaunchFusedT<G, E, 0>(f, p, st);      \
-    else if (output_kind == 1) LaunchFusedT<G, E, 1>(f, p, st); \
-    else LaunchFusedT<G, E, 2>(f, p, st);                       \
-    return true;                                                \
-  }
-// Packed outputs stay with the single-wave kernel (general formats) / the two-phase march (the fixed formats):
-// their emit code doubles the march's instruction count, and k_fused_pc has the march on half of a workgroup's
-// waves -- measured at 8K d1.0: sRGB u16 RGBA / f16 RGBA 1.12 ms against 0.78 ms single-wave, sRGB RGBA8 0.50 ms
-// against 0.42 ms two-phase (profiles/r03_packed_paths.txt).
+#if JXLHIP_FUSED_PART == 2
+bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st) {
+  if (!FusedSupported(f, gab, epf_iters, output_kind)) return false;
 #define JXLHIP_FUSED_PCX(G, E)                                    \
   if (gab == G && epf_iters == E) {                               \
     if (output_kind == 0) LaunchFusedPcT<G, E, 0>(f, p, st);      \
     else LaunchFusedPcT<G, E, 1>(f, p, st);                       \
     return true;                                                  \
   }
-#if JXLHIP_FUSED_PART == 2
-bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st) {
-  if (output_kind == JXLHIP_OUT_PACKED) return false;
   JXLHIP_FUSED_PCX(1, 1)
   JXLHIP_FUSED_PCX(0, 0)
-#ifndef JXLHIP_FUSED_LEAN
   JXLHIP_FUSED_PCX(0, 1)
   JXLHIP_FUSED_PCX(1, 0)
   JXLHIP_FUSED_PCX(0, 2)
   JXLHIP_FUSED_PCX(1, 2)
-#endif
+#undef JXLHIP_FUSED_PCX
   return false;
 }
 #elif JXLHIP_FUSED_PART == 3
@@ -2016,7 +1047,6 @@ bool LaunchFusedPC(const DevFrame& f, const FilterParams& p, int gab, int epf_it
 // set, as LaunchEpf0).  false: geometry / configuration not covered (the caller then must not have skipped the DCT8 cells).
 bool FusedEpf0Supported(const DevFrame& f, int gab) {
   (void)gab;
-  if (!FusedPcEnabled()) return false;
   if (f.xsize < 16 || f.ysize < 16) return false;
   const uint32_t tail = f.ysize & 7u;
   if (tail >= 1 && tail <= 3) return false;  // (as FusedSupported: mirror rows below the frame leave the last block row)
@@ -2028,13 +1058,12 @@ bool LaunchFusedEpf0(const DevFrame& f, const FilterParams& p, int gab, float* c
   if (!FusedEpf0Supported(f, gab)) return false;
   const int oy0 = 0, oy1 = (int)f.ysize;
   const unsigned strips = (f.xsize + kFusedUse - 1) / kFusedUse;
-  const int RH = FusedRowsPC(strips, oy1 - oy0, (gab != 0 && JXLHIP_PC0_PART_LDS == 0) ? 4 : JXLHIP_PC_PER_CU);
+  // (with Gaborish the march wants 175 VGPRs: two waves per SIMD = four windows per CU)
+  const int RH = FusedRowsPC(strips, oy1 - oy0, gab != 0 ? 4 : kPcPerCu);
   const unsigned nwg = strips * ((oy1 - oy0 + RH - 1) / RH);
   const dim3 grid((nwg + 7) & ~7u);
-  const int role_env = jxlhip_env::Get().fused_pc0_role.load(std::memory_order_relaxed);  // experiments: -1 = wave 0 always marches
-  const int role_shift = role_env != jxlhip_env::Switches::kUnset ? role_env : JXLHIP_FUSED_PC0_ROLE_DEFAULT;
 #define JXLHIP_PC0(G, CT) \
-  hipLaunchKernelGGL((k_fused_pc0<G, CT>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, oy0, oy1, dst[0], dst[1], dst[2], role_shift)
+  hipLaunchKernelGGL((k_fused_pc0<G, CT>), grid, dim3(128), 0, st, f, p, RH, (int)strips, (int)nwg, oy0, oy1, dst[0], dst[1], dst[2])
   if (f.coeff_type == JXLHIP_COEFF_I16) {
     if (gab) JXLHIP_PC0(1, int16_t);
     else JXLHIP_PC0(0, int16_t);
@@ -2045,39 +1074,6 @@ bool LaunchFusedEpf0(const DevFrame& f, const FilterParams& p, int gab, float* c
 #undef JXLHIP_PC0
   return true;
 }
-#elif JXLHIP_FUSED_PART == 0
-bool LaunchFused(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind,
-                 hipStream_t st) {
-  if (!FusedSupported(f, gab, epf_iters, output_kind)) return false;
-  {
-    if (FusedPcEnabled() && LaunchFusedPC(f, p, gab, epf_iters, output_kind, st)) return true;
-  }
-#ifdef JXLHIP_FUSED_LEAN  // experiment builds (tools/build_variant.py): the BASELINE stage list only, seconds to compile
-  if (gab == 1 && epf_iters == 1 && output_kind == 1 && f.coeff_type == JXLHIP_COEFF_I16) {
-    const unsigned strips = (f.xsize + kFusedUse - 1) / kFusedUse;
-    const unsigned wgx = (strips + 3) / 4;
-    const int RH = FusedRowsPerWave(wgx, f.fy1 - f.fy0);
-    const dim3 grid(wgx, (f.fy1 - f.fy0 + RH - 1) / RH);
-    hipLaunchKernelGGL((k_fused<1, 1, 1, -1, int16_t>), grid, dim3(256), 0, st, f, p, RH);
-    return true;
-  }
-  return false;
-#else
-  JXLHIP_FUSED(0, 0)
-  JXLHIP_FUSED(1, 0)
-  JXLHIP_FUSED(0, 2)
-  return LaunchFusedB(f, p, gab, epf_iters, output_kind, st);
 #endif
-}
-#elif JXLHIP_FUSED_PART == 1
-bool LaunchFusedB(const DevFrame& f, const FilterParams& p, int gab, int epf_iters, int output_kind, hipStream_t st) {
-#ifndef JXLHIP_FUSED_LEAN
-  JXLHIP_FUSED(0, 1)
-  JXLHIP_FUSED(1, 1)
-#endif
-  return false;
-}
-#endif
-#undef JXLHIP_FUSED
 
 }  // namespace jxlhip

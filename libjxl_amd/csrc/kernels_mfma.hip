@@ -410,23 +410,6 @@ void MfmaDct16Constants(float* host /* 256 floats */) {
   }
 }
 
-// The operand tables of the fused kernel's tile producer (kernels_fused.hip, ProduceTiles): [0, 256) the 16-point table
-// above; [256, 512) the same layout for diag(B8, B8), two 8-point IDCTs side by side: entry [4 h + step][n] is
-// B8[k % 8][n % 8] when k and n lie in the same half, else 0
-void TileProducerConstants(float* host /* 512 floats */) {
-  MfmaDct16Constants(host);
-  double B8[8][8];
-  for (int k = 0; k < 8; k++) {
-    double v[8] = {0};
-    v[k] = 1.0;
-    IdctHost(v, 8);
-    for (int n = 0; n < 8; n++) B8[k][n] = v[n];
-  }
-  for (int k = 0; k < 16; k++)
-    for (int n = 0; n < 16; n++)
-      host[256 + (k & 3) * 64 + (k >> 2) * 16 + n] = (k >> 3) == (n >> 3) ? (float)B8[k & 7][n & 7] : 0.0f;
-}
-
 void LaunchMfma16(const DevFrame& f, const WorkLists& wl, uint32_t cells, hipStream_t st) {
   const int cls = kClsMedium0 + 2;  // DCT16X16 (kMediumStrategy[2] == 4)
   uint32_t grid = cells / 4 / 4 + 1;  // varblocks / 4 waves

@@ -6,6 +6,8 @@
 //   k_dequant_dc      : DequantDC, 4:4:4 (lib/jxl/compressed_dc.cc:201-232)
 //   k_smooth_dc       : AdaptiveDCSmoothing (lib/jxl/compressed_dc.cc:63-197)
 #include "dev_common.h"
+#include <atomic>
+
 #include "kernels.h"
 
 namespace jxlhip {
@@ -327,6 +329,22 @@ __global__ __launch_bounds__(256) void k_zero_u32(uint32_t* __restrict__ p, uint
 }
 void LaunchZeroU32(uint32_t* p, uint32_t n, hipStream_t st) {
   if (n) hipLaunchKernelGGL(k_zero_u32, dim3((n + 255u) / 256u), dim3(256), 0, st, p, n);
+}
+
+// Compute units of the device the calling thread has current: what the launch geometry of the persistent /
+// generation-filling kernels is sized from (256 on a whole MI355X, 32 on a CPX partition of it).
+unsigned DeviceCus() {
+  static std::atomic<unsigned> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  unsigned n = cached[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = (unsigned)v;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
 }
 
 void LaunchExpandSparse(const uint8_t* sparse, const uint32_t* offsets, int16_t* dense, uint32_t g0, uint32_t n, hipStream_t st) {
