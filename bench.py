@@ -43,6 +43,80 @@ METRIC = {"c1": "Mpixels/s decode (VarDCT d1.0, 1024x1024 RGB)", "c2": "Mpixels/
           "c5": "Mpixels/s decode (VarDCT d0.5, 8K HDR, DCT32x32)"}
 
 
+# Instruction-issue roofline (round 6): the SIMDs of an MI355X retire one wave64 VALU instruction of
+# the decoder's kind of code -- packed fp32, DPP neighbours, conversions, three-operand fma -- per ~4.15 shader cycles with
+# four waves per SIMD (tools/probes/valu_issue.hip, profiles/r05_valu_issue_probe.txt: "mix: pk_fma,pk_add,add_dpp,fma",
+# 4 waves/SIMD, 4.15 cyc/instr/SIMD at the 2.4 GHz event clock; plain v_fma_f32 alone reaches 2.39).  1024 SIMDs.
+VALU_ISSUE_PEAK_GINSTR = 1024 * 2.4 / 4.15   # 592 G wave-instructions/s: the probe's mix
+VALU_ISSUE_PEAK_FMA_GINSTR = 1024 * 2.4 / 2.39  # 1028: plain v_fma_f32, for scale
+
+
+class ClockSampler:
+    """Device clocks seen WHILE the timed steps run (a thread polling sysfs every ~0.3 ms): the pool's boxes differ by up
+    to 30 % on the same code (profiles/r05_box_spread.txt), and a reader of the line must be able to tell a slow box from
+    a regression.  sclk / mclk in MHz from the amdgpu hwmon nodes (freq1_input / freq2_input, Hz) or, failing that, the
+    starred level of pp_dpm_sclk / pp_dpm_mclk; None when the box exposes neither."""
+
+    def __init__(self, device_index=0):
+        import glob
+        self.paths = {}
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))]
+        if cards:
+            c = cards[min(device_index, len(cards) - 1)]
+            for key, hw, dpm in (("sclk", "freq1_input", "pp_dpm_sclk"), ("mclk", "freq2_input", "pp_dpm_mclk")):
+                h = glob.glob(os.path.join(c, "hwmon/hwmon*/" + hw))
+                if h:
+                    self.paths[key] = ("hz", h[0])
+                elif os.path.exists(os.path.join(c, dpm)):
+                    self.paths[key] = ("dpm", os.path.join(c, dpm))
+        self.samples = {k: [] for k in self.paths}
+        self._stop = None
+        self._thread = None
+
+    def _read(self, kind, path):
+        try:
+            txt = open(path).read()
+            if kind == "hz":
+                return float(txt.strip()) / 1e6
+            for line in txt.splitlines():
+                if line.rstrip().endswith("*"):
+                    return float("".join(ch for ch in line.split(":")[1] if ch.isdigit() or ch == "."))
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def start(self):
+        import threading
+        if not self.paths:
+            return
+        self.samples = {k: [] for k in self.paths}
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                for k, (kind, path) in self.paths.items():
+                    v = self._read(kind, path)
+                    if v is not None:
+                        self.samples[k].append(v)
+                self._stop.wait(0.0003)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+        self._thread = None
+        out = {}
+        for k, v in self.samples.items():
+            if v:
+                w = sorted(v)
+                out[k + "_mhz"] = {"min": round(w[0]), "median": round(w[len(w) // 2]), "max": round(w[-1]), "samples": len(w)}
+        return out or None
+
+
 def algorithmic_bytes(xsize, ysize, coeff_bytes):
     """B = Wp*Hp*3*sizeof(coef) + Nblk*18 + W*H*12."""
     wp, hp = (xsize + 7) // 8 * 8, (ysize + 7) // 8 * 8
@@ -431,6 +505,120 @@ def e2e_block(torch, local):
     return res
 
 
+def single_process_multi(args, torch):
+    """`--gpus N --multi-mode single`: ONE process, one jxlhip_create_multi context over the N devices (include/jxl_hip.h):
+    the stripes, the halo rows and the gather into devices[0] are stream-ordered peer copies below the C ABI -- no
+    torch.distributed, no NCCL bootstrap.  The frame is handed over ONCE through the host-pointer calls (the multi
+    context routes every group to the device that owns it); a step = jxlhip_decode_frame into a frame on devices[0]
+    (the gather inside the step, like `value` of the process mode).  Checked once against a one-device context."""
+    import ctypes as C
+    from libjxl_amd import VarDctDecoder, abi, synth
+    n = args.gpus
+    name = args.config or "c4"
+    cfg = dict(CONFIGS[name])
+    for k in ("width", "height", "gab", "epf", "mix"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    custom = any(getattr(args, k) is not None for k in ("width", "height", "gab", "epf", "mix"))
+    xs, ys = cfg["width"], cfg["height"]
+    ndev = torch.cuda.device_count()
+    forced = os.environ.get("JXLHIP_BENCH_DEVICE")
+    devices = [int(forced)] * n if forced is not None else [i % ndev for i in range(n)]
+    params, t = synth.synth_frame(xs, ys, mix=resolve_mix(cfg["mix"]), gab=bool(cfg["gab"]), epf_iters=cfg["epf"], device="cpu",
+                                  coeff_type=int(cfg["coeff32"]), intensity_target=cfg["intensity"], quant_mul=cfg["quant_mul"])
+    L = abi.load_library()
+    one = VarDctDecoder(devices[0])
+    one.begin_frame(params)
+    dq = one.default_dequant_tables()
+    table_host = dq.cpu().numpy()
+    ctx = C.c_void_p()
+    devs = (C.c_int * n)(*devices)
+
+    def chk(rc, what):
+        if rc:
+            raise SystemExit(f"{what}: {L.jxlhip_last_error(ctx).decode() if ctx else rc}")
+    chk(L.jxlhip_create_multi(devs, n, None, C.byref(ctx)), "jxlhip_create_multi")
+    p = abi.make_params(params)
+    chk(L.jxlhip_frame_begin(ctx, C.byref(p)), "frame_begin")
+    npy = {k: ([x.numpy() for x in v] if isinstance(v, list) else v.numpy()) for k, v in t.items()}
+    dc3 = (C.c_void_p * 3)(*[a.ctypes.data for a in npy["dc"]])
+    chk(L.jxlhip_upload_side_info(ctx, npy["ac_strategy"].ctypes.data, npy["raw_quant"].ctypes.data, npy["epf_sharpness"].ctypes.data,
+                                  npy["ytox_map"].ctypes.data, npy["ytob_map"].ctypes.data, dc3, table_host.ctypes.data), "upload_side_info")
+    ng = ((xs + 255) // 256) * ((ys + 255) // 256)
+    for g in range(ng):
+        ptrs = (C.c_void_p * 3)(*[c[g * 65536:].ctypes.data for c in npy["coeffs"]])
+        chk(L.jxlhip_submit_group(ctx, g, ptrs, 65536), "submit_group")
+    full = torch.empty((ys, xs, 3), dtype=torch.float32, device=f"cuda:{devices[0]}")
+
+    def step():
+        chk(L.jxlhip_decode_frame(ctx, C.c_void_p(full.data_ptr()), xs * 12, 0), "decode_frame")
+
+    def sync():
+        chk(L.jxlhip_sync(ctx), "sync")
+    step()
+    sync()
+    # the one-device frame of the same inputs
+    dev_t = {k: ([x.to(f"cuda:{devices[0]}") for x in v] if isinstance(v, list) else v.to(f"cuda:{devices[0]}")) for k, v in t.items()}
+    one.set_inputs(dev_t, dq)
+    ref = one.decode_frame()
+    one.sync()
+    same = bool(torch.equal(ref, full))
+    ck = lambda x: int(x.view(torch.int32).to(torch.int64).sum().item() & 0xFFFFFFFFFFFF)  # noqa: E731
+    sums = (ck(full), ck(ref))
+    del ref, dev_t
+    one.close()
+    settle = int(math.ceil(args.settle_ms / max(0.04, xs * ys / (100e9 * n) * 1e3))) if args.settle_ms > 0 else 0
+    for i in range(settle + args.warmup):
+        step()
+        if i % 16 == 15:
+            sync()
+    sync()
+    clocks = ClockSampler(devices[0])
+    clocks.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    clk = clocks.stop()
+    host_frame = None
+    try:  # every stripe through its own device's PCIe link into a host frame (jxlhip_decode_frame_host)
+        import numpy as np
+        host = np.zeros((ys, xs, 3), np.float32)
+        chk(L.jxlhip_decode_frame_host(ctx, host.ctypes.data, xs * 12, 0), "decode_frame_host")
+        t1 = time.perf_counter()
+        reps = max(2, min(args.steps, 8))
+        for _ in range(reps):
+            chk(L.jxlhip_decode_frame_host(ctx, host.ctypes.data, xs * 12, 0), "decode_frame_host")
+        host_frame = {"value": round(xs * ys / ((time.perf_counter() - t1) / reps) / 1e6, 1), "unit": "Mpixels/s",
+                      "what": "jxlhip_decode_frame_host on the same context: every stripe leaves through its own device's PCIe link, "
+                              "no gather on one device; synchronous per frame"}
+    except SystemExit as ex:
+        host_frame = {"error": str(ex)[:200]}
+    L.jxlhip_destroy(ctx)
+    px = xs * ys
+    ms_step = dt / args.steps * 1e3
+    cb = 4 if cfg["coeff32"] else 2
+    b_alg = algorithmic_bytes(xs, ys, cb)
+    ach = b_alg / (ms_step * 1e-3) / 1e9
+    line = {"metric": METRIC[name] if not custom else "Mpixels/s decode (VarDCT, custom workload)", "value": round(px / (dt / args.steps) / 1e6, 1),
+            "unit": "Mpixels/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}{'*' if custom else ''}: {xs}x{ys} RGB VarDCT frame, gab={cfg['gab']} epf_iters={cfg['epf']}, "
+                                   f"{'int32' if cfg['coeff32'] else 'int16'} coefficients, strategy mix {cfg['mix']}, linear RGB f32 out",
+                       "n_multi_mode": "single", "devices": devices, "stripes": n, "gather_in_step": True,
+                       "device_settle_ms": args.settle_ms, "device_settle_steps": settle,
+                       "gathered_frame_equals_one_gpu_frame": same, "gathered_frame_checksum": sums[0], "one_gpu_frame_checksum": sums[1],
+                       "device_clocks_during_timed_steps": {"value": clk} if clk else None,
+                       "scaling_basis": "one process, jxlhip_create_multi: `value` has the gather into devices[0] inside the step "
+                                        "(peer copies: bound by devices[0]'s incoming xGMI links, DESIGN.md section 7)"},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS / n, 4), "traffic": None,
+                         "what": "frame's algorithmic bytes / whole step / (N x 8 TB/s)", "algorithmic_bytes_frame": b_alg},
+            "host_frame": host_frame}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -447,6 +635,17 @@ def main():
                          "explicit area mix 'strategy:share,...' (e.g. 18:1 = all 64x64)")
     ap.add_argument("--coeff32", action="store_true", default=None)
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the output stripes sharded")
+    ap.add_argument("--multi-mode", choices=("process", "single"), default="process",
+                    help="N>1: 'process' = one process per GPU, halo rows and the gather over torch.distributed / RCCL "
+                         "(libjxl_amd/stripes.py; the driver's launch); 'single' = ONE process over the N devices through "
+                         "jxlhip_create_multi (stream-ordered peer copies below the C ABI, no NCCL bootstrap): run it as "
+                         "plain `python bench.py --gpus N --multi-mode single` (under torch.distributed.run rank 0 does "
+                         "the work and the other ranks only keep the barriers)")
+    ap.add_argument("--gather-mode", choices=("streamed", "after"), default="streamed",
+                    help="N>1: 'streamed' (default) = every rank posts its rows to rank 0 as their launches are queued "
+                         "and leaves them in flight across the next step (StripeDecoder.decode_gathered: a step costs "
+                         "max(kernels, gather)); 'after' = rounds 2-5: the gather starts when the stripe is done and the "
+                         "step waits for it (kernels + gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (N=1)")
     ap.add_argument("--settle-ms", type=float, default=60.0,
@@ -468,9 +667,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.multi_mode == "single" and args.gpus > 1:
+        if rank == 0:
+            single_process_multi(args, torch)
+        return
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run")
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (or --multi-mode single)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the VarDCT back-end has no CPU path")
     # (smoke tests of the N > 1 path on a one-GPU box: JXLHIP_BENCH_DEVICE=0 puts every rank on that device and
@@ -507,6 +710,8 @@ def main():
     out = dec.alloc_output()
     gather = world > 1 and not args.no_gather
     full = sd.alloc_gather(out) if gather else None
+    streamed = gather and args.gather_mode == "streamed"
+    out_b = dec.alloc_output() if streamed else None  # the stripe buffers alternate: frame k's rows travel while k + 1 is decoded
 
     # N = 1, the side figure `frames_in_flight`: a pool of decoder contexts, one HIP stream each, every context with
     # its OWN device copy of the coefficient stream, the side info and the dequant tables (round 4 shared one copy: frame
@@ -541,9 +746,17 @@ def main():
             counter[0] += 1
             d.decode_frame(o)
             return
+        if streamed:
+            counter[0] += 1
+            sd.decode_gathered(out if counter[0] & 1 else out_b, full)
+            return
         sd.decode(out)
         if gather:
             sd.gather(out, full)
+
+    def drain():
+        if streamed:
+            sd.wait_gather()  # the current stream waits for every transfer still in flight (rank 0: every receive)
 
     def step_one():
         dec.decode_frame(out)
@@ -576,20 +789,29 @@ def main():
     settle_steps = int(math.ceil(args.settle_ms / max(0.04, xs * ys / (100e9 * world) * 1e3))) if args.settle_ms > 0 else 0
     settle_on = [True]
 
-    def timed(fn):
+    clocks = ClockSampler(local)
+    clock_log = {}
+
+    def timed(fn, tag=None):
         for i in range(settle_steps if settle_on[0] else 0):
             fn()
             if i % 16 == 15:
                 dec.sync()
         for _ in range(args.warmup):
             fn()
+        drain()
         dec.sync()  # also surfaces stream errors
         fence()
+        if tag and rank == 0:
+            clocks.start()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             fn()
+        drain()
         fence()
         t = time.perf_counter() - t0
+        if tag and rank == 0:
+            clock_log[tag] = clocks.stop()
         if world > 1:
             tt = torch.tensor([t], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -605,8 +827,31 @@ def main():
         dt_unsettled = timed(step_one)
         settle_on[0] = True
     note("set-up done; timed steps")
-    dt = timed(step_one if world == 1 else step)
+    dt = timed(step_one if world == 1 else step, tag="value")
     note("timed steps done")
+    # N > 1: what arrived on rank 0 is the frame one GPU decodes (checked once, untimed: a whole-frame context on rank 0's
+    # device; the stripes' two-phase / fused kernels and the whole frame's are held bit-identical by the test suite)
+    gathered_equals_one_gpu = gathered_checksum = one_gpu_checksum = None
+    ranks_seen = None
+    if world > 1:
+        mine = torch.tensor([rank, local, torch.cuda.current_device()], dtype=torch.int64, device=red_dev)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        ranks_seen = [dict(rank=int(v[0]), local_rank=int(v[1]), device=int(v[2])) for v in seen]
+        if gather and rank == 0:
+            try:
+                whole = VarDctDecoder(local)
+                whole.begin_frame(params)
+                whole.set_inputs(t, dq)
+                ref = whole.decode_frame()
+                whole.sync()
+                gathered_equals_one_gpu = bool(torch.equal(ref, full))
+                gathered_checksum = int(full.view(torch.int32).to(torch.int64).sum().item() & 0xFFFFFFFFFFFF)
+                one_gpu_checksum = int(ref.view(torch.int32).to(torch.int64).sum().item() & 0xFFFFFFFFFFFF)
+                whole.close()
+                del ref, whole
+            except Exception as ex:
+                gathered_equals_one_gpu = repr(ex)[:200]
     # `graph_replay`: the frame's launches recorded ONCE into a hipGraph (stream capture around jxlhip_decode_frame) and
     # replayed per step -- what a caller that decodes frame after frame of one geometry (video, a tile server) can do;
     # the library needs nothing but to keep its per-frame state inside the graph (context.hip: DecodeFrameCoded).
@@ -644,7 +889,7 @@ def main():
     if world == 1 and inflight > 1:
         for d, _ in slots:
             d.set_concurrency_hint(inflight)  # (only moves the frame size from which the fused kernel is taken)
-        dt_flight = timed(step)
+        dt_flight = timed(step, tag="frames_in_flight")
         for d, _ in slots:
             d.set_concurrency_hint(1)  # from here on `dec` runs alone again: the per-kernel pass
         for d2, o2 in slots[1:]:
@@ -759,6 +1004,31 @@ def main():
                         "WRITE_SIZE passes of this command, tools/pmc_traffic.sh; commit " + str(tj.get("_commit", "?")) + ")")
             except Exception:
                 traffic = None
+        # instruction-issue roofline: wave-instructions of the step's launches (SQ_INSTS_VALU, a rocprofv3 --pmc pass of this
+        # command, replayed from profiles/pmc_valu.json like `traffic`) over the step, against the probe's issue peak
+        valu = None
+        vf = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if os.path.exists(vf) and world == 1 and name == "c3" and not custom:
+            try:
+                vj = json.load(open(vf))
+                n_valu = sum(v.get("SQ_INSTS_VALU", 0) for k, v in vj.items() if not k.startswith("_"))
+                n_salu = sum(v.get("SQ_INSTS_SALU", 0) for k, v in vj.items() if not k.startswith("_"))
+                ach = n_valu / (ms_step * 1e-3) / 1e9
+                valu = {"bound": "valu-issue", "achieved": round(ach, 1), "peak": round(VALU_ISSUE_PEAK_GINSTR, 1),
+                        "unit": "G wave-instructions/s", "frac": round(ach / VALU_ISSUE_PEAK_GINSTR, 4),
+                        "valu_instructions_per_step": int(n_valu), "salu_instructions_per_step": int(n_salu),
+                        "per_kernel": {k: v for k, v in vj.items() if not k.startswith("_")},
+                        "peak_source": "tools/probes/valu_issue.hip, profiles/r05_valu_issue_probe.txt: the mix pk_fma / pk_add / add_dpp / "
+                                       "fma at 4 waves per SIMD retires one wave64 instruction per 4.15 cycles per SIMD (2.4 GHz event "
+                                       "clock) x 1024 SIMDs; plain v_fma_f32 alone: 2.39 cycles = "
+                                       f"{VALU_ISSUE_PEAK_FMA_GINSTR:.0f} G/s (frac_of_fma_peak below)",
+                        "frac_of_fma_peak": round(ach / VALU_ISSUE_PEAK_FMA_GINSTR, 4),
+                        "counter_source": "profiles/pmc_valu.json (replayed: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU pass of this "
+                                          "command, tools/pmc_valu.sh; commit " + str(vj.get("_commit", "?")) + ")"}
+            except Exception:
+                valu = None
+        hbm_frac = achieved / HBM_PEAK_GBS
+        bound = "valu-issue" if (valu and valu["frac"] > hbm_frac) else "hbm"
         line = {
             "metric": METRIC[name] if not custom else "Mpixels/s decode (VarDCT, custom workload)", "value": round(value, 1),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -776,8 +1046,20 @@ def main():
                        "phase_ms_max_over_ranks": phase_ms,
                        "host_enqueue_us_per_step_max_over_ranks": host_enqueue_us,
                        "interior_first": os.environ.get("JXLHIP_STRIPES_INTERIOR_FIRST", "1") != "0" if world > 1 else None,
-                       "kernel_ms": kern},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                       "kernel_ms": kern,
+                       "kernel_ms_sum": round(sum(kern.values()), 4),
+                       "kernel_ms_what": "a pass of its own with ONE HIP event between consecutive launches on the launch stream "
+                                         "(jxlhip_profile_enable): an event between two launches keeps the second from being "
+                                         "dispatched behind the first, so every launch reads a few us longer than inside the timed "
+                                         "steps and the parts can add up to more than ms_per_step (rounds 1-5 recorded two events "
+                                         "per boundary: +9 %); rocprofv3's averages of the same step: profiles/r06_c3_kernel_stats.csv",
+                       "device_clocks_during_timed_steps": clock_log or None,
+                       "n_multi_mode": args.multi_mode if world > 1 else None,
+                       "gather_mode": (args.gather_mode if gather else None),
+                       "ranks_seen": ranks_seen,
+                       "gathered_frame_equals_one_gpu_frame": gathered_equals_one_gpu,
+                       "gathered_frame_checksum": gathered_checksum, "one_gpu_frame_checksum": one_gpu_checksum},
+            "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "what": "frame's algorithmic bytes / whole step (all launches + gaps) of `value`: ONE frame in flight, "
                                  "settled clocks",
@@ -792,6 +1074,10 @@ def main():
                          "algorithmic_bytes_frame": b_alg_frame,
                          "kernel_own_bytes_per_launch": b_own},
         }
+        if valu:
+            line["roofline_valu"] = valu
+            line["roofline"]["bound_what"] = ("the higher of roofline.frac (HBM: algorithmic bytes / step / 8 TB/s) and roofline_valu.frac "
+                                              "(instruction issue: wave-instructions / step / the probe's peak)")
         if world == 1:
             line["one_frame_in_flight"] = {"value": round(value, 1), "unit": "Mpixels/s", "ms_per_step": round(ms_step, 4),
                                            "what": "= `value` (round 4 reported the frames-in-flight rate as `value` and this "
@@ -821,6 +1107,17 @@ def main():
             line["sharded"] = {"value": round(px / (dt_sharded / args.steps) / 1e6, 1), "unit": "Mpixels/s",
                                "ms_per_step": round(dt_sharded / args.steps * 1e3, 4),
                                "what": "the same frame, output stripes left in each GPU's HBM (no gather)"}
+        if world > 1:
+            line["config"]["scaling_basis"] = (
+                "`value` = the frame GATHERED on rank 0 inside the step (BASELINE configs[3]): 7/8 of a 1.59 GB float frame over "
+                "rank 0's 7 point-to-point xGMI links = >= 1.3 ms at the 153 GB/s link rate against ~1.1 ms for the whole frame on "
+                "ONE GPU -- its floor is the gather, whatever the kernels do (streamed: max(kernels, gather) per step).  The split "
+                "itself is measured by `sharded` (stripes left in each GPU's HBM) and `host_sharded` (every stripe through its own "
+                "GPU's PCIe link): the >= 6x of the north star is claimed on `sharded`; DESIGN.md section 7 holds the expected "
+                "N = 2 / 4 / 8 figures of all three")
+            line["config"]["value_gathered"] = round(value, 1)
+            line["config"]["value_sharded"] = round(px / (dt_sharded / args.steps) / 1e6, 1) if dt_sharded else None
+            line["config"]["value_host_sharded"] = round(px / (dt_host_sharded / args.steps) / 1e6, 1) if dt_host_sharded else None
         if dt_host_sharded is not None:
             line["host_sharded"] = {"value": round(px / (dt_host_sharded / args.steps) / 1e6, 1), "unit": "Mpixels/s",
                                     "ms_per_step": round(dt_host_sharded / args.steps * 1e3, 4),

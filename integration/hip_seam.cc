@@ -60,10 +60,43 @@
 #include "jxl_hip_entropy.h"
 #include "jxl_hip_frame.h"
 
+// The seam's switches, read from the environment ONCE per process (first use), not per frame on the decoder's threads
+// (getenv races with a host application's setenv): JXLHIP_SEAM_DISABLE (everything to libjxl's CPU path),
+// JXLHIP_SEAM_LIBJXL_DC (the DC groups stay with libjxl), JXLHIP_SEAM_VERBOSE, JXLHIP_SEAM_DEVICE.  The tests, which
+// switch them inside one process, call jxlhip_seam_reload_env().
+namespace {
+struct SeamSwitches {
+  std::atomic<bool> loaded{false}, disable{false}, libjxl_dc{false}, verbose{false};
+  std::atomic<int> device{0};
+  std::mutex mu;
+};
+SeamSwitches g_sw;
+void LoadSeamSwitchesLocked() {
+  g_sw.disable.store(getenv("JXLHIP_SEAM_DISABLE") != nullptr);
+  g_sw.libjxl_dc.store(getenv("JXLHIP_SEAM_LIBJXL_DC") != nullptr);
+  g_sw.verbose.store(getenv("JXLHIP_SEAM_VERBOSE") != nullptr);
+  const char* e = getenv("JXLHIP_SEAM_DEVICE");
+  g_sw.device.store(e ? atoi(e) : 0);
+  g_sw.loaded.store(true, std::memory_order_release);
+}
+const SeamSwitches& Seam() {
+  if (!g_sw.loaded.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lock(g_sw.mu);
+    if (!g_sw.loaded.load(std::memory_order_relaxed)) LoadSeamSwitchesLocked();
+  }
+  return g_sw;
+}
+}  // namespace
+
 extern "C" {
 static std::atomic<int> g_frames{0};
 // how many frames went through the HIP back-end (the GPU test asserts the path was actually taken)
 __attribute__((visibility("default"))) int jxlhip_seam_frames_decoded() { return g_frames.load(); }
+// tests: read the JXLHIP_SEAM_* switches again (JXLHIP_SEAM_DEVICE only counts before the first frame)
+__attribute__((visibility("default"))) void jxlhip_seam_reload_env() {
+  std::lock_guard<std::mutex> lock(g_sw.mu);
+  LoadSeamSwitchesLocked();
+}
 }
 
 namespace jxl {
@@ -142,7 +175,7 @@ void FillFrameHeader(const FrameDecoder* fd, jxlhip_frame_header* mfh) {
 // (quantizer and the global Modular tree), which its DC-group decoder needs.
 void JxlHipAfterDcGlobal(FrameDecoder* fd, const BitReader* br) {
   (void)DcStateOf(fd, /*take=*/true);  // (a frame decoder that starts over)
-  if (getenv("JXLHIP_SEAM_DISABLE") || getenv("JXLHIP_SEAM_LIBJXL_DC")) return;
+  if (Seam().disable.load(std::memory_order_relaxed) || Seam().libjxl_dc.load(std::memory_order_relaxed)) return;
   const FrameHeader& fh = fd->frame_header_;
   const FrameDimensions& dim = fd->frame_dim_;
   const ImageMetadata& md = fh.nonserialized_metadata->m;
@@ -166,7 +199,10 @@ void JxlHipAfterDcGlobal(FrameDecoder* fd, const BitReader* br) {
   st->ytox.assign(nt, 0);
   st->ytob.assign(nt, 0);
   std::lock_guard<std::mutex> lock(g_dc_mu);
-  if (g_dc.size() >= 8) g_dc.erase(g_dc.begin());  // (frames that never reached their AC groups)
+  // (entries leave when their frame reaches its AC groups or starts over, DcStateOf(.., take); what is dropped here are
+  // frames that never got there -- with 64 slots a process must hold 64 half-decoded frames before a live one loses its
+  // fast path, which then only costs speed: its DC groups fall back to libjxl's own decode)
+  if (g_dc.size() >= 64) g_dc.erase(g_dc.begin());
   g_dc.emplace_back(fd, std::move(st));
 }
 
@@ -233,8 +269,7 @@ namespace {
 jxlhip_ctx* Context() {
   static jxlhip_ctx* ctx = [] {
     jxlhip_ctx* c = nullptr;
-    const char* e = getenv("JXLHIP_SEAM_DEVICE");
-    if (jxlhip_create(e ? atoi(e) : 0, &c) != JXLHIP_OK) return static_cast<jxlhip_ctx*>(nullptr);
+    if (jxlhip_create(Seam().device.load(std::memory_order_relaxed), &c) != JXLHIP_OK) return static_cast<jxlhip_ctx*>(nullptr);
     return c;
   }();
   return ctx;
@@ -255,8 +290,8 @@ Status JxlHipTryAcGroups(FrameDecoder* fd, const FrameDecoder::SectionInfo* sect
                          size_t ac_global_bit, FrameDecoder::SectionStatus* section_status, bool* done) {
   *done = false;
   const std::shared_ptr<DcFrameState> dc_state = DcStateOf(fd, /*take=*/true);  // (JxlHipDcGroup's state: its job is done)
-  if (getenv("JXLHIP_SEAM_DISABLE")) return true;
-  const bool verbose = getenv("JXLHIP_SEAM_VERBOSE") != nullptr;
+  if (Seam().disable.load(std::memory_order_relaxed)) return true;
+  const bool verbose = Seam().verbose.load(std::memory_order_relaxed);
   if (verbose && dc_state)
     fprintf(stderr, "jxlhip seam: %u of %zu DC groups decoded by the product's front-end into libjxl's state\n",
             dc_state->groups_taken.load(), static_cast<size_t>(fd->frame_dim_.num_dc_groups));

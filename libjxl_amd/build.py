@@ -10,7 +10,10 @@ CSRC = os.path.join(_HERE, "csrc")
 BUILD = os.path.join(CSRC, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+         # the gfx950 code objects travel zstd-compressed inside the fat binary (the HIP runtime unpacks them when the
+         # library is loaded: measured on the GPU box, profiles/r06_library_size.txt): 12.1 -> ~4 MB
+         "--offload-compress"]
 LIB_SOURCES = ["context.hip", "kernels_blocks.hip", "kernels_filters.hip", "kernels_filters_fast.hip", "kernels_filters_fast_b.hip", "kernels_filters_fast_c.hip",
                "kernels_filters_fast_d.hip",
                "kernels_fused.hip", "kernels_fused_epf0.hip", "kernels_mfma.hip", "kernels_epf0.hip", "kernels_tables.hip", "entropy.cc"]
@@ -50,7 +53,7 @@ def _compile(src):
 
 def _link(target, objs, extra=()):
     if _stale(target, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs + list(extra)
+        cmd = [HIPCC, "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-o", target] + objs + list(extra)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed for %s:\n%s" % (target, r.stderr[-4000:]))
@@ -70,29 +73,73 @@ def _uint(b, i):
     raise ValueError(hex(t))
 
 
+LLVM_BIN = os.environ.get("JXLHIP_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+
+def _code_objects(so):
+    """The gfx950 code objects inside a built library, as bytes: the .hip_fatbin section is a sequence of offload bundles,
+    one per translation unit, zstd-compressed since round 6 (--offload-compress: magic CCOB, 64-bit total size at offset
+    8) or plain (__CLANG_OFFLOAD_BUNDLE__); clang-offload-bundler unpacks either."""
+    import struct
+    import tempfile
+    out = []
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        r = subprocess.run([os.path.join(LLVM_BIN, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so],
+                           capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(fat):
+            raise RuntimeError("llvm-objcopy could not read .hip_fatbin of %s: %s" % (so, r.stderr[-400:]))
+        b = open(fat, "rb").read()
+        blobs, i = [], 0
+        while i < len(b):
+            if b[i:i + 4] == b"CCOB":
+                size = struct.unpack_from("<Q", b, i + 8)[0]
+                blobs.append(b[i:i + size])
+                i += size
+            elif b[i:i + 24] == b"__CLANG_OFFLOAD_BUNDLE__":
+                j = b.find(b"__CLANG_OFFLOAD_BUNDLE__", i + 24)
+                k = b.find(b"CCOB", i + 24)
+                ends = [x for x in (j, k) if x > 0]
+                end = min(ends) if ends else len(b)
+                blobs.append(b[i:end])
+                i = end
+            else:
+                i += 1  # padding between bundles
+        for n, blob in enumerate(blobs):
+            src, dst = os.path.join(td, "b%d.bin" % n), os.path.join(td, "b%d.co" % n)
+            open(src, "wb").write(blob)
+            r = subprocess.run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + src, "--output=" + dst],
+                               capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(dst):
+                raise RuntimeError("clang-offload-bundler could not unpack bundle %d of %s: %s" % (n, so, r.stderr[-400:]))
+            out.append(open(dst, "rb").read())
+    return out
+
+
 def kernel_resources(so):
     """{mangled kernel name: {scratch, vgprs, spills}} from the code-object metadata inside a built library (the AMDGPU
     msgpack notes: .private_segment_fixed_size, .symbol, .vgpr_count, .vgpr_spill_count; the keys of a kernel record are
     sorted)."""
     import re
-    b = open(so, "rb").read()
     out = {}
-    for m in re.finditer(rb"\xbb\.private_segment_fixed_size", b):
-        scratch = _uint(b, m.end())
-        s = b.find(b"\xa7.symbol", m.end(), m.end() + 400)
-        if s < 0:
-            continue
-        t = b[s + 8]
-        if t == 0xD9:
-            n, at = b[s + 9], s + 10
-        elif t == 0xDA:
-            n, at = int.from_bytes(b[s + 9:s + 11], "big"), s + 11
-        else:
-            n, at = t & 0x1F, s + 9
-        name = b[at:at + n].decode()
-        v = b.find(b"\xab.vgpr_count", at, at + 600)
-        sp = b.find(b"\xb1.vgpr_spill_count", at, at + 700)
-        out[name] = dict(scratch=scratch, vgprs=_uint(b, v + 12), spills=_uint(b, sp + 18))
+    for b in _code_objects(so):
+        for m in re.finditer(rb"\xbb\.private_segment_fixed_size", b):
+            scratch = _uint(b, m.end())
+            s = b.find(b"\xa7.symbol", m.end(), m.end() + 400)
+            if s < 0:
+                continue
+            t = b[s + 8]
+            if t == 0xD9:
+                n, at = b[s + 9], s + 10
+            elif t == 0xDA:
+                n, at = int.from_bytes(b[s + 9:s + 11], "big"), s + 11
+            else:
+                n, at = t & 0x1F, s + 9
+            name = b[at:at + n].decode()
+            v = b.find(b"\xab.vgpr_count", at, at + 600)
+            sp = b.find(b"\xb1.vgpr_spill_count", at, at + 700)
+            out[name] = dict(scratch=scratch, vgprs=_uint(b, v + 12), spills=_uint(b, sp + 18))
     return out
 
 
@@ -102,7 +149,10 @@ def check_no_scratch(so, pattern="k_fused_pc"):
     believes those registers hold their values from the asm statement on, so a spill or a scratch copy of one of them
     in between stores a value that has not arrived (a 128-VGPR ablation build did exactly that and faulted).  A ROCm
     point release that changes the register allocation must fail HERE, not corrupt memory on the GPU."""
-    bad = {k: v for k, v in kernel_resources(so).items() if pattern in k and (v["scratch"] or v["spills"])}
+    res = kernel_resources(so)
+    if not any(pattern in k for k in res):  # (a check that finds no kernel to look at has checked nothing)
+        raise RuntimeError("no %s kernel found in the metadata of %s" % (pattern, os.path.basename(so)))
+    bad = {k: v for k, v in res.items() if pattern in k and (v["scratch"] or v["spills"])}
     if bad:
         os.remove(so)
         raise RuntimeError("refusing to ship %s: %d %s kernels use scratch (inline-asm prefetch registers may be "

@@ -51,9 +51,11 @@ constexpr int kStageSlots = 128, kStageSlotsFirst = 32;
 // context's first frame -- all a one-shot tool ever decodes -- waited for them)
 constexpr int kStageChunk = 32;
 
-struct ProfSpan {
-  hipEvent_t a, b;
-  int slot;
+// jxlhip_profile_enable: ONE event between consecutive launches (it ends the span of the launch before it and starts
+// the span of the one after: rounds 1-5 recorded two, and the pass inflated every launch by ~9 %)
+struct ProfMarkRec {
+  hipEvent_t ev;
+  int slot_after;  // kernel slot of the span that STARTS at this event; < 0: none (the end of a group of launches)
 };
 
 }  // namespace
@@ -188,8 +190,7 @@ struct jxlhip_ctx {
   size_t cell_info_items = 0;
   // profiling
   bool profiling = false;
-  std::vector<ProfSpan> spans;
-  hipEvent_t prof_prev = nullptr;
+  std::vector<ProfMarkRec> marks;
 };
 
 namespace {
@@ -229,27 +230,18 @@ void ProfBegin(jxlhip_ctx* c) {
   hipEvent_t e;
   (void)hipEventCreate(&e);
   (void)hipEventRecord(e, c->stream);
-  c->prof_prev = e;
+  c->marks.push_back({e, -1});
 }
-// closes the span [prev, now) for `slot` and opens the next one
+// closes the span [previous mark, now) for `slot` and opens the next one
 void ProfMark(jxlhip_ctx* c, int slot) {
-  if (!c->profiling) return;
+  if (!c->profiling || c->marks.empty()) return;
+  c->marks.back().slot_after = slot;
   hipEvent_t e;
   (void)hipEventCreate(&e);
   (void)hipEventRecord(e, c->stream);
-  c->spans.push_back({c->prof_prev, e, slot});
-  hipEvent_t n;
-  (void)hipEventCreate(&n);
-  (void)hipEventRecord(n, c->stream);
-  c->prof_prev = n;
+  c->marks.push_back({e, -1});
 }
-void ProfEnd(jxlhip_ctx* c) {
-  if (!c->profiling || !c->prof_prev) return;
-  // prof_prev of the last span is unused as a start; keep it alive in a
-  // zero-length span so it is destroyed with the others
-  c->spans.push_back({c->prof_prev, c->prof_prev, -1});
-  c->prof_prev = nullptr;
-}
+void ProfEnd(jxlhip_ctx* c) { (void)c; }  // (the last mark's slot_after stays -1: nothing starts there)
 
 // Pinned staging slots: memory from the caller's JxlMemoryManager when there is one (pinned in place
 // with hipHostRegister: "caller owns the host memory, the library pins it"), else hipHostMalloc.
@@ -432,11 +424,8 @@ void jxlhip_destroy(jxlhip_ctx* c) {
   if (!c->children.empty()) return MultiDestroy(c);
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  for (auto& s : c->spans) {
-    if (s.a) (void)hipEventDestroy(s.a);
-    if (s.b && s.b != s.a) (void)hipEventDestroy(s.b);
-  }
-  if (c->prof_prev) (void)hipEventDestroy(c->prof_prev);
+  for (auto& m : c->marks)
+    if (m.ev) (void)hipEventDestroy(m.ev);
   for (int i = 0; i < kPoolStreams; i++) {
     if (c->pool[i]) {
       (void)hipStreamSynchronize(c->pool[i]);
@@ -2015,18 +2004,18 @@ int jxlhip_profile_read(jxlhip_ctx* c, float ms[JXLHIP_KERNEL_COUNT],
     ms[i] = 0;
     launches[i] = 0;
   }
-  for (auto& s : c->spans) {
-    if (s.slot >= 0 && s.slot < JXLHIP_KERNEL_COUNT) {
+  for (size_t i = 0; i + 1 < c->marks.size(); i++) {
+    const int slot = c->marks[i].slot_after;
+    if (slot >= 0 && slot < JXLHIP_KERNEL_COUNT) {
       float t = 0;
-      if (hipEventElapsedTime(&t, s.a, s.b) == hipSuccess) {
-        ms[s.slot] += t;
-        launches[s.slot]++;
+      if (hipEventElapsedTime(&t, c->marks[i].ev, c->marks[i + 1].ev) == hipSuccess) {
+        ms[slot] += t;
+        launches[slot]++;
       }
     }
-    (void)hipEventDestroy(s.a);
-    if (s.b != s.a) (void)hipEventDestroy(s.b);
   }
-  c->spans.clear();
+  for (auto& m : c->marks) (void)hipEventDestroy(m.ev);
+  c->marks.clear();
   return JXLHIP_OK;
 }
 

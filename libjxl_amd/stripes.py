@@ -124,6 +124,8 @@ class StripeDecoder:
         self.rows = [stripe_pixel_rows(params["ysize"], a, b) for a, b in self.parts]
         decoder.begin_frame(self.params)
         self._halo = None  # persistent send / receive buffers of the halo exchange
+        self._gather_pending = []  # decode_gathered: (step, request) of the transfers still in flight
+        self._gather_step = 0
         # device tensors over a host-only backend (a one-GPU smoke test): staged through the host
         self.staged = bool(world > 1 and dist.is_initialized() and dist.get_backend(group) == "gloo" and
                            getattr(decoder, "tensor_device", "cuda") != "cpu")
@@ -162,9 +164,93 @@ class StripeDecoder:
         req.wait()
         return full
 
-    def decode(self, out, timing=None):
+    # -- the same gather, STREAMED with the step (round 6) ------------------------------------------------
+    # gather() above starts when the whole stripe is done and makes the compute stream wait for it: a step costs
+    # kernels + gather.  decode_gathered() posts a stripe's rows to rank 0 as soon as the launches that write them are
+    # queued -- the interior rows (all but the two boundary block rows) while the halo rows still travel, the boundary rows
+    # behind stripe_finish -- and does NOT wait for them: the caller alternates between two stripe buffers, so that the
+    # rows of frame k travel while frame k + 1 is decoded, and a step costs max(kernels, gather).  What bounds it then is
+    # rank 0's incoming links (7/8 of the frame over 7 point-to-point xGMI links), not the sum.
+    def _post_rows(self, out, full, ya, yb):
+        """Rows [ya, yb) of this rank's stripe (frame coordinates) to rank 0's frame; rank 0 posts the matching receives
+        for the SAME chunk of every peer (chunk k of peer r = the k-th call of peer r: per-peer order is what pairs
+        them).  Returns the request object (wait() = the current stream waits), or None when there is nothing to move."""
+        y0 = self.rows[self.rank][0]
+        if self.rank != 0:
+            if yb <= ya:
+                return None
+            return _post([(out[ya - y0:yb - y0], 0)], [], self.group, self.staged)
+        if yb > ya:
+            full[ya:yb].copy_(out[ya - y0:yb - y0], non_blocking=True)
+        return None
+
+    def _post_peer_receives(self, full, which):
+        """Rank 0: receives for chunk `which` (0 interior, 1 top boundary rows, 2 bottom boundary rows) of every peer."""
+        recvs = []
+        for r in range(1, self.world):
+            a, b = self._chunk_rows(r, which)
+            if b > a:
+                recvs.append((full[a:b], r))
+        return _post([], recvs, self.group, self.staged) if recvs else None
+
+    def _chunk_rows(self, r, which):
+        """Frame rows of chunk `which` of rank r's stripe -- the split decode() makes: interior = all but the block rows
+        next to a neighbour, top / bottom = those block rows (empty on the frame's outer sides)."""
+        y0, y1 = self.rows[r]
+        ya = y0 + 8 if r > 0 else y0
+        yb = y1 - 8 if r + 1 < self.world else y1
+        if not self._splits(r):
+            return (y0, y1) if which == 0 else (y0, y0)
+        return [(ya, yb), (y0, ya), (yb, y1)][which]
+
+    def _splits(self, r):
+        y0, y1 = self.rows[r]
+        ya = y0 + 8 if r > 0 else y0
+        yb = y1 - 8 if r + 1 < self.world else y1
+        return bool(self.interior_first and yb - ya >= 8 and self.dec.params.lf.epf_iters < 3 and self.dec.halo_rows() > 0)
+
+    def wait_gather(self, older_than=None):
+        """The current stream waits for the streamed-gather transfers posted before step `older_than` (None: for all of
+        them -- the end of a run, or before the frame is read on rank 0)."""
+        keep = []
+        for step, req in self._gather_pending:
+            if older_than is None or step < older_than:
+                req.wait()
+            else:
+                keep.append((step, req))
+        self._gather_pending = keep
+
+    def decode_gathered(self, out, full):
+        """decode(out) with the rows streamed into rank 0's `full` as they are produced (see above).  The transfers are
+        left in flight across ONE following step: pass a different stripe buffer than at the step before (two buffers
+        alternating); before a buffer is written again the transfers of the step that used it have been waited for
+        here.  wait_gather() before the frame is read / at the end of a run."""
+        if self.world == 1:
+            return self.dec.decode_frame(out)
+        step = self._gather_step
+        self._gather_step += 1
+        self.wait_gather(older_than=step - 1)  # everything of step - 2 and before (the last user of this buffer)
+
+        def chunk(which):
+            a, b = self._chunk_rows(self.rank, which)
+            req = self._post_rows(out, full, a, b)
+            if req is not None:
+                self._gather_pending.append((step, req))
+            if self.rank == 0:
+                r0 = self._post_peer_receives(full, which)
+                if r0 is not None:
+                    self._gather_pending.append((step, r0))
+
+        self.decode(out, on_interior=lambda: chunk(0))
+        chunk(1)
+        chunk(2)
+        return out
+
+    def decode(self, out, timing=None, on_interior=None):
         """Both phases of this rank's stripe.  timing: an optional dict that receives torch.cuda.Event pairs around the
-        phases ("blocks", "interior", "halo_wait", "boundary"), for bench.py's per-phase report."""
+        phases ("blocks", "interior", "halo_wait", "boundary"), for bench.py's per-phase report.  on_interior: called once
+        the interior rows' launches are queued (decode_gathered posts their transfer there); when the stripe is not split
+        it is called at the end, with every row queued."""
         d = self.dec
         if self.world == 1:
             # no neighbours: both phases in one call, walked in bands so that the
@@ -187,7 +273,8 @@ class StripeDecoder:
         # the two neighbours point to point (RCCL over the direct xGMI link; requests are ordered on streams: wait()
         # makes the compute stream wait, not the host)
         b = self._halo_buffers() if h else None
-        fast = timing is None and hasattr(d, "stripe_begin")  # three calls into the library per frame instead of up to nine
+        fast = hasattr(d, "stripe_begin")  # three calls into the library per frame instead of up to nine (also under `timing`:
+                                           # the per-phase report describes the sequence that is timed)
         mark("t0")
         if fast:
             d.stripe_begin(b["up_send"] if h and up else None, b["dn_send"] if h and dn else None)
@@ -197,6 +284,8 @@ class StripeDecoder:
         if h == 0:
             d.decode_filters(out)
             mark("interior")
+            if on_interior:
+                on_interior()
             return out
         sends, recvs = [], []
         if up:
@@ -221,6 +310,8 @@ class StripeDecoder:
         split = self.interior_first and yb - ya >= 8 and d.params.lf.epf_iters < 3
         if split:
             d.decode_filters(out, rows=(ya, yb))
+            if on_interior:
+                on_interior()
         mark("interior")
         req.wait()
         mark("halo_wait")
@@ -237,4 +328,6 @@ class StripeDecoder:
             else:
                 d.decode_filters(out)
         mark("boundary")
+        if on_interior and not split:
+            on_interior()
         return out

@@ -50,6 +50,8 @@ def ref(oracle):
 
 def load(path):
     L = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+    if hasattr(L, "jxlhip_seam_reload_env"):  # the seam reads its JXLHIP_SEAM_* switches once per process: the tests switch them
+        L.jxlhip_seam_reload_env()
     L.JxlDecoderCreate.restype = C.c_void_p
     L.JxlDecoderCreate.argtypes = [C.c_void_p]
     L.JxlDecoderDestroy.argtypes = [C.c_void_p]

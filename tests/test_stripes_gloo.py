@@ -210,3 +210,67 @@ def test_stripe_decoder_three_call_form_and_timed_pass_over_gloo(tmp_path, fast,
     mp.spawn(_flow_worker, args=(3, port, str(tmp_path), True, fast, timed), nprocs=3, join=True)
     for r in range(3):
         assert (tmp_path / ("r%d" % r)).read_text() == "ok", (tmp_path / ("r%d" % r)).read_text()
+
+
+class _PaintingDecoder(_RecordingDecoderFast):
+    """... whose decode_filters really writes the rows it is asked for: row y of frame number n becomes 1000 n + y, so
+    that a gathered frame says which step and which row every value came from."""
+    frame_no = 0
+
+    def decode_filters(self, out, rows=None):
+        super().decode_filters(out, rows)
+        y0 = self.frame["stripe_group_y0"] * 256
+        y1 = min(self.frame["ysize"], (self.frame["stripe_group_y0"] + self.frame["stripe_group_rows"]) * 256)
+        a, b = rows if rows is not None else (y0, y1)
+        if b > a:
+            out[a - y0:b - y0] = (1000.0 * self.frame_no + torch.arange(a, b, dtype=torch.float32)).view(-1, 1, 1)
+
+
+def _gather_worker(rank, world, port, result_dir, interior_first, epf):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["JXLHIP_STRIPES_INTERIOR_FIRST"] = "1" if interior_first else "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libjxl_amd import stripes
+    xs, ys = 40, 256 * 7 + 100
+    d = _PaintingDecoder(rank, xs, epf=epf)
+    sd = stripes.StripeDecoder(d, dict(xsize=xs, ysize=ys), rank, world)
+    y0, y1 = sd.rows[rank]
+    outs = [torch.zeros((y1 - y0, xs, 3)), torch.zeros((y1 - y0, xs, 3))]
+    full = sd.alloc_gather(outs[0])
+    ok = True
+    for n in range(1, 6):  # five frames back to back, two stripe buffers alternating, nothing waited for in between
+        d.frame_no = n
+        sd.decode_gathered(outs[n & 1], full)
+        if n == 3:  # a reader in the middle of the run: everything posted so far must have landed
+            sd.wait_gather()
+            if rank == 0:
+                want = (1000.0 * n + torch.arange(ys, dtype=torch.float32)).view(-1, 1, 1).expand(ys, xs, 3)
+                ok &= bool(torch.equal(full, want))
+    sd.wait_gather()
+    if rank == 0:
+        want = (1000.0 * 5 + torch.arange(ys, dtype=torch.float32)).view(-1, 1, 1).expand(ys, xs, 3)
+        ok &= bool(torch.equal(full, want))
+        ok &= len(sd._gather_pending) == 0
+    # the interior rows were posted BEFORE the halo rows were imported (the transfer starts while the exchange runs)
+    if interior_first and epf < 3:
+        first_import = min([i for i, c in enumerate(d.calls) if c[0] == "import"], default=len(d.calls))
+        first_filter = min(i for i, c in enumerate(d.calls) if c[0] == "filters")
+        ok &= first_filter < first_import
+    open(os.path.join(result_dir, "r%d" % rank), "w").write("ok" if ok else "bad")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("interior_first,epf", [(True, 1), (False, 1), (True, 3)])
+def test_streamed_gather_over_gloo(tmp_path, interior_first, epf):
+    """StripeDecoder.decode_gathered (round 6): every rank posts its stripe's rows to rank 0 as soon as their launches
+    are queued -- interior rows first, then the boundary block rows -- and leaves the transfers in flight across the next
+    step (two stripe buffers alternating).  Three ranks over gloo, five frames back to back: rank 0's frame holds exactly
+    the rows of the LAST frame of every rank at the end, and of frame 3 when a reader waits in the middle; unsplit
+    stripes (interior-first off, or epf_iters = 3) travel as one chunk."""
+    port = 29500 + (os.getpid() + 41 + 2 * int(interior_first) + epf) % 2000
+    mp.spawn(_gather_worker, args=(3, port, str(tmp_path), interior_first, epf), nprocs=3, join=True)
+    for r in range(3):
+        assert (tmp_path / ("r%d" % r)).read_text() == "ok"
