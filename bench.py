@@ -703,6 +703,8 @@ def main():
     params, t = synth.synth_frame(xs, ys, mix=mix, gab=bool(cfg["gab"]), epf_iters=cfg["epf"],
                                   device=f"cuda:{local}", coeff_type=int(cfg["coeff32"]),
                                   intensity_target=cfg["intensity"], quant_mul=cfg["quant_mul"])
+    if os.environ.get("JXLHIP_BENCH_NO_USED_ACS"):  # experiments: the caller does not know the frame's strategies (the merged phase-1 launch)
+        params["used_acs"] = 0
     dec = VarDctDecoder(local)
     sd = stripes.StripeDecoder(dec, params, rank, world)
     dq = dec.default_dequant_tables()

@@ -18,6 +18,15 @@ LIB_SOURCES = ["context.hip", "kernels_blocks.hip", "kernels_filters.hip", "kern
                "kernels_filters_fast_d.hip",
                "kernels_fused.hip", "kernels_fused_epf0.hip", "kernels_mfma.hip", "kernels_epf0.hip", "kernels_tables.hip", "entropy.cc"]
 RUNNER_SOURCES = ["runner.cc"]
+# Per-file flags.  kernels_blocks.hip: the SLP vectoriser pairs the butterflies of the in-register IDCTs into packed
+# fp32 operations (v_pk_fma / v_pk_add / v_pk_mul on aligned register PAIRS, stitched together with v_mov): the pairs
+# pushed k_transform_r<short> over its 168 registers (148 spilled VGPRs whose traffic reached HBM: 8K frames of DCT32X32
+# read 1.44x / wrote 1.21x their bytes) -- without it the kernel needs 165 and spills nothing, k_transform_r16 drops from
+# 113 to 93 (five waves per SIMD), and a packed instruction holds the SIMD ~1.6x as long as a plain one anyway
+# (tools/probes/valu_issue.hip).  Explicit vector types (filters_march.h) are not affected.
+EXTRA_FLAGS = {"kernels_blocks.hip": ["-fno-slp-vectorize"]}
+if os.environ.get("JXLHIP_BUILD_NO_SLP_ALL"):  # experiment builds
+    EXTRA_FLAGS = {k: ["-fno-slp-vectorize"] for k in LIB_SOURCES if k.endswith(".hip")}
 
 
 def _deps():
@@ -42,9 +51,9 @@ def _compile(src):
     extra = [os.path.join(CSRC, "kernels_fused.hip")] if src == "kernels_fused_epf0.hip" else []  # it #includes it
     if src.startswith("kernels_filters_fast_"):
         extra = [os.path.join(CSRC, "kernels_filters_fast.hip")]
-    if _stale(obj, [path] + extra + _deps()):
+    if _stale(obj, [path] + extra + _deps() + [os.path.abspath(__file__)]):
         lang = ["-x", "hip"] if src.endswith(".hip") else []
-        cmd = [HIPCC] + FLAGS + lang + ["-c", path, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + lang + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

@@ -22,6 +22,19 @@
 
 namespace jxlhip {
 
+// strategy -> covered blocks x | y << 8 | class << 16, in constant memory: indexed by a runtime strategy, the constexpr
+// tables of dev_common.h would be copied to the thread's scratch
+struct StrategyWord {
+  uint32_t v[JXLHIP_NUM_STRATEGIES];
+};
+__host__ __device__ constexpr StrategyWord MakeStrategyWords() {
+  StrategyWord w{};
+  for (int s = 0; s < JXLHIP_NUM_STRATEGIES; s++)
+    w.v[s] = (uint32_t)kCoveredX[s] | ((uint32_t)kCoveredY[s] << 8) | ((uint32_t)(uint8_t)ClassOfStrategy(s) << 16);
+  return w;
+}
+__constant__ StrategyWord kStrategyWords = MakeStrategyWords();
+
 // ---------------------------------------------------------------- k_prepare
 // One workgroup (1024 threads) per AC group of the stripe; thread i owns cell
 // (i / gw, i % gw) of the group's clipped block rectangle (BlockGroupRect,
@@ -64,7 +77,8 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
     s = 0;
     first = false;
   }
-  const uint32_t cx = kCoveredX[s], cy = kCoveredY[s];
+  const uint32_t sw = kStrategyWords.v[s];
+  const uint32_t cx = sw & 0xffu, cy = (sw >> 8) & 0xffu;
   if (first && (bx + cx > gw || by + cy > gh)) {
     bad = true;
     first = false;
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   // per-wave class histogram.  Fused mode: DCT8 varblocks are decoded by the fused kernel from cell_info and stay off
   // the work list -- except, in a STRIPE (fused == 2), those of the stripe's first / last block row next to a
   // neighbouring stripe: they are decoded into the planes as well (the halo rows the neighbour pulls).
-  const int cls_frame = first ? (int)kClassLut.v[s] : -1;
+  const int cls_frame = first ? (int)(int8_t)(sw >> 16) : -1;
   const bool edge_row = f.fused == 2 && ((aby == (f.y0 >> 3) && f.group_y0 > 0) ||
                                          (aby == ((f.y1 - 1) >> 3) && f.group_y0 + f.group_rows < f.ysg));
   const int cls = (f.fused && cls_frame == kClsDct8 && !edge_row) ? -1 : cls_frame;
@@ -144,7 +158,10 @@ __global__ __launch_bounds__(1024) void k_prepare(DevFrame f, WorkLists wl, uint
   }
   // ComputeSigma (epf.cc:69-79), one cell per thread
   if (with_sigma && valid) {
-    float sigma = cell_sq[tid] * lut.v[cell_sharp & 7];
+    float sharp_mul = lut.v[0];  // (a select chain: a dynamic index into the kernel argument would put the table in scratch)
+#pragma unroll
+    for (int i = 1; i < 8; i++) sharp_mul = (cell_sharp & 7u) == (uint32_t)i ? lut.v[i] : sharp_mul;
+    float sigma = cell_sq[tid] * sharp_mul;
     sigma = sigma < -1e-4f ? sigma : -1e-4f;
     f.inv_sigma[cell] = 1.0f / sigma;
   }
@@ -608,9 +625,35 @@ __device__ __forceinline__ void TransposeTile(float* w, int lane) {
   }
 }
 
-template <int R, int C, int STRATEGY, typename CT>
+// The same transposition through LDS (round 6), for the units that run inside the merged k_transform_r -- whose
+// workgroups carry family A's 50 KB allocation whether they use it or not: lane (varblock b, row j) writes its S values
+// as row j of a padded S x (S + 1) tile and reads column j back.  Pure data movement (bit-identical); 2 S LDS
+// instructions instead of the exchange network's ~8 S VALU instructions and its send / receive temporaries -- the
+// 32-point classes no longer need more than the kernel's 168 registers.  Row stride S + 1: the writes of a wave
+// instruction (lanes = rows) and its reads (lanes = columns) fall on distinct banks.  The tile belongs to ONE wave
+// (a unit's varblocks are split by wave): LDS operations of a wave execute in order, no barrier.
+typedef __attribute__((address_space(3))) float LdsTile;
+template <int S>
+__device__ __forceinline__ void TransposeTileLds(float* w, int b, int j, LdsTile* wave_lds) {
+  LdsTile* tile = wave_lds + b * (S * (S + 1));
+  LdsTile* row = tile + j * (S + 1);
+#pragma unroll
+  for (int a = 0; a < S; a++) row[a] = w[a];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int a = 0; a < S; a++) w[a] = tile[a * (S + 1) + j];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();  // (the tile is rewritten by the next transposition)
+}
+// bytes of LDS a workgroup of four waves needs for it
+template <int S>
+constexpr int TransposeLdsBytes() { return 4 * (64 / S) * S * (S + 1) * 4; }
+
+template <int R, int C, int STRATEGY, typename CT, bool LDS_T = false>
 __device__ __forceinline__ void RowLaneUnit(const DevFrame& f, const WorkItem* __restrict__ list,
-                                            uint32_t first, uint32_t n) {
+                                            uint32_t first, uint32_t n, unsigned char* smem = nullptr) {
   constexpr int S = R < C ? R : C, L = R < C ? C : R;
   constexpr int BPS = 64 / S;  // varblocks per wave
   constexpr int CY = R / 8, CX = C / 8;
@@ -624,82 +667,85 @@ __device__ __forceinline__ void RowLaneUnit(const DevFrame& f, const WorkItem* _
   const bool valid = vb < n;
   const WorkItem it = list[valid ? vb : n - 1];
   const BlockHdr h = MakeHdr(f, it);
-  uint4 raw[3][kVec];
-#pragma unroll
-  for (int c = 0; c < 3; c++) {
+  // The lane's coefficient rows, one channel per register set and at most TWO sets alive: Y and X are requested up front,
+  // B when Y's set has been unpacked -- its loads travel during the Y and X transforms.  (Rounds 1-5 requested all three
+  // up front: 48 VGPRs of raw rows for the 32-point classes, which pushed the merged k_transform_r over its 168 registers:
+  // 148 spilled VGPRs, and the spill traffic reached HBM -- 8K frames of DCT32X32 / DCT32X8 alone read 1.44-1.47x and wrote
+  // 1.21-1.27x their bytes, profiles/r06_transform_overread.txt.)
+  uint4 raw_a[kVec], raw_b[kVec];
+  auto request = [&](int c, uint4* r) {
     const uint4* p = (const uint4*)((const CT*)f.coeffs[c] + h.coef + (size_t)j * L);
 #pragma unroll
-    for (int i = 0; i < kVec; i++) raw[c][i] = p[i];
-  }
+    for (int i = 0; i < kVec; i++) r[i] = p[i];
+  };
+  request(1, raw_a);
+  request(0, raw_b);
   // lowest frequencies from the DC patch (LowestFrequenciesFromDC, dec_transforms-inl.h:691-818):
   // CY-point DCTs down the columns, CX-point DCTs along the rows, resampling scales; the lanes
   // holding the LLF corner compute the whole (at most 2x2) patch and keep their entries
   constexpr int kLlfLanes = CY < CX ? CY : CX;
   constexpr int kLlfRegs = CY < CX ? CX : CY;
-  float llf[3][kLlfRegs];
-  if (j < kLlfLanes) {
+  // (per channel, when the channel is transformed: three channels' patches held from the start cost the 32-point classes
+  // twelve registers they do not have)
+  auto llf_of = [&](int c, float* out) {
+    const float* dc = f.dc[c] + (size_t)h.aby * f.xsb + h.abx;
+    float dp[CY][CX];
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float* dc = f.dc[c] + (size_t)h.aby * f.xsb + h.abx;
-      float dp[CY][CX];
+    for (int x = 0; x < CX; x++) {
+      float v[CY];
+#pragma unroll
+      for (int y = 0; y < CY; y++) v[y] = dc[(size_t)y * f.xsb + x];
+      DctReg<CY>(v);
+#pragma unroll
+      for (int y = 0; y < CY; y++) dp[y][x] = (1.0f / CY) * v[y];
+    }
+#pragma unroll
+    for (int y = 0; y < CY; y++) {
+      float v[CX];
+#pragma unroll
+      for (int x = 0; x < CX; x++) v[x] = dp[y][x];
+      DctReg<CX>(v);
+      const float ry = kResampleUpHost[CY + y];
 #pragma unroll
       for (int x = 0; x < CX; x++) {
-        float v[CY];
-#pragma unroll
-        for (int y = 0; y < CY; y++) v[y] = dc[(size_t)y * f.xsb + x];
-        DctReg<CY>(v);
-#pragma unroll
-        for (int y = 0; y < CY; y++) dp[y][x] = (1.0f / CY) * v[y];
-      }
-#pragma unroll
-      for (int y = 0; y < CY; y++) {
-        float v[CX];
-#pragma unroll
-        for (int x = 0; x < CX; x++) v[x] = dp[y][x];
-        DctReg<CX>(v);
-        const float ry = kResampleUpHost[CY + y];
-#pragma unroll
-        for (int x = 0; x < CX; x++) {
-          const float val = (1.0f / CX) * v[x];
-          if constexpr (CY < CX) {
-            if (j == y) llf[c][x] = val * ry * kResampleUpHost[CX + x];
-          } else {
-            if (j == x) llf[c][y] = val * kResampleUpHost[CX + x] * ry;
-          }
+        const float val = (1.0f / CX) * v[x];
+        if constexpr (CY < CX) {
+          if (j == y) out[x] = val * ry * kResampleUpHost[CX + x];
+        } else {
+          if (j == x) out[y] = val * kResampleUpHost[CX + x] * ry;
         }
-      }
-    }
-  }
-  const float* __restrict__ tab = f.dequant + DequantOffset(STRATEGY) + j * L;
-  auto unpack = [&](const uint4* r, int32_t* q) {
-    if constexpr (sizeof(CT) == 2) {
-#pragma unroll
-      for (int i = 0; i < kVec; i++) {
-        const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          q[i * 8 + 2 * k] = (int32_t)(int16_t)(w[k] & 0xffffu);
-          q[i * 8 + 2 * k + 1] = (int32_t)w[k] >> 16;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < kVec; i++) {
-        q[i * 4] = (int32_t)r[i].x;
-        q[i * 4 + 1] = (int32_t)r[i].y;
-        q[i * 4 + 2] = (int32_t)r[i].z;
-        q[i * 4 + 3] = (int32_t)r[i].w;
       }
     }
   };
-  float vy[L];
-  {
-    int32_t q[L];
-    unpack(raw[1], q);
+  const float* __restrict__ tab = f.dequant + DequantOffset(STRATEGY) + j * L;
+  // one 16-byte piece of a row -> its coefficients as integers (8 of 16 bits, 4 of 32 bits)
+  constexpr int kPer = 16 / (int)sizeof(CT);
+  auto unpack_piece = [&](const uint4 r, int32_t* q) {
+    if constexpr (sizeof(CT) == 2) {
+      const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int k = 0; k < L; k++)
-      vy[k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tab[R * C + k] * h.sy);
+      for (int k = 0; k < 4; k++) {
+        q[2 * k] = (int32_t)(int16_t)(w[k] & 0xffffu);
+        q[2 * k + 1] = (int32_t)w[k] >> 16;
+      }
+    } else {
+      q[0] = (int32_t)r.x, q[1] = (int32_t)r.y, q[2] = (int32_t)r.z, q[3] = (int32_t)r.w;
+    }
+  };
+  // Dequantisation piece by piece (DequantLane, dec_group.cc:115-153): the 32-point classes fence the pieces off from
+  // each other -- left alone the scheduler unpacks a whole row and requests its whole table row first (32 + 32 registers
+  // beside the 32 of vy, the 32 being produced and the next channel's pending rows: over the kernel's 168)
+  float vy[L];
+#pragma unroll
+  for (int i = 0; i < kVec; i++) {
+    int32_t q[kPer];
+    unpack_piece(raw_a[i], q);
+#pragma unroll
+    for (int k = 0; k < kPer; k++)
+      vy[i * kPer + k] = AdjustQuantBias(q[k], f.biases[1], f.biases[3]) * (tab[R * C + i * kPer + k] * h.sy);
+    if constexpr (L > 16) __builtin_amdgcn_sched_barrier(0);
   }
+  request(2, raw_a);  // B: in flight while Y and X are transformed
 #pragma unroll
   for (int ci = 0; ci < 3; ci++) {
     const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
@@ -710,27 +756,39 @@ __device__ __forceinline__ void RowLaneUnit(const DevFrame& f, const WorkItem* _
     } else {
       const float sc = c == 0 ? h.sx : h.sb;
       const float cc = c == 0 ? h.x_cc : h.b_cc;
-      int32_t q[L];
-      unpack(raw[c], q);
 #pragma unroll
-      for (int k = 0; k < L; k++) {
-        const float d = AdjustQuantBias(q[k], f.biases[c], f.biases[3]) * (tab[c * R * C + k] * sc);
-        v[k] = __builtin_fmaf(cc, vy[k], d);
+      for (int i = 0; i < kVec; i++) {
+        int32_t q[kPer];
+        unpack_piece(c == 0 ? raw_b[i] : raw_a[i], q);
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+          const float d = AdjustQuantBias(q[k], f.biases[c], f.biases[3]) * (tab[c * R * C + i * kPer + k] * sc);
+          v[i * kPer + k] = __builtin_fmaf(cc, vy[i * kPer + k], d);
+        }
+        if constexpr (L > 16) __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (j < kLlfLanes) {
+      float llf[kLlfRegs];
+      llf_of(c, llf);
 #pragma unroll
-      for (int k = 0; k < kLlfRegs; k++) v[k] = llf[c][k];
+      for (int k = 0; k < kLlfRegs; k++) v[k] = llf[k];
     }
     IdctReg<L>(v);
 #pragma unroll
-    for (int t = 0; t < kTiles; t++) TransposeTile<S>(v + t * S, lane);
+    for (int t = 0; t < kTiles; t++) {
+      if constexpr (LDS_T) TransposeTileLds<S>(v + t * S, lane & (BPS - 1), j, (LdsTile*)smem + wave * (BPS * S * (S + 1)));
+      else TransposeTile<S>(v + t * S, lane);
+    }
 #pragma unroll
     for (int t = 0; t < kTiles; t++) IdctReg<S>(v + t * S);
     if constexpr (R < C) {
       // v[t*S + a] = pixel (a, t*S + j): back to rows
 #pragma unroll
-      for (int t = 0; t < kTiles; t++) TransposeTile<S>(v + t * S, lane);
+      for (int t = 0; t < kTiles; t++) {
+        if constexpr (LDS_T) TransposeTileLds<S>(v + t * S, lane & (BPS - 1), j, (LdsTile*)smem + wave * (BPS * S * (S + 1)));
+        else TransposeTile<S>(v + t * S, lane);
+      }
       // lane j = pixel row j (R = S <= 8 rows... or 16), all C columns
       if (valid) {
 #pragma unroll
@@ -1280,6 +1338,8 @@ __device__ __forceinline__ UnitPick PickUnit(const FamilyEntry (&fam)[N], const 
 }
 
 static constexpr int kLdsFamilyA = MediumGeom<64, 64>::kLdsBytes;
+static_assert(TransposeLdsBytes<32>() <= kLdsFamilyA && TransposeLdsBytes<16>() <= kLdsFamilyA && TransposeLdsBytes<8>() <= kLdsFamilyA,
+              "the row-per-lane units of k_transform_r transpose through family A's allocation");
 static_assert(sizeof(BlockHdr) <= 48, "header slots are 48 bytes");
 static_assert(MediumGeom<64, 32>::kLdsBytes <= kLdsFamilyA && MediumGeom<32, 64>::kLdsBytes <= kLdsFamilyA, "");
 
@@ -1433,11 +1493,11 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(De
   UnitDispatch(kFamilyR, wl,
                [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
                  switch (index) {
-                   case 0: RowLaneUnit<32, 32, 5, CT>(f, list, first, n); break;
-                   case 1: RowLaneUnit<32, 16, 10, CT>(f, list, first, n); break;
-                   case 2: RowLaneUnit<16, 32, 11, CT>(f, list, first, n); break;
-                   case 3: RowLaneUnit<32, 8, 8, CT>(f, list, first, n); break;
-                   case 4: RowLaneUnit<8, 32, 9, CT>(f, list, first, n); break;
+                   case 0: RowLaneUnit<32, 32, 5, CT, true>(f, list, first, n, smem); break;
+                   case 1: RowLaneUnit<32, 16, 10, CT, true>(f, list, first, n, smem); break;
+                   case 2: RowLaneUnit<16, 32, 11, CT, true>(f, list, first, n, smem); break;
+                   case 3: RowLaneUnit<32, 8, 8, CT, true>(f, list, first, n, smem); break;
+                   case 4: RowLaneUnit<8, 32, 9, CT, true>(f, list, first, n, smem); break;
                    case 5: RowLaneUnit<16, 16, 4, CT>(f, list, first, n); break;
                    case 6: RowLaneUnit<16, 8, 6, CT>(f, list, first, n); break;
                    default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;

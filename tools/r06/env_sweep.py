@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--height", type=int, default=4320)
     ap.add_argument("--gab", type=int, default=1)
     ap.add_argument("--epf", type=int, default=1)
-    ap.add_argument("--used-acs", action="store_true", help="hand the frame's used_acs mask to the decoder")
+    ap.add_argument("--used-acs", action="store_true", help="hand the mix's used_acs mask to the decoder")
+    ap.add_argument("--no-used-acs", action="store_true", help="used_acs = 0 (unknown): everything rides in the merged phase-1 launch")
     ap.add_argument("--envs", default="")
     args = ap.parse_args()
     import torch
@@ -36,6 +37,8 @@ def main():
         for s in mix:
             m |= 1 << int(s)
         params["used_acs"] = m
+    if args.no_used_acs:
+        params["used_acs"] = 0
     ref = None
     touched = set()
     for spec in args.envs.split(";"):
