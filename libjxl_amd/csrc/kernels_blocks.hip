@@ -1498,9 +1498,9 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(De
                    case 2: RowLaneUnit<16, 32, 11, CT, true>(f, list, first, n, smem); break;
                    case 3: RowLaneUnit<32, 8, 8, CT, true>(f, list, first, n, smem); break;
                    case 4: RowLaneUnit<8, 32, 9, CT, true>(f, list, first, n, smem); break;
-                   case 5: RowLaneUnit<16, 16, 4, CT>(f, list, first, n); break;
-                   case 6: RowLaneUnit<16, 8, 6, CT>(f, list, first, n); break;
-                   default: RowLaneUnit<8, 16, 7, CT>(f, list, first, n); break;
+                   case 5: RowLaneUnit<16, 16, 4, CT, true>(f, list, first, n, smem); break;
+                   case 6: RowLaneUnit<16, 8, 6, CT, true>(f, list, first, n, smem); break;
+                   default: RowLaneUnit<8, 16, 7, CT, true>(f, list, first, n, smem); break;
                  }
                },
                idx - big_wgs, r_wgs, (f.mfma32 != nullptr ? 1u : 0u) | (f.mfma16 != nullptr ? 1u << 5 : 0u));
@@ -1558,6 +1558,9 @@ static void LaunchBlocksT(const DevFrame& f, const WorkLists& wl, uint32_t cells
     const uint32_t big_wgs = have_big ? (grid_a < big_cap ? grid_a : big_cap) : 0u;
     const uint32_t special_wgs = specials_in_r ? grid_specials : 0u;
     const uint32_t dct8_wgs = dct8_in_r ? grid_dct8 : 0u;
+    // (round 6, again: the 16-point classes in a launch of their own -- 93 VGPRs, no LDS, five waves per SIMD, where inside
+    // this launch they run at three: all-DCT16X16 frames 159 against 115 us -- cost 9 us more per frame on both the d1 mix
+    // and genuine-content shares, profiles/r06_transform_overread.txt; the single launch stays)
     hipLaunchKernelGGL((k_transform_r<CT>), dim3(special_wgs + big_wgs + grid_r16 + dct8_wgs), dim3(256), 0, s0, f, wl,
                        big_wgs, special_wgs, grid_r16, dct8_wgs);
   } else {
