@@ -1122,6 +1122,180 @@ __device__ __forceinline__ void MediumUnit(const DevFrame& f, const WorkItem* __
   }
 }
 
+// ---------------------------------------------------- family A, the next varblock's loads in flight (round 6)
+// MediumUnit above handles a 64-point varblock as load -> wait -> dequantise -> two passes -> store, one varblock at a
+// time and three workgroups per CU (its 50 KB of LDS): measured per phase (tools/r06/medium_timing.py,
+// profiles/r06_medium_timing.txt) the two IDCT passes are 3 % of a varblock's time, the load phase 52 % and the store
+// phase 39 % -- a wave's vmcnt counter retires loads AND stores in issue order, so the loads of varblock k + 1, issued
+// behind the 16 KB of stores of varblock k, are only "there" when those stores have drained.  Here a workgroup walks its
+// varblocks itself (one varblock per task, whatever the class) and requests varblock k + 1's coefficient rows, dequant
+// table vectors and DC column -- 116 registers that nothing else needs at that point -- BETWEEN varblock k's second pass
+// and its stores: they travel during the store phase, and waiting for them does not wait for the stores behind them.
+// 16-bit coefficients only (32-bit rows would be 72 registers more: MediumUnit keeps those frames).
+struct APrefetch {
+  uint2 x[6], y[6], b[6];     // the thread's 4 coefficients per step and channel (6 steps of 768 for 64x64, 3 for the halves)
+  float dc[8];                // lanes < CX of each channel wave: the DC column of LowestFrequenciesFromDC's first step
+};
+
+template <int R, int C, int STRATEGY>
+__device__ __forceinline__ void ARequest(const DevFrame& f, const BlockHdr& h, APrefetch& P) {
+  using G = MediumGeom<R, C>;
+  static_assert(G::NB == 1 && G::ML == 64, "one 64-point varblock per task");
+  constexpr int SIZE = R * C;
+  constexpr int kIter = (SIZE + 767) / 768;
+  static_assert(kIter <= 6 && G::CY <= 8, "APrefetch capacity");
+  const int tid = Tid();
+  const int c = tid >> 6, lane = tid & 63;
+  {
+    const float* dc = f.dc[c] + (size_t)h.aby * f.xsb + h.abx + (lane < G::CX ? lane : 0);
+#pragma unroll
+    for (int y = 0; y < 8; y++) P.dc[y] = y < G::CY ? dc[(size_t)y * f.xsb] : 0.0f;
+  }
+  // EVERY element of P is written here, unconditionally (threads past the varblock's end repeat its first vector, steps
+  // the class does not have get zeros): an element that is only sometimes written would stay alive, as far as the register
+  // allocator can tell, across the passes of every varblock -- 54 registers the 64-point IDCTs do not have
+#pragma unroll
+  for (int it = 0; it < 6; it++) {
+    if (it < kIter) {
+      const int k4 = tid * 4 + it * 768;
+      const int kk = k4 < SIZE ? k4 : 0;
+      const size_t at = h.coef + kk;
+      P.x[it] = *(const uint2*)((const int16_t*)f.coeffs[0] + at);
+      P.y[it] = *(const uint2*)((const int16_t*)f.coeffs[1] + at);
+      P.b[it] = *(const uint2*)((const int16_t*)f.coeffs[2] + at);
+    } else {
+      P.x[it] = P.y[it] = P.b[it] = make_uint2(0u, 0u);
+    }
+  }
+}
+
+// dequantisation + LLF + both passes of one varblock whose loads are in P; the pixels end up in the LDS buffer
+// (the arithmetic of MediumBatch with one varblock per batch, statement for statement)
+template <int R, int C, int STRATEGY>
+__device__ __forceinline__ void AHead(const DevFrame& f, const BlockHdr& h, const APrefetch& P, unsigned char* smem) {
+  using G = MediumGeom<R, C>;
+  constexpr int L = G::L, LP = G::LP, TP = G::TP, BUF = G::BUF, CY = G::CY, CX = G::CX;
+  constexpr int SIZE = R * C;
+  constexpr int kIter = (SIZE + 767) / 768;
+  float(*buf)[BUF] = reinterpret_cast<float(*)[BUF]>(smem);
+  float(*dcp)[CY * CX] = reinterpret_cast<float(*)[CY * CX]>(smem + 12 * BUF);
+  const int tid = Tid();
+  const int c = tid >> 6, i = tid & 63;
+  float* m = &buf[c][0];
+  float* dp = &dcp[c][0];
+  if (i < CX) {  // LLF step 1
+    float v[CY];
+#pragma unroll
+    for (int y = 0; y < CY; y++) v[y] = P.dc[y];
+    DctReg<CY>(v);
+#pragma unroll
+    for (int y = 0; y < CY; y++) dp[y * CX + i] = (1.0f / CY) * v[y];
+  }
+  // the table vectors: L2 hits, requested here (a table row per thread and step: 72 registers that are free now and were
+  // not while the previous varblock's passes ran)
+  const float* __restrict__ tab = f.dequant + DequantOffset(STRATEGY);
+  float4 tx[kIter], ty[kIter], tb[kIter];
+#pragma unroll
+  for (int it = 0; it < kIter; it++) {
+    const int k4 = tid * 4 + it * 768;
+    const int kk = k4 < SIZE ? k4 : 0;
+    tx[it] = *(const float4*)(tab + kk);
+    ty[it] = *(const float4*)(tab + SIZE + kk);
+    tb[it] = *(const float4*)(tab + 2 * SIZE + kk);
+  }
+#pragma unroll
+  for (int it = 0; it < kIter; it++) {
+    const int k = tid * 4 + it * 768;
+    if (k < SIZE) {
+      int32_t qx[4], qy[4], qb[4];
+      UnpackCoeffs<int16_t>(P.x[it], qx);
+      UnpackCoeffs<int16_t>(P.y[it], qy);
+      UnpackCoeffs<int16_t>(P.b[it], qb);
+      const float mx[4] = {tx[it].x, tx[it].y, tx[it].z, tx[it].w};
+      const float my[4] = {ty[it].x, ty[it].y, ty[it].z, ty[it].w};
+      const float mb[4] = {tb[it].x, tb[it].y, tb[it].z, tb[it].w};
+      const int row = k / L, col = k % L;
+      float* ox = &buf[0][row * LP + col];
+      float* oy = &buf[1][row * LP + col];
+      float* ob = &buf[2][row * LP + col];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float dy = AdjustQuantBias(qy[j], f.biases[1], f.biases[3]) * (my[j] * h.sy);
+        const float dx = AdjustQuantBias(qx[j], f.biases[0], f.biases[3]) * (mx[j] * h.sx);
+        const float db = AdjustQuantBias(qb[j], f.biases[2], f.biases[3]) * (mb[j] * h.sb);
+        ox[j] = __builtin_fmaf(h.x_cc, dy, dx);
+        oy[j] = dy;
+        ob[j] = __builtin_fmaf(h.b_cc, dy, db);
+      }
+    }
+  }
+  __syncthreads();
+  if (i < CY) {  // LLF step 2
+    float v[CX];
+#pragma unroll
+    for (int x = 0; x < CX; x++) v[x] = dp[i * CX + x];
+    DctReg<CX>(v);
+    const float ry = ResampleUpSel<CY>(i);
+#pragma unroll
+    for (int x = 0; x < CX; x++) {
+      const float val = (1.0f / CX) * v[x];
+      if constexpr (CY < CX) {
+        m[i * LP + x] = val * ry * kResampleUpHost[CX + x];
+      } else {
+        m[x * LP + i] = val * kResampleUpHost[CX + x] * ry;
+      }
+    }
+  }
+  __syncthreads();
+  {  // pass 1
+    float v[C];
+    if (i < R) {
+#pragma unroll
+      for (int j = 0; j < C; j++) v[j] = (R < C) ? m[i * LP + j] : m[j * LP + i];
+      IdctReg<C>(v);
+    }
+    __syncthreads();
+    if (i < R) {
+#pragma unroll
+      for (int j = 0; j < C; j++) m[i * TP + j] = v[j];
+    }
+  }
+  __syncthreads();
+  if (i < C) {  // pass 2
+    float v[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) v[j] = m[j * TP + i];
+    IdctReg<R>(v);
+#pragma unroll
+    for (int j = 0; j < R; j++) m[j * TP + i] = v[j];
+  }
+  __builtin_amdgcn_wave_barrier();
+  // (the next varblock's requests follow: not above this pass, whose 64-point IDCT needs the registers they land in)
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// the channel wave moves its pixel rectangle to the block-major planes (as MediumBatch: whole 16-byte tile parts)
+template <int R, int C>
+__device__ __forceinline__ void AStore(const DevFrame& f, const BlockHdr& h, unsigned char* smem) {
+  using G = MediumGeom<R, C>;
+  constexpr int TP = G::TP, BUF = G::BUF, CX = G::CX;
+  constexpr int kParts = R * C / 4;
+  float(*buf)[BUF] = reinterpret_cast<float(*)[BUF]>(smem);
+  const int tid = Tid();
+  const int c = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int e0 = 0; e0 < kParts; e0 += 64) {
+    const int r = e0 + lane;
+    const int t = r >> 4, part = r & 15;
+    const int ty = t / CX, tx = t % CX;
+    const float* src = &buf[c][(ty * 8 + (part >> 1)) * TP + tx * 8 + (part & 1) * 4];
+    *(float4*)(TilePtr(f, c, h.aby + ty, h.abx + tx) + part * 4) = make_float4(src[0], src[1], src[2], src[3]);
+    // (four parts at a time: left alone the scheduler reads all sixteen parts ahead -- 64 registers beside the 116 of the
+    // next varblock's loads in flight)
+    if ((e0 & 192) == 192) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ------------------------------------------------------------------- k_large
 // Strategies 21..26 (128x128 .. 256x256; legal but never emitted by libjxl).  One workgroup per varblock; 1-D
 // transforms of up to 256 points run on per-thread scratch arrays; the
@@ -1379,6 +1553,54 @@ __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const 
   }
 }
 
+// one varblock per task for every class of the family
+static constexpr FamilyEntry kFamilyA1[3] = {{kClsMedium0 + 8, 1}, {kClsMedium0 + 9, 1}, {kClsMedium0 + 10, 1}};
+
+__device__ __forceinline__ void FamilyALoop16(const DevFrame& f, const WorkLists& wl, unsigned char* smem, uint32_t wg_index,
+                                              uint32_t num_wgs) {
+  uint32_t cnt[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) cnt[i] = wl.count[kFamilyA1[i].cls * kCounterPad];
+  uint32_t u = wg_index;
+  UnitPick cur = PickUnit(kFamilyA1, cnt, u);
+  if (cur.index < 0) return;
+  BlockHdr hc = MakeHdr(f, wl.list[cur.cls][cur.first]);
+  APrefetch P;
+#define JXLHIP_AREQUEST(INDEX, H)                      \
+  switch (INDEX) {                                     \
+    case 0: ARequest<64, 64, 18>(f, H, P); break;      \
+    case 1: ARequest<64, 32, 19>(f, H, P); break;      \
+    default: ARequest<32, 64, 20>(f, H, P); break;     \
+  }
+  JXLHIP_AREQUEST(cur.index, hc)
+  for (;;) {
+    const UnitPick nxt = PickUnit(kFamilyA1, cnt, u + num_wgs);
+    WorkItem in{};
+    if (nxt.index >= 0) in = wl.list[nxt.cls][nxt.first];  // (travels during this varblock's arithmetic)
+    switch (cur.index) {
+      case 0: AHead<64, 64, 18>(f, hc, P, smem); break;
+      case 1: AHead<64, 32, 19>(f, hc, P, smem); break;
+      default: AHead<32, 64, 20>(f, hc, P, smem); break;
+    }
+    BlockHdr hn{};
+    if (nxt.index >= 0) {
+      hn = MakeHdr(f, in);
+      JXLHIP_AREQUEST(nxt.index, hn)  // in front of this varblock's stores: see above
+    }
+    switch (cur.index) {
+      case 0: AStore<64, 64>(f, hc, smem); break;
+      case 1: AStore<64, 32>(f, hc, smem); break;
+      default: AStore<32, 64>(f, hc, smem); break;
+    }
+    if (nxt.index < 0) return;
+    __syncthreads();  // the next varblock reuses the LDS
+    cur = nxt;
+    hc = hn;
+    u += num_wgs;
+  }
+#undef JXLHIP_AREQUEST
+}
+
 // Family A (64-point transforms, ~5 % of a d1.0 frame) is compiled for three waves per SIMD
 // (168 VGPRs, what its LDS use allows anyway); the 64-point transforms would like ~180 and
 // spill a few values to scratch instead.  In row-per-lane form (64 values per lane, > 256
@@ -1386,15 +1608,19 @@ __device__ __forceinline__ void UnitDispatch(const FamilyEntry (&fam)[N], const 
 template <typename CT>
 __global__ __launch_bounds__(192, sizeof(CT) == 2 ? 3 : 2) void k_transform_a(DevFrame f, WorkLists wl) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsFamilyA];
-  UnitDispatch(kFamilyA, wl,
-               [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
-                 switch (index) {
-                   case 0: MediumUnit<64, 64, 18, CT>(f, list, first, n, smem); break;
-                   case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
-                   default: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
-                 }
-               },
-               blockIdx.x, gridDim.x);
+  if constexpr (sizeof(CT) == 2) {
+    FamilyALoop16(f, wl, smem, blockIdx.x, gridDim.x);
+  } else {
+    UnitDispatch(kFamilyA, wl,
+                 [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
+                   switch (index) {
+                     case 0: MediumUnit<64, 64, 18, CT>(f, list, first, n, smem); break;
+                     case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
+                     default: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
+                   }
+                 },
+                 blockIdx.x, gridDim.x);
+  }
 }
 
 template <typename CT>
@@ -1479,15 +1705,19 @@ __global__ __launch_bounds__(256, sizeof(CT) == 2 ? 3 : 2) void k_transform_r(De
   }
   if (idx < big_wgs) {
     if (threadIdx.x >= 192) return;
-    UnitDispatch(kFamilyA, wl,
-                 [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
-                   switch (index) {
-                     case 0: MediumUnit<64, 64, 18, CT>(f, list, first, n, smem); break;
-                     case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
-                     default: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
-                   }
-                 },
-                 idx, big_wgs);
+    if constexpr (sizeof(CT) == 2) {
+      FamilyALoop16(f, wl, smem, idx, big_wgs);
+    } else {
+      UnitDispatch(kFamilyA, wl,
+                   [&](int index, const WorkItem* __restrict__ list, uint32_t first, uint32_t n) {
+                     switch (index) {
+                       case 0: MediumUnit<64, 64, 18, CT>(f, list, first, n, smem); break;
+                       case 1: MediumUnit<64, 32, 19, CT>(f, list, first, n, smem); break;
+                       default: MediumUnit<32, 64, 20, CT>(f, list, first, n, smem); break;
+                     }
+                   },
+                   idx, big_wgs);
+    }
     return;
   }
   UnitDispatch(kFamilyR, wl,
