@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Round 6 experiment driver: the banded frame (phase 1 of band b + 1 beside the fused kernel of band b) against the
+"""RECORD OF AN EXPERIMENT THAT WAS NOT SHIPPED: the JXLHIP_PIPE_* switches this script sets exist only in a library built
+with tools/r06/band_pipeline.patch, a diff against commit 353abba (the tree before round 6's pruning: it no longer applies to
+HEAD).  Results: profiles/r06_band_pipeline_sweep.txt, profiles/r06_band_pipeline_timeline.txt, DESIGN.md section 4b.
+
+Round 6 experiment driver: the banded frame (phase 1 of band b + 1 beside the fused kernel of band b) against the
 one-band frame, over the knobs of context.hip's DecodeFramePipelined.  Every configuration is a fresh context (the
 switches are read when a context is created), decodes the SAME frame, must be bit-equal to the one-band output, and is
 timed like bench.py's `value`: one context, one frame at a time, after a settle phase.
