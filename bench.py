@@ -60,16 +60,30 @@ class ClockSampler:
     def __init__(self, device_index=0):
         import glob
         self.paths = {}
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))]
-        if cards:
-            c = cards[min(device_index, len(cards) - 1)]
+        self.card = None
+        # the DRM node of THIS HIP device: by PCI address (a container may see the sysfs nodes of every GPU of the host and
+        # only one of them as a HIP device); failing that, every amdgpu card is polled and the busiest one reported
+        roots = []
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            if os.path.isdir("/sys/bus/pci/devices/" + addr):
+                roots = ["/sys/bus/pci/devices/" + addr]
+                self.card = addr
+        except Exception:
+            roots = []
+        if not roots:
+            roots = [c for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+                     if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))]
+        for n, c in enumerate(roots):
             for key, hw, dpm in (("sclk", "freq1_input", "pp_dpm_sclk"), ("mclk", "freq2_input", "pp_dpm_mclk")):
                 h = glob.glob(os.path.join(c, "hwmon/hwmon*/" + hw))
+                name = key if len(roots) == 1 else f"{key}@{os.path.basename(os.path.dirname(c)) if c.endswith('/device') else os.path.basename(c)}"
                 if h:
-                    self.paths[key] = ("hz", h[0])
+                    self.paths[name] = ("hz", h[0])
                 elif os.path.exists(os.path.join(c, dpm)):
-                    self.paths[key] = ("dpm", os.path.join(c, dpm))
+                    self.paths[name] = ("dpm", os.path.join(c, dpm))
         self.samples = {k: [] for k in self.paths}
         self._stop = None
         self._thread = None
@@ -114,6 +128,15 @@ class ClockSampler:
             if v:
                 w = sorted(v)
                 out[k + "_mhz"] = {"min": round(w[0]), "median": round(w[len(w) // 2]), "max": round(w[-1]), "samples": len(w)}
+        if self.card is None and len(out) > 2:
+            # no PCI match: the card whose shader clock ran highest is the one that worked
+            best = max((k for k in out if k.startswith("sclk@")), key=lambda k: out[k]["median"], default=None)
+            if best:
+                tag = best[len("sclk"):-len("_mhz")]
+                out = {"sclk_mhz": out[best], **({"mclk_mhz": out["mclk" + tag + "_mhz"]} if "mclk" + tag + "_mhz" in out else {}),
+                       "card": tag[1:], "picked": "highest median shader clock of %d amdgpu cards" % (len(out) // 2)}
+        elif self.card:
+            out["pci"] = self.card
         return out or None
 
 
